@@ -1,0 +1,294 @@
+"""ctypes binding of the C-ABI declared in include/geneevolve_amd.h.
+
+This is the stub a Python host would add; the C++ host binding is shown in INTEGRATION.md.
+`GevLibrary(path, prefix)` binds any shared library that exports the ABI under `prefix`
+(the product library exports `gev_*`).  No compute happens in Python: every method is one
+C call on caller-owned numpy buffers.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libgeneevolve_amd.so")
+
+
+class GevError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class gev_couple(C.Structure):
+    _fields_ = [("pos_male", C.c_uint64), ("pos_female", C.c_uint64), ("inbreed", C.c_int32), ("num_offspring", C.c_int32)]
+
+
+class gev_part(C.Structure):
+    _fields_ = [("st", C.c_uint64), ("en", C.c_uint64), ("hap_index", C.c_uint64), ("root_population", C.c_int32), ("reserved", C.c_int32)]
+
+
+class gev_move(C.Structure):
+    _fields_ = [("src_pop", C.c_int32), ("dst_pop", C.c_int32), ("src_pos", C.c_uint64)]
+
+
+COUPLE_DTYPE = np.dtype([("pos_male", "<u8"), ("pos_female", "<u8"), ("inbreed", "<i4"), ("num_offspring", "<i4")])
+PART_DTYPE = np.dtype([("st", "<u8"), ("en", "<u8"), ("hap_index", "<u8"), ("root_population", "<i4"), ("reserved", "<i4")])
+MOVE_DTYPE = np.dtype([("src_pop", "<i4"), ("dst_pop", "<i4"), ("src_pos", "<u8")])
+
+# every symbol include/geneevolve_amd.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "last_error", "version", "create", "destroy", "set_rmap", "set_mutmap", "set_snps", "set_cvs",
+    "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
+    "reproduce", "compute_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
+    "import_rows", "download_haps", "download_cv", "download_intervals", "download_mutations",
+    "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals",
+]
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def words_for(nbits):
+    return (int(nbits) + 63) // 64
+
+
+def pack_rows(bits01):
+    """uint8 [rows][L] of 0/1 -> uint64 [rows][ceil(L/64)] in the C-ABI packing."""
+    b = np.asarray(bits01, dtype=np.uint8)
+    pad = (-b.shape[1]) % 64
+    if pad:
+        b = np.concatenate([b, np.zeros((b.shape[0], pad), dtype=np.uint8)], axis=1)
+    return np.ascontiguousarray(np.packbits(b, axis=1, bitorder="little")).view(np.uint64)
+
+
+def bytes_to_words(packed_u8, L):
+    """np.packbits(..., bitorder='little') bytes [rows][ceil(L/8)] -> uint64 words."""
+    rows = packed_u8.shape[0]
+    w = words_for(L)
+    out = np.zeros((rows, w * 8), dtype=np.uint8)
+    out[:, :packed_u8.shape[1]] = packed_u8
+    return out.view(np.uint64)
+
+
+def unpack_rows(words, L):
+    return np.unpackbits(np.ascontiguousarray(words).view(np.uint8), axis=1, bitorder="little")[:, :L]
+
+
+class GevLibrary:
+    def __init__(self, path=DEFAULT_LIB, prefix="gev_"):
+        if not os.path.exists(path):
+            raise GevError(-3, f"native library not found: {path} (build it: python -c 'import __graft_entry__ as g; g.build()')")
+        self.path, self.prefix = path, prefix
+        self.lib = C.CDLL(path)
+        self.has_device_arg = prefix == "gev_"
+        f = self._f("last_error"); f.restype = C.c_char_p; f.argtypes = []
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def exports(self, name):
+        try:
+            self._f(name)
+            return True
+        except AttributeError:
+            return False
+
+    def last_error(self):
+        s = self._f("last_error")()
+        return s.decode() if s else ""
+
+    def check(self, rc):
+        if rc != 0:
+            raise GevError(rc, self.last_error())
+
+    def create(self, n_pop, nchr, nphen, device=-1):
+        return GevContext(self, n_pop, nchr, nphen, device)
+
+
+class GevContext:
+    """One simulation context = one GPU (reference: one Simulation object)."""
+
+    def __init__(self, lib, n_pop, nchr, nphen, device=-1):
+        self.L, self.n_pop, self.nchr, self.nphen = lib, n_pop, nchr, nphen
+        h = C.c_void_p()
+        if lib.has_device_arg:
+            rc = lib._f("create")(C.byref(h), C.c_int(device), C.c_int(n_pop), C.c_int(nchr), C.c_int(nphen))
+        else:
+            rc = lib._f("create")(C.byref(h), C.c_int(n_pop), C.c_int(nchr), C.c_int(nphen))
+        lib.check(rc)
+        self.h = h
+        self._nsnp = {}
+        self._ncv = {}
+
+    def close(self):
+        if self.h:
+            f = self.L._f("destroy"); f.restype = None
+            f(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        self.L.check(self.L._f(name)(self.h, *args))
+
+    # ---- static inputs
+    def set_rmap(self, pop, chr, bp, prob, bp_dist):
+        bp = _arr(bp, np.uint64); prob = _arr(prob, np.float64)
+        self._call("set_rmap", C.c_int(pop), C.c_int(chr), _p(bp), _p(prob), C.c_size_t(len(bp)), C.c_uint64(int(bp_dist)))
+
+    def set_mutmap(self, pop, chr, bp, rate):
+        bp = _arr(bp, np.uint64); rate = _arr(rate, np.float64)
+        self._call("set_mutmap", C.c_int(pop), C.c_int(chr), _p(bp), _p(rate), C.c_size_t(len(bp)))
+
+    def set_snps(self, pop, chr, pos):
+        pos = _arr(pos, np.uint64)
+        self._nsnp[(pop, chr)] = len(pos)
+        self._call("set_snps", C.c_int(pop), C.c_int(chr), _p(pos), C.c_size_t(len(pos)))
+
+    def set_cvs(self, pop, phen, chr, bp, a, d, vd):
+        bp = _arr(bp, np.uint64); a = _arr(a, np.float64); d = _arr(d, np.float64)
+        self._ncv[(pop, phen, chr)] = len(bp)
+        self._call("set_cvs", C.c_int(pop), C.c_int(phen), C.c_int(chr), _p(bp), _p(a), _p(d), C.c_size_t(len(bp)), C.c_double(vd))
+
+    def upload_founders(self, pop, chr, words, L):
+        words = _arr(words, np.uint64)
+        self._call("upload_founders", C.c_int(pop), C.c_int(chr), _p(words), C.c_size_t(words.shape[1]), C.c_size_t(words.shape[0]), C.c_size_t(L))
+
+    def upload_cv_founders(self, pop, phen, chr, words, ncv):
+        words = _arr(words, np.uint64)
+        self._call("upload_cv_founders", C.c_int(pop), C.c_int(phen), C.c_int(chr), _p(words), C.c_size_t(words.shape[1]), C.c_size_t(words.shape[0]), C.c_size_t(ncv))
+
+    def synth_founders(self, pop, chr, nhap, seed):
+        self._call("synth_founders", C.c_int(pop), C.c_int(chr), C.c_size_t(nhap), C.c_uint64(seed))
+
+    def synth_cv_founders(self, pop, phen, chr, nhap, seed):
+        self._call("synth_cv_founders", C.c_int(pop), C.c_int(phen), C.c_int(chr), C.c_size_t(nhap), C.c_uint64(seed))
+
+    # ---- generation steps
+    def init_gen0(self, pop, n_people, seed_gen0, want_sex=True):
+        sex = np.zeros(n_people, dtype=np.uint8) if want_sex else None
+        self._call("init_gen0", C.c_int(pop), C.c_size_t(n_people), C.c_uint32(int(seed_gen0)), _p(sex))
+        return sex
+
+    def reproduce(self, pop, couples, seed_reproduce, mut_seeds=None, want_sex=True):
+        """couples: int array [n,4] (pos_male,pos_female,inbreed,num_offspring) or COUPLE_DTYPE array"""
+        if couples.dtype != COUPLE_DTYPE:
+            c = np.zeros(len(couples), dtype=COUPLE_DTYPE)
+            c["pos_male"], c["pos_female"], c["inbreed"], c["num_offspring"] = couples[:, 0], couples[:, 1], couples[:, 2], couples[:, 3]
+            couples = c
+        couples = np.ascontiguousarray(couples)
+        n_people = int(couples["num_offspring"][couples["inbreed"] == 0].sum())
+        ms = None if mut_seeds is None else _arr(mut_seeds, np.uint32)
+        sex = np.zeros(n_people, dtype=np.uint8) if want_sex else None
+        self._call("reproduce", C.c_int(pop), _p(couples), C.c_size_t(len(couples)), C.c_uint32(int(seed_reproduce)),
+                   _p(ms), C.c_size_t(0 if ms is None else len(ms)), C.c_size_t(n_people), _p(sex))
+        return sex
+
+    def compute_ad(self, pop, per_chr=True):
+        n = self.pop_size(pop)
+        add = np.zeros((n, self.nphen)); dom = np.zeros((n, self.nphen))
+        addc = np.zeros((n, self.nchr, self.nphen)) if per_chr else None
+        domc = np.zeros((n, self.nchr, self.nphen)) if per_chr else None
+        self._call("compute_ad", C.c_int(pop), _p(add), _p(dom), _p(addc), _p(domc))
+        return add, dom, addc, domc
+
+    def get_cv_freq(self, pop, phen, chr):
+        ncv = self._ncv[(pop, phen, chr)]
+        f = np.zeros(ncv)
+        self._call("get_cv_freq", C.c_int(pop), C.c_int(phen), C.c_int(chr), _p(f), C.c_size_t(ncv))
+        return f
+
+    def migrate(self, moves):
+        """moves: list/array of (src_pop, src_pos, dst_pop) in reference append order"""
+        m = np.zeros(len(moves), dtype=MOVE_DTYPE)
+        for i, (sp, pos, dp) in enumerate(moves):
+            m[i] = (sp, dp, pos)
+        self._call("migrate", _p(m), C.c_size_t(len(m)))
+
+    # ---- downloads
+    def pop_size(self, pop):
+        n = C.c_size_t()
+        self._call("pop_size", C.c_int(pop), C.byref(n))
+        return n.value
+
+    def download_haps(self, pop, chr, row_begin=0, n_rows=None):
+        L = self._nsnp[(pop, chr)]
+        if n_rows is None:
+            n_rows = 2 * self.pop_size(pop) - row_begin
+        w = words_for(L)
+        out = np.zeros((n_rows, w), dtype=np.uint64)
+        self._call("download_haps", C.c_int(pop), C.c_int(chr), C.c_size_t(row_begin), C.c_size_t(n_rows), _p(out), C.c_size_t(w))
+        return out
+
+    def download_cv(self, pop, phen, chr):
+        ncv = self._ncv[(pop, phen, chr)]
+        w = words_for(ncv)
+        out = np.zeros((2 * self.pop_size(pop), w), dtype=np.uint64)
+        self._call("download_cv", C.c_int(pop), C.c_int(phen), C.c_int(chr), _p(out), C.c_size_t(w))
+        return out
+
+    def download_intervals(self, pop, chr):
+        n = C.c_size_t()
+        self._call("download_intervals", C.c_int(pop), C.c_int(chr), None, None, C.byref(n))
+        parts = np.zeros(n.value, dtype=PART_DTYPE)
+        off = np.zeros(2 * self.pop_size(pop) + 1, dtype=np.uint64)
+        self._call("download_intervals", C.c_int(pop), C.c_int(chr), _p(parts), _p(off), C.byref(n))
+        return parts, off
+
+    def download_mutations(self, pop, chr):
+        n = C.c_size_t()
+        self._call("download_mutations", C.c_int(pop), C.c_int(chr), None, None, C.byref(n))
+        muts = np.zeros(n.value, dtype=np.uint64)
+        off = np.zeros(2 * self.pop_size(pop) + 1, dtype=np.uint64)
+        self._call("download_mutations", C.c_int(pop), C.c_int(chr), _p(muts), _p(off), C.byref(n))
+        return muts, off
+
+    # ---- product-only entry points
+    def reserve(self, pop, max_people):
+        self._call("reserve", C.c_int(pop), C.c_size_t(max_people))
+
+    def plane_ptr(self, pop, chr):
+        p = C.c_void_p(); s = C.c_size_t(); n = C.c_size_t()
+        self._call("plane_ptr", C.c_int(pop), C.c_int(chr), C.byref(p), C.byref(s), C.byref(n))
+        return p.value, s.value, n.value
+
+    def stream(self):
+        p = C.c_void_p()
+        self._call("stream", C.byref(p))
+        return p.value
+
+    def last_reproduce_ms(self):
+        ms = (C.c_float * 4)()
+        self._call("last_reproduce_ms", ms)
+        return [float(x) for x in ms]
+
+    def set_track_intervals(self, on):
+        self._call("set_track_intervals", C.c_int(1 if on else 0))
+
+    def export_size(self, pop, positions):
+        pos = _arr(positions, np.uint64); b = C.c_size_t()
+        self._call("export_size", C.c_int(pop), _p(pos), C.c_size_t(len(pos)), C.byref(b))
+        return b.value
+
+    def export_rows(self, pop, positions, device_ptr, nbytes):
+        pos = _arr(positions, np.uint64)
+        self._call("export_rows", C.c_int(pop), _p(pos), C.c_size_t(len(pos)), C.c_void_p(device_ptr), C.c_size_t(nbytes))
+
+    def remove_rows(self, pop, positions):
+        pos = _arr(positions, np.uint64)
+        self._call("remove_rows", C.c_int(pop), _p(pos), C.c_size_t(len(pos)))
+
+    def import_rows(self, pop, device_ptr, nbytes, n):
+        self._call("import_rows", C.c_int(pop), C.c_void_p(device_ptr), C.c_size_t(nbytes), C.c_size_t(n))

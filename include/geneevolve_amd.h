@@ -1,0 +1,197 @@
+/* geneevolve_amd.h -- C-ABI of the MI355X-native GeneEvolve reproduction hot path.
+ *
+ * The reference (MMesbahU/GeneEvolve) has no plugin/FFI interface; the seam is the set of
+ * private members of class Simulation (reference src/Simulation.h:64-144) listed below.  A
+ * maintainer replaces their bodies with calls to this library (INTEGRATION.md shows the
+ * patch).  Every entry point names the reference code it replaces.
+ *
+ *   reference seam (src/Simulation.h)                      entry point here
+ *   ------------------------------------------------------ ---------------------------------
+ *   ras_init_parameters (readers, src/Simulation.cpp:164)  gev_set_rmap / gev_set_mutmap /
+ *                                                          gev_set_snps / gev_set_cvs /
+ *                                                          gev_upload_founders / gev_upload_cv_founders
+ *   bool ras_initial_human_gen0(int ipop)          :86     gev_init_gen0
+ *   std::vector<Human> reproduce(int,int)          :81     gev_reproduce
+ *   bool ras_compute_AD(int ipop,int gen_num)      :80     gev_compute_ad
+ *   bool ras_do_migration(int gen_ind)             :71     gev_migrate (+ gev_export_rows /
+ *                                                          gev_import_rows across GPUs)
+ *   ras_convert_interval_to_hap_matrix             :105    gev_download_haps
+ *   ras_write_hap_to_interval_format               :116    gev_download_intervals
+ *
+ * Conventions (mirroring the reference's): every call returns 0 on success and a negative
+ * GEV_E* code on failure (the reference returns bool false and prints one line; the line is
+ * available from gev_last_error()).  No exceptions cross the boundary.  The caller owns every
+ * host buffer it passes; the library owns all device memory.  Exactly one host thread drives
+ * one context (the reference is single threaded).  One context lives on one GPU; one process
+ * per GPU.
+ *
+ * Bit packing of every genotype buffer crossing the boundary: haplotype-major rows
+ * (row = 2*individual + chromatid, as Hap_SNP.hap in reference src/format_hap.h:18-31),
+ * locus ii of a row is bit (ii & 63) of 64-bit little-endian word ii >> 6; rows are
+ * `row_stride_words` words apart; pad bits are zero.
+ *
+ * RNG coupling: the host keeps drawing Simulation::ras_glob_seed()
+ * (src/Simulation.cpp:17-21) exactly as the reference does and hands the values in:
+ * 1 value per gev_init_gen0, 1 per gev_reproduce plus 1 per (offspring, chromosome) when a
+ * mutation map is loaded (the draw inside ras_add_mutation, src/Simulation.cpp:2500).
+ */
+#ifndef GENEEVOLVE_AMD_H
+#define GENEEVOLVE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEV_OK          0
+#define GEV_EINVAL     -1   /* bad argument / inconsistent sizes                                   */
+#define GEV_ESTATE     -2   /* call order violated (e.g. reproduce before init_gen0)               */
+#define GEV_EDEVICE    -3   /* HIP runtime error, no device, out of device memory                  */
+#define GEV_ENAN       -4   /* "A or D is nan" (reference src/Simulation.cpp:2716-2720)            */
+#define GEV_EUNSUPPORTED -5 /* input outside the dense-equivalence preconditions   */
+
+typedef struct gev_ctx gev_ctx;
+
+/* class Couples_Info, reference src/Population.h:165-180.  pos_* index the CURRENT
+ * generation of the population by position (not by ID). */
+typedef struct gev_couple {
+    uint64_t pos_male;
+    uint64_t pos_female;
+    int32_t  inbreed;        /* != 0: couple is skipped (src/Simulation.cpp:2440) */
+    int32_t  num_offspring;
+} gev_couple;
+
+/* class part, reference src/Population.h:20-51, without gen0_indv (a pure function of
+ * hap_index and root_population: founder id + ".1"/".2", src/Simulation.cpp:3031-3033)
+ * and without mutation_pos (see gev_download_mutations). */
+typedef struct gev_part {
+    uint64_t st;
+    uint64_t en;
+    uint64_t hap_index;
+    int32_t  root_population;
+    int32_t  reserved;
+} gev_part;
+
+/* one migrant: individual at position src_pos of population src_pop (positions BEFORE the
+ * migration step) moves to dst_pop.  Order = the order in which the reference appends
+ * migrants (src/Simulation.cpp:971-981). */
+typedef struct gev_move {
+    int32_t  src_pop;
+    int32_t  dst_pop;
+    uint64_t src_pos;
+} gev_move;
+
+const char* gev_last_error(void);
+const char* gev_version(void);
+
+/* device < 0: use the current HIP device. */
+int  gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen);
+void gev_destroy(gev_ctx* ctx);
+
+/* ---- static inputs (what ras_init_parameters loads) -------------------------------------- */
+/* rMap + _recom_prob of one chromosome (src/Population.h:183-189, src/Population.cpp:471-480).
+ * bp_dist = rMap::bp_dist_in_rmap (src/Population.cpp:396-397). */
+int gev_set_rmap(gev_ctx*, int pop, int chr, const uint64_t* bp, const double* recom_prob,
+                 size_t R, uint64_t bp_dist);
+/* MutationMap of one chromosome (src/Population.h:192-197); rates already range-checked by the
+ * reader (src/Population.cpp:458).  M may be 0. */
+int gev_set_mutmap(gev_ctx*, int pop, int chr, const uint64_t* bp, const double* rate, size_t M);
+/* Legend.pos of the founder panel (src/format_hap.h); must be non-decreasing. */
+int gev_set_snps(gev_ctx*, int pop, int chr, const uint64_t* pos, size_t L);
+/* CV_INFO of one phenotype x chromosome (src/Population.h:201-208): bp, genetic_value_a,
+ * genetic_value_d in FILE order (the A/D sum runs in this order); vd = Phenotype_scheme::_vd. */
+int gev_set_cvs(gev_ctx*, int pop, int phen, int chr, const uint64_t* bp, const double* a,
+                const double* d, size_t C, double vd);
+/* Hap_SNP.hap founder panel, haplotype-major bit rows (nhap rows x L loci). */
+int gev_upload_founders(gev_ctx*, int pop, int chr, const uint64_t* bits, size_t row_stride_words,
+                        size_t nhap, size_t L);
+/* CV.val of one phenotype x chromosome (src/Population.h:212-216), columns in FILE order. */
+int gev_upload_cv_founders(gev_ctx*, int pop, int phen, int chr, const uint64_t* bits,
+                           size_t row_stride_words, size_t nhap, size_t C);
+/* Synthetic founder panel generated on the device (bench / large parity cases): allele of
+ * (hap, locus) ~ Bernoulli(f_locus), f_locus ~ U(0.05,0.5), counter-based hash of `seed`.
+ * Not a reference function: SURVEY.md section 8(d) prescribes device-side generation. */
+int gev_synth_founders(gev_ctx*, int pop, int chr, size_t nhap, uint64_t seed);
+int gev_synth_cv_founders(gev_ctx*, int pop, int phen, int chr, size_t nhap, uint64_t seed);
+
+/* ---- Simulation::ras_initial_human_gen0 (src/Simulation.cpp:3000-3072) --------------------
+ * individual i = founder haplotypes 2i, 2i+1 as two whole-chromosome parts
+ * [rmap.bp[0], rmap.bp[last]); sex[i] = rand()%2+1 after srand(seed_gen0).
+ * sex_out: n_people bytes (1 = male, 2 = female) or NULL. */
+int gev_init_gen0(gev_ctx*, int pop, size_t n_people, uint32_t seed_gen0, uint8_t* sex_out);
+
+/* ---- Simulation::reproduce (src/Simulation.cpp:2394-2493) ---------------------------------
+ * Replaces the population's current generation by its offspring.
+ *  seed_reproduce : the ras_glob_seed() value drawn at :2398
+ *  mut_seeds      : NULL when no mutation map is loaded (_mutation_map.size()==0, :2459);
+ *                   else the n_people*nchr ras_glob_seed() values drawn inside
+ *                   ras_add_mutation (:2500), in call order (offspring-major, chromosome-minor)
+ *  n_people       : sum of num_offspring over couples with inbreed==0 (checked)
+ *  sex_out        : n_people bytes, Human::sex of each offspring (:2472), or NULL
+ * Pedigree ids and common_sibling (:2473-2484) are pure host bookkeeping and stay with the host. */
+int gev_reproduce(gev_ctx*, int pop, const gev_couple* couples, size_t n_couples,
+                  uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds,
+                  size_t n_people, uint8_t* sex_out);
+
+/* ---- Simulation::ras_compute_AD + ras_find_cv (src/Simulation.cpp:2624-2815) --------------
+ * additive/dominance : [n_people * nphen], index ih*nphen + iphen  (Human::additive/dominance, raw)
+ * add_chr/dom_chr    : [n_people * nchr * nphen], index (ih*nchr + ichr)*nphen + iphen, or NULL
+ * bv = additive + dominance is left to the host (:2715, :2744). */
+int gev_compute_ad(gev_ctx*, int pop, double* additive, double* dominance,
+                   double* add_chr, double* dom_chr);
+/* population allele frequency frq[icv] of the last gev_compute_ad (:2647-2655), FILE order. */
+int gev_get_cv_freq(gev_ctx*, int pop, int phen, int chr, double* frq, size_t C);
+
+/* ---- Simulation::ras_do_migration (src/Simulation.cpp:877-989) ----------------------------
+ * The host decides WHO moves exactly as the reference does; the library moves the rows:
+ * migrants are removed from their origin populations (stable order of the remainder, :960-966)
+ * and appended to their destinations in `moves` order (:971-981). */
+int gev_migrate(gev_ctx*, const gev_move* moves, size_t n_moves);
+/* Cross-GPU form of the same step (one context per GPU, exchange done by the caller over
+ * RCCL): pack the complete state of the individuals at `positions` into one contiguous device
+ * buffer / remove them / append individuals packed by a peer.  Record layout is opaque but
+ * identical across contexts with identical static inputs; gev_export_size gives the byte count. */
+int gev_export_size(gev_ctx*, int pop, const uint64_t* positions, size_t n, size_t* bytes);
+int gev_export_rows(gev_ctx*, int pop, const uint64_t* positions, size_t n, void* device_buf, size_t bytes);
+int gev_remove_rows(gev_ctx*, int pop, const uint64_t* positions, size_t n);
+int gev_import_rows(gev_ctx*, int pop, const void* device_buf, size_t bytes, size_t n);
+
+/* ---- output materialisation --------------------------------------------------------------
+ * == Simulation::ras_convert_interval_to_hap_matrix (src/Simulation.cpp:1186-1230):
+ * rows [row_begin, row_begin+n_rows) of the 2*n_people x L matrix, mutations applied. */
+int gev_download_haps(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_rows,
+                      uint64_t* bits, size_t row_stride_words);
+/* CV genotype matrix of ras_find_cv (the --debug .cvval dump, :2665-2683), FILE column order. */
+int gev_download_cv(gev_ctx*, int pop, int phen, int chr, uint64_t* bits, size_t row_stride_words);
+/* ancestry interval lists (the .int output, :1596-1633): hap_offsets has 2*n_people+1 entries;
+ * parts of haplotype row r are out[hap_offsets[r] .. hap_offsets[r+1]).  Call with out==NULL to
+ * get the total count in *n_parts. */
+int gev_download_intervals(gev_ctx*, int pop, int chr, gev_part* out, uint64_t* hap_offsets,
+                           size_t* n_parts);
+/* mutation positions carried by each haplotype row (union of part::mutation_pos over its
+ * parts), ascending per row, duplicates kept.  Same calling convention as above. */
+int gev_download_mutations(gev_ctx*, int pop, int chr, uint64_t* out, uint64_t* hap_offsets,
+                           size_t* n_mut);
+
+/* ---- introspection ------------------------------------------------------------------------ */
+int gev_pop_size(gev_ctx*, int pop, size_t* n_people);
+/* device pointer + stride of the resident genotype plane of the current generation (founder
+ * alleles only: mutations are kept as a sparse overlay). */
+int gev_plane_ptr(gev_ctx*, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows);
+/* reserve device capacity for populations of up to max_people (avoids reallocation) */
+int gev_reserve(gev_ctx*, int pop, size_t max_people);
+/* HIP stream the context launches on (hipStream_t as void*), for event timing by the caller */
+int gev_stream(gev_ctx*, void** stream);
+/* timing of the kernels of the last gev_reproduce measured with HIP events on that stream:
+ * ms[0] = sampling (crossover + mutation + seed chain), ms[1] = dense stitch (genotype planes),
+ * ms[2] = sparse state (mutation lists, intervals, CV planes), ms[3] = total. */
+int gev_last_reproduce_ms(gev_ctx*, float ms[4]);
+/* enable/disable keeping the ancestry interval state on the device (default on) */
+int gev_set_track_intervals(gev_ctx*, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENEEVOLVE_AMD_H */

@@ -12,7 +12,7 @@
 //       (glibc srand/rand, libstdc++ minstd_rand0 / uniform_real / uniform_int /
 //       normal), plus direct calls of Simulation::ras_sim_loc_rec and
 //       Simulation::recombine (reference src/Simulation.cpp:2973, :2903).
-//   GEV_DUMP=<prefix> [GEV_DUMP_GENS=1,2,..] [GEV_DUMP_DENSE=1] ref_harness <GeneEvolve args...>
+//   GEV_DUMP=<prefix> [GEV_DUMP_GENS=1,2,..] [GEV_DUMP_DENSE=1 [GEV_DENSE_GENS=0,1,..]] ref_harness <GeneEvolve args...>
 //       drives ras_init_parameters -> ras_init_generation0 -> one generation at a time
 //       using the reference's own member functions in the order of
 //       Simulation::sim_next_generation (src/Simulation.cpp:1890-2082), and dumps the
@@ -121,6 +121,11 @@ static int run_sim(int argc, char** argv)
         while (p < t.size()) { gens.insert(atoi(t.c_str() + p)); p = t.find(',', p); if (p == std::string::npos) break; p++; }
     }
     bool dense = getenv("GEV_DUMP_DENSE") != nullptr;
+    std::set<int> dense_gens;
+    if (const char* s = getenv("GEV_DENSE_GENS")) {
+        std::string t(s); size_t p = 0;
+        while (p < t.size()) { dense_gens.insert(atoi(t.c_str() + p)); p = t.find(',', p); if (p == std::string::npos) break; p++; }
+    }
 
     Parameters par;
     std::vector<std::string> vec_arg(argc + 2);
@@ -132,6 +137,7 @@ static int run_sim(int argc, char** argv)
     sim.par = par;
     sim.glob_generator.seed(par._seed);                  // Simulation::run, src/Simulation.cpp:75-76
     if (!sim.ras_init_parameters()) return 3;            // :83
+    std::default_random_engine snap0 = sim.glob_generator;   // the ras_glob_seed() stream gen 0 will consume
     if (!sim.ras_init_generation0()) return 4;           // :91
 
     int nphen = (int)sim.population[0]._pheno_scheme.size();
@@ -139,12 +145,19 @@ static int run_sim(int argc, char** argv)
         std::string f = std::string(prefix) + ".gen0.txt";
         g_out = fopen(f.c_str(), "w");
         fprintf(g_out, "GEN 0 npop %d\n", sim._n_pop);
+        {   // first 64 ras_glob_seed() values from the state before ras_init_generation0: the seed of
+            // ras_initial_human_gen0 (:3003) of each population is one of them (identified by the packer)
+            std::uniform_int_distribution<unsigned> d(1, 1000000);
+            fprintf(g_out, "GLOBSEQ");
+            for (int i = 0; i < 64; i++) fprintf(g_out, " %u", d(snap0));
+            fprintf(g_out, "\n");
+        }
         for (int ipop = 0; ipop < sim._n_pop; ipop++) {
             dump_humans(sim, ipop, "POST");
             // additive/dominance were rescaled by ras_scale_AD_compute_GEF; per-chr values are raw
             dump_ad(sim, ipop);
         }
-        if (dense) dump_dense(sim);
+        if (dense && want_gen(dense_gens, 0)) dump_dense(sim);
         fclose(g_out);
     }
 
@@ -193,16 +206,21 @@ static int run_sim(int argc, char** argv)
         if (sim._n_pop > 1) {                                            // :1994-1999
             for (int ipop = 0; ipop < sim._n_pop; ipop++) {
                 fprintf(g_out, "PREMIG pop %d n %zu\n", ipop, sim.population[ipop].h.size());
-                for (size_t i = 0; i < sim.population[ipop].h.size(); i++) fprintf(g_out, "I %lu\n", sim.population[ipop].h[i].ID);
+                // fingerprint = phenotype value (contains the N(0,1) noise term): identifies an individual across the move
+                for (size_t i = 0; i < sim.population[ipop].h.size(); i++) fprintf(g_out, "I %lu %a\n", sim.population[ipop].h[i].ID, sim.population[ipop].h[i].phen[0]);
             }
             if (!sim.ras_do_migration(gen_num - 1)) return 9;
-            for (int ipop = 0; ipop < sim._n_pop; ipop++) dump_humans(sim, ipop, "POSTMIG");
+            for (int ipop = 0; ipop < sim._n_pop; ipop++) {
+                dump_humans(sim, ipop, "POSTMIG");
+                fprintf(g_out, "POSTFP pop %d n %zu\n", ipop, sim.population[ipop].h.size());
+                for (size_t i = 0; i < sim.population[ipop].h.size(); i++) fprintf(g_out, "J %lu %a\n", sim.population[ipop].h[i].ID, sim.population[ipop].h[i].phen[0]);
+            }
         }
         for (int ipop = 0; ipop < sim._n_pop; ipop++)                    // :2003-2006
             sim.ras_save_human_info_to_Pop_info_prev_gen(ipop);
         for (int ipop = 0; ipop < sim._n_pop; ipop++)                    // :2018 (the .info file, used to validate this driver)
             sim.population[ipop].ras_save_human_info(gen_num);
-        if (w && dense) dump_dense(sim);
+        if (w && dense && want_gen(dense_gens, gen_num)) dump_dense(sim);
         fclose(g_out);
     }
     return 0;

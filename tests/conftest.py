@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import oracle_api
+    return oracle_api.load()
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The product library (HIP).  Fails loudly when it is missing: there is no fallback."""
+    from geneevolve_amd.capi import GevLibrary
+    return GevLibrary()

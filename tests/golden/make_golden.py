@@ -1,0 +1,461 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the REAL reference.
+
+Runs only in the build container (needs /root/reference): builds oracle/_ref with
+oracle/Makefile.ref (the unmodified reference + oracle/ref_harness.cpp), writes small input
+files in the reference's own formats, runs the harness and packs its
+lossless dumps into tests/golden/*.npz.  The fixtures are data only: inputs as arrays and the
+reference's outputs (couples, ras_glob_seed values, sex, interval lists, mutation lists,
+raw A/D, dense haplotype matrices).
+
+    python tests/golden/make_golden.py            # regenerate everything
+
+Cases
+  kat.txt.gz   RNG known-answer vectors + direct ras_sim_loc_rec / recombine calls
+  ex1sub       Examples.zip:Example1 inputs (first 300 founders), 3 chr, assortative mating,
+               Poisson family sizes, NO mutation map  -> serial rand() chain mode
+  ex1mut       same inputs, --RM, mutation map at 2e-3/row -> task-parallel mode
+  dense        tiny synthetic chromosome with SNPs every 7 bp and a hot mutation map so that
+               mutations land on SNPs and CVs; 2 phenotypes, unsorted CV file order, vd>0
+  mig2         two populations with different founder panels / CV effects and migration
+  syn1k        BASELINE config-1 shape: 1000 ind x 10000 SNPs, 1 chr of 100 Mb, 10 gen, mutation
+"""
+import gzip
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+import zipfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+ORACLE = os.path.join(ROOT, "oracle")
+HARNESS = os.path.join(ORACLE, "_ref", "ref_harness")
+WORK = "/tmp/gev_golden_work"
+
+sys.path.insert(0, ROOT)
+from tests.synth import synth_bits, synth_thresholds  # noqa: E402  (shared deterministic generator)
+
+
+def sh(cmd, **kw):
+    subprocess.run(cmd, check=True, **kw)
+
+
+# ----------------------------------------------------------------------------- input writers
+def write_hap(path, bits):  # bits [nhap][L]; file is SNP-major text (format_hap.cpp:62-121)
+    with open(path, "w") as f:
+        for i in range(bits.shape[1]):
+            f.write(" ".join("1" if b else "0" for b in bits[:, i]) + "\n")
+
+
+def write_legend(path, pos):
+    with open(path, "w") as f:
+        f.write("id pos al0 al1\n")
+        for i, p in enumerate(pos):
+            f.write(f"rs{i+1} {int(p)} A C\n")
+
+
+def write_indv(path, n, prefix="id"):
+    with open(path, "w") as f:
+        for i in range(n):
+            f.write(f"{prefix}{i+1}\n")
+
+
+def write_map(path, header, chrs_rows):  # chrs_rows: list of (chr_label, bp[], val[])
+    with open(path, "w") as f:
+        f.write(header + "\n")
+        for c, bp, val in chrs_rows:
+            for b, v in zip(bp, val):
+                f.write(f"{c} {int(b)} {float(v)!r}\n")
+
+
+def write_cvinfo(path, chrs_rows):  # (chr, bp[], a[], d[])
+    with open(path, "w") as f:
+        f.write("chr pos a d\n")
+        for c, bp, a, d in chrs_rows:
+            for b, x, y in zip(bp, a, d):
+                f.write(f"{c} {int(b)} {float(x)!r} {float(y)!r}\n")
+
+
+def write_popinfo(path, rows):
+    with open(path, "w") as f:
+        f.write("pop_size mat_cor offspring_dist selection_func selection_func_par1 selection_func_par2\n")
+        for r in rows:
+            f.write(r + "\n")
+
+
+# ----------------------------------------------------------------------------- dump parser
+def hexf(s):
+    return float.fromhex(s)
+
+
+def parse_dump(path):
+    """-> dict of sections of one generation dump written by oracle/ref_harness.cpp"""
+    out = {"couples": {}, "seed": {}, "mutseeds": {}, "offspring": {}, "ad": {}, "dense": {},
+           "premig": {}, "postmig": {}, "post": {}}
+    cur = None
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            k = t[0]
+            if k == "GEN":
+                out["gen"] = int(t[1]); out["npop"] = int(t[3])
+            elif k == "COUPLES":
+                cur = out["couples"].setdefault(int(t[2]), [])
+            elif k == "C":
+                cur.append([int(x) for x in t[1:5]])
+            elif k == "SEED_REPRODUCE":
+                out["seed"][int(t[2])] = int(t[3])
+            elif k == "MUTSEEDS":
+                cur = out["mutseeds"].setdefault(int(t[2]), [])
+            elif k == "S":
+                cur.append(int(t[1]))
+            elif k in ("OFFSPRING", "POSTMIG", "POST"):
+                cur = {"n": int(t[4]), "nchr": int(t[6]), "H": [], "P": []}
+                out[k.lower()][int(t[2])] = cur
+            elif k == "H":
+                cur["H"].append([int(x) for x in t[1:6]])
+            elif k == "P":
+                cur["P"].append([int(x) for x in t[1:]])
+            elif k == "AD":
+                cur = {"n": int(t[4]), "nchr": int(t[6]), "nphen": int(t[8]), "A": []}
+                out["ad"][int(t[2])] = cur
+            elif k == "A":
+                cur["A"].append((int(t[1]), int(t[2]), [hexf(x) for x in t[3:]]))
+            elif k == "DENSE":
+                cur = []
+                out["dense"][(int(t[2]), int(t[4]))] = cur
+            elif k == "D":
+                cur.append(t[1])
+            elif k == "PREMIG":
+                cur = out["premig"].setdefault(int(t[2]), [])
+            elif k == "I":
+                cur.append((int(t[1]), hexf(t[2])))
+            elif k == "POSTFP":
+                cur = out.setdefault("postfp", {}).setdefault(int(t[2]), [])
+            elif k == "J":
+                cur.append((int(t[1]), hexf(t[2])))
+            elif k == "GLOBSEQ":
+                out["globseq"] = [int(x) for x in t[1:]]
+    return out
+
+
+def pack_humans(sec, prefix, arrs):
+    """interval + mutation lists of one population -> CSR arrays keyed by `prefix`"""
+    n, nchr = sec["n"], sec["nchr"]
+    H = np.array(sec["H"], dtype=np.int64).reshape(n, 5)
+    arrs[prefix + "sex"] = H[:, 1].astype(np.uint8)
+    arrs[prefix + "ids"] = H[:, 2:5].astype(np.int64)
+    parts = [[[] for _ in range(2 * n)] for _ in range(nchr)]
+    for p in sec["P"]:
+        ih, c, hp = p[0], p[1], p[2]
+        parts[c][2 * ih + hp].append(p[3:])
+    for c in range(nchr):
+        off = [0]; rows = []; moff = [0]; muts = []
+        for r in range(2 * n):
+            rowm = []
+            for q in parts[c][r]:
+                rows.append(q[:4])
+                rowm.extend(q[5:5 + q[4]])
+            off.append(len(rows))
+            muts.extend(sorted(rowm))
+            moff.append(len(muts))
+        arrs[f"{prefix}chr{c}_part_off"] = np.array(off, dtype=np.uint64)
+        arrs[f"{prefix}chr{c}_parts"] = np.array(rows, dtype=np.int64).reshape(-1, 4)
+        arrs[f"{prefix}chr{c}_mut_off"] = np.array(moff, dtype=np.uint64)
+        arrs[f"{prefix}chr{c}_muts"] = np.array(muts, dtype=np.uint64)
+
+
+def pack_ad(sec, prefix, arrs, totals=True):
+    n, nchr, nphen = sec["n"], sec["nchr"], sec["nphen"]
+    add = np.zeros((n, nphen)); dom = np.zeros((n, nphen))
+    addc = np.zeros((n, nchr, nphen)); domc = np.zeros((n, nchr, nphen))
+    for ih, p, v in sec["A"]:
+        add[ih, p], dom[ih, p] = v[0], v[1]
+        for c in range(nchr):
+            addc[ih, c, p], domc[ih, c, p] = v[3 + 2 * c], v[4 + 2 * c]
+    if totals:
+        arrs[prefix + "additive"] = add; arrs[prefix + "dominance"] = dom
+    arrs[prefix + "add_chr"] = addc; arrs[prefix + "dom_chr"] = domc
+
+
+def pack_dense(rows, L):
+    a = (np.frombuffer("".join(rows).encode(), dtype=np.uint8) - 48).reshape(len(rows), L)
+    return np.packbits(a, axis=1, bitorder="little")
+
+
+# ----------------------------------------------------------------------------- case runner
+class Case:
+    """Static inputs of one population; knows how to write the reference's input files."""
+
+    def __init__(self, name):
+        self.name = name
+        self.pops = []        # list of dicts
+        self.args_extra = []
+
+    def add_pop(self, **kw):
+        self.pops.append(kw)
+
+
+def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_parts_gens=None):
+    wd = os.path.join(WORK, case.name)
+    shutil.rmtree(wd, ignore_errors=True)
+    os.makedirs(wd)
+    args = []
+    arrs = {"n_pop": np.int64(len(case.pops)), "seed": np.int64(seed)}
+    for ip, P in enumerate(case.pops):
+        chrs = P["chrs"]                      # list of chr labels
+        nchr = len(chrs)
+        pre = f"pop{ip}_"
+        arrs["nchr"] = np.int64(nchr); arrs["nphen"] = np.int64(len(P["phens"]))
+        # founder panels
+        with open(os.path.join(wd, f"p{ip}.hapaddr.txt"), "w") as f:
+            f.write("chr hap legend sample\n")
+            for ic, c in enumerate(chrs):
+                base = os.path.join(wd, f"p{ip}.chr{c}")
+                write_hap(base + ".hap", P["founders"][ic]); write_legend(base + ".legend", P["snp_pos"][ic])
+                write_indv(base + ".indv", P["founders"][ic].shape[0] // 2, prefix=f"p{ip}i")
+                f.write(f"{c} {base}.hap {base}.legend {base}.indv\n")
+                arrs[f"{pre}chr{ic}_snp_pos"] = np.asarray(P["snp_pos"][ic], dtype=np.uint64)
+                if P.get("founders_synth_seed") is not None:     # regenerated by tests/synth.py, not stored
+                    arrs[f"{pre}chr{ic}_founders_synth_seed"] = np.uint64(P["founders_synth_seed"])
+                else:
+                    arrs[f"{pre}chr{ic}_founders"] = np.packbits(P["founders"][ic].astype(np.uint8), axis=1, bitorder="little")
+        arrs[f"{pre}n_founder_hap"] = np.int64(P["founders"][0].shape[0])
+        # maps
+        write_map(os.path.join(wd, f"p{ip}.rmap.txt"), "chr bp cM", [(c, P["rmap_bp"][ic], P["rmap_cM"][ic]) for ic, c in enumerate(chrs)])
+        for ic in range(nchr):
+            bp = np.asarray(P["rmap_bp"][ic], dtype=np.uint64); cM = np.asarray(P["rmap_cM"][ic], dtype=np.float64)
+            prob = np.zeros(len(cM)); prob[1:] = (cM[1:] - cM[:-1]) * .01      # Population.cpp:471-480
+            arrs[f"{pre}chr{ic}_rmap_bp"] = bp; arrs[f"{pre}chr{ic}_rmap_prob"] = prob
+            arrs[f"{pre}chr{ic}_bp_dist"] = np.uint64(bp[1] - bp[0])           # Population.cpp:396-397
+        a = ["--file_gen_info", os.path.join(wd, f"p{ip}.popinfo.txt"), "--file_hap_name", os.path.join(wd, f"p{ip}.hapaddr.txt"),
+             "--file_recom_map", os.path.join(wd, f"p{ip}.rmap.txt")]
+        write_popinfo(os.path.join(wd, f"p{ip}.popinfo.txt"), P["popinfo"])
+        arrs[f"{pre}has_mut"] = np.int64(1 if P.get("mut_bp") is not None else 0)
+        if P.get("mut_bp") is not None:
+            write_map(os.path.join(wd, f"p{ip}.mmap.txt"), "chr bp mutation_rate", [(c, P["mut_bp"][ic], P["mut_rate"][ic]) for ic, c in enumerate(chrs)])
+            a += ["--file_mutation_map", os.path.join(wd, f"p{ip}.mmap.txt")]
+            for ic in range(nchr):
+                r = np.asarray(P["mut_rate"][ic], dtype=np.float64).copy(); r[(r < 0) | (r > 1)] = 0   # Population.cpp:458
+                arrs[f"{pre}chr{ic}_mut_bp"] = np.asarray(P["mut_bp"][ic], dtype=np.uint64); arrs[f"{pre}chr{ic}_mut_rate"] = r
+        if P.get("RM"):
+            a += ["--RM"]
+        for iph, ph in enumerate(P["phens"]):
+            write_cvinfo(os.path.join(wd, f"p{ip}.ph{iph}.cvinfo.txt"), [(c, ph["bp"][ic], ph["a"][ic], ph["d"][ic]) for ic, c in enumerate(chrs)])
+            with open(os.path.join(wd, f"p{ip}.ph{iph}.cvaddr.txt"), "w") as f:
+                for ic, c in enumerate(chrs):
+                    fn = os.path.join(wd, f"p{ip}.ph{iph}.chr{c}.cv.hap")
+                    write_hap(fn, ph["val"][ic]); f.write(f"{c} {fn}\n")
+                    arrs[f"{pre}ph{iph}_chr{ic}_cv_bp"] = np.asarray(ph["bp"][ic], dtype=np.uint64)
+                    arrs[f"{pre}ph{iph}_chr{ic}_cv_a"] = np.asarray(ph["a"][ic], dtype=np.float64)
+                    arrs[f"{pre}ph{iph}_chr{ic}_cv_d"] = np.asarray(ph["d"][ic], dtype=np.float64)
+                    if ph.get("val_synth_seed") is not None:
+                        arrs[f"{pre}ph{iph}_chr{ic}_cv_val_synth_seed"] = np.uint64(ph["val_synth_seed"])
+                    else:
+                        arrs[f"{pre}ph{iph}_chr{ic}_cv_val"] = np.packbits(ph["val"][ic].astype(np.uint8), axis=1, bitorder="little")
+            a += ["--file_cv_info", os.path.join(wd, f"p{ip}.ph{iph}.cvinfo.txt"), "--file_cvs", os.path.join(wd, f"p{ip}.ph{iph}.cvaddr.txt")]
+            arrs[f"{pre}ph{iph}_vd"] = np.float64(ph.get("vd", -1.0))
+        for key in ("va", "vd", "ve"):
+            for ph in P["phens"]:
+                if key in ph:
+                    a += [f"--{key}", repr(float(ph[key]))]
+        if ip > 0:
+            args.append("--next_population")
+        args += a
+    args += ["--seed", str(seed), "--prefix", os.path.join(wd, "out")] + case.args_extra
+    env = dict(os.environ, GEV_DUMP=os.path.join(wd, "d"), GEV_DUMP_DENSE="1",
+               GEV_DENSE_GENS=",".join(str(g) for g in sorted(set(dense_gens) | {0})))
+    with open(os.path.join(wd, "log.txt"), "w") as log:
+        sh([HARNESS] + args, env=env, stdout=log, stderr=subprocess.STDOUT)
+    # validate the harness driver against the stock CLI on this very input
+    wd2 = os.path.join(wd, "cli"); os.makedirs(wd2)
+    args2 = [x if x != os.path.join(wd, "out") else os.path.join(wd2, "out") for x in args]
+    with open(os.path.join(wd2, "log.txt"), "w") as log:
+        sh([os.path.join(ORACLE, "_ref", "GeneEvolve_ref")] + args2, stdout=log, stderr=subprocess.STDOUT)
+    ngen = len(case.pops[0]["popinfo"])
+    for g in range(ngen + 1):
+        for ip in range(len(case.pops)):
+            fa = os.path.join(wd, f"out.info.pop{ip+1}.gen{g}.txt"); fb = os.path.join(wd2, f"out.info.pop{ip+1}.gen{g}.txt")
+            assert open(fa, "rb").read() == open(fb, "rb").read(), f"harness != CLI at gen {g} pop {ip+1}"
+    arrs["n_gen"] = np.int64(ngen)
+
+    # gen 0
+    d0 = parse_dump(os.path.join(wd, "d.gen0.txt"))
+    arrs["globseq"] = np.array(d0["globseq"], dtype=np.uint32)
+    for ip in range(len(case.pops)):
+        pack_humans(d0["post"][ip], f"g0_pop{ip}_", arrs)
+        pack_ad(d0["ad"][ip], f"g0_pop{ip}_", arrs, totals=False)
+    for (ip, ic), rows in d0["dense"].items():
+        L = len(case.pops[ip]["snp_pos"][ic])
+        store_dense(arrs, f"g0_pop{ip}_chr{ic}_dense", pack_dense(rows, L), hash_only_dense)
+    # generations
+    for g in range(1, ngen + 1):
+        d = parse_dump(os.path.join(wd, f"d.gen{g}.txt"))
+        for ip in range(len(case.pops)):
+            pre = f"g{g}_pop{ip}_"
+            arrs[pre + "couples"] = np.array(d["couples"][ip], dtype=np.int64).reshape(-1, 4)
+            arrs[pre + "seed_reproduce"] = np.uint32(d["seed"][ip])
+            arrs[pre + "mut_seeds"] = np.array(d["mutseeds"][ip], dtype=np.uint32)
+            tmp = {}
+            pack_humans(d["offspring"][ip], pre, tmp)
+            if keep_parts_gens is not None and g not in keep_parts_gens:   # keep only hashes of the big lists
+                for k in list(tmp):
+                    if "_part" in k or "_mut" in k:
+                        tmp[k + "_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(tmp.pop(k)).tobytes()).digest(), dtype=np.uint8)
+            arrs.update(tmp)
+            pack_ad(d["ad"][ip], pre, arrs)
+            if d["premig"]:
+                pack_humans(d["postmig"][ip], pre + "postmig_", arrs)
+        if d["premig"]:
+            # WHO moved (the host's decision in ras_do_migration, src/Simulation.cpp:899-937), recovered by
+            # matching (ID, phenotype) fingerprints; listed in the reference's append order (:971-981):
+            # destination blocks are contiguous tails of the post-migration vectors.
+            npop = len(case.pops)
+            where = {}
+            for ip in range(npop):
+                for pos, fp in enumerate(d["premig"][ip]):
+                    assert (ip, fp) not in where
+                    where[(ip, fp)] = pos
+            tails = {}
+            for j in range(npop):
+                t = []
+                for pos, fp in enumerate(d["postfp"][j]):
+                    src = [i for i in range(npop) if i != j and (i, fp) in where]
+                    own = (j, fp) in where
+                    assert own != bool(src) and len(src) <= 1, "fingerprint collision"
+                    if src:
+                        t.append((src[0], where[(src[0], fp)]))
+                    else:
+                        assert not t, "stayers must precede migrants"
+                tails[j] = t
+            moves = []
+            for i in range(npop):
+                for j in range(npop):
+                    if i != j:
+                        moves += [(i, pos, j) for (si, pos) in tails[j] if si == i]
+            arrs[f"g{g}_moves"] = np.array(moves, dtype=np.int64).reshape(-1, 3)
+        if g in dense_gens:
+            for (ip, ic), rows in d["dense"].items():
+                L = len(case.pops[ip]["snp_pos"][ic])
+                store_dense(arrs, f"g{g}_pop{ip}_chr{ic}_dense", pack_dense(rows, L), hash_only_dense)
+    out = os.path.join(HERE, (out_name or case.name) + ".npz")
+    np.savez_compressed(out, **arrs)
+    print(f"wrote {out}: {os.path.getsize(out)/1e6:.2f} MB")
+
+
+def store_dense(arrs, key, packed, hash_only):
+    if hash_only:
+        arrs[key + "_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(packed).tobytes()).digest(), dtype=np.uint8)
+        arrs[key + "_head"] = packed[:8].copy()
+    else:
+        arrs[key] = packed
+
+
+# ----------------------------------------------------------------------------- the cases
+def read_hap_text(path, nhap_keep):
+    rows = []
+    with open(path) as f:
+        for line in f:
+            rows.append([line[2 * i] == "1" for i in range(nhap_keep)])
+    return np.array(rows, dtype=np.uint8).T.copy()        # [hap][snp]
+
+
+def example1_inputs(n_founder_ind=300):
+    ex = os.path.join(WORK, "Examples")
+    if not os.path.isdir(ex):
+        with zipfile.ZipFile(os.path.join(REF, "Examples.zip")) as z:
+            z.extractall(WORK)
+    chrs = [1, 2, 3]
+    nh = 2 * n_founder_ind
+    founders, snp_pos = [], []
+    for c in chrs:
+        founders.append(read_hap_text(os.path.join(ex, f"ref.chr{c}.hap"), nh))
+        snp_pos.append(np.loadtxt(os.path.join(ex, f"ref.chr{c}.legend"), skiprows=1, usecols=1, dtype=np.float64).astype(np.uint64))
+    rm = np.loadtxt(os.path.join(ex, "Recom.Map.b37.50KbDiff"), skiprows=1)
+    rmap_bp = [rm[rm[:, 0] == c, 1].astype(np.uint64) for c in chrs]
+    rmap_cM = [rm[rm[:, 0] == c, 2] for c in chrs]
+    cvi = np.loadtxt(os.path.join(ex, "cv.info"), skiprows=1)
+    ph = {"bp": [cvi[cvi[:, 0] == c, 1].astype(np.uint64) for c in chrs], "a": [cvi[cvi[:, 0] == c, 2] for c in chrs],
+          "d": [cvi[cvi[:, 0] == c, 3] for c in chrs], "val": [read_hap_text(os.path.join(ex, f"cv.chr{c}.hap"), nh) for c in chrs]}
+    return dict(chrs=chrs, founders=founders, snp_pos=snp_pos, rmap_bp=rmap_bp, rmap_cM=rmap_cM, phens=[ph])
+
+
+def main():
+    os.makedirs(WORK, exist_ok=True)
+    sh(["make", "-f", "Makefile.ref", "-j8"], cwd=ORACLE, stdout=subprocess.DEVNULL)
+    # ---- KAT
+    kat = os.path.join(WORK, "kat.txt")
+    sh([HARNESS, "KAT", kat])
+    with open(kat, "rb") as f, gzip.GzipFile(os.path.join(HERE, "kat.txt.gz"), "wb", mtime=0) as g:
+        g.write(f.read())
+    print("wrote kat.txt.gz")
+
+    # ---- ex1sub: literal Example1 inputs (subset of founders), assortative, no mutation
+    base = example1_inputs(300)
+    c = Case("ex1sub")
+    c.add_pop(popinfo=["300 0 p thr 1 1"] * 4, **base)
+    run_case(c, 12345, dense_gens={1, 4})
+
+    # ---- ex1mut: same inputs, random mating + hot mutation map
+    c = Case("ex1mut")
+    mut_bp = base["rmap_bp"]; mut_rate = [np.full(len(b), 2e-3) for b in mut_bp]
+    mut_rate[1][5] = 1.5; mut_rate[1][6] = -0.5          # out-of-range rates are zeroed by the reader
+    c.add_pop(popinfo=["300 0 p thr 1 1"] * 4, RM=True, mut_bp=mut_bp, mut_rate=mut_rate, **base)
+    run_case(c, 777, dense_gens={1, 4})
+
+    # ---- dense: mutations land on SNPs and CVs; 2 phenotypes; unsorted CV order; vd > 0
+    rs = np.random.RandomState(2024)
+    R = 201
+    rbp = (1000 + 100 * np.arange(R)).astype(np.uint64)
+    rcM = np.cumsum(np.r_[0.0, np.full(R - 1, 1.0)])                    # 1 cM/row -> prob 0.01
+    snp = np.arange(900, 21200, 7).astype(np.uint64)                    # some SNPs outside [bp0, bpEnd)
+    nf = 200
+    founders = (rs.rand(nf, len(snp)) < rs.uniform(0.05, 0.5, len(snp))).astype(np.uint8)
+    phens = []
+    for k in range(2):
+        cvbp = rs.choice(np.arange(950, 21100), size=150, replace=False).astype(np.uint64)   # file order unsorted
+        cvbp[:40] = rs.choice(snp, 40, replace=False)
+        phens.append({"bp": [cvbp], "a": [rs.randn(150)], "d": [rs.randn(150) * 0.3],
+                      "val": [(rs.rand(nf, 150) < 0.3).astype(np.uint8)], "vd": 0.2 if k == 0 else 0.0, "va": 0.5, "ve": 0.3})
+    c = Case("dense")
+    c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=phens, RM=True,
+              mut_bp=[rbp], mut_rate=[np.full(R, 0.02)], popinfo=["120 0 p thr 1 1"] * 6)
+    run_case(c, 4242, dense_gens={1, 2, 3, 4, 5, 6})
+
+    # ---- mig2: two populations + migration
+    c = Case("mig2")
+    cvbp = np.sort(rs.choice(np.arange(1000, 21000), size=60, replace=False)).astype(np.uint64)   # shared CV grid
+    for ip in range(2):
+        f2 = (rs.rand(160, len(snp)) < rs.uniform(0.05, 0.5, len(snp))).astype(np.uint8)
+        ph = {"bp": [cvbp], "a": [rs.randn(60)], "d": [rs.randn(60) * 0.2], "val": [(rs.rand(160, 60) < 0.4).astype(np.uint8)]}
+        c.add_pop(chrs=[1], founders=[f2], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph], RM=True,
+                  mut_bp=[rbp], mut_rate=[np.full(R, 0.01)], popinfo=["100 0 p thr 1 1"] * 4)
+    with open(os.path.join(WORK, "mig.txt"), "w") as f:
+        for g in range(4):
+            f.write("0.9 0.1 0.2 0.8\n")
+    c.args_extra = ["--file_migration", os.path.join(WORK, "mig.txt")]
+    run_case(c, 9001, dense_gens={1, 2, 3, 4})
+
+    # ---- syn1k: config-1 shape, deterministic synthetic founders (tests/synth.py), hashes only
+    L, N0 = 10000, 1000
+    snp = (1000 + 10000 * np.arange(L)).astype(np.uint64)
+    R = 2001
+    rbp = (1000 + 50000 * np.arange(R)).astype(np.uint64)
+    rcM = 1e-6 * (rbp - rbp[0]).astype(np.float64)                         # 1 cM/Mb -> 5e-4 per 50 kb row
+    founders = synth_bits(12345, 2 * N0, L)
+    cvbp = np.sort(rs.choice(np.arange(1000, 100001000, 100), size=1000, replace=False)).astype(np.uint64)
+    ph = {"bp": [cvbp], "a": [rs.randn(1000)], "d": [np.zeros(1000)], "val": [synth_bits(999, 2 * N0, 1000)], "val_synth_seed": 999,
+          "va": 0.5, "vd": 0.0, "ve": 0.5}
+    c = Case("syn1k")
+    c.add_pop(chrs=[1], founders=[founders], founders_synth_seed=12345, snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph], RM=True,
+              mut_bp=[rbp], mut_rate=[np.r_[0.0, np.full(R - 1, 5e-4)]], popinfo=["1000 0 p thr 1 1"] * 10)
+    run_case(c, 12345, dense_gens={1, 5, 10}, hash_only_dense=True, keep_parts_gens={1, 10})
+
+
+if __name__ == "__main__":
+    main()

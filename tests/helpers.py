@@ -1,0 +1,161 @@
+"""Shared test plumbing: load a golden fixture, feed its static inputs through the C-ABI of
+any library (oracle `gevo_*` or product `gev_*`), replay generations, compare state."""
+import hashlib
+import os
+
+import numpy as np
+
+from geneevolve_amd.capi import bytes_to_words, words_for
+from tests.synth import synth_packed
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_fixture(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def find_gen0_seeds(fx, oracle_lib):
+    """The harness dumps the ras_glob_seed() stream gen 0 consumes; the seed of each
+    population's ras_initial_human_gen0 is the entry that reproduces its gen-0 sexes."""
+    from oracle import oracle_api
+    seeds = []
+    for ip in range(int(fx["n_pop"])):
+        sex = fx[f"g0_pop{ip}_sex"]
+        found = None
+        for s in fx["globseq"]:
+            r = oracle_api.kat_rand(oracle_lib, int(s), len(sex))
+            if np.array_equal((r % 2 + 1).astype(np.uint8), sex):
+                found = int(s); break
+        assert found is not None, "gen-0 seed not identifiable"
+        seeds.append(found)
+    return seeds
+
+
+def setup_static(ctx, fx):
+    """ras_init_parameters equivalent: maps, SNP/CV grids, founder panels."""
+    n_pop, nchr, nphen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"])
+    for ip in range(n_pop):
+        pre = f"pop{ip}_"
+        nh = int(fx[pre + "n_founder_hap"])
+        for ic in range(nchr):
+            ctx.set_rmap(ip, ic, fx[f"{pre}chr{ic}_rmap_bp"], fx[f"{pre}chr{ic}_rmap_prob"], int(fx[f"{pre}chr{ic}_bp_dist"]))
+            if int(fx[pre + "has_mut"]):
+                ctx.set_mutmap(ip, ic, fx[f"{pre}chr{ic}_mut_bp"], fx[f"{pre}chr{ic}_mut_rate"])
+            pos = fx[f"{pre}chr{ic}_snp_pos"]
+            ctx.set_snps(ip, ic, pos)
+            if f"{pre}chr{ic}_founders" in fx:
+                ctx.upload_founders(ip, ic, bytes_to_words(fx[f"{pre}chr{ic}_founders"], len(pos)), len(pos))
+            else:
+                ctx.upload_founders(ip, ic, synth_packed(int(fx[f"{pre}chr{ic}_founders_synth_seed"]), nh, len(pos)), len(pos))
+            for iph in range(nphen):
+                k = f"{pre}ph{iph}_chr{ic}_"
+                ctx.set_cvs(ip, iph, ic, fx[k + "cv_bp"], fx[k + "cv_a"], fx[k + "cv_d"], float(fx[f"{pre}ph{iph}_vd"]))
+                ncv = len(fx[k + "cv_bp"])
+                if k + "cv_val" in fx:
+                    ctx.upload_cv_founders(ip, iph, ic, bytes_to_words(fx[k + "cv_val"], ncv), ncv)
+                else:
+                    ctx.upload_cv_founders(ip, iph, ic, synth_packed(int(fx[k + "cv_val_synth_seed"]), nh, ncv), ncv)
+
+
+def derive_moves(fx, g):
+    """WHO moved in generation g as (src_pop, src_pos, dst_pop) in the reference's append
+    order; recorded by tests/golden/make_golden.py from the reference run."""
+    return [tuple(int(x) for x in m) for m in fx[f"g{g}_moves"]]
+
+
+def compare_lists(ctx, fx, key_prefix, ip, nchr, label):
+    for ic in range(nchr):
+        parts, off = ctx.download_intervals(ip, ic)
+        muts, moff = ctx.download_mutations(ip, ic)
+        got = np.stack([parts["st"].astype(np.int64), parts["en"].astype(np.int64), parts["hap_index"].astype(np.int64),
+                        parts["root_population"].astype(np.int64)], axis=1).reshape(-1, 4)
+        k = f"{key_prefix}chr{ic}_"
+        if k + "parts" in fx:
+            assert np.array_equal(off, fx[k + "part_off"]), f"{label}: interval offsets differ (chr {ic})"
+            assert np.array_equal(got, fx[k + "parts"]), f"{label}: interval lists differ (chr {ic})"
+            assert np.array_equal(moff, fx[k + "mut_off"]), f"{label}: mutation offsets differ (chr {ic})"
+            assert np.array_equal(muts, fx[k + "muts"]), f"{label}: mutation lists differ (chr {ic})"
+        else:
+            assert np.array_equal(sha(off), fx[k + "part_off_sha"]), f"{label}: interval offsets hash (chr {ic})"
+            assert np.array_equal(sha(got), fx[k + "parts_sha"]), f"{label}: interval lists hash (chr {ic})"
+            assert np.array_equal(sha(moff), fx[k + "mut_off_sha"]), f"{label}: mutation offsets hash (chr {ic})"
+            assert np.array_equal(sha(muts), fx[k + "muts_sha"]), f"{label}: mutation lists hash (chr {ic})"
+
+
+def compare_dense(ctx, fx, g, ip, nchr, label):
+    checked = 0
+    for ic in range(nchr):
+        L = len(fx[f"pop{ip}_chr{ic}_snp_pos"])
+        k = f"g{g}_pop{ip}_chr{ic}_dense"
+        if k in fx or k + "_sha" in fx:
+            words = ctx.download_haps(ip, ic)
+            packed = np.ascontiguousarray(words).view(np.uint8)[:, :(L + 7) // 8]
+            if k in fx:
+                assert np.array_equal(packed, fx[k]), f"{label}: dense genotype matrix differs (gen {g} chr {ic})"
+            else:
+                assert np.array_equal(packed[:8], fx[k + "_head"]), f"{label}: dense head differs (gen {g} chr {ic})"
+                assert np.array_equal(sha(packed), fx[k + "_sha"]), f"{label}: dense hash differs (gen {g} chr {ic})"
+            checked += 1
+    return checked
+
+
+def bits_equal(a, b):
+    """bit-exact comparison of float64 arrays (NaN-safe, distinguishes -0.0)"""
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
+
+
+def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_lists=True, max_gen=None):
+    """Run the whole fixture through `lib` and compare every dumped quantity."""
+    n_pop, nchr, nphen, ngen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"]), int(fx["n_gen"])
+    if max_gen:
+        ngen = min(ngen, max_gen)
+    ctx = lib.create(n_pop, nchr, nphen, device) if lib.has_device_arg else lib.create(n_pop, nchr, nphen)
+    setup_static(ctx, fx)
+
+    def cmp_float(a, b, what):
+        if float_exact:
+            assert bits_equal(a, b), f"{label}: {what} not bit-identical (max abs diff {np.max(np.abs(a-b))})"
+        else:
+            assert np.allclose(a, b, rtol=0, atol=1e-6), f"{label}: {what} differs by more than 1e-6"
+
+    for ip in range(n_pop):
+        n0 = len(fx[f"g0_pop{ip}_sex"])
+        sex = ctx.init_gen0(ip, n0, gen0_seeds[ip])
+        assert np.array_equal(sex, fx[f"g0_pop{ip}_sex"]), f"{label}: gen-0 sex differs"
+    for ip in range(n_pop):
+        _, _, addc, domc = ctx.compute_ad(ip)
+        cmp_float(addc, fx[f"g0_pop{ip}_add_chr"], "gen-0 additive_chr")
+        cmp_float(domc, fx[f"g0_pop{ip}_dom_chr"], "gen-0 dominance_chr")
+        if check_lists:
+            compare_lists(ctx, fx, f"g0_pop{ip}_", ip, nchr, label + " gen0")
+        compare_dense(ctx, fx, 0, ip, nchr, label)
+    n_dense = 0
+    for g in range(1, ngen + 1):
+        for ip in range(n_pop):
+            pre = f"g{g}_pop{ip}_"
+            ms = fx[pre + "mut_seeds"]
+            sex = ctx.reproduce(ip, fx[pre + "couples"], int(fx[pre + "seed_reproduce"]), ms if len(ms) else None)
+            assert np.array_equal(sex, fx[pre + "sex"]), f"{label}: offspring sex differs at gen {g} pop {ip}"
+            add, dom, addc, domc = ctx.compute_ad(ip)
+            cmp_float(addc, fx[pre + "add_chr"], f"additive_chr gen {g}")
+            cmp_float(domc, fx[pre + "dom_chr"], f"dominance_chr gen {g}")
+            cmp_float(add, fx[pre + "additive"], f"additive gen {g}")
+            cmp_float(dom, fx[pre + "dominance"], f"dominance gen {g}")
+            if check_lists:
+                compare_lists(ctx, fx, pre, ip, nchr, f"{label} gen {g} pop {ip}")
+        if f"g{g}_moves" in fx:
+            ctx.migrate(derive_moves(fx, g))
+            for ip in range(n_pop):
+                assert ctx.pop_size(ip) == len(fx[f"g{g}_pop{ip}_postmig_sex"])
+                if check_lists:
+                    compare_lists(ctx, fx, f"g{g}_pop{ip}_postmig_", ip, nchr, f"{label} gen {g} post-migration pop {ip}")
+        for ip in range(n_pop):
+            n_dense += compare_dense(ctx, fx, g, ip, nchr, label)
+    ctx.close()
+    return n_dense
