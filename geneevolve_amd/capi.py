@@ -43,6 +43,7 @@ ABI_SYMBOLS = [
     "reproduce", "compute_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals",
+    "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
 

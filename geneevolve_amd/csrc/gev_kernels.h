@@ -1,0 +1,665 @@
+// gev_kernels.h -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the reproduction hot path.
+// Included once by gev_library.hip.  Every kernel names the reference code it replaces
+// (MMesbahU/GeneEvolve, paths relative to the reference root).
+//
+// Data layout in HBM (one population, one chromosome):
+//   genotype plane   uint8 [2*n_people][stride]   row = 2*individual + chromatid, locus ii = bit
+//                    (ii&7) of byte ii>>3 (== bit ii&63 of LE word ii>>6); stride % 128 == 0.
+//                    Holds FOUNDER alleles only; mutations are a sparse per-row overlay because
+//                    the reference treats part::mutation_pos as a set (flip applied at read
+//                    time, src/Simulation.cpp:1218-1222), not as an in-place toggle.
+//   CV plane         same packing on the (sorted) CV grid, 1 + ceil(log2(n_pop)) sub-rows per
+//                    row: allele bits, then root-population id bits (a/d are looked up in the
+//                    root population, src/Simulation.cpp:2778-2779)
+//   mutation lists   CSR  off[2n+1] (u32), pos[] (u64, ascending per row)
+//   interval lists   CSR  off[2n+1] (u32), gev_part[] -- the reference's own state, kept for
+//                    --out_interval parity
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/geneevolve_amd.h"
+#include "rng_device.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// static per-chromosome tables, resident on the device
+struct ChrDev {
+    const GevThr* rthr;   // [R]  recombination thresholds        (_recom_prob)
+    const u64*    rbp;    // [R]  rMap::bp
+    const GevThr* mthr;   // [M]  mutation thresholds             (MutationMap::mutation_rate)
+    const u64*    mbp;    // [M]  MutationMap::bp
+    u64 bp_dist;          // rMap::bp_dist_in_rmap
+    u64 bp0, bp_end;      // rmap.bp[0], rmap.bp[R-1]: every haplotype covers [bp0, bp_end)
+    u32 R, M;
+};
+
+// per-generation sampling results (all chromosomes; task t = offspring*nchr + chr, gamete G = 2t+s)
+struct SampleDev {
+    u32* seed_pat;   // [T+1] srand seed of the paternal gamete of task t (src/Simulation.cpp:2447)
+    u32* seed_mat;   // [T]   (:2453)
+    u32* k;          // [2T]  crossover count of gamete G
+    u32* bk_off;     // [2T+1] exclusive scan of k
+    u64* bk;         // breakpoints, ascending per gamete (:2990)
+    uint8_t* start;  // [2T]  starting haplotype (:2449, :2455)
+    u32* nmut;       // [T]   new mutations of task t (:2513)
+    u32* nm_off;     // [T+1]
+    u64* nm_pos;     // bp_mut (:2520)
+    uint8_t* nm_side;// h01 (:2522)
+    uint8_t* sex;    // [n_people] (:2472)
+    const u32* father;  // [n_people] position of the father in the parent generation (:2438)
+    const u32* mother;  // [n_people]
+};
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of u32 counts (CSR offsets); n+1 outputs
+// ------------------------------------------------------------------------------------------
+#define SCAN_ITEMS 1024
+__device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* lds /*>=8*/, u32& block_total)
+{
+    const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { u32 o = __shfl_up(inc, d); if (lane >= (u32)d) inc += o; }
+    if (lane == 63) lds[wid] = inc;
+    __syncthreads();
+    u32 wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { u32 s = lds[w]; if ((u32)w < wid) wave_off += s; tot += s; }
+    __syncthreads();
+    block_total = tot;
+    return wave_off + inc - v;
+}
+__global__ void __launch_bounds__(256) k_scan_partial(const u32* __restrict__ in, size_t n, u32* __restrict__ sums)
+{
+    __shared__ u32 lds[8];
+    const size_t base = (size_t)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    u32 s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (base + j < n) s += in[base + j];
+    u32 tot; block_exclusive_scan_256(s, lds, tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) k_scan_sums(u32* __restrict__ sums, size_t nb)
+{
+    __shared__ u32 lds[8];
+    u32 carry = 0;
+    for (size_t base = 0; base < nb; base += 256) {
+        const size_t i = base + threadIdx.x;
+        u32 v = i < nb ? sums[i] : 0, tot;
+        u32 ex = block_exclusive_scan_256(v, lds, tot);
+        if (i < nb) sums[i] = carry + ex;
+        carry += tot;
+    }
+}
+// slots 0..n (slot n counts as 0 and receives the total): launch with ceil((n+1)/SCAN_ITEMS) blocks
+__global__ void __launch_bounds__(256) k_scan_final(const u32* __restrict__ in, size_t n, const u32* __restrict__ sums, u32* __restrict__ out)
+{
+    __shared__ u32 lds[8];
+    const size_t base = (size_t)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    u32 v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
+    u32 tot; u32 ex = block_exclusive_scan_256(s, lds, tot) + sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (base + j <= n) out[base + j] = ex; ex += v[j]; }
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic founders (tests/synth.py is the specification) and gen-0 masking
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 x)
+{
+    u64 z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void k_synth_thresholds(u32* __restrict__ thr, size_t L, u64 seed)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const u64 u = mix64(seed ^ 0xA5A5A5A5A5A5A5A5ull ^ ((u64)i * 0x9E3779B97F4A7C15ull)) >> 32;
+    thr[i] = (u32)(214748365ull + ((u * 1932735283ull) >> 32));
+}
+// one thread = one 64-bit word of one row
+__global__ void k_synth_rows(u64* __restrict__ plane, size_t stride_w64, size_t nrows, size_t L, const u32* __restrict__ thr, u64 seed)
+{
+    const size_t words = (L + 63) / 64;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nrows * words) return;
+    const size_t r = q / words, w = q % words;
+    const u64 off = seed * 0xD1342543DE82EF95ull;
+    u64 bits = 0;
+    for (u32 b = 0; b < 64; b++) {
+        const size_t i = w * 64 + b;
+        if (i >= L) break;
+        const u64 ctr = (((u64)r << 32) | (u64)i) + off;
+        if ((u32)(mix64(ctr) >> 32) < thr[i]) bits |= 1ull << b;
+    }
+    plane[r * stride_w64 + w] = bits;
+}
+// Gen-0 haplotypes cover [bp0, bp_end) only (src/Simulation.cpp:3029-3034): loci outside that
+// range read 0 in every materialisation (:1210).  Zero them once; stitching preserves zeros.
+__global__ void k_mask_rows(u32* __restrict__ plane, size_t stride_w32, size_t nrows, u32 lo, u32 hi)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nrows * stride_w32) return;
+    const size_t w = q % stride_w32;
+    const u32 b0 = (u32)w * 32, b1 = b0 + 32;
+    u32 m = 0xffffffffu;
+    if (b1 <= lo || b0 >= hi) m = 0;
+    else {
+        if (b0 < lo) m &= 0xffffffffu << (lo - b0);
+        if (b1 > hi) m &= 0xffffffffu >> (b1 - hi);
+    }
+    if (m != 0xffffffffu) plane[q] &= m;
+}
+__global__ void k_fill_u32(u32* p, size_t n, u32 v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// gen-0 interval state: one whole-chromosome part per haplotype (src/Simulation.cpp:3031-3034)
+__global__ void k_init_parts(gev_part* __restrict__ parts, u32* __restrict__ off, size_t nrows, u64 bp0, u64 bp_end, int pop)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nrows) return;
+    off[r] = (u32)r;
+    if (r < nrows) parts[r] = gev_part{bp0, bp_end, (u64)r, pop, 0};
+}
+// sex[i] = rand()%2+1 for i = 0..n-1 after srand(seed) (src/Simulation.cpp:3005, 3036). One wave.
+__global__ void __launch_bounds__(64) k_sex_sequence(const GevRngTables* __restrict__ T, u32 seed, size_t n, uint8_t* __restrict__ sex)
+{
+    GlibcWave g; g.seed(T, seed);
+    const u32 lane = threadIdx.x;
+    for (size_t base = 0; base < n; base += 64) {
+        if (base) g.next_block(T);
+        if (base + lane < n) sex[base + lane] = (uint8_t)(((g.x >> 1) & 1) + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: mutation sampling  == Simulation::ras_add_mutation (src/Simulation.cpp:2497-2552)
+// one wave per (offspring, chromosome) task
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mut_count(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
+                                                   const u32* __restrict__ mut_seeds, size_t n_tasks, u32* __restrict__ nmut)
+{
+    const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tasks) return;
+    const ChrDev& C = chrs[t % nchr];
+    const u32 S = mut_seeds[t];
+    u32 n = 0;
+    if (C.M >= 2) n = wave_scan_hits(T, S + 2u, C.mthr, 1, C.M - 1, [](u32) {});      // generator_u(seed+2), i = 1..M-1
+    if ((threadIdx.x & 63) == 0) nmut[t] = n;
+}
+__global__ void __launch_bounds__(256) k_mut_fill(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
+                                                  const u32* __restrict__ mut_seeds, size_t n_tasks, SampleDev sd)
+{
+    const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tasks) return;
+    const u32 lane = threadIdx.x & 63;
+    const int c = (int)(t % nchr);
+    const ChrDev& C = chrs[c];
+    const u32 S = mut_seeds[t];
+    GlibcWave g; g.seed(T, S);                                   // srand(seed), :2501
+    u32 xg = minstd_seed(S + 1u);                                // generator(seed+1), :2503
+    const u32 off = sd.nm_off[t];
+    u32 h = 0;
+    if (C.M >= 2)
+        wave_scan_hits(T, S + 2u, C.mthr, 1, C.M - 1, [&](u32 row) {
+            const u64 bp_mut = uniform_int_fallback(xg, C.mbp[row - 1], C.mbp[row]);    // :2516-2520
+            const u32 side = g.out(T, h) & 1u;                                           // rand()%2, :2522
+            if (lane == 0) { sd.nm_pos[off + h] = bp_mut; sd.nm_side[off + h] = (uint8_t)side; }
+            h++;
+        });
+    u32 n = h;
+    if (c == nchr - 1) {                                         // sex = rand()%2+1 after the last chromosome, :2472
+        const u32 s = (g.out(T, n) & 1u) + 1u;
+        if (lane == 0) sd.sex[t / nchr] = (uint8_t)s;
+        n++;
+    }
+    const u32 nxt = g.out(T, n);                                 // seed_loc of the next task, :2447
+    if (lane == 0) sd.seed_pat[t + 1] = nxt;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1/K3: crossover sampling == Simulation::ras_sim_loc_rec (:2973-2995) and the rand() chain of
+// Simulation::reproduce (:2447-2455)
+// ------------------------------------------------------------------------------------------
+struct PairOut { u32 seed_mat, k_pat, k_mat, start_pat, start_mat; };
+// leaves g seeded with seed_mat; the next rand() of the reference is g.out(k_mat+1)
+__device__ __forceinline__ PairOut gamete_pair_pass1(const GevRngTables* __restrict__ T, const ChrDev& C, u32 seed_pat, GlibcWave& g)
+{
+    PairOut o;
+    o.k_pat = wave_scan_hits(T, seed_pat + 1u, C.rthr, 0, C.R, [](u32) {});
+    g.seed(T, seed_pat);
+    o.start_pat = g.out(T, o.k_pat) & 1u;         // rand()%2 after k_pat position draws, :2449
+    o.seed_mat = g.out(T, o.k_pat + 1);           // :2453
+    o.k_mat = wave_scan_hits(T, o.seed_mat + 1u, C.rthr, 0, C.R, [](u32) {});
+    g.seed(T, o.seed_mat);
+    o.start_mat = g.out(T, o.k_mat) & 1u;         // :2455
+    return o;
+}
+// task-parallel form (a mutation map is loaded: every task's chain restarts at srand(S), see
+// SURVEY.md section 7.2-1).  seed_pat[t] for t>0 was written by k_mut_fill.
+__global__ void __launch_bounds__(256) k_rec_pass1(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
+                                                   u32 seed_reproduce, size_t n_tasks, SampleDev sd)
+{
+    const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tasks) return;
+    const u32 lane = threadIdx.x & 63;
+    GlibcWave g;
+    u32 seed_pat;
+    if (t == 0) { g.seed(T, seed_reproduce); seed_pat = g.out(T, 0); }     // srand(seed) :2400, first rand() :2447
+    else seed_pat = sd.seed_pat[t];
+    const PairOut o = gamete_pair_pass1(T, chrs[t % nchr], seed_pat, g);
+    if (lane == 0) {
+        sd.seed_pat[t] = seed_pat; sd.seed_mat[t] = o.seed_mat;
+        sd.k[2 * t] = o.k_pat; sd.k[2 * t + 1] = o.k_mat;
+        sd.start[2 * t] = (uint8_t)o.start_pat; sd.start[2 * t + 1] = (uint8_t)o.start_mat;
+    }
+}
+// serial form (no mutation map): every gamete's seed depends on the previous gamete's crossover
+// count, so one wave walks the chain; each link is still a wave-parallel scan.
+__global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
+                                                  u32 seed_reproduce, size_t n_tasks, SampleDev sd)
+{
+    const u32 lane = threadIdx.x;
+    GlibcWave g; g.seed(T, seed_reproduce);
+    u32 seed = g.out(T, 0);
+    for (size_t t = 0; t < n_tasks; t++) {
+        const int c = (int)(t % nchr);
+        const PairOut o = gamete_pair_pass1(T, chrs[c], seed, g);
+        if (lane == 0) {
+            sd.seed_pat[t] = seed; sd.seed_mat[t] = o.seed_mat;
+            sd.k[2 * t] = o.k_pat; sd.k[2 * t + 1] = o.k_mat;
+            sd.start[2 * t] = (uint8_t)o.start_pat; sd.start[2 * t + 1] = (uint8_t)o.start_mat;
+        }
+        u32 n = o.k_mat + 1;
+        if (c == nchr - 1) {                                       // :2472
+            const u32 s = (g.out(T, n) & 1u) + 1u;
+            if (lane == 0) sd.sex[t / nchr] = (uint8_t)s;
+            n++;
+        }
+        seed = g.out(T, n);
+    }
+}
+// pass 2: one wave per gamete re-scans and writes the breakpoints bp[j] + rand()%dist (:2990)
+__global__ void __launch_bounds__(256) k_rec_pass2(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
+                                                   size_t n_gametes, SampleDev sd)
+{
+    const size_t G = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (G >= n_gametes) return;
+    const u32 lane = threadIdx.x & 63;
+    const size_t t = G >> 1;
+    if (sd.k[G] == 0) return;
+    const ChrDev& C = chrs[t % nchr];
+    const u32 seed = (G & 1) ? sd.seed_mat[t] : sd.seed_pat[t];
+    GlibcWave g; g.seed(T, seed);
+    const u32 off = sd.bk_off[G];
+    u32 h = 0;
+    wave_scan_hits(T, seed + 1u, C.rthr, 0, C.R, [&](u32 row) {
+        const u64 v = C.rbp[row] + (u64)g.out(T, h) % C.bp_dist;
+        if (lane == 0) sd.bk[off + h] = v;
+        h++;
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: dense stitch -- the HBM-roofline kernel.
+// Dense equivalent of Simulation::recombine (:2903-2958) applied to the materialised haplotypes
+// (ras_convert_interval_to_hap_matrix, :1186-1230): at locus position x the offspring gamete
+// copies parental haplotype  start ^ parity(#{breakpoints c : c <= x}).  In locus-index space a
+// gamete row is a concatenation of bit ranges of the parent's two rows AT THE SAME OFFSETS, so
+// all but <= k 16-byte chunks per row are plain 16-byte copies from ONE parent row: algorithmic
+// traffic = L/8 read + L/8 written per gamete.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 lower_bound_u64(const u64* __restrict__ a, u32 n, u64 v)   // #{a[i] < v}
+{
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+#define STITCH_THREADS 256
+#define STITCH_KMAX 256          // boundaries staged in LDS per row; more spill to a global-memory walk
+#define STITCH_UNROLL 4
+// one workgroup = one output row x one span of chunks; 16 B per lane per access
+__global__ void __launch_bounds__(STITCH_THREADS) k_stitch_rows(
+    uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t stride, u32 chunks_per_row, u32 blocks_per_row,
+    const u64* __restrict__ pos, u32 L, int chr, int nchr, SampleDev sd)
+{
+    __shared__ u32 s_idx[STITCH_KMAX];
+    const u32 row = blockIdx.x / blocks_per_row;          // output row = 2*offspring + s
+    const u32 span = blockIdx.x % blocks_per_row;
+    const u32 i = row >> 1, s = row & 1;
+    const size_t G = 2 * ((size_t)i * nchr + chr) + s;
+    const u32 parent = s ? sd.mother[i] : sd.father[i];
+    const u32 start = sd.start[G];
+    const u32 k = sd.k[G];
+    const u64* bk = sd.bk + sd.bk_off[G];
+    const uint4* __restrict__ A = (const uint4*)(src + (size_t)(2 * parent + start) * stride);
+    const uint4* __restrict__ B = (const uint4*)(src + (size_t)(2 * parent + (start ^ 1)) * stride);
+    uint4* __restrict__ D = (uint4*)(dst + (size_t)row * stride);
+    const u32 kk = k < STITCH_KMAX ? k : STITCH_KMAX;
+    for (u32 m = threadIdx.x; m < kk; m += STITCH_THREADS) s_idx[m] = lower_bound_u64(pos, L, bk[m]);   // loci >= idx are past breakpoint m
+    __syncthreads();
+    const u32 per_block = (chunks_per_row + blocks_per_row - 1) / blocks_per_row;
+    const u32 q0 = span * per_block;
+    const u32 q1 = min(q0 + per_block, chunks_per_row);
+    if (k == 0) {                                           // locs.size()<3: the parent's haplotype unchanged (:2910)
+        for (u32 q = q0 + threadIdx.x; q < q1; q += STITCH_THREADS * STITCH_UNROLL) {
+            uint4 v[STITCH_UNROLL];
+#pragma unroll
+            for (int u = 0; u < STITCH_UNROLL; u++) { const u32 qq = q + u * STITCH_THREADS; if (qq < q1) v[u] = A[qq]; }
+#pragma unroll
+            for (int u = 0; u < STITCH_UNROLL; u++) { const u32 qq = q + u * STITCH_THREADS; if (qq < q1) D[qq] = v[u]; }
+        }
+        return;
+    }
+    for (u32 q = q0 + threadIdx.x; q < q1; q += STITCH_THREADS) {
+        const u32 bit0 = q * 128u, bit1 = bit0 + 128u;
+        // boundaries <= bit0 decide the source at the chunk's first locus
+        u32 cnt = 0;
+        if (k <= STITCH_KMAX) {
+            if (k <= 8) { for (u32 m = 0; m < k; m++) cnt += (s_idx[m] <= bit0); }
+            else { u32 lo = 0, hi = k; while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (s_idx[mid] <= bit0) lo = mid + 1; else hi = mid; } cnt = lo; }
+        } else {
+            for (u32 m = 0; m < k; m++) cnt += (lower_bound_u64(pos, L, bk[m]) <= bit0);
+        }
+        u32 nxt = 0xffffffffu;                               // first boundary inside (bit0, bit1)
+        if (cnt < k) nxt = (k <= STITCH_KMAX) ? s_idx[cnt] : lower_bound_u64(pos, L, bk[cnt]);
+        if (nxt >= bit1) {
+            D[q] = (cnt & 1) ? B[q] : A[q];
+        } else {
+            const uint4 a = A[q], b = B[q];
+            u32 aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, ow[4];
+            u32 mask[4];                                     // 1 = take B
+            const u32 init = (cnt & 1) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int w = 0; w < 4; w++) mask[w] = init;
+            for (u32 m = cnt; m < k; m++) {
+                const u32 id = (k <= STITCH_KMAX) ? s_idx[m] : lower_bound_u64(pos, L, bk[m]);
+                if (id >= bit1) break;
+                const u32 rel = id - bit0;                   // toggle every bit >= rel
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const u32 wb = w * 32u;
+                    u32 t = 0;
+                    if (rel <= wb) t = 0xffffffffu; else if (rel < wb + 32u) t = 0xffffffffu << (rel - wb);
+                    mask[w] ^= t;
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 4; w++) ow[w] = (aw[w] & ~mask[w]) | (bw[w] & mask[w]);
+            D[q] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+    }
+}
+// small planes (CV grid: ~125 B rows): one thread = one 32-bit word of one sub-row
+__global__ void __launch_bounds__(256) k_stitch_small(
+    u32* __restrict__ dst, const u32* __restrict__ src, u32 stride_w32, u32 sub_w32, u32 nsub, size_t n_rows_out,
+    const u64* __restrict__ pos, u32 Cn, int chr, int nchr, SampleDev sd)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 used = sub_w32 * nsub;
+    if (q >= n_rows_out * used) return;
+    const u32 row = (u32)(q / used), wq = (u32)(q % used);
+    const u32 w = wq % sub_w32;
+    const u32 i = row >> 1, s = row & 1;
+    const size_t G = 2 * ((size_t)i * nchr + chr) + s;
+    const u32 parent = s ? sd.mother[i] : sd.father[i];
+    const u32 start = sd.start[G];
+    const u32 k = sd.k[G];
+    const u64* bk = sd.bk + sd.bk_off[G];
+    const u32 a = src[(size_t)(2 * parent + start) * stride_w32 + wq];
+    const u32 b = src[(size_t)(2 * parent + (start ^ 1)) * stride_w32 + wq];
+    const u32 bit0 = w * 32u;
+    u32 mask = 0;
+    for (u32 m = 0; m < k; m++) {
+        const u32 id = lower_bound_u64(pos, Cn, bk[m]);
+        u32 t = 0;
+        if (id <= bit0) t = 0xffffffffu; else if (id < bit0 + 32u) t = 0xffffffffu << (id - bit0);
+        mask ^= t;
+    }
+    dst[(size_t)row * stride_w32 + wq] = (a & ~mask) | (b & mask);
+}
+
+// ------------------------------------------------------------------------------------------
+// sparse overlay: mutation lists.  Offspring row = { x in parent hap h : start^parity(x) == h }
+// (recombine + modify_part_for_mutation_pos, :2903-2970) + new mutations of its side that fall
+// inside [bp0, bp_end) (ras_add_mutation only appends to a part that contains bp_mut, :2526-2545)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 parity_at(const u64* __restrict__ bk, u32 k, u64 x)   // #{c <= x} & 1
+{
+    u32 n = 0;
+    for (u32 m = 0; m < k; m++) n += (bk[m] <= x);
+    return n & 1u;
+}
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_mutlist(
+    const u32* __restrict__ p_off, const u64* __restrict__ p_pos,    // parent generation CSR
+    u32* __restrict__ o_cnt, const u32* __restrict__ o_off, u64* __restrict__ o_pos,
+    size_t n_rows_out, int chr, int nchr, u64 bp0, u64 bp_end, int has_mut, SampleDev sd)
+{
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows_out) return;
+    const u32 i = (u32)(row >> 1), s = (u32)(row & 1);
+    const size_t t = (size_t)i * nchr + chr, G = 2 * t + s;
+    const u32 parent = s ? sd.mother[i] : sd.father[i];
+    const u32 start = sd.start[G], k = sd.k[G];
+    const u64* bk = sd.bk + sd.bk_off[G];
+    const u32 a0 = p_off[2 * parent], a1 = p_off[2 * parent + 1], b1 = p_off[2 * parent + 2];   // hap0 = [a0,a1), hap1 = [a1,b1)
+    u32 ia = a0, ib = a1, in = 0, nn = 0;
+    const u64* npos = nullptr; const uint8_t* nside = nullptr;
+    if (has_mut) { in = sd.nm_off[t]; nn = sd.nm_off[t + 1]; npos = sd.nm_pos; nside = sd.nm_side; }
+    u32 n = 0;
+    u64* out = FILL ? o_pos + o_off[row] : nullptr;
+    const u64 INF = ~0ull;
+    while (true) {
+        // advance each stream to its next qualifying element
+        while (ia < a1 && (start ^ parity_at(bk, k, p_pos[ia])) != 0u) ia++;
+        while (ib < b1 && (start ^ parity_at(bk, k, p_pos[ib])) != 1u) ib++;
+        while (in < nn && !(nside[in] == s && npos[in] >= bp0 && npos[in] < bp_end)) in++;
+        const u64 va = ia < a1 ? p_pos[ia] : INF, vb = ib < b1 ? p_pos[ib] : INF, vn = in < nn ? npos[in] : INF;
+        if (va == INF && vb == INF && vn == INF) break;
+        u64 v;
+        if (va <= vb && va <= vn) { v = va; ia++; } else if (vb <= vn) { v = vb; ib++; } else { v = vn; in++; }
+        if (FILL) out[n] = v;
+        n++;
+    }
+    if (!FILL) o_cnt[row] = n;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: ancestry interval lists == Simulation::recombine (:2903-2958), statement by statement on CSR
+// ------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_parts(
+    const u32* __restrict__ p_off, const gev_part* __restrict__ p_parts,
+    u32* __restrict__ o_cnt, const u32* __restrict__ o_off, gev_part* __restrict__ o_parts,
+    size_t n_rows_out, int chr, int nchr, u64 bp0, u64 bp_end, SampleDev sd)
+{
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows_out) return;
+    const u32 i = (u32)(row >> 1), s = (u32)(row & 1);
+    const size_t G = 2 * ((size_t)i * nchr + chr) + s;
+    const u32 parent = s ? sd.mother[i] : sd.father[i];
+    u32 hap = sd.start[G];
+    const u32 k = sd.k[G];
+    const u64* bk = sd.bk + sd.bk_off[G];
+    gev_part* out = FILL ? o_parts + o_off[row] : nullptr;
+    u32 n = 0;
+    if (k == 0) {                                                       // locs.size() < 3, :2910
+        const u32 h0 = p_off[2 * parent + hap], h1 = p_off[2 * parent + hap + 1];
+        for (u32 j = h0; j < h1; j++) { if (FILL) out[n] = p_parts[j]; n++; }
+        if (!FILL) o_cnt[row] = n;
+        return;
+    }
+    for (u32 i1 = 1; i1 <= k + 1; i1++) {                               // locs = [bp0, bk..., bp_end]
+        const u64 Lc = (i1 == 1) ? bp0 : bk[i1 - 2];
+        const u64 Rc = (i1 == k + 1) ? bp_end : bk[i1 - 1];
+        const u32 h0 = p_off[2 * parent + hap], h1 = p_off[2 * parent + hap + 1];
+        u32 i2 = h0;
+        while (i2 < h1 && p_parts[i2].en <= Lc) i2++;                                               // :2918
+        if (i2 < h1 && p_parts[i2].st < Lc && Lc < p_parts[i2].en && Rc < p_parts[i2].en) {         // :2922
+            if (FILL) { gev_part p = p_parts[i2]; p.st = Lc; p.en = Rc; out[n] = p; } n++; i2++;
+        }
+        if (i2 < h1 && p_parts[i2].st < Lc && Lc < p_parts[i2].en && Rc >= p_parts[i2].en) {        // :2931
+            if (FILL) { gev_part p = p_parts[i2]; p.st = Lc; out[n] = p; } n++; i2++;
+        }
+        while (i2 < h1 && p_parts[i2].en <= Rc && Lc <= p_parts[i2].st) {                           // :2939
+            if (FILL) out[n] = p_parts[i2]; n++; i2++;
+        }
+        if (i2 < h1 && p_parts[i2].st < Rc && Rc < p_parts[i2].en) {                                 // :2947
+            if (FILL) { gev_part p = p_parts[i2]; p.en = Rc; out[n] = p; } n++;
+        }
+        hap ^= 1u;                                                                                   // :2955
+    }
+    if (!FILL) o_cnt[row] = n;
+}
+
+// ------------------------------------------------------------------------------------------
+// K6/K7: ras_find_cv + ras_compute_AD (src/Simulation.cpp:2624-2815)
+// ------------------------------------------------------------------------------------------
+// resolve CV alleles: founder allele from the stitched CV plane, flipped where the CV position is
+// in the row's mutation set (:2770-2775).  One thread per haplotype row.
+__global__ void __launch_bounds__(256) k_cv_apply_mut(
+    const u32* __restrict__ plane, u32 stride_w32, u32 sub_w32, u32* __restrict__ out /*[rows][sub_w32]*/, size_t n_rows,
+    const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ cvpos_sorted, u32 Cn)
+{
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const u32* in = plane + row * stride_w32;
+    u32* o = out + row * sub_w32;
+    for (u32 w = 0; w < sub_w32; w++) o[w] = in[w];
+    for (u32 j = m_off[row]; j < m_off[row + 1]; j++) {
+        const u64 x = m_pos[j];
+        u32 c = lower_bound_u64(cvpos_sorted, Cn, x);
+        for (; c < Cn && cvpos_sorted[c] == x; c++) {               // set semantics: flipped = !founder, idempotent
+            const u32 f = (in[c >> 5] >> (c & 31)) & 1u;
+            if (f) o[c >> 5] &= ~(1u << (c & 31)); else o[c >> 5] |= (1u << (c & 31));
+        }
+    }
+}
+// allele counts per CV column (sorted order): f = sum_ih cv0+cv1 (:2647-2655), exact integers
+__global__ void __launch_bounds__(256) k_cv_count(const u32* __restrict__ cvm, u32 sub_w32, size_t n_rows, u32 Cn, u32* __restrict__ counts)
+{
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t rows_per = (n_rows + gridDim.y - 1) / gridDim.y;
+    const size_t r0 = (size_t)blockIdx.y * rows_per, r1 = min(r0 + rows_per, n_rows);
+    if (c >= Cn) return;
+    u32 n = 0;
+    for (size_t r = r0; r < r1; r++) n += (cvm[r * sub_w32 + (c >> 5)] >> (c & 31)) & 1u;
+    if (n) atomicAdd(&counts[c], n);
+}
+// frq[icv] = f / (2*n_human) in FILE order (:2655)
+__global__ void k_cv_freq(const u32* __restrict__ counts, const u32* __restrict__ col_of_icv, u32 Cn, size_t n_human, double* __restrict__ frq)
+{
+    const u32 icv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (icv >= Cn) return;
+    const double f = (double)counts[col_of_icv[icv]];
+    frq[icv] = f / (double)(2 * n_human);
+}
+// per individual, CVs in FILE order, sequential FP64 (no contraction: built with -ffp-contract=off):
+//   A += (t - 2p)(a + d(q-p));  D += {-2pp, 2pq, -2qq}[t] * d      (:2686-2712)
+// a, d are the mean of the two haplotypes' root-population values (:2695-2696)
+__global__ void __launch_bounds__(256) k_ad_accumulate(
+    const u32* __restrict__ cvm, u32 sub_w32, const u32* __restrict__ plane, u32 stride_w32, u32 rp_bits,
+    const u32* __restrict__ col_of_icv, const double* __restrict__ frq,
+    const double* const* __restrict__ a_of_pop, const double* const* __restrict__ d_of_pop, int own_pop,
+    const u64* __restrict__ cvpos_file, u64 bp0, u64 bp_end, double vd, u32 Cn, size_t n_human,
+    double* __restrict__ add_out, double* __restrict__ dom_out, size_t out_stride, u32* __restrict__ nan_flag)
+{
+    const size_t ih = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ih >= n_human) return;
+    const u32* r0 = cvm + (2 * ih) * sub_w32; const u32* r1 = cvm + (2 * ih + 1) * sub_w32;
+    const u32* p0 = plane + (2 * ih) * stride_w32; const u32* p1 = plane + (2 * ih + 1) * stride_w32;
+    double A_chr = 0, D_chr = 0;
+    for (u32 icv = 0; icv < Cn; icv++) {
+        const u32 c = col_of_icv[icv];
+        const u32 t = ((r0[c >> 5] >> (c & 31)) & 1u) + ((r1[c >> 5] >> (c & 31)) & 1u);
+        u32 rp0 = own_pop, rp1 = own_pop;
+        if (rp_bits) {
+            rp0 = 0; rp1 = 0;
+            for (u32 b = 0; b < rp_bits; b++) {
+                rp0 |= ((p0[(1 + b) * sub_w32 + (c >> 5)] >> (c & 31)) & 1u) << b;
+                rp1 |= ((p1[(1 + b) * sub_w32 + (c >> 5)] >> (c & 31)) & 1u) << b;
+            }
+        }
+        // a CV outside [bp0,bp_end) is covered by no part: its a, d stay 0 (Human_CV ctor, Population.h:99-108)
+        const u64 x = cvpos_file[icv];
+        const bool covered = (x >= bp0 && x < bp_end);
+        const double a0 = covered ? a_of_pop[rp0][icv] : 0.0, a1 = covered ? a_of_pop[rp1][icv] : 0.0;
+        const double d0 = covered ? d_of_pop[rp0][icv] : 0.0, d1 = covered ? d_of_pop[rp1][icv] : 0.0;
+        const double a = (a0 + a1) / 2;
+        double d = (d0 + d1) / 2;
+        if (vd == 0) d = 0;
+        const double p = frq[icv];
+        const double q = 1 - p;
+        const double alpha = a + d * (q - p);
+        A_chr += ((double)t - 2 * p) * alpha;
+        const double ct = (t == 0) ? (-2 * p * p) : (t == 1 ? (2 * p * q) : (-2 * q * q));
+        D_chr += ct * d;
+    }
+    add_out[ih * out_stride] = A_chr;
+    dom_out[ih * out_stride] = D_chr;
+    if (A_chr != A_chr || D_chr != D_chr) atomicMin(nan_flag, (u32)(ih < 0xffffffffull ? ih : 0xfffffffeull));
+}
+// sum over chromosomes in order (:2729-2746)
+__global__ void k_ad_sum_chr(const double* __restrict__ chr_vals /*[n][nchr][nphen]*/, double* __restrict__ tot /*[n][nphen]*/, size_t n, int nchr, int nphen)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n * nphen) return;
+    const size_t ih = q / nphen; const int p = (int)(q % nphen);
+    double s = 0;
+    for (int c = 0; c < nchr; c++) s += chr_vals[(ih * nchr + c) * nphen + p];
+    tot[q] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// output materialisation == ras_convert_interval_to_hap_matrix (:1186-1230): plane XOR overlay
+// ------------------------------------------------------------------------------------------
+// rows [row0, row0+n) already copied into `out` (stride out_w32 words); flip loci whose position is in the row's set
+__global__ void __launch_bounds__(256) k_snp_apply_mut(
+    const u32* __restrict__ plane, size_t stride_w32, u32* __restrict__ out, size_t out_w32, size_t row0, size_t n_rows,
+    const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ pos, u32 L)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const u32* in = plane + (row0 + r) * stride_w32;
+    u32* o = out + r * out_w32;
+    for (u32 j = m_off[row0 + r]; j < m_off[row0 + r + 1]; j++) {
+        const u64 x = m_pos[j];
+        u32 c = lower_bound_u64(pos, L, x);
+        for (; c < L && pos[c] == x; c++) {
+            const u32 f = (in[c >> 5] >> (c & 31)) & 1u;
+            if (f) o[c >> 5] &= ~(1u << (c & 31)); else o[c >> 5] |= (1u << (c & 31));
+        }
+    }
+}
+// generic row gather (migration, capacity growth, download staging): dst row r <- src row map[r]
+__global__ void __launch_bounds__(256) k_gather_rows16(uint4* __restrict__ dst, size_t dst_stride16, const uint4* __restrict__ src, size_t src_stride16,
+                                                       const u32* __restrict__ map, size_t n_rows, u32 chunks)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_rows * chunks) return;
+    const size_t r = q / chunks; const u32 c = (u32)(q % chunks);
+    dst[r * dst_stride16 + c] = src[(size_t)map[r] * src_stride16 + c];
+}
+// CSR gather: count / fill of rows selected by map (element size templated)
+__global__ void k_csr_gather_count(const u32* __restrict__ s_off, const u32* __restrict__ map, size_t n_rows, u32* __restrict__ cnt)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows) cnt[r] = s_off[map[r] + 1] - s_off[map[r]];
+}
+template <class E>
+__global__ void k_csr_gather_fill(const u32* __restrict__ s_off, const E* __restrict__ s_val, const u32* __restrict__ map, size_t n_rows,
+                                  const u32* __restrict__ d_off, E* __restrict__ d_val)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const u32 a = s_off[map[r]], n = s_off[map[r] + 1] - a, o = d_off[r];
+    for (u32 j = 0; j < n; j++) d_val[o + j] = s_val[a + j];
+}

@@ -1,0 +1,1012 @@
+// gev_library.hip -- C-ABI (include/geneevolve_amd.h) over the HIP kernels of gev_kernels.h.
+// MI355X (gfx950) only.  Host side = plumbing: argument checks, device memory, launch order.
+// No CPU fallback of any kernel exists: without a GPU every compute entry point fails loudly.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC gev_library.hip -o libgeneevolve_amd.so
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "gev_kernels.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(GEV_EDEVICE, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #expr); } while (0)
+#define GEVC(expr) do { int rc_ = (expr); if (rc_ != GEV_OK) return rc_; } while (0)
+#define KCHECK() HIPC(hipGetLastError())
+
+static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+static inline size_t round_up(size_t a, size_t b) { return ceil_div(a, b) * b; }
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept { p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    int ensure(size_t need, hipStream_t st, bool keep = false, double slack = 1.0)
+    {
+        if (need <= bytes && p) return GEV_OK;
+        size_t want = std::max<size_t>((size_t)(need * slack), 256);
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess && want > need) { want = std::max<size_t>(need, 256); e = hipMalloc(&q, want); }
+        if (e != hipSuccess) return fail(GEV_EDEVICE, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        if (p) {
+            if (keep && bytes) { HIPC(hipMemcpyAsync(q, p, bytes, hipMemcpyDeviceToDevice, st)); }
+            HIPC(hipStreamSynchronize(st));
+            (void)hipFree(p);
+        }
+        p = q; bytes = want;
+        return GEV_OK;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct ChrStatic {                       // one population x one chromosome
+    std::vector<u64> rbp; std::vector<double> rprob; u64 bp_dist = 0;
+    std::vector<u64> mbp; std::vector<double> mrate; bool mut_set = false;
+    std::vector<u64> pos;                // Legend.pos
+    DevBuf d_rthr, d_rbp, d_mthr, d_mbp, d_pos;
+    size_t L = 0, stride = 0;            // plane row stride in bytes (multiple of 128)
+    u32 idx_lo = 0, idx_hi = 0;          // loci inside [bp0, bp_end)
+    size_t founder_rows = 0;
+};
+struct CvStatic {                        // one population x phenotype x chromosome
+    std::vector<u64> bp; std::vector<double> a, d; double vd = 0; bool set = false;
+    std::vector<u32> col_of_icv;         // file index -> column in the sorted CV plane
+    std::vector<u32> icv_of_col;
+    DevBuf d_pos_sorted, d_pos_file, d_col_of_icv, d_icv_of_col, d_a, d_d, d_frq, d_counts, d_aptr, d_dptr;
+    u32 C = 0, sub_w32 = 0, stride_w32 = 0;
+    u32 idx_lo = 0, idx_hi = 0;
+    size_t founder_rows = 0;
+    bool frq_valid = false;
+};
+struct ChrState {
+    DevBuf plane[2], moff[2], mpos[2], poff[2], parts[2];
+};
+struct PopState {
+    std::vector<ChrStatic> cs;                         // [chr]
+    std::vector<std::vector<CvStatic>> cv;             // [phen][chr]
+    std::vector<ChrState> st;                          // [chr]
+    std::vector<std::vector<std::array<DevBuf, 2>>> cvp; // [phen][chr][2]
+    DevBuf d_chrdev;
+    int cur = 0;
+    size_t n_people = 0, cap_people = 0;
+    bool finalized = false, gen0 = false;
+};
+
+struct gev_ctx {
+    int device = 0, n_pop = 0, nchr = 0, nphen = 0;
+    u32 rp_bits = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float last_ms[4] = {0, 0, 0, 0};
+    bool track_intervals = true;
+    std::vector<PopState> pop;
+    DevBuf d_tables;
+    // per-generation scratch
+    DevBuf d_father, d_mother, d_mutseeds, d_seed_pat, d_seed_mat, d_k, d_bk_off, d_bk, d_start, d_nmut, d_nm_off, d_nm_pos, d_nm_side, d_sex;
+    DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
+    std::map<double, GevThr> thr_cache;
+};
+
+// ------------------------------------------------------------------------------------------
+static int scan_u32(gev_ctx* c, const u32* in, size_t n, u32* out /*n+1*/, u32* total_host)
+{
+    const size_t nb = ceil_div(n + 1, SCAN_ITEMS);
+    GEVC(c->d_sums.ensure(nb * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(256), 0, c->stream, in, n, c->d_sums.as<u32>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, c->stream, c->d_sums.as<u32>(), nb);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(256), 0, c->stream, in, n, c->d_sums.as<u32>(), out);
+    KCHECK();
+    if (total_host) {
+        HIPC(hipMemcpyAsync(total_host, out + n, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    return GEV_OK;
+}
+static int h2d(gev_ctx* c, DevBuf& b, const void* src, size_t bytes)
+{
+    GEVC(b.ensure(std::max<size_t>(bytes, 16), c->stream));
+    if (bytes) HIPC(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));          // src may be a caller-owned temporary
+    return GEV_OK;
+}
+static int make_thresholds(gev_ctx* c, const std::vector<double>& p, std::vector<GevThr>& out)
+{
+    out.resize(p.size());
+    for (size_t i = 0; i < p.size(); i++) {
+        auto it = c->thr_cache.find(p[i]);
+        if (it == c->thr_cache.end()) {
+            GevThr t;
+            if (p[i] != p[i]) return fail(GEV_EINVAL, "probability of map row %zu is NaN", i);
+            if (!gev_make_threshold(p[i], t)) return fail(GEV_EUNSUPPORTED, "threshold window wider than 2 for probability %a", p[i]);
+            it = c->thr_cache.emplace(p[i], t).first;
+        }
+        out[i] = it->second;
+    }
+    return GEV_OK;
+}
+static int check_idx(gev_ctx* c, int pop, int chr, int phen = 0)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    if (pop < 0 || pop >= c->n_pop) return fail(GEV_EINVAL, "population index %d out of range", pop);
+    if (chr < 0 || chr >= c->nchr) return fail(GEV_EINVAL, "chromosome index %d out of range", chr);
+    if (phen < 0 || phen >= c->nphen) return fail(GEV_EINVAL, "phenotype index %d out of range", phen);
+    return GEV_OK;
+}
+
+// bit-column permutation of small planes (CV grid): out column j <- in column src_col[j]
+__global__ void k_permute_cols(const u32* __restrict__ in, size_t in_w32, u32* __restrict__ out, size_t out_w32, u32 used_w32,
+                               const u32* __restrict__ src_col, u32 Cn, size_t n_rows)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_rows * used_w32) return;
+    const size_t r = q / used_w32; const u32 w = (u32)(q % used_w32);
+    u32 v = 0;
+    for (u32 b = 0; b < 32; b++) {
+        const u32 j = w * 32 + b;
+        if (j >= Cn) break;
+        const u32 s = src_col[j];
+        v |= ((in[r * in_w32 + (s >> 5)] >> (s & 31)) & 1u) << b;
+    }
+    out[r * out_w32 + w] = v;
+}
+__global__ void k_fill_rp(u32* __restrict__ plane, size_t stride_w32, u32 sub_w32, u32 rp_bits, u32 pop, size_t n_rows)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 used = sub_w32 * rp_bits;
+    if (q >= n_rows * used) return;
+    const size_t r = q / used; const u32 w = (u32)(q % used);
+    const u32 b = w / sub_w32;
+    plane[r * stride_w32 + sub_w32 + w] = ((pop >> b) & 1u) ? 0xffffffffu : 0u;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* gev_last_error(void) { return g_err.c_str(); }
+const char* gev_version(void) { return "geneevolve_amd 0.1 (gfx950)"; }
+
+int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
+{
+    if (!out) return fail(GEV_EINVAL, "gev_create: out is null");
+    *out = nullptr;
+    if (n_pop < 1 || nchr < 1 || nphen < 1) return fail(GEV_EINVAL, "gev_create: n_pop, nchr, nphen must be >= 1");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(GEV_EDEVICE, "no HIP device available (%s): this library has no CPU fallback", hipGetErrorString(e));
+    if (device < 0) HIPC(hipGetDevice(&device));
+    if (device >= ndev) return fail(GEV_EDEVICE, "device %d not present (%d devices)", device, ndev);
+    HIPC(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPC(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(GEV_EDEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    std::unique_ptr<gev_ctx> c(new gev_ctx());
+    c->device = device; c->n_pop = n_pop; c->nchr = nchr; c->nphen = nphen;
+    while ((1u << c->rp_bits) < (u32)n_pop) c->rp_bits++;
+    HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& ev : c->ev) HIPC(hipEventCreate(&ev));
+    c->pop.resize(n_pop);
+    for (auto& P : c->pop) {
+        P.cs.resize(nchr); P.st.resize(nchr);
+        P.cv.resize(nphen); P.cvp.resize(nphen);
+        for (int p = 0; p < nphen; p++) { P.cv[p].resize(nchr); P.cvp[p].resize(nchr); }
+    }
+    GevRngTables T; gev_build_rng_tables(T);
+    GEVC(h2d(c.get(), c->d_tables, &T, sizeof T));
+    *out = c.release();
+    return GEV_OK;
+}
+void gev_destroy(gev_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    hipStream_t s = c->stream;
+    delete c;
+    if (s) (void)hipStreamDestroy(s);
+}
+
+// ---- static inputs -----------------------------------------------------------------------
+int gev_set_rmap(gev_ctx* c, int pop, int chr, const u64* bp, const double* prob, size_t R, u64 bp_dist)
+{
+    GEVC(check_idx(c, pop, chr));
+    if (!bp || !prob || R < 2) return fail(GEV_EINVAL, "set_rmap: need >= 2 map rows");
+    if (bp_dist == 0) return fail(GEV_EINVAL, "set_rmap: bp_dist_in_rmap is 0 (rand() %% 0 in the reference, src/Simulation.cpp:2990)");
+    if (R > 0x7fffffffu) return fail(GEV_EINVAL, "set_rmap: too many rows");
+    // dense-equivalence precondition: breakpoints bp[j] + rand()%dist must come out ascending
+    for (size_t j = 0; j + 1 < R; j++)
+        if (bp[j + 1] < bp[j] + bp_dist) return fail(GEV_EUNSUPPORTED, "set_rmap: map rows %zu,%zu are closer than bp_dist_in_rmap=%llu: the reference would emit unsorted breakpoints (overlapping parts), which has no dense equivalent", j, j + 1, (unsigned long long)bp_dist);
+    ChrStatic& S = c->pop[pop].cs[chr];
+    S.rbp.assign(bp, bp + R); S.rprob.assign(prob, prob + R); S.bp_dist = bp_dist;
+    std::vector<GevThr> thr;
+    GEVC(make_thresholds(c, S.rprob, thr));
+    HIPC(hipSetDevice(c->device));
+    GEVC(h2d(c, S.d_rthr, thr.data(), R * sizeof(GevThr)));
+    GEVC(h2d(c, S.d_rbp, bp, R * sizeof(u64)));
+    c->pop[pop].finalized = false;
+    return GEV_OK;
+}
+int gev_set_mutmap(gev_ctx* c, int pop, int chr, const u64* bp, const double* rate, size_t M)
+{
+    GEVC(check_idx(c, pop, chr));
+    if (M && (!bp || !rate)) return fail(GEV_EINVAL, "set_mutmap: null arrays");
+    if (M > 0x7fffffffu) return fail(GEV_EINVAL, "set_mutmap: too many rows");
+    for (size_t i = 1; i < M; i++) {
+        if (bp[i] < bp[i - 1]) return fail(GEV_EUNSUPPORTED, "set_mutmap: bp must be non-decreasing (row %zu)", i);
+        if (bp[i] - bp[i - 1] >= 2147483645ull) return fail(GEV_EUNSUPPORTED, "set_mutmap: interval %zu spans >= 2^31 bp (uniform_int_distribution up-scaling branch)", i);
+    }
+    ChrStatic& S = c->pop[pop].cs[chr];
+    S.mbp.assign(bp, bp + M); S.mrate.assign(rate, rate + M); S.mut_set = true;
+    std::vector<GevThr> thr;
+    GEVC(make_thresholds(c, S.mrate, thr));
+    HIPC(hipSetDevice(c->device));
+    GEVC(h2d(c, S.d_mthr, thr.data(), M * sizeof(GevThr)));
+    GEVC(h2d(c, S.d_mbp, bp, M * sizeof(u64)));
+    c->pop[pop].finalized = false;
+    return GEV_OK;
+}
+int gev_set_snps(gev_ctx* c, int pop, int chr, const u64* pos, size_t L)
+{
+    GEVC(check_idx(c, pop, chr));
+    if (L && !pos) return fail(GEV_EINVAL, "set_snps: null positions");
+    if (L >= 0xffffff00ull) return fail(GEV_EINVAL, "set_snps: too many loci");
+    for (size_t i = 1; i < L; i++) if (pos[i] < pos[i - 1]) return fail(GEV_EUNSUPPORTED, "set_snps: positions must be non-decreasing (locus %zu)", i);
+    ChrStatic& S = c->pop[pop].cs[chr];
+    S.pos.assign(pos, pos + L); S.L = L;
+    S.stride = std::max<size_t>(round_up(ceil_div(L, 8), 128), 128);
+    HIPC(hipSetDevice(c->device));
+    GEVC(h2d(c, S.d_pos, pos, L * sizeof(u64)));
+    c->pop[pop].finalized = false;
+    return GEV_OK;
+}
+int gev_set_cvs(gev_ctx* c, int pop, int phen, int chr, const u64* bp, const double* a, const double* d, size_t C, double vd)
+{
+    GEVC(check_idx(c, pop, chr, phen));
+    if (C && (!bp || !a || !d)) return fail(GEV_EINVAL, "set_cvs: null arrays");
+    if (C > 0x7fffff00u) return fail(GEV_EINVAL, "set_cvs: too many CVs");
+    CvStatic& V = c->pop[pop].cv[phen][chr];
+    V.bp.assign(bp, bp + C); V.a.assign(a, a + C); V.d.assign(d, d + C); V.vd = vd; V.C = (u32)C; V.set = true;
+    // sorted column order (stable: equal positions keep file order)
+    V.icv_of_col.resize(C);
+    for (u32 i = 0; i < C; i++) V.icv_of_col[i] = i;
+    std::stable_sort(V.icv_of_col.begin(), V.icv_of_col.end(), [&](u32 x, u32 y) { return V.bp[x] < V.bp[y]; });
+    V.col_of_icv.resize(C);
+    for (u32 j = 0; j < C; j++) V.col_of_icv[V.icv_of_col[j]] = j;
+    std::vector<u64> sorted(C);
+    for (u32 j = 0; j < C; j++) sorted[j] = V.bp[V.icv_of_col[j]];
+    V.sub_w32 = (u32)std::max<size_t>(ceil_div(C, 32), 1);
+    V.stride_w32 = (u32)round_up((size_t)V.sub_w32 * (1 + c->rp_bits), 4);
+    HIPC(hipSetDevice(c->device));
+    GEVC(h2d(c, V.d_pos_sorted, sorted.data(), C * sizeof(u64)));
+    GEVC(h2d(c, V.d_pos_file, V.bp.data(), C * sizeof(u64)));
+    GEVC(h2d(c, V.d_col_of_icv, V.col_of_icv.data(), C * sizeof(u32)));
+    GEVC(h2d(c, V.d_icv_of_col, V.icv_of_col.data(), C * sizeof(u32)));
+    GEVC(h2d(c, V.d_a, a, C * sizeof(double)));
+    GEVC(h2d(c, V.d_d, d, C * sizeof(double)));
+    GEVC(V.d_frq.ensure(std::max<size_t>(C, 1) * sizeof(double), c->stream));
+    GEVC(V.d_counts.ensure(std::max<size_t>(C, 1) * sizeof(u32), c->stream));
+    V.frq_valid = false;
+    c->pop[pop].finalized = false;
+    return GEV_OK;
+}
+
+static int ensure_capacity(gev_ctx* c, int pop, size_t people)
+{
+    PopState& P = c->pop[pop];
+    if (people <= P.cap_people) return GEV_OK;
+    const size_t rows = 2 * people;
+    for (int k = 0; k < c->nchr; k++) {
+        if (!P.cs[k].stride) return fail(GEV_ESTATE, "set_snps must precede allocation (pop %d chr %d)", pop, k);
+        for (int b = 0; b < 2; b++) {
+            GEVC(P.st[k].plane[b].ensure(rows * P.cs[k].stride, c->stream, /*keep=*/b == P.cur));
+            GEVC(P.st[k].moff[b].ensure((rows + 1) * sizeof(u32), c->stream, b == P.cur));
+            GEVC(P.st[k].poff[b].ensure((rows + 1) * sizeof(u32), c->stream, b == P.cur));
+        }
+        for (int p = 0; p < c->nphen; p++) {
+            if (!P.cv[p][k].set) return fail(GEV_ESTATE, "set_cvs must precede allocation (pop %d phen %d chr %d)", pop, p, k);
+            for (int b = 0; b < 2; b++)
+                GEVC(P.cvp[p][k][b].ensure(rows * P.cv[p][k].stride_w32 * sizeof(u32), c->stream, b == P.cur));
+        }
+    }
+    P.cap_people = people;
+    return GEV_OK;
+}
+int gev_reserve(gev_ctx* c, int pop, size_t max_people)
+{
+    GEVC(check_idx(c, pop, 0));
+    HIPC(hipSetDevice(c->device));
+    return ensure_capacity(c, pop, max_people);
+}
+
+int gev_upload_founders(gev_ctx* c, int pop, int chr, const u64* bits, size_t row_stride_words, size_t nhap, size_t L)
+{
+    GEVC(check_idx(c, pop, chr));
+    PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr];
+    if (!bits || nhap < 2 || (nhap & 1)) return fail(GEV_EINVAL, "upload_founders: need an even number (>=2) of haplotype rows");
+    if (L != S.L) return fail(GEV_EINVAL, "upload_founders: L=%zu but set_snps gave %zu loci", L, S.L);
+    if (row_stride_words * 64 < L) return fail(GEV_EINVAL, "upload_founders: row stride too small");
+    HIPC(hipSetDevice(c->device));
+    GEVC(P.st[chr].plane[P.cur].ensure(nhap * S.stride, c->stream));
+    HIPC(hipMemsetAsync(P.st[chr].plane[P.cur].p, 0, nhap * S.stride, c->stream));
+    HIPC(hipMemcpy2DAsync(P.st[chr].plane[P.cur].p, S.stride, bits, row_stride_words * 8, ceil_div(L, 8), nhap, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (L % 8) {   // clear pad bits of the last byte (the contract says pad bits are zero; do not trust it)
+        hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(nhap * (S.stride / 4), 256)), dim3(256), 0, c->stream,
+                           P.st[chr].plane[P.cur].as<u32>(), S.stride / 4, nhap, 0u, (u32)L);
+        KCHECK();
+    }
+    S.founder_rows = nhap; P.gen0 = false;
+    return GEV_OK;
+}
+int gev_synth_founders(gev_ctx* c, int pop, int chr, size_t nhap, u64 seed)
+{
+    GEVC(check_idx(c, pop, chr));
+    PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr];
+    if (nhap < 2 || (nhap & 1)) return fail(GEV_EINVAL, "synth_founders: need an even number of haplotypes");
+    if (!S.L) return fail(GEV_ESTATE, "synth_founders: set_snps first");
+    HIPC(hipSetDevice(c->device));
+    GEVC(P.st[chr].plane[P.cur].ensure(nhap * S.stride, c->stream));
+    HIPC(hipMemsetAsync(P.st[chr].plane[P.cur].p, 0, nhap * S.stride, c->stream));
+    GEVC(c->d_thr32.ensure(S.L * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(k_synth_thresholds, dim3((unsigned)ceil_div(S.L, 256)), dim3(256), 0, c->stream, c->d_thr32.as<u32>(), S.L, seed);
+    const size_t words = ceil_div(S.L, 64);
+    hipLaunchKernelGGL(k_synth_rows, dim3((unsigned)ceil_div(nhap * words, 256)), dim3(256), 0, c->stream,
+                       P.st[chr].plane[P.cur].as<u64>(), S.stride / 8, nhap, S.L, c->d_thr32.as<u32>(), seed);
+    KCHECK();
+    HIPC(hipStreamSynchronize(c->stream));
+    S.founder_rows = nhap; P.gen0 = false;
+    return GEV_OK;
+}
+// CV founders arrive in FILE column order; the plane keeps columns sorted by position
+static int cv_founders_from_tmp(gev_ctx* c, int pop, int phen, int chr, size_t nhap, size_t tmp_w32)
+{
+    PopState& P = c->pop[pop]; CvStatic& V = P.cv[phen][chr];
+    GEVC(P.cvp[phen][chr][P.cur].ensure(nhap * V.stride_w32 * sizeof(u32), c->stream));
+    HIPC(hipMemsetAsync(P.cvp[phen][chr][P.cur].p, 0, nhap * V.stride_w32 * sizeof(u32), c->stream));
+    if (V.C) {
+        hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)ceil_div(nhap * V.sub_w32, 256)), dim3(256), 0, c->stream,
+                           c->d_tmp.as<u32>(), tmp_w32, P.cvp[phen][chr][P.cur].as<u32>(), (size_t)V.stride_w32, V.sub_w32,
+                           V.d_icv_of_col.as<u32>(), V.C, nhap);
+        KCHECK();
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+    V.founder_rows = nhap; P.gen0 = false;
+    return GEV_OK;
+}
+int gev_upload_cv_founders(gev_ctx* c, int pop, int phen, int chr, const u64* bits, size_t row_stride_words, size_t nhap, size_t C)
+{
+    GEVC(check_idx(c, pop, chr, phen));
+    CvStatic& V = c->pop[pop].cv[phen][chr];
+    if (!V.set) return fail(GEV_ESTATE, "upload_cv_founders: set_cvs first");
+    if (C != V.C) return fail(GEV_EINVAL, "upload_cv_founders: C=%zu but set_cvs gave %u", C, V.C);
+    if (!bits || nhap < 2 || (nhap & 1) || row_stride_words * 64 < C) return fail(GEV_EINVAL, "upload_cv_founders: bad arguments");
+    HIPC(hipSetDevice(c->device));
+    GEVC(h2d(c, c->d_tmp, bits, nhap * row_stride_words * 8));
+    return cv_founders_from_tmp(c, pop, phen, chr, nhap, row_stride_words * 2);
+}
+int gev_synth_cv_founders(gev_ctx* c, int pop, int phen, int chr, size_t nhap, u64 seed)
+{
+    GEVC(check_idx(c, pop, chr, phen));
+    CvStatic& V = c->pop[pop].cv[phen][chr];
+    if (!V.set) return fail(GEV_ESTATE, "synth_cv_founders: set_cvs first");
+    if (nhap < 2 || (nhap & 1)) return fail(GEV_EINVAL, "synth_cv_founders: need an even number of haplotypes");
+    HIPC(hipSetDevice(c->device));
+    const size_t w64 = std::max<size_t>(ceil_div(V.C, 64), 1);
+    GEVC(c->d_tmp.ensure(nhap * w64 * 8, c->stream));
+    GEVC(c->d_thr32.ensure(std::max<size_t>(V.C, 1) * sizeof(u32), c->stream));
+    HIPC(hipMemsetAsync(c->d_tmp.p, 0, nhap * w64 * 8, c->stream));
+    if (V.C) {
+        hipLaunchKernelGGL(k_synth_thresholds, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, c->stream, c->d_thr32.as<u32>(), (size_t)V.C, seed);
+        hipLaunchKernelGGL(k_synth_rows, dim3((unsigned)ceil_div(nhap * w64, 256)), dim3(256), 0, c->stream,
+                           c->d_tmp.as<u64>(), w64, nhap, (size_t)V.C, c->d_thr32.as<u32>(), seed);
+        KCHECK();
+    }
+    return cv_founders_from_tmp(c, pop, phen, chr, nhap, w64 * 2);
+}
+
+// static tables that depend on several setters
+static int finalize_static(gev_ctx* c, int pop)
+{
+    PopState& P = c->pop[pop];
+    if (P.finalized) return GEV_OK;
+    std::vector<ChrDev> cd(c->nchr);
+    for (int k = 0; k < c->nchr; k++) {
+        ChrStatic& S = P.cs[k];
+        if (S.rbp.empty()) return fail(GEV_ESTATE, "population %d chromosome %d: set_rmap missing", pop, k);
+        const u64 bp0 = S.rbp.front(), bpe = S.rbp.back();
+        S.idx_lo = (u32)(std::lower_bound(S.pos.begin(), S.pos.end(), bp0) - S.pos.begin());
+        S.idx_hi = (u32)(std::lower_bound(S.pos.begin(), S.pos.end(), bpe) - S.pos.begin());
+        cd[k] = ChrDev{S.d_rthr.as<GevThr>(), S.d_rbp.as<u64>(), S.d_mthr.as<GevThr>(), S.d_mbp.as<u64>(), S.bp_dist, bp0, bpe,
+                       (u32)S.rbp.size(), (u32)S.mbp.size()};
+        for (int p = 0; p < c->nphen; p++) {
+            CvStatic& V = P.cv[p][k];
+            if (!V.set) continue;
+            std::vector<u64> sorted(V.C);
+            for (u32 j = 0; j < V.C; j++) sorted[j] = V.bp[V.icv_of_col[j]];
+            V.idx_lo = (u32)(std::lower_bound(sorted.begin(), sorted.end(), bp0) - sorted.begin());
+            V.idx_hi = (u32)(std::lower_bound(sorted.begin(), sorted.end(), bpe) - sorted.begin());
+        }
+    }
+    GEVC(h2d(c, P.d_chrdev, cd.data(), cd.size() * sizeof(ChrDev)));
+    P.finalized = true;
+    return GEV_OK;
+}
+// with several populations the dense state needs one shared coordinate system
+static int check_multipop(gev_ctx* c)
+{
+    for (int pop = 1; pop < c->n_pop; pop++)
+        for (int k = 0; k < c->nchr; k++) {
+            const ChrStatic& A = c->pop[0].cs[k]; const ChrStatic& B = c->pop[pop].cs[k];
+            if (A.pos != B.pos) return fail(GEV_EUNSUPPORTED, "populations 0 and %d have different SNP grids on chromosome %d", pop, k);
+            if (A.rbp.front() != B.rbp.front() || A.rbp.back() != B.rbp.back()) return fail(GEV_EUNSUPPORTED, "populations 0 and %d have different map ranges on chromosome %d", pop, k);
+            for (int p = 0; p < c->nphen; p++)
+                if (c->pop[0].cv[p][k].bp != c->pop[pop].cv[p][k].bp) return fail(GEV_EUNSUPPORTED, "populations 0 and %d have different CV positions (phenotype %d chromosome %d)", pop, p, k);
+        }
+    // per (phen, chr): table of every population's a[] and d[] device arrays, stored with each population
+    for (int pop = 0; pop < c->n_pop; pop++)
+        for (int p = 0; p < c->nphen; p++)
+            for (int k = 0; k < c->nchr; k++) {
+                std::vector<const double*> ap(c->n_pop), dp(c->n_pop);
+                for (int r = 0; r < c->n_pop; r++) { ap[r] = c->pop[r].cv[p][k].d_a.as<double>(); dp[r] = c->pop[r].cv[p][k].d_d.as<double>(); }
+                GEVC(h2d(c, c->pop[pop].cv[p][k].d_aptr, ap.data(), ap.size() * sizeof(double*)));
+                GEVC(h2d(c, c->pop[pop].cv[p][k].d_dptr, dp.data(), dp.size() * sizeof(double*)));
+            }
+    return GEV_OK;
+}
+
+// ---- Simulation::ras_initial_human_gen0 ---------------------------------------------------
+int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint8_t* sex_out)
+{
+    GEVC(check_idx(c, pop, 0));
+    if (n_people < 1) return fail(GEV_EINVAL, "init_gen0: n_people must be >= 1");
+    if (2 * n_people >= 0xffffffffull) return fail(GEV_EINVAL, "init_gen0: too many people");
+    HIPC(hipSetDevice(c->device));
+    PopState& P = c->pop[pop];
+    GEVC(finalize_static(c, pop));
+    const size_t rows = 2 * n_people;
+    for (int k = 0; k < c->nchr; k++) {
+        if (P.cs[k].founder_rows < rows) return fail(GEV_ESTATE, "init_gen0: population %d chromosome %d has %zu founder haplotypes, %zu needed", pop, k, P.cs[k].founder_rows, rows);
+        for (int p = 0; p < c->nphen; p++)
+            if (P.cv[p][k].founder_rows < rows) return fail(GEV_ESTATE, "init_gen0: population %d phenotype %d chromosome %d has %zu CV founder haplotypes, %zu needed", pop, p, k, P.cv[p][k].founder_rows, rows);
+    }
+    GEVC(ensure_capacity(c, pop, std::max(n_people, P.cap_people)));
+    for (int k = 0; k < c->nchr; k++) {
+        ChrStatic& S = P.cs[k]; ChrState& st = P.st[k];
+        hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(rows * (S.stride / 4), 256)), dim3(256), 0, c->stream,
+                           st.plane[P.cur].as<u32>(), S.stride / 4, rows, S.idx_lo, S.idx_hi);
+        HIPC(hipMemsetAsync(st.moff[P.cur].p, 0, (rows + 1) * sizeof(u32), c->stream));
+        GEVC(st.parts[P.cur].ensure(rows * sizeof(gev_part), c->stream));
+        hipLaunchKernelGGL(k_init_parts, dim3((unsigned)ceil_div(rows + 1, 256)), dim3(256), 0, c->stream,
+                           st.parts[P.cur].as<gev_part>(), st.poff[P.cur].as<u32>(), rows, S.rbp.front(), S.rbp.back(), pop);
+        for (int p = 0; p < c->nphen; p++) {
+            CvStatic& V = P.cv[p][k];
+            hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(rows * V.stride_w32, 256)), dim3(256), 0, c->stream,
+                               P.cvp[p][k][P.cur].as<u32>(), (size_t)V.stride_w32, rows, V.idx_lo, V.idx_hi);
+            // k_mask_rows zeroed the (still empty) root-population sub-rows too; write them now
+            if (c->rp_bits)
+                hipLaunchKernelGGL(k_fill_rp, dim3((unsigned)ceil_div(rows * V.sub_w32 * c->rp_bits, 256)), dim3(256), 0, c->stream,
+                                   P.cvp[p][k][P.cur].as<u32>(), (size_t)V.stride_w32, V.sub_w32, c->rp_bits, (u32)pop, rows);
+            V.frq_valid = false;
+        }
+    }
+    GEVC(c->d_sex.ensure(n_people, c->stream));
+    hipLaunchKernelGGL(k_sex_sequence, dim3(1), dim3(64), 0, c->stream, c->d_tables.as<GevRngTables>(), (u32)seed_gen0, n_people, c->d_sex.as<uint8_t>());
+    KCHECK();
+    if (sex_out) HIPC(hipMemcpyAsync(sex_out, c->d_sex.p, n_people, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    P.n_people = n_people; P.gen0 = true;
+    return GEV_OK;
+}
+
+// ---- Simulation::reproduce ----------------------------------------------------------------
+int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_couples, uint32_t seed_reproduce,
+                  const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people, uint8_t* sex_out)
+{
+    GEVC(check_idx(c, pop, 0));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "reproduce: population %d has no current generation (call gev_init_gen0)", pop);
+    if (n_couples && !couples) return fail(GEV_EINVAL, "reproduce: null couples");
+    HIPC(hipSetDevice(c->device));
+    const int nchr = c->nchr;
+    // offspring enumeration order of the couple loop (src/Simulation.cpp:2433-2443)
+    std::vector<u32> father, mother;
+    father.reserve(n_people); mother.reserve(n_people);
+    for (size_t it = 0; it < n_couples; it++) {
+        if (couples[it].inbreed) continue;
+        if (couples[it].num_offspring < 0) return fail(GEV_EINVAL, "reproduce: couple %zu has negative num_offspring", it);
+        if (couples[it].num_offspring && (couples[it].pos_male >= P.n_people || couples[it].pos_female >= P.n_people))
+            return fail(GEV_EINVAL, "reproduce: couple %zu references position beyond the population (%zu people)", it, P.n_people);
+        for (int ns = 0; ns < couples[it].num_offspring; ns++) { father.push_back((u32)couples[it].pos_male); mother.push_back((u32)couples[it].pos_female); }
+    }
+    if (father.size() != n_people) return fail(GEV_EINVAL, "reproduce: n_people=%zu but the couples list yields %zu offspring", n_people, father.size());
+    if (n_people == 0) return fail(GEV_EINVAL, "reproduce: no offspring");
+    const size_t T = n_people * (size_t)nchr;
+    if (2 * T >= 0xffffffffull) return fail(GEV_EINVAL, "reproduce: too many gametes");
+    const bool has_mut = mut_seeds != nullptr;
+    if (has_mut && n_mut_seeds != T) return fail(GEV_EINVAL, "reproduce: n_mut_seeds=%zu, expected n_people*nchr=%zu", n_mut_seeds, T);
+    GEVC(finalize_static(c, pop));
+    GEVC(ensure_capacity(c, pop, n_people));
+    hipStream_t st = c->stream;
+    const GevRngTables* Tb = c->d_tables.as<GevRngTables>();
+    const ChrDev* chrs = P.d_chrdev.as<ChrDev>();
+
+    GEVC(h2d(c, c->d_father, father.data(), n_people * sizeof(u32)));
+    GEVC(h2d(c, c->d_mother, mother.data(), n_people * sizeof(u32)));
+    GEVC(c->d_seed_pat.ensure((T + 1) * sizeof(u32), st)); GEVC(c->d_seed_mat.ensure(T * sizeof(u32), st));
+    GEVC(c->d_k.ensure(2 * T * sizeof(u32), st)); GEVC(c->d_bk_off.ensure((2 * T + 1) * sizeof(u32), st));
+    GEVC(c->d_start.ensure(2 * T, st)); GEVC(c->d_sex.ensure(n_people, st));
+    GEVC(c->d_nmut.ensure(T * sizeof(u32), st)); GEVC(c->d_nm_off.ensure((T + 1) * sizeof(u32), st));
+    GEVC(c->d_bk.ensure(16, st)); GEVC(c->d_nm_pos.ensure(16, st)); GEVC(c->d_nm_side.ensure(16, st));
+    if (has_mut) GEVC(h2d(c, c->d_mutseeds, mut_seeds, T * sizeof(u32)));
+
+    SampleDev sd;
+    auto fill_sd = [&]() {
+        sd.seed_pat = c->d_seed_pat.as<u32>(); sd.seed_mat = c->d_seed_mat.as<u32>(); sd.k = c->d_k.as<u32>();
+        sd.bk_off = c->d_bk_off.as<u32>(); sd.bk = c->d_bk.as<u64>(); sd.start = c->d_start.as<uint8_t>();
+        sd.nmut = c->d_nmut.as<u32>(); sd.nm_off = c->d_nm_off.as<u32>(); sd.nm_pos = c->d_nm_pos.as<u64>();
+        sd.nm_side = c->d_nm_side.as<uint8_t>(); sd.sex = c->d_sex.as<uint8_t>();
+        sd.father = c->d_father.as<u32>(); sd.mother = c->d_mother.as<u32>();
+    };
+    fill_sd();
+    HIPC(hipEventRecord(c->ev[0], st));
+    // ---- sampling
+    const unsigned task_blocks = (unsigned)ceil_div(T, 4);
+    if (has_mut) {
+        hipLaunchKernelGGL(k_mut_count, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, c->d_mutseeds.as<u32>(), T, sd.nmut);
+        KCHECK();
+        u32 tot = 0;
+        GEVC(scan_u32(c, sd.nmut, T, sd.nm_off, &tot));
+        GEVC(c->d_nm_pos.ensure(std::max<size_t>(tot, 2) * sizeof(u64), st, false, 1.25));
+        GEVC(c->d_nm_side.ensure(std::max<size_t>(tot, 16), st, false, 1.25));
+        fill_sd();
+        hipLaunchKernelGGL(k_mut_fill, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, c->d_mutseeds.as<u32>(), T, sd);
+        hipLaunchKernelGGL(k_rec_pass1, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, (u32)seed_reproduce, T, sd);
+    } else {
+        hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, (u32)seed_reproduce, T, sd);
+    }
+    KCHECK();
+    {
+        u32 tot = 0;
+        GEVC(scan_u32(c, sd.k, 2 * T, sd.bk_off, &tot));
+        GEVC(c->d_bk.ensure(std::max<size_t>(tot, 2) * sizeof(u64), st, false, 1.25));
+        fill_sd();
+        hipLaunchKernelGGL(k_rec_pass2, dim3((unsigned)ceil_div(2 * T, 4)), dim3(256), 0, st, Tb, chrs, nchr, 2 * T, sd);
+        KCHECK();
+    }
+    HIPC(hipEventRecord(c->ev[1], st));
+    // ---- sparse state: mutation lists + ancestry intervals
+    const int cur = P.cur, alt = P.cur ^ 1;
+    const size_t rows = 2 * n_people;
+    GEVC(c->d_cnt.ensure((rows + 1) * sizeof(u32), st));
+    const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
+    for (int k = 0; k < nchr; k++) {
+        ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
+        const u64 bp0 = S.rbp.front(), bpe = S.rbp.back();
+        u32 tot = 0;
+        hipLaunchKernelGGL((k_mutlist<false>), dim3(row_blocks), dim3(256), 0, st, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
+                           c->d_cnt.as<u32>(), (const u32*)nullptr, (u64*)nullptr, rows, k, nchr, bp0, bpe, (int)has_mut, sd);
+        KCHECK();
+        GEVC(scan_u32(c, c->d_cnt.as<u32>(), rows, cs.moff[alt].as<u32>(), &tot));
+        GEVC(cs.mpos[alt].ensure(std::max<size_t>(tot, 2) * sizeof(u64), st, false, 1.25));
+        hipLaunchKernelGGL((k_mutlist<true>), dim3(row_blocks), dim3(256), 0, st, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
+                           (u32*)nullptr, cs.moff[alt].as<u32>(), cs.mpos[alt].as<u64>(), rows, k, nchr, bp0, bpe, (int)has_mut, sd);
+        KCHECK();
+        if (c->track_intervals) {
+            hipLaunchKernelGGL((k_parts<false>), dim3(row_blocks), dim3(256), 0, st, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
+                               c->d_cnt.as<u32>(), (const u32*)nullptr, (gev_part*)nullptr, rows, k, nchr, bp0, bpe, sd);
+            KCHECK();
+            GEVC(scan_u32(c, c->d_cnt.as<u32>(), rows, cs.poff[alt].as<u32>(), &tot));
+            GEVC(cs.parts[alt].ensure(std::max<size_t>(tot, 1) * sizeof(gev_part), st, false, 1.25));
+            hipLaunchKernelGGL((k_parts<true>), dim3(row_blocks), dim3(256), 0, st, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
+                               (u32*)nullptr, cs.poff[alt].as<u32>(), cs.parts[alt].as<gev_part>(), rows, k, nchr, bp0, bpe, sd);
+            KCHECK();
+        }
+        for (int p = 0; p < c->nphen; p++) {
+            CvStatic& V = P.cv[p][k];
+            const u32 nsub = 1 + c->rp_bits;
+            hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows * V.sub_w32 * nsub, 256)), dim3(256), 0, st,
+                               P.cvp[p][k][alt].as<u32>(), P.cvp[p][k][cur].as<u32>(), V.stride_w32, V.sub_w32, nsub, rows,
+                               V.d_pos_sorted.as<u64>(), V.C, k, nchr, sd);
+            KCHECK();
+            V.frq_valid = false;
+        }
+    }
+    HIPC(hipEventRecord(c->ev[2], st));
+    // ---- dense stitch of the genotype planes (the HBM-bound kernel)
+    for (int k = 0; k < nchr; k++) {
+        ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
+        const u32 chunks = (u32)(S.stride / 16);
+        // enough workgroups to fill 256 CUs even for small populations; one span >= 4 KiB
+        u32 bpr = 1;
+        while (rows * bpr < 4096 && chunks / (bpr * 2) >= 256) bpr *= 2;
+        const size_t nblk = rows * bpr;
+        if (nblk > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
+        hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)nblk), dim3(STITCH_THREADS), 0, st,
+                           cs.plane[alt].as<uint8_t>(), cs.plane[cur].as<uint8_t>(), S.stride, chunks, bpr,
+                           S.d_pos.as<u64>(), (u32)S.L, k, nchr, sd);
+        KCHECK();
+    }
+    HIPC(hipEventRecord(c->ev[3], st));
+    if (sex_out) HIPC(hipMemcpyAsync(sex_out, c->d_sex.p, n_people, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    float t;
+    HIPC(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); c->last_ms[0] = t;
+    HIPC(hipEventElapsedTime(&t, c->ev[2], c->ev[3])); c->last_ms[1] = t;
+    HIPC(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); c->last_ms[2] = t;
+    HIPC(hipEventElapsedTime(&t, c->ev[0], c->ev[3])); c->last_ms[3] = t;
+    P.cur = alt; P.n_people = n_people;
+    return GEV_OK;
+}
+
+// ---- Simulation::ras_compute_AD -----------------------------------------------------------
+int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, double* add_chr, double* dom_chr)
+{
+    GEVC(check_idx(c, pop, 0));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "compute_ad: population %d has no current generation", pop);
+    HIPC(hipSetDevice(c->device));
+    if (!c->pop[pop].cv[0][0].d_aptr.p) GEVC(check_multipop(c));
+    hipStream_t st = c->stream;
+    const size_t n = P.n_people, rows = 2 * n;
+    const int nchr = c->nchr, nphen = c->nphen;
+    GEVC(c->d_addchr.ensure(n * nchr * nphen * sizeof(double), st)); GEVC(c->d_domchr.ensure(n * nchr * nphen * sizeof(double), st));
+    GEVC(c->d_add.ensure(n * nphen * sizeof(double), st)); GEVC(c->d_dom.ensure(n * nphen * sizeof(double), st));
+    GEVC(c->d_flag.ensure(16, st));
+    HIPC(hipMemsetAsync(c->d_flag.p, 0xff, 4, st));
+    for (int p = 0; p < nphen; p++)
+        for (int k = 0; k < nchr; k++) {
+            CvStatic& V = P.cv[p][k]; ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
+            double* ao = c->d_addchr.as<double>() + (size_t)k * nphen + p;
+            double* dout = c->d_domchr.as<double>() + (size_t)k * nphen + p;
+            GEVC(c->d_cvm.ensure(std::max<size_t>(rows * V.sub_w32 * sizeof(u32), 16), st));
+            hipLaunchKernelGGL(k_cv_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st,
+                               P.cvp[p][k][P.cur].as<u32>(), V.stride_w32, V.sub_w32, c->d_cvm.as<u32>(), rows,
+                               cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), V.d_pos_sorted.as<u64>(), V.C);
+            HIPC(hipMemsetAsync(V.d_counts.p, 0, std::max<size_t>(V.C, 1) * sizeof(u32), st));
+            if (V.C) {
+                const unsigned gy = (unsigned)std::min<size_t>(std::max<size_t>(rows / 512, 1), 256);
+                hipLaunchKernelGGL(k_cv_count, dim3((unsigned)ceil_div(V.C, 256), gy), dim3(256), 0, st, c->d_cvm.as<u32>(), V.sub_w32, rows, V.C, V.d_counts.as<u32>());
+                hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, st, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n, V.d_frq.as<double>());
+            }
+            hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                               c->d_cvm.as<u32>(), V.sub_w32, P.cvp[p][k][P.cur].as<u32>(), V.stride_w32, c->rp_bits,
+                               V.d_col_of_icv.as<u32>(), V.d_frq.as<double>(), V.d_aptr.as<const double*>(), V.d_dptr.as<const double*>(), pop,
+                               V.d_pos_file.as<u64>(), S.rbp.front(), S.rbp.back(), V.vd, V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
+            KCHECK();
+            V.frq_valid = true;
+        }
+    hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_addchr.as<double>(), c->d_add.as<double>(), n, nchr, nphen);
+    hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_domchr.as<double>(), c->d_dom.as<double>(), n, nchr, nphen);
+    KCHECK();
+    u32 flag = 0;
+    HIPC(hipMemcpyAsync(&flag, c->d_flag.p, 4, hipMemcpyDeviceToHost, st));
+    if (additive) HIPC(hipMemcpyAsync(additive, c->d_add.p, n * nphen * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (dominance) HIPC(hipMemcpyAsync(dominance, c->d_dom.p, n * nphen * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (add_chr) HIPC(hipMemcpyAsync(add_chr, c->d_addchr.p, n * nchr * nphen * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (dom_chr) HIPC(hipMemcpyAsync(dom_chr, c->d_domchr.p, n * nchr * nphen * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if (flag != 0xffffffffu) return fail(GEV_ENAN, "Error: A or D is nan for human %u", flag);
+    return GEV_OK;
+}
+int gev_get_cv_freq(gev_ctx* c, int pop, int phen, int chr, double* frq, size_t C)
+{
+    GEVC(check_idx(c, pop, chr, phen));
+    CvStatic& V = c->pop[pop].cv[phen][chr];
+    if (!V.frq_valid) return fail(GEV_ESTATE, "get_cv_freq: call gev_compute_ad first");
+    if (C != V.C || !frq) return fail(GEV_EINVAL, "get_cv_freq: C=%zu, expected %u", C, V.C);
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipMemcpyAsync(frq, V.d_frq.p, C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return GEV_OK;
+}
+
+// ---- Simulation::ras_do_migration (row movement part) -------------------------------------
+struct Seg { int src_pop; std::vector<u32> people; };     // individuals (positions in src_pop's current generation)
+// rebuild population `dst` in its alternate buffers from segments of the CURRENT buffers; caller flips
+static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, size_t n_new)
+{
+    PopState& D = c->pop[dst];
+    hipStream_t st = c->stream;
+    const int alt = D.cur ^ 1;
+    const size_t rows_new = 2 * n_new;
+    // capacity of the alternate buffers (the current ones keep their content)
+    if (n_new > D.cap_people) GEVC(ensure_capacity(c, dst, n_new));
+    GEVC(c->d_cnt.ensure((rows_new + 1) * sizeof(u32), st));
+    for (int k = 0; k < c->nchr; k++) {
+        ChrStatic& S = D.cs[k]; ChrState& ds = D.st[k];
+        for (int pass = 0; pass < 2; pass++) {          // 0: mutation lists, 1: interval lists
+            if (pass == 1 && !c->track_intervals) continue;
+            size_t row0 = 0;
+            for (const Seg& sg : segs) {                // counts
+                if (sg.people.empty()) continue;
+                PopState& Sp = c->pop[sg.src_pop]; ChrState& ss = Sp.st[k];
+                std::vector<u32> map(2 * sg.people.size());
+                for (size_t j = 0; j < sg.people.size(); j++) { map[2 * j] = 2 * sg.people[j]; map[2 * j + 1] = 2 * sg.people[j] + 1; }
+                GEVC(h2d(c, c->d_map, map.data(), map.size() * sizeof(u32)));
+                const u32* soff = pass == 0 ? ss.moff[Sp.cur].as<u32>() : ss.poff[Sp.cur].as<u32>();
+                hipLaunchKernelGGL(k_csr_gather_count, dim3((unsigned)ceil_div(map.size(), 256)), dim3(256), 0, st, soff, c->d_map.as<u32>(), map.size(), c->d_cnt.as<u32>() + row0);
+                KCHECK();
+                HIPC(hipStreamSynchronize(st));
+                row0 += map.size();
+            }
+            u32 tot = 0;
+            u32* doff = pass == 0 ? ds.moff[alt].as<u32>() : ds.poff[alt].as<u32>();
+            GEVC(scan_u32(c, c->d_cnt.as<u32>(), rows_new, doff, &tot));
+            if (pass == 0) GEVC(ds.mpos[alt].ensure(std::max<size_t>(tot, 2) * sizeof(u64), st, false, 1.25));
+            else GEVC(ds.parts[alt].ensure(std::max<size_t>(tot, 1) * sizeof(gev_part), st, false, 1.25));
+            row0 = 0;
+            for (const Seg& sg : segs) {                // fill
+                if (sg.people.empty()) continue;
+                PopState& Sp = c->pop[sg.src_pop]; ChrState& ss = Sp.st[k];
+                std::vector<u32> map(2 * sg.people.size());
+                for (size_t j = 0; j < sg.people.size(); j++) { map[2 * j] = 2 * sg.people[j]; map[2 * j + 1] = 2 * sg.people[j] + 1; }
+                GEVC(h2d(c, c->d_map, map.data(), map.size() * sizeof(u32)));
+                if (pass == 0)
+                    hipLaunchKernelGGL((k_csr_gather_fill<u64>), dim3((unsigned)ceil_div(map.size(), 256)), dim3(256), 0, st,
+                                       ss.moff[Sp.cur].as<u32>(), ss.mpos[Sp.cur].as<u64>(), c->d_map.as<u32>(), map.size(), doff + row0, ds.mpos[alt].as<u64>());
+                else
+                    hipLaunchKernelGGL((k_csr_gather_fill<gev_part>), dim3((unsigned)ceil_div(map.size(), 256)), dim3(256), 0, st,
+                                       ss.poff[Sp.cur].as<u32>(), ss.parts[Sp.cur].as<gev_part>(), c->d_map.as<u32>(), map.size(), doff + row0, ds.parts[alt].as<gev_part>());
+                KCHECK();
+                HIPC(hipStreamSynchronize(st));
+                row0 += map.size();
+            }
+        }
+        // planes
+        size_t row0 = 0;
+        for (const Seg& sg : segs) {
+            if (sg.people.empty()) continue;
+            PopState& Sp = c->pop[sg.src_pop];
+            std::vector<u32> map(2 * sg.people.size());
+            for (size_t j = 0; j < sg.people.size(); j++) { map[2 * j] = 2 * sg.people[j]; map[2 * j + 1] = 2 * sg.people[j] + 1; }
+            GEVC(h2d(c, c->d_map, map.data(), map.size() * sizeof(u32)));
+            const u32 chunks = (u32)(S.stride / 16);
+            hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(map.size() * chunks, 256)), dim3(256), 0, st,
+                               (uint4*)(ds.plane[alt].as<uint8_t>() + row0 * S.stride), S.stride / 16,
+                               (const uint4*)Sp.st[k].plane[Sp.cur].p, Sp.cs[k].stride / 16, c->d_map.as<u32>(), map.size(), chunks);
+            for (int p = 0; p < c->nphen; p++) {
+                CvStatic& V = D.cv[p][k];
+                const u32 cch = V.stride_w32 / 4;
+                hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(map.size() * cch, 256)), dim3(256), 0, st,
+                                   (uint4*)(D.cvp[p][k][alt].as<u32>() + row0 * V.stride_w32), (size_t)cch,
+                                   (const uint4*)Sp.cvp[p][k][Sp.cur].p, (size_t)Sp.cv[p][k].stride_w32 / 4, c->d_map.as<u32>(), map.size(), cch);
+                V.frq_valid = false;
+            }
+            KCHECK();
+            HIPC(hipStreamSynchronize(st));
+            row0 += map.size();
+        }
+    }
+    return GEV_OK;
+}
+int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    if (n_moves && !moves) return fail(GEV_EINVAL, "migrate: null moves");
+    HIPC(hipSetDevice(c->device));
+    if (c->n_pop > 1 && !c->pop[0].cv[0][0].d_aptr.p) GEVC(check_multipop(c));
+    std::vector<std::vector<uint8_t>> gone(c->n_pop);
+    for (int p = 0; p < c->n_pop; p++) {
+        if (!c->pop[p].gen0) return fail(GEV_ESTATE, "migrate: population %d has no current generation", p);
+        gone[p].assign(c->pop[p].n_people, 0);
+    }
+    for (size_t i = 0; i < n_moves; i++) {
+        const gev_move& m = moves[i];
+        if (m.src_pop < 0 || m.src_pop >= c->n_pop || m.dst_pop < 0 || m.dst_pop >= c->n_pop || m.src_pop == m.dst_pop)
+            return fail(GEV_EINVAL, "migrate: move %zu has bad population indices", i);
+        if (m.src_pos >= c->pop[m.src_pop].n_people || gone[m.src_pop][m.src_pos]) return fail(GEV_EINVAL, "migrate: move %zu: position out of range or moved twice", i);
+        gone[m.src_pop][m.src_pos] = 1;
+    }
+    std::vector<std::vector<Seg>> plan(c->n_pop);
+    std::vector<size_t> n_new(c->n_pop);
+    for (int p = 0; p < c->n_pop; p++) {
+        Seg keep; keep.src_pop = p;
+        for (size_t i = 0; i < c->pop[p].n_people; i++) if (!gone[p][i]) keep.people.push_back((u32)i);   // stayers keep their order (:960-966)
+        plan[p].push_back(std::move(keep));
+    }
+    for (size_t i = 0; i < n_moves; i++) {                                                              // migrants appended in `moves` order (:971-981)
+        const gev_move& m = moves[i];
+        if (plan[m.dst_pop].back().src_pop != m.src_pop || plan[m.dst_pop].size() == 1) { Seg s; s.src_pop = m.src_pop; plan[m.dst_pop].push_back(std::move(s)); }
+        plan[m.dst_pop].back().people.push_back((u32)m.src_pos);
+    }
+    for (int p = 0; p < c->n_pop; p++) {
+        n_new[p] = 0;
+        for (auto& s : plan[p]) n_new[p] += s.people.size();
+        if (n_new[p] == 0) return fail(GEV_EINVAL, "migrate: population %d would become empty", p);
+    }
+    // grow every destination first (capacity growth copies the current buffers), then gather
+    for (int p = 0; p < c->n_pop; p++) if (n_new[p] > c->pop[p].cap_people) GEVC(ensure_capacity(c, p, n_new[p]));
+    for (int p = 0; p < c->n_pop; p++) GEVC(gather_population(c, p, plan[p], n_new[p]));
+    for (int p = 0; p < c->n_pop; p++) { c->pop[p].cur ^= 1; c->pop[p].n_people = n_new[p]; }
+    return GEV_OK;
+}
+int gev_export_size(gev_ctx*, int, const uint64_t*, size_t, size_t*) { return fail(GEV_EUNSUPPORTED, "gev_export_size: cross-GPU row exchange is not implemented yet"); }
+int gev_export_rows(gev_ctx*, int, const uint64_t*, size_t, void*, size_t) { return fail(GEV_EUNSUPPORTED, "gev_export_rows: cross-GPU row exchange is not implemented yet"); }
+int gev_remove_rows(gev_ctx*, int, const uint64_t*, size_t) { return fail(GEV_EUNSUPPORTED, "gev_remove_rows: cross-GPU row exchange is not implemented yet"); }
+int gev_import_rows(gev_ctx*, int, const void*, size_t, size_t) { return fail(GEV_EUNSUPPORTED, "gev_import_rows: cross-GPU row exchange is not implemented yet"); }
+
+// ---- output materialisation ---------------------------------------------------------------
+int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, u64* bits, size_t row_stride_words)
+{
+    GEVC(check_idx(c, pop, chr));
+    PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
+    if (!P.gen0) return fail(GEV_ESTATE, "download_haps: population %d has no current generation", pop);
+    if (row_begin + n_rows > 2 * P.n_people) return fail(GEV_EINVAL, "download_haps: rows [%zu,%zu) beyond 2*n_people=%zu", row_begin, row_begin + n_rows, 2 * P.n_people);
+    if (n_rows && (!bits || row_stride_words * 64 < S.L)) return fail(GEV_EINVAL, "download_haps: bad output buffer");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t max_rows = std::max<size_t>((64u << 20) / S.stride, 1);
+    GEVC(c->d_stage.ensure(std::min(max_rows, std::max<size_t>(n_rows, 1)) * S.stride, st));
+    const size_t copy_bytes = std::min(row_stride_words * 8, S.stride);
+    for (size_t r0 = 0; r0 < n_rows; r0 += max_rows) {
+        const size_t nr = std::min(max_rows, n_rows - r0);
+        HIPC(hipMemcpyAsync(c->d_stage.p, cs.plane[P.cur].as<uint8_t>() + (row_begin + r0) * S.stride, nr * S.stride, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_snp_apply_mut, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st,
+                           cs.plane[P.cur].as<u32>(), S.stride / 4, c->d_stage.as<u32>(), S.stride / 4, row_begin + r0, nr,
+                           cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)S.L);
+        KCHECK();
+        if (row_stride_words * 8 > copy_bytes)
+            for (size_t r = 0; r < nr; r++) memset((uint8_t*)(bits + (r0 + r) * row_stride_words) + copy_bytes, 0, row_stride_words * 8 - copy_bytes);
+        HIPC(hipMemcpy2DAsync(bits + r0 * row_stride_words, row_stride_words * 8, c->d_stage.p, S.stride, copy_bytes, nr, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+    }
+    return GEV_OK;
+}
+int gev_download_cv(gev_ctx* c, int pop, int phen, int chr, u64* bits, size_t row_stride_words)
+{
+    GEVC(check_idx(c, pop, chr, phen));
+    PopState& P = c->pop[pop]; CvStatic& V = P.cv[phen][chr]; ChrState& cs = P.st[chr];
+    if (!P.gen0) return fail(GEV_ESTATE, "download_cv: population %d has no current generation", pop);
+    if (!bits || row_stride_words * 64 < V.C) return fail(GEV_EINVAL, "download_cv: bad output buffer");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t rows = 2 * P.n_people;
+    GEVC(c->d_cvm.ensure(std::max<size_t>(rows * V.sub_w32 * sizeof(u32), 16), st));
+    GEVC(c->d_tmp.ensure(rows * row_stride_words * 8, st));
+    hipLaunchKernelGGL(k_cv_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st,
+                       P.cvp[phen][chr][P.cur].as<u32>(), V.stride_w32, V.sub_w32, c->d_cvm.as<u32>(), rows,
+                       cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), V.d_pos_sorted.as<u64>(), V.C);
+    HIPC(hipMemsetAsync(c->d_tmp.p, 0, rows * row_stride_words * 8, st));
+    if (V.C)
+        hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)ceil_div(rows * V.sub_w32, 256)), dim3(256), 0, st,
+                           c->d_cvm.as<u32>(), (size_t)V.sub_w32, c->d_tmp.as<u32>(), row_stride_words * 2, V.sub_w32, V.d_col_of_icv.as<u32>(), V.C, rows);
+    KCHECK();
+    HIPC(hipMemcpyAsync(bits, c->d_tmp.p, rows * row_stride_words * 8, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    return GEV_OK;
+}
+int gev_download_intervals(gev_ctx* c, int pop, int chr, gev_part* out, u64* hap_offsets, size_t* n_parts)
+{
+    GEVC(check_idx(c, pop, chr));
+    PopState& P = c->pop[pop]; ChrState& cs = P.st[chr];
+    if (!P.gen0) return fail(GEV_ESTATE, "download_intervals: population %d has no current generation", pop);
+    if (!c->track_intervals) return fail(GEV_ESTATE, "download_intervals: interval tracking is disabled");
+    if (!n_parts) return fail(GEV_EINVAL, "download_intervals: n_parts is null");
+    HIPC(hipSetDevice(c->device));
+    const size_t rows = 2 * P.n_people;
+    std::vector<u32> off(rows + 1);
+    HIPC(hipMemcpyAsync(off.data(), cs.poff[P.cur].p, (rows + 1) * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    *n_parts = off[rows];
+    if (hap_offsets) for (size_t r = 0; r <= rows; r++) hap_offsets[r] = off[r];
+    if (out && off[rows]) {
+        HIPC(hipMemcpyAsync(out, cs.parts[P.cur].p, (size_t)off[rows] * sizeof(gev_part), hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    return GEV_OK;
+}
+int gev_download_mutations(gev_ctx* c, int pop, int chr, u64* out, u64* hap_offsets, size_t* n_mut)
+{
+    GEVC(check_idx(c, pop, chr));
+    PopState& P = c->pop[pop]; ChrState& cs = P.st[chr];
+    if (!P.gen0) return fail(GEV_ESTATE, "download_mutations: population %d has no current generation", pop);
+    if (!n_mut) return fail(GEV_EINVAL, "download_mutations: n_mut is null");
+    HIPC(hipSetDevice(c->device));
+    const size_t rows = 2 * P.n_people;
+    std::vector<u32> off(rows + 1);
+    HIPC(hipMemcpyAsync(off.data(), cs.moff[P.cur].p, (rows + 1) * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    *n_mut = off[rows];
+    if (hap_offsets) for (size_t r = 0; r <= rows; r++) hap_offsets[r] = off[r];
+    if (out && off[rows]) {
+        HIPC(hipMemcpyAsync(out, cs.mpos[P.cur].p, (size_t)off[rows] * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    return GEV_OK;
+}
+
+// ---- introspection ------------------------------------------------------------------------
+int gev_pop_size(gev_ctx* c, int pop, size_t* n) { GEVC(check_idx(c, pop, 0)); if (!n) return fail(GEV_EINVAL, "null"); *n = c->pop[pop].n_people; return GEV_OK; }
+int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows)
+{
+    GEVC(check_idx(c, pop, chr));
+    PopState& P = c->pop[pop];
+    if (dptr) *dptr = P.st[chr].plane[P.cur].p;
+    if (row_stride_bytes) *row_stride_bytes = P.cs[chr].stride;
+    if (n_rows) *n_rows = 2 * P.n_people;
+    return GEV_OK;
+}
+int gev_stream(gev_ctx* c, void** s) { if (!c || !s) return fail(GEV_EINVAL, "null"); *s = (void*)c->stream; return GEV_OK; }
+int gev_last_reproduce_ms(gev_ctx* c, float ms[4]) { if (!c || !ms) return fail(GEV_EINVAL, "null"); for (int i = 0; i < 4; i++) ms[i] = c->last_ms[i]; return GEV_OK; }
+int gev_set_track_intervals(gev_ctx* c, int on) { if (!c) return fail(GEV_EINVAL, "null"); c->track_intervals = on != 0; return GEV_OK; }
+
+// ---- diagnostics (tests only; no simulation state involved) --------------------------------
+__global__ void __launch_bounds__(64) k_dbg_rand(const GevRngTables* __restrict__ T, u32 seed, u32 n, int* __restrict__ out)
+{
+    GlibcWave g; g.seed(T, seed);
+    for (u32 i = 0; i < n; i++) { const u32 v = g.out(T, i); if (threadIdx.x == 0) out[i] = (int)v; }
+}
+// one gamete of ras_sim_loc_rec: breakpoints + the next two rand() outputs
+__global__ void __launch_bounds__(64) k_dbg_sim_loc_rec(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int chr, u32 seed,
+                                                        u64* __restrict__ locs, u32 cap, u32* __restrict__ n_out, int* __restrict__ next2)
+{
+    const ChrDev& C = chrs[chr];
+    GlibcWave g; g.seed(T, seed);
+    u32 h = 0;
+    wave_scan_hits(T, seed + 1u, C.rthr, 0, C.R, [&](u32 row) {
+        const u64 v = C.rbp[row] + (u64)g.out(T, h) % C.bp_dist;
+        if (threadIdx.x == 0 && h < cap) locs[h] = v;
+        h++;
+    });
+    const u32 a = g.out(T, h), b = g.out(T, h + 1);
+    if (threadIdx.x == 0) { *n_out = h; next2[0] = (int)a; next2[1] = (int)b; }
+}
+int gev_dbg_tables(void* out, size_t bytes)
+{
+    if (bytes != sizeof(GevRngTables)) return fail(GEV_EINVAL, "gev_dbg_tables: expected %zu bytes", sizeof(GevRngTables));
+    GevRngTables T; gev_build_rng_tables(T); memcpy(out, &T, sizeof T); return GEV_OK;
+}
+int gev_dbg_threshold(double p, uint32_t out[4])
+{
+    GevThr t;
+    if (!gev_make_threshold(p, t)) return fail(GEV_EUNSUPPORTED, "window wider than 2");
+    out[0] = t.a_lo; out[1] = t.a_hi; out[2] = t.b0; out[3] = t.b1; return GEV_OK;
+}
+double gev_dbg_canonical(uint32_t a, uint32_t b) { return gev_canonical(a, b); }
+int gev_dbg_rand(gev_ctx* c, uint32_t seed, uint32_t n, int* out)
+{
+    if (!c || !out) return fail(GEV_EINVAL, "null");
+    HIPC(hipSetDevice(c->device));
+    GEVC(c->d_tmp.ensure(std::max<size_t>(n, 4) * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_dbg_rand, dim3(1), dim3(64), 0, c->stream, c->d_tables.as<GevRngTables>(), seed, n, c->d_tmp.as<int>());
+    KCHECK();
+    HIPC(hipMemcpyAsync(out, c->d_tmp.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return GEV_OK;
+}
+int gev_dbg_sim_loc_rec(gev_ctx* c, int pop, int chr, uint32_t seed, uint64_t* locs, uint32_t cap, uint32_t* n, int next2[2])
+{
+    GEVC(check_idx(c, pop, chr));
+    HIPC(hipSetDevice(c->device));
+    GEVC(finalize_static(c, pop));
+    GEVC(c->d_tmp.ensure((size_t)cap * 8 + 64, c->stream));
+    u64* dl = c->d_tmp.as<u64>(); u32* dn = (u32*)(dl + cap); int* dx = (int*)(dn + 2);
+    hipLaunchKernelGGL(k_dbg_sim_loc_rec, dim3(1), dim3(64), 0, c->stream, c->d_tables.as<GevRngTables>(), c->pop[pop].d_chrdev.as<ChrDev>(), chr, seed, dl, cap, dn, dx);
+    KCHECK();
+    HIPC(hipMemcpyAsync(n, dn, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(next2, dx, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpyAsync(locs, dl, (size_t)std::min(*n, cap) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return GEV_OK;
+}
+
+} // extern "C"

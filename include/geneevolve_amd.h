@@ -191,6 +191,17 @@ int gev_last_reproduce_ms(gev_ctx*, float ms[4]);
 /* enable/disable keeping the ancestry interval state on the device (default on) */
 int gev_set_track_intervals(gev_ctx*, int on);
 
+/* ---- diagnostics: RNG building blocks exposed for the parity tests (no simulation state) ----
+ * gev_dbg_tables / gev_dbg_threshold / gev_dbg_canonical run on the host (table and threshold
+ * construction); gev_dbg_rand / gev_dbg_sim_loc_rec run the device generators:
+ * glibc srand(seed);rand()xN and one Simulation::ras_sim_loc_rec call (src/Simulation.cpp:2973). */
+int    gev_dbg_tables(void* out, size_t bytes);
+int    gev_dbg_threshold(double p, uint32_t out[4] /* a_lo, a_hi, b0, b1 */);
+double gev_dbg_canonical(uint32_t a, uint32_t b);
+int    gev_dbg_rand(gev_ctx*, uint32_t seed, uint32_t n, int* out);
+int    gev_dbg_sim_loc_rec(gev_ctx*, int pop, int chr, uint32_t seed, uint64_t* locs, uint32_t cap,
+                           uint32_t* n, int next2[2]);
+
 #ifdef __cplusplus
 }
 #endif

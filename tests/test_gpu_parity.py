@@ -1,0 +1,194 @@
+"""GPU parity tests (pytest -m gpu): the HIP library, called through the C-ABI, against
+ (1) the golden fixtures generated from the real reference (bit-exact, incl. FP64 A/D),
+ (2) the CPU oracle on seeded synthetic inputs,
+ (3) size-independent properties at larger sizes."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from geneevolve_amd import capi
+from geneevolve_amd.host import GlobSeedStream, Simulation, SyntheticConfig, synthetic_random_mate
+from oracle import oracle_api
+from tests import helpers
+from tests.synth import synth_packed
+
+pytestmark = pytest.mark.gpu
+
+
+def kat_lines(tag):
+    with gzip.open(os.path.join(helpers.GOLDEN, "kat.txt.gz"), "rt") as f:
+        return [l.split() for l in f if l.startswith(tag + " ")]
+
+
+def test_native_library_is_the_hip_build(gpu_lib):
+    assert gpu_lib.path.endswith("geneevolve_amd/csrc/libgeneevolve_amd.so")
+    v = gpu_lib.lib.gev_version; v.restype = C.c_char_p
+    assert b"gfx950" in v()
+
+
+def test_device_glibc_rand_matches_oracle(gpu_lib, oracle_lib):
+    ctx = gpu_lib.create(1, 1, 1)
+    rs = np.random.RandomState(3)
+    for seed in [0, 1, 2, 12345, 2147483646, 2147483647, 2147483648, 4294967295] + [int(x) for x in rs.randint(0, 2**32, 20, dtype=np.uint64)]:
+        out = np.zeros(200, dtype=np.int32)
+        gpu_lib.check(gpu_lib.lib.gev_dbg_rand(ctx.h, C.c_uint32(seed), C.c_uint32(200), out.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(out, oracle_api.kat_rand(oracle_lib, seed, 200)), f"srand({seed})"
+    ctx.close()
+
+
+def test_device_sim_loc_rec_matches_reference_vectors(gpu_lib):
+    m = kat_lines("LOCMAP")[0]
+    R, bp0, dist = int(m[1]), int(m[2]), int(m[3])
+    prob = np.array([float.fromhex(x) for x in m[4:]])
+    bp = (bp0 + dist * np.arange(R)).astype(np.uint64)
+    ctx = gpu_lib.create(1, 1, 1)
+    ctx.set_rmap(0, 0, bp, prob, dist)
+    for t in kat_lines("LOC"):
+        seed = int(t[1]); nxt = [int(t[2]), int(t[3])]; n = int(t[4])
+        want = np.array([int(x) for x in t[5:5 + n]], dtype=np.uint64)
+        locs = np.zeros(512, dtype=np.uint64); k = C.c_uint32(); nx = (C.c_int * 2)()
+        gpu_lib.check(gpu_lib.lib.gev_dbg_sim_loc_rec(ctx.h, 0, 0, C.c_uint32(seed), locs.ctypes.data_as(C.c_void_p), C.c_uint32(512), C.byref(k), nx))
+        assert k.value == n - 2, f"seed {seed}: crossover count"
+        assert np.array_equal(locs[:k.value], want[1:-1]), f"seed {seed}: breakpoints"
+        assert [nx[0], nx[1]] == nxt, f"seed {seed}: rand() state after the call"
+    ctx.close()
+
+
+def test_synth_founders_match_specification(gpu_lib):
+    cfg = SyntheticConfig(64, 1000, n_cv=77)
+    ctx = gpu_lib.create(1, 1, 1)
+    cfg.apply_static(ctx)
+    ctx.synth_founders(0, 0, 128, 4242)
+    ctx.synth_cv_founders(0, 0, 0, 128, 777)
+    ctx.init_gen0(0, 64, 5)
+    got = ctx.download_haps(0, 0)
+    want = synth_packed(4242, 128, 1000)
+    assert np.array_equal(got, want)
+    gotcv = ctx.download_cv(0, 0, 0)
+    assert np.array_equal(gotcv, synth_packed(777, 128, 77))
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k"])
+def test_gpu_replays_reference_generations_bit_exact(gpu_lib, oracle_lib, case):
+    fx = helpers.load_fixture(case)
+    seeds = helpers.find_gen0_seeds(fx, oracle_lib)
+    n_dense = helpers.replay_case(gpu_lib, fx, seeds, f"gpu/{case}")
+    assert n_dense >= 2
+
+
+def run_pair(gpu_lib, oracle_lib, cfg, n_gen, seed, check_every=1):
+    """same seeded synthetic scenario through the HIP library and the oracle"""
+    g = gpu_lib.create(1, cfg.nchr, cfg.nphen)
+    o = oracle_lib.create(1, cfg.nchr, cfg.nphen)
+    cfg.apply_static(g); cfg.apply_static(o)
+    nh = 2 * cfg.n_ind
+    for c in range(cfg.nchr):
+        g.synth_founders(0, c, nh, cfg.seed + c)
+        o.upload_founders(0, c, synth_packed(cfg.seed + c, nh, cfg.n_loci), cfg.n_loci)
+        for p in range(cfg.nphen):
+            ncv = len(cfg.cv[p][c][0])
+            g.synth_cv_founders(0, p, c, nh, cfg.seed + 100 + 7 * p + c)
+            o.upload_cv_founders(0, p, c, synth_packed(cfg.seed + 100 + 7 * p + c, nh, ncv), ncv)
+    sg = Simulation(g, seed, cfg.nchr, cfg.with_mutation)
+    so = Simulation(o, seed, cfg.nchr, cfg.with_mutation)
+    sg.ras_initial_human_gen0(0, cfg.n_ind); so.ras_initial_human_gen0(0, cfg.n_ind)
+    assert np.array_equal(sg.sex[0], so.sex[0])
+    rng = np.random.default_rng(seed)
+    for gen in range(1, n_gen + 1):
+        couples = synthetic_random_mate(sg.sex[0], cfg.n_ind, rng)
+        sg.couples[0] = couples; so.couples[0] = couples
+        sx_g = sg.reproduce(0, gen); sx_o = so.reproduce(0, gen)
+        assert np.array_equal(sx_g, sx_o), f"sex differs at generation {gen}"
+        ag = sg.ras_compute_AD(0, gen, per_chr=True); ao = so.ras_compute_AD(0, gen, per_chr=True)
+        for x, y, nm in zip(ag, ao, ("additive", "dominance", "additive_chr", "dominance_chr")):
+            assert helpers.bits_equal(x, y), f"{nm} not bit-identical at generation {gen}"
+        if gen % check_every == 0 or gen == n_gen:
+            for c in range(cfg.nchr):
+                assert np.array_equal(g.download_haps(0, c), o.download_haps(0, c)), f"dense genotypes differ (gen {gen} chr {c})"
+                pg, og = g.download_intervals(0, c); po, oo = o.download_intervals(0, c)
+                assert np.array_equal(og, oo) and np.array_equal(pg, po), f"interval lists differ (gen {gen} chr {c})"
+                mg, mog = g.download_mutations(0, c); mo, moo = o.download_mutations(0, c)
+                assert np.array_equal(mog, moo) and np.array_equal(mg, mo), f"mutation lists differ (gen {gen} chr {c})"
+                for p in range(cfg.nphen):
+                    assert np.array_equal(g.download_cv(0, p, c), o.download_cv(0, p, c))
+                    assert helpers.bits_equal(g.get_cv_freq(0, p, c), o.get_cv_freq(0, p, c))
+    g.close(); o.close()
+
+
+def test_gpu_vs_oracle_task_parallel_mode(gpu_lib, oracle_lib):
+    # hot maps: ~10 crossovers and ~10 mutations per gamete, 2 chromosomes, 2 phenotypes, dominance on
+    cfg = SyntheticConfig(300, 5000, nchr=2, chrom_bp=2_000_000, map_step=1000, rec_per_row=5e-3, mut_per_row=5e-3,
+                          n_cv=300, nphen=2, seed=11, vd=0.4)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=5, seed=2024)
+
+
+def test_gpu_vs_oracle_serial_chain_mode(gpu_lib, oracle_lib):
+    cfg = SyntheticConfig(200, 3000, nchr=3, chrom_bp=1_000_000, map_step=1000, rec_per_row=3e-3, n_cv=100, seed=5, with_mutation=False)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=4, seed=99)
+
+
+def test_gpu_vs_oracle_many_crossovers_per_gamete(gpu_lib, oracle_lib):
+    # > 64 rand() outputs per srand (second output block) and > STITCH_KMAX boundaries per row
+    cfg = SyntheticConfig(40, 40000, nchr=1, chrom_bp=4_000_000, map_step=1000, rec_per_row=0.1, mut_per_row=0.05, n_cv=200, seed=3, vd=0.1)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=3, seed=7)
+
+
+def test_config1_shape_against_oracle(gpu_lib, oracle_lib):
+    # BASELINE config 1 shape: 1k individuals x 10k SNPs, 1 chr of 100 Mb, 2001 map rows, 1000 CVs
+    cfg = SyntheticConfig(1000, 10000, seed=12345)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=10, seed=12345, check_every=5)
+
+
+def test_edge_cases(gpu_lib, oracle_lib):
+    cfg = SyntheticConfig(8, 130, nchr=1, chrom_bp=100_000, map_step=1000, rec_per_row=0.02, mut_per_row=0.02, n_cv=3, seed=9)
+    g = gpu_lib.create(1, 1, 1); o = oracle_lib.create(1, 1, 1)
+    for ctx in (g, o):
+        cfg.apply_static(ctx)
+    g.synth_founders(0, 0, 16, 1); o.upload_founders(0, 0, synth_packed(1, 16, 130), 130)
+    g.synth_cv_founders(0, 0, 0, 16, 2); o.upload_cv_founders(0, 0, 0, synth_packed(2, 16, 3), 3)
+    g.init_gen0(0, 8, 77); o.init_gen0(0, 8, 77)
+    # ragged families: zero-offspring couples, inbred couples skipped, one big family, population shrinks then grows
+    couples = np.array([[0, 1, 0, 0], [2, 3, 1, 5], [4, 5, 0, 7], [6, 7, 0, 1], [1, 0, 0, 2]])
+    gs = GlobSeedStream(5).draw(1 + 10)
+    assert np.array_equal(g.reproduce(0, couples, gs[0], gs[1:]), o.reproduce(0, couples, gs[0], gs[1:]))
+    assert g.pop_size(0) == 10
+    assert np.array_equal(g.download_haps(0, 0), o.download_haps(0, 0))
+    couples = np.array([[i % 10, (i * 3 + 1) % 10, 0, 3] for i in range(12)])
+    gs = GlobSeedStream(6).draw(1 + 36)
+    assert np.array_equal(g.reproduce(0, couples, gs[0], gs[1:]), o.reproduce(0, couples, gs[0], gs[1:]))
+    assert np.array_equal(g.download_haps(0, 0), o.download_haps(0, 0))
+    # error behaviour: wrong n_people / out-of-range positions / bad seeds count are refused, state untouched
+    with pytest.raises(capi.GevError):
+        g.reproduce(0, np.array([[0, 99, 0, 1]]), 1, np.array([1], dtype=np.uint32))
+    with pytest.raises(capi.GevError):
+        g.reproduce(0, np.array([[0, 1, 0, 2]]), 1, np.array([1], dtype=np.uint32))
+    assert g.pop_size(0) == 36
+    g.close(); o.close()
+
+
+def test_full_row_properties_at_scale(gpu_lib):
+    """size-independent properties where the oracle would be too slow: 20k individuals x 200k loci.
+    With recombination and mutation switched off every offspring haplotype must equal one of its
+    parent's two haplotypes (k = 0 path), and allele counts are conserved under 2 offspring/couple."""
+    n, L = 20000, 200000
+    cfg = SyntheticConfig(n, L, rec_per_row=0.0, mut_per_row=0.0, n_cv=100, seed=1)
+    g = gpu_lib.create(1, 1, 1)
+    cfg.apply_static(g)
+    g.synth_founders(0, 0, 2 * n, 1); g.synth_cv_founders(0, 0, 0, 2 * n, 2)
+    sex = g.init_gen0(0, n, 1)
+    parents = g.download_haps(0, 0, 0, 2000)
+    rng = np.random.default_rng(1)
+    fa = rng.integers(0, 1000, n); mo = rng.integers(0, 1000, n)
+    c = np.stack([fa, mo, np.zeros(n, dtype=np.int64), np.ones(n, dtype=np.int64)], axis=1)
+    seeds = GlobSeedStream(3).draw(1 + n)
+    g.reproduce(0, c, seeds[0], seeds[1:])
+    kids = g.download_haps(0, 0, 0, 4000)
+    for i in range(2000):
+        for s, par in ((0, fa[i]), (1, mo[i])):
+            row = kids[2 * i + s]
+            assert np.array_equal(row, parents[2 * par]) or np.array_equal(row, parents[2 * par + 1])
+    g.close()

@@ -1,0 +1,43 @@
+"""CPU tests of the host-side mirror (geneevolve_amd/host.py)."""
+import gzip
+import os
+
+import numpy as np
+
+from geneevolve_amd.host import GlobSeedStream, SyntheticConfig, synthetic_random_mate
+from oracle import oracle_api
+from tests import helpers
+
+
+def test_glob_seed_stream_matches_reference_vectors():
+    with gzip.open(os.path.join(helpers.GOLDEN, "kat.txt.gz"), "rt") as f:
+        rows = [l.split() for l in f if l.startswith("GLOB ")]
+    assert rows
+    for t in rows:
+        want = np.array([int(x) for x in t[2:]], dtype=np.uint32)
+        g = GlobSeedStream(int(t[1]))
+        got = np.concatenate([g.draw(5), g.draw(len(want) - 5)])      # split draws keep the engine state
+        assert np.array_equal(got, want)
+
+
+def test_glob_seed_stream_long_run_with_rejections(oracle_lib):
+    n = 200000                                                   # ~45 rejections expected
+    want = oracle_api.kat_uint(oracle_lib, 12345, 1, 1000000, n).astype(np.uint32)
+    g = GlobSeedStream(12345)
+    got = np.concatenate([g.draw(70000), g.draw(1), g.draw(n - 70001)])
+    assert np.array_equal(got, want)
+
+
+def test_fixture_gen0_seed_is_first_glob_draw(oracle_lib):
+    fx = helpers.load_fixture("ex1sub")
+    seeds = helpers.find_gen0_seeds(fx, oracle_lib)
+    assert seeds[0] == int(GlobSeedStream(int(fx["seed"])).draw(1)[0])
+
+
+def test_synthetic_random_mate_shapes():
+    rng = np.random.default_rng(0)
+    sex = rng.integers(1, 3, 1000).astype(np.uint8)
+    c = synthetic_random_mate(sex, 1000, rng)
+    assert len(c) == 1000 and (sex[c["pos_male"]] == 1).all() and (sex[c["pos_female"]] == 2).all()
+    cfg = SyntheticConfig(100, 1000, n_cv=50)
+    assert len(cfg.rmap_bp) == 2001 and cfg.rmap_prob[0] == 0 and len(cfg.snp_pos) == 1000
