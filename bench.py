@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- generations/sec of the reproduction hot path (gev_reproduce + gev_compute_ad)
+on BASELINE.json's config 2: 100k individuals x 1M biallelic SNPs, 1 chromosome of 100 Mb,
+uniform recombination map (2001 rows, 5e-4/row), mutation 1e-8/bp (5e-4/row), 1000 CVs.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; each rank advances its OWN population of the full config-2 size (weak
+scaling: populations shard across GPUs); no data-path collective is
+needed without migration.  A step = one generation: host makes the couples list from the
+returned sexes (mating is outside the hot path), then Simulation::reproduce and
+Simulation::ras_compute_AD run on the GPU through the C-ABI.  The founder panel is generated on
+the device before the timed region, so genotype state is resident in HBM throughout.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_rows):
+algorithmic bytes per launch = 2N rows x (L/8 read + L/8 written) = N*L/2, divided by its
+duration measured with HIP events on the library's own stream.  `cpu_baseline` times the
+bit-exact CPU oracle (a port of the reference algorithm, oracle/gev_oracle.cpp) on a bounded
+sample of the same workload on this box's host cores (1 thread: the reference is single threaded).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(args, n_loci_unused):
+    """oracle on a bounded sample: N_s individuals, same maps / CVs; the reference's (and the
+    oracle's) generation cost is linear in N and independent of the SNP count,
+    so generations/sec at N = 100k is rate(N_s) * N_s / N."""
+    from geneevolve_amd.host import Simulation, SyntheticConfig, synthetic_random_mate
+    from oracle import oracle_api
+    from tests.synth import synth_packed
+    ns = args.cpu_sample_ind
+    cfg = SyntheticConfig(ns, 1024, seed=12345)
+    ol = oracle_api.load()
+    o = ol.create(1, 1, 1)
+    cfg.apply_static(o)
+    o.upload_founders(0, 0, synth_packed(1, 2 * ns, 1024), 1024)
+    o.upload_cv_founders(0, 0, 0, synth_packed(2, 2 * ns, 1000), 1000)
+    so = Simulation(o, 12345, 1, True)
+    so.ras_initial_human_gen0(0, ns)
+    rng = np.random.default_rng(0)
+    times = []
+    for gen in range(1, args.cpu_sample_gens + 1):
+        so.couples[0] = synthetic_random_mate(so.sex[0], ns, rng)
+        t0 = time.perf_counter()
+        so.reproduce(0, gen)
+        so.ras_compute_AD(0, gen)
+        times.append(time.perf_counter() - t0)
+    o.close()
+    per_gen = float(np.mean(times))
+    return {"value": (1.0 / per_gen) * ns / args.n_ind, "unit": "generations/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (bit-exact CPU port) timed on {ns} individuals x {args.cpu_sample_gens} generations "
+                      f"({per_gen:.2f} s/generation), same maps/CVs/mutation rate; scaled linearly in N to {args.n_ind} individuals "
+                      f"(generation cost is independent of the SNP count); host has {os.cpu_count()} cores, 1 used"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-ind", type=int, default=100_000)
+    ap.add_argument("--n-loci", type=int, default=1_000_000)
+    ap.add_argument("--n-cv", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-ind", type=int, default=20000)
+    ap.add_argument("--cpu-sample-gens", type=int, default=4)
+    ap.add_argument("--no-intervals", action="store_true", help="do not keep the ancestry interval state on the device")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from geneevolve_amd.capi import GevLibrary
+    from geneevolve_amd.host import Simulation, SyntheticConfig, synthetic_random_mate
+    lib = GevLibrary()                                   # the HIP library or nothing
+    cfg = SyntheticConfig(args.n_ind, args.n_loci, n_cv=args.n_cv, seed=12345 + rank)
+    ctx = lib.create(1, 1, 1, local_rank)
+    if args.no_intervals:
+        ctx.set_track_intervals(False)
+    cfg.apply_static(ctx)
+    ctx.synth_founders(0, 0, 2 * args.n_ind, 1000 + rank)
+    ctx.synth_cv_founders(0, 0, 0, 2 * args.n_ind, 2000 + rank)
+    sim = Simulation(ctx, 12345 + rank, 1, True)
+    sim.ras_initial_human_gen0(0, args.n_ind)
+    rng = np.random.default_rng(rank)
+    total = args.warmup + args.steps
+    # the ras_glob_seed() stream is a pure function of --seed and of counts known in advance
+    # (1 + N*nchr draws per generation): draw it before the timed region
+    seeds = [sim.ras_glob_seed(1 + args.n_ind) for _ in range(total)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stitch_ms, sample_ms, sparse_ms, ad_ms = [], [], [], []
+
+    def step(i):
+        sim.couples[0] = synthetic_random_mate(sim.sex[0], args.n_ind, rng)     # host mating (outside the hot path)
+        sim.reproduce(0, i + 1, seeds=seeds[i])                                  # Simulation::reproduce
+        t0 = time.perf_counter()
+        sim.ras_compute_AD(0, i + 1)                                             # Simulation::ras_compute_AD
+        ad_ms.append((time.perf_counter() - t0) * 1e3)
+        ms = ctx.last_reproduce_ms()
+        sample_ms.append(ms[0]); stitch_ms.append(ms[1]); sparse_ms.append(ms[2])
+
+    for i in range(args.warmup):
+        step(i)
+    del stitch_ms[:], sample_ms[:], sparse_ms[:], ad_ms[:]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        gens_per_s = world * args.steps / dt
+        alg_bytes = args.n_ind * args.n_loci / 2.0          # per stitch launch (1 chromosome)
+        stitch = float(np.mean(stitch_ms))
+        achieved = alg_bytes / (stitch * 1e-3) / 1e9
+        out = {
+            "metric": "generations/sec", "value": gens_per_s,
+            "unit": f"generations/s of {args.n_ind} individuals x {args.n_loci} loci populations (summed over GPUs)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 bit-planes + f64 A/D",
+            "data": "synthetic (device-generated founder panel, uniform maps, SURVEY.md 8(d) config C2)",
+            "config": {"workload": "BASELINE config 2: 100k individuals x 1M SNPs, 1 population per GPU, 1 chromosome (100 Mb), "
+                                   "uniform recombination map 2001 rows @ 5e-4, mutation 1e-8/bp, 1000 CVs, random mating",
+                       "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU",
+                       "interval_state_tracked": not args.no_intervals},
+            "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci / dt,
+            "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
+                         "dense_stitch": stitch, "compute_ad_incl_copy": float(np.mean(ad_ms))},
+            "roofline": {"bound": "hbm", "kernel": "k_stitch_rows", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": stitch},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.n_loci)
+            out["gpu_over_cpu"] = (gens_per_s / world) / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
