@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "compute_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_cv", "download_intervals", "download_mutations",
-    "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals",
+    "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -274,6 +274,9 @@ class GevContext:
         ms = (C.c_float * 4)()
         self._call("last_reproduce_ms", ms)
         return [float(x) for x in ms]
+
+    def set_stitch_mode(self, mode):
+        self._call("set_stitch_mode", C.c_int(mode))
 
     def set_track_intervals(self, on):
         self._call("set_track_intervals", C.c_int(1 if on else 0))

@@ -397,6 +397,137 @@ __global__ void __launch_bounds__(STITCH_THREADS) k_stitch_rows(
         }
     }
 }
+// ------------------------------------------------------------------------------------------
+// K5, parent-major form (the production path).  Every gamete of one parent reads the same two
+// rows and needs, in expectation, half of each.  One workgroup per PARENT: per 16-byte chunk it
+// loads row0 and/or row1 only if some gamete of the group needs it, then writes every gamete's
+// chunk.  With g gametes per parent the fraction of the parent's 2*L/8 bytes that is read is
+// 1-2^-g in expectation, so HBM reads fall below the per-gamete algorithmic L/8 (random mating,
+// g ~ Poisson(2): 0.63 of it) while the algorithmic work per generation is unchanged.
+// Grouping (gametes by source individual) is a counting sort: k_group_hist -> scan -> k_group_fill.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_group_hist(const u32* __restrict__ father, const u32* __restrict__ mother, size_t n_rows_out, u32* __restrict__ hist)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows_out) return;
+    atomicAdd(&hist[(r & 1) ? mother[r >> 1] : father[r >> 1]], 1u);
+}
+__global__ void __launch_bounds__(256) k_group_fill(const u32* __restrict__ father, const u32* __restrict__ mother, size_t n_rows_out,
+                                                    const u32* __restrict__ goff, u32* __restrict__ cursor, u32* __restrict__ glist)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows_out) return;
+    const u32 p = (r & 1) ? mother[r >> 1] : father[r >> 1];
+    glist[goff[p] + atomicAdd(&cursor[p], 1u)] = (u32)r;      // order inside a group is irrelevant: every gamete owns its output row
+}
+#define PM_GMAX 16           // gametes of one parent handled per pass
+#define PM_KTOT 256          // their boundaries staged in LDS
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4u mask_from(u32 rel)           // ones at bit positions >= rel of a 128-bit chunk
+{
+    v4u t;
+    t.x = rel < 32 ? 0xffffffffu << rel : 0u;
+    t.y = rel <= 32 ? 0xffffffffu : (rel < 64 ? 0xffffffffu << (rel - 32) : 0u);
+    t.z = rel <= 64 ? 0xffffffffu : (rel < 96 ? 0xffffffffu << (rel - 64) : 0u);
+    t.w = rel <= 96 ? 0xffffffffu : (rel < 128 ? 0xffffffffu << (rel - 96) : 0u);
+    return t;
+}
+// boundary m of a staged gamete as a locus index: from LDS, or (one oversize gamete) from global memory
+struct PmIdx {
+    const u32* lds; const u64* bk; const u64* pos; u32 L; bool big;
+    __device__ __forceinline__ u32 at(u32 m) const { return big ? lower_bound_u64(pos, L, bk[m]) : lds[m]; }
+};
+// #{boundaries <= bit0} and the first boundary after them
+__device__ __forceinline__ void pm_locate(const PmIdx& I, u32 k, u32 bit0, u32& cnt, u32& nxt)
+{
+    if (k <= 8 && !I.big) { cnt = 0; for (u32 m = 0; m < k; m++) cnt += (I.lds[m] <= bit0); }
+    else { u32 lo = 0, hi = k; while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (I.at(mid) <= bit0) lo = mid + 1; else hi = mid; } cnt = lo; }
+    nxt = cnt < k ? I.at(cnt) : 0xffffffffu;
+}
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(256) k_stitch_parent(
+    uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t stride, u32 chunks_per_row, u32 blocks_per_parent,
+    const u64* __restrict__ pos, u32 L, int chr, int nchr, const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd)
+{
+    __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big;
+    const u32 parent = blockIdx.x / blocks_per_parent, span = blockIdx.x % blocks_per_parent;
+    const u32 g0 = goff[parent], g1 = goff[parent + 1];
+    if (g0 == g1) return;
+    const v4u* __restrict__ R0 = (const v4u*)(src + (size_t)(2 * parent) * stride);
+    const v4u* __restrict__ R1 = (const v4u*)(src + (size_t)(2 * parent + 1) * stride);
+    const u32 per_block = (chunks_per_row + blocks_per_parent - 1) / blocks_per_parent;
+    const u32 q0 = span * per_block, q1 = min(q0 + per_block, chunks_per_row);
+    u32 gb = g0;
+    while (gb < g1) {
+        __syncthreads();                                   // previous batch consumed
+        if (threadIdx.x == 0) {
+            u32 n = 0, kt = 0, big = 0;
+            while (gb + n < g1 && n < PM_GMAX) {
+                const u32 row = glist[gb + n];
+                const size_t G = 2 * ((size_t)(row >> 1) * nchr + chr) + (row & 1);
+                const u32 k = sd.k[G];
+                if (kt + k > PM_KTOT) { if (n == 0) { big = 1; } else break; }
+                s_row[n] = row; s_start[n] = sd.start[G]; s_k[n] = k; s_kb[n] = kt; s_bkoff[n] = sd.bk_off[G];
+                kt += k; n++;
+                if (big) break;
+            }
+            s_n = n; s_big = big;
+        }
+        __syncthreads();
+        const u32 n = s_n; const bool big = s_big != 0;
+        if (!big)
+            for (u32 j = 0; j < n; j++)
+                for (u32 m = threadIdx.x; m < s_k[j]; m += 256) s_idx[s_kb[j] + m] = lower_bound_u64(pos, L, sd.bk[s_bkoff[j] + m]);
+        __syncthreads();
+        for (u32 q = q0 + threadIdx.x; q < q1; q += 256 * UNROLL) {
+            bool need0[UNROLL], need1[UNROLL];
+            v4u a[UNROLL], b[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                need0[u] = false; need1[u] = false;
+                const u32 qq = q + u * 256;
+                if (qq >= q1) continue;
+                const u32 bit0 = qq * 128u, bit1 = bit0 + 128u;
+                for (u32 j = 0; j < n; j++) {
+                    const PmIdx I{s_idx + s_kb[j], sd.bk + s_bkoff[j], pos, L, big};
+                    u32 cnt, nxt; pm_locate(I, s_k[j], bit0, cnt, nxt);
+                    const u32 sel = s_start[j] ^ (cnt & 1u);
+                    const bool mixed = nxt < bit1;
+                    need0[u] |= mixed || sel == 0u; need1[u] |= mixed || sel == 1u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const u32 qq = q + u * 256;
+                if (need0[u]) a[u] = NT ? __builtin_nontemporal_load(&R0[qq]) : R0[qq];
+                if (need1[u]) b[u] = NT ? __builtin_nontemporal_load(&R1[qq]) : R1[qq];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const u32 qq = q + u * 256;
+                if (qq >= q1) continue;
+                const u32 bit0 = qq * 128u, bit1 = bit0 + 128u;
+                for (u32 j = 0; j < n; j++) {
+                    const PmIdx I{s_idx + s_kb[j], sd.bk + s_bkoff[j], pos, L, big};
+                    const u32 k = s_k[j];
+                    u32 cnt, nxt; pm_locate(I, k, bit0, cnt, nxt);
+                    const u32 sel = s_start[j] ^ (cnt & 1u);
+                    v4u o;
+                    if (nxt >= bit1) o = sel ? b[u] : a[u];
+                    else {
+                        v4u mask = sel ? (v4u)(0xffffffffu) : (v4u)(0u);       // 1 = take row1
+                        for (u32 m = cnt; m < k; m++) { const u32 id = I.at(m); if (id >= bit1) break; mask ^= mask_from(id - bit0); }
+                        o = (a[u] & ~mask) | (b[u] & mask);
+                    }
+                    v4u* D = (v4u*)(dst + (size_t)s_row[j] * stride);
+                    if (NT) __builtin_nontemporal_store(o, &D[qq]); else D[qq] = o;
+                }
+            }
+        }
+        gb += n;
+    }
+}
+
 // small planes (CV grid: ~125 B rows): one thread = one 32-bit word of one sub-row
 __global__ void __launch_bounds__(256) k_stitch_small(
     u32* __restrict__ dst, const u32* __restrict__ src, u32 stride_w32, u32 sub_w32, u32 nsub, size_t n_rows_out,
@@ -603,6 +734,69 @@ __global__ void __launch_bounds__(256) k_ad_accumulate(
         const double ct = (t == 0) ? (-2 * p * p) : (t == 1 ? (2 * p * q) : (-2 * q * q));
         D_chr += ct * d;
     }
+    add_out[ih * out_stride] = A_chr;
+    dom_out[ih * out_stride] = D_chr;
+    if (A_chr != A_chr || D_chr != D_chr) atomicMin(nan_flag, (u32)(ih < 0xffffffffull ? ih : 0xfffffffeull));
+}
+// Single-root-population fast path.  Per CV the three possible contributions are computed once
+// with EXACTLY the expressions of the per-individual loop (same operations, same order, so the
+// sums stay bit-identical):  tab[icv] = { (0-2p)alpha, (1-2p)alpha, (2-2p)alpha, -2pp*d, 2pq*d, -2qq*d }.
+__global__ void k_cv_table(const u32* __restrict__ counts, const u32* __restrict__ col_of_icv, u32 Cn, size_t n_human,
+                           const double* __restrict__ a_file, const double* __restrict__ d_file, const u64* __restrict__ cvpos_file,
+                           u64 bp0, u64 bp_end, double vd, double* __restrict__ frq, double* __restrict__ tab)
+{
+    const u32 icv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (icv >= Cn) return;
+    const double f = (double)counts[col_of_icv[icv]];
+    const double p = f / (double)(2 * n_human);
+    frq[icv] = p;
+    const u64 x = cvpos_file[icv];
+    const bool covered = (x >= bp0 && x < bp_end);
+    const double a0 = covered ? a_file[icv] : 0.0, d0 = covered ? d_file[icv] : 0.0;
+    const double a = (a0 + a0) / 2;
+    double d = (d0 + d0) / 2;
+    if (vd == 0) d = 0;
+    const double q = 1 - p;
+    const double alpha = a + d * (q - p);
+    tab[6 * icv + 0] = ((double)0u - 2 * p) * alpha;
+    tab[6 * icv + 1] = ((double)1u - 2 * p) * alpha;
+    tab[6 * icv + 2] = ((double)2u - 2 * p) * alpha;
+    tab[6 * icv + 3] = (-2 * p * p) * d;
+    tab[6 * icv + 4] = (2 * p * q) * d;
+    tab[6 * icv + 5] = (-2 * q * q) * d;
+}
+// One thread per individual; the block's 2*IPB haplotype rows are staged through LDS with a
+// coalesced read ([hap][individual][S+1] layout: row stride S+1 words is odd -> conflict-free
+// column reads).  col_of_icv / tab are wave-uniform (scalar loads); t selects per lane.
+template <int IPB>
+__global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(
+    const u32* __restrict__ cvm, u32 sub_w32, const u32* __restrict__ col_of_icv, const double* __restrict__ tab, u32 Cn, size_t n_human,
+    double* __restrict__ add_out, double* __restrict__ dom_out, size_t out_stride, u32* __restrict__ nan_flag)
+{
+    extern __shared__ u32 s_rows[];
+    const u32 S1 = sub_w32 | 1u;                                 // odd row stride
+    const size_t ih0 = (size_t)blockIdx.x * IPB;
+    const size_t n_here = min((size_t)IPB, n_human - ih0);
+    const u32 words = (u32)(2 * n_here) * sub_w32;
+    const u32* src = cvm + 2 * ih0 * sub_w32;
+    for (u32 e = threadIdx.x; e < words; e += IPB) {
+        const u32 row = e / sub_w32, w = e - row * sub_w32;     // row = 2*local_individual + hap
+        s_rows[((row & 1u) * IPB + (row >> 1)) * S1 + w] = src[e];
+    }
+    __syncthreads();
+    if (threadIdx.x >= n_here) return;
+    const u32* r0 = s_rows + (size_t)threadIdx.x * S1;
+    const u32* r1 = s_rows + ((size_t)IPB + threadIdx.x) * S1;
+    double A_chr = 0, D_chr = 0;
+    for (u32 icv = 0; icv < Cn; icv++) {
+        const u32 c = col_of_icv[icv];
+        const u32 t = ((r0[c >> 5] >> (c & 31)) & 1u) + ((r1[c >> 5] >> (c & 31)) & 1u);
+        const double a0 = tab[6 * icv + 0], a1 = tab[6 * icv + 1], a2 = tab[6 * icv + 2];
+        const double d0 = tab[6 * icv + 3], d1 = tab[6 * icv + 4], d2 = tab[6 * icv + 5];
+        A_chr += (t == 0) ? a0 : (t == 1 ? a1 : a2);
+        D_chr += (t == 0) ? d0 : (t == 1 ? d1 : d2);
+    }
+    const size_t ih = ih0 + threadIdx.x;
     add_out[ih * out_stride] = A_chr;
     dom_out[ih * out_stride] = D_chr;
     if (A_chr != A_chr || D_chr != D_chr) atomicMin(nan_flag, (u32)(ih < 0xffffffffull ? ih : 0xfffffffeull));

@@ -70,7 +70,7 @@ struct CvStatic {                        // one population x phenotype x chromos
     std::vector<u64> bp; std::vector<double> a, d; double vd = 0; bool set = false;
     std::vector<u32> col_of_icv;         // file index -> column in the sorted CV plane
     std::vector<u32> icv_of_col;
-    DevBuf d_pos_sorted, d_pos_file, d_col_of_icv, d_icv_of_col, d_a, d_d, d_frq, d_counts, d_aptr, d_dptr;
+    DevBuf d_pos_sorted, d_pos_file, d_col_of_icv, d_icv_of_col, d_a, d_d, d_frq, d_counts, d_aptr, d_dptr, d_tab;
     u32 C = 0, sub_w32 = 0, stride_w32 = 0;
     u32 idx_lo = 0, idx_hi = 0;
     size_t founder_rows = 0;
@@ -101,6 +101,8 @@ struct gev_ctx {
     DevBuf d_tables;
     // per-generation scratch
     DevBuf d_father, d_mother, d_mutseeds, d_seed_pat, d_seed_mat, d_k, d_bk_off, d_bk, d_start, d_nmut, d_nm_off, d_nm_pos, d_nm_side, d_sex;
+    DevBuf d_ghist, d_goff, d_glist;
+    int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
     DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
     std::map<double, GevThr> thr_cache;
 };
@@ -631,17 +633,37 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     }
     HIPC(hipEventRecord(c->ev[2], st));
     // ---- dense stitch of the genotype planes (the HBM-bound kernel)
+    const size_t n_parent = P.n_people;
+    if (c->stitch_mode == 0) {
+        // group the gametes by source individual (same grouping for every chromosome)
+        GEVC(c->d_ghist.ensure((n_parent + 1) * sizeof(u32), st)); GEVC(c->d_goff.ensure((n_parent + 1) * sizeof(u32), st));
+        GEVC(c->d_glist.ensure(rows * sizeof(u32), st));
+        HIPC(hipMemsetAsync(c->d_ghist.p, 0, (n_parent + 1) * sizeof(u32), st));
+        hipLaunchKernelGGL(k_group_hist, dim3(row_blocks), dim3(256), 0, st, sd.father, sd.mother, rows, c->d_ghist.as<u32>());
+        KCHECK();
+        GEVC(scan_u32(c, c->d_ghist.as<u32>(), n_parent, c->d_goff.as<u32>(), nullptr));
+        HIPC(hipMemsetAsync(c->d_ghist.p, 0, (n_parent + 1) * sizeof(u32), st));
+        hipLaunchKernelGGL(k_group_fill, dim3(row_blocks), dim3(256), 0, st, sd.father, sd.mother, rows, c->d_goff.as<u32>(), c->d_ghist.as<u32>(), c->d_glist.as<u32>());
+        KCHECK();
+    }
+    HIPC(hipEventRecord(c->ev[4], st));
     for (int k = 0; k < nchr; k++) {
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         const u32 chunks = (u32)(S.stride / 16);
         // enough workgroups to fill 256 CUs even for small populations; one span >= 4 KiB
+        const size_t units = c->stitch_mode == 0 ? n_parent : rows;
         u32 bpr = 1;
-        while (rows * bpr < 4096 && chunks / (bpr * 2) >= 256) bpr *= 2;
-        const size_t nblk = rows * bpr;
+        while (units * bpr < 4096 && chunks / (bpr * 2) >= 256) bpr *= 2;
+        const size_t nblk = units * bpr;
         if (nblk > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
-        hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)nblk), dim3(STITCH_THREADS), 0, st,
-                           cs.plane[alt].as<uint8_t>(), cs.plane[cur].as<uint8_t>(), S.stride, chunks, bpr,
-                           S.d_pos.as<u64>(), (u32)S.L, k, nchr, sd);
+        if (c->stitch_mode == 0)
+            hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)nblk), dim3(256), 0, st,
+                               cs.plane[alt].as<uint8_t>(), cs.plane[cur].as<uint8_t>(), S.stride, chunks, bpr,
+                               S.d_pos.as<u64>(), (u32)S.L, k, nchr, c->d_goff.as<u32>(), c->d_glist.as<u32>(), sd);
+        else
+            hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)nblk), dim3(STITCH_THREADS), 0, st,
+                               cs.plane[alt].as<uint8_t>(), cs.plane[cur].as<uint8_t>(), S.stride, chunks, bpr,
+                               S.d_pos.as<u64>(), (u32)S.L, k, nchr, sd);
         KCHECK();
     }
     HIPC(hipEventRecord(c->ev[3], st));
@@ -649,7 +671,7 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     HIPC(hipStreamSynchronize(st));
     float t;
     HIPC(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); c->last_ms[0] = t;
-    HIPC(hipEventElapsedTime(&t, c->ev[2], c->ev[3])); c->last_ms[1] = t;
+    HIPC(hipEventElapsedTime(&t, c->ev[4], c->ev[3])); c->last_ms[1] = t;
     HIPC(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); c->last_ms[2] = t;
     HIPC(hipEventElapsedTime(&t, c->ev[0], c->ev[3])); c->last_ms[3] = t;
     P.cur = alt; P.n_people = n_people;
@@ -684,12 +706,27 @@ int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, dou
             if (V.C) {
                 const unsigned gy = (unsigned)std::min<size_t>(std::max<size_t>(rows / 512, 1), 256);
                 hipLaunchKernelGGL(k_cv_count, dim3((unsigned)ceil_div(V.C, 256), gy), dim3(256), 0, st, c->d_cvm.as<u32>(), V.sub_w32, rows, V.C, V.d_counts.as<u32>());
-                hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, st, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n, V.d_frq.as<double>());
             }
-            hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
-                               c->d_cvm.as<u32>(), V.sub_w32, P.cvp[p][k][P.cur].as<u32>(), V.stride_w32, c->rp_bits,
-                               V.d_col_of_icv.as<u32>(), V.d_frq.as<double>(), V.d_aptr.as<const double*>(), V.d_dptr.as<const double*>(), pop,
-                               V.d_pos_file.as<u64>(), S.rbp.front(), S.rbp.back(), V.vd, V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
+            // fast path: one root population and the block's rows fit LDS; else the general per-individual kernel
+            const u32 S1 = V.sub_w32 | 1u;
+            int ipb = 0;
+            if (c->rp_bits == 0 && V.C) { for (int cand : {256, 128, 64}) if ((size_t)2 * cand * S1 * 4 <= 64 * 1024) { ipb = cand; break; } }
+            if (ipb) {
+                GEVC(V.d_tab.ensure((size_t)V.C * 6 * sizeof(double), st));
+                hipLaunchKernelGGL(k_cv_table, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, st, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n,
+                                   V.d_a.as<double>(), V.d_d.as<double>(), V.d_pos_file.as<u64>(), S.rbp.front(), S.rbp.back(), V.vd, V.d_frq.as<double>(), V.d_tab.as<double>());
+                const size_t lds = (size_t)2 * ipb * S1 * 4;
+                const unsigned nb = (unsigned)ceil_div(n, ipb);
+                if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb), dim3(256), lds, st, c->d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
+                else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb), dim3(128), lds, st, c->d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
+                else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb), dim3(64), lds, st, c->d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
+            } else {
+                if (V.C) hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, st, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n, V.d_frq.as<double>());
+                hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                                   c->d_cvm.as<u32>(), V.sub_w32, P.cvp[p][k][P.cur].as<u32>(), V.stride_w32, c->rp_bits,
+                                   V.d_col_of_icv.as<u32>(), V.d_frq.as<double>(), V.d_aptr.as<const double*>(), V.d_dptr.as<const double*>(), pop,
+                                   V.d_pos_file.as<u64>(), S.rbp.front(), S.rbp.back(), V.vd, V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
+            }
             KCHECK();
             V.frq_valid = true;
         }
@@ -947,6 +984,7 @@ int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_
 int gev_stream(gev_ctx* c, void** s) { if (!c || !s) return fail(GEV_EINVAL, "null"); *s = (void*)c->stream; return GEV_OK; }
 int gev_last_reproduce_ms(gev_ctx* c, float ms[4]) { if (!c || !ms) return fail(GEV_EINVAL, "null"); for (int i = 0; i < 4; i++) ms[i] = c->last_ms[i]; return GEV_OK; }
 int gev_set_track_intervals(gev_ctx* c, int on) { if (!c) return fail(GEV_EINVAL, "null"); c->track_intervals = on != 0; return GEV_OK; }
+int gev_set_stitch_mode(gev_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return fail(GEV_EINVAL, "stitch mode must be 0 (parent-major) or 1 (gamete-major)"); c->stitch_mode = mode; return GEV_OK; }
 
 // ---- diagnostics (tests only; no simulation state involved) --------------------------------
 __global__ void __launch_bounds__(64) k_dbg_rand(const GevRngTables* __restrict__ T, u32 seed, u32 n, int* __restrict__ out)

@@ -190,6 +190,9 @@ int gev_stream(gev_ctx*, void** stream);
 int gev_last_reproduce_ms(gev_ctx*, float ms[4]);
 /* enable/disable keeping the ancestry interval state on the device (default on) */
 int gev_set_track_intervals(gev_ctx*, int on);
+/* dense-stitch kernel: 0 = parent-major k_stitch_parent (default), 1 = gamete-major k_stitch_rows.
+ * Same results; kept selectable for A/B measurement and parity cross-checks. */
+int gev_set_stitch_mode(gev_ctx*, int mode);
 
 /* ---- diagnostics: RNG building blocks exposed for the parity tests (no simulation state) ----
  * gev_dbg_tables / gev_dbg_threshold / gev_dbg_canonical run on the host (table and threshold

@@ -80,9 +80,10 @@ def test_gpu_replays_reference_generations_bit_exact(gpu_lib, oracle_lib, case):
     assert n_dense >= 2
 
 
-def run_pair(gpu_lib, oracle_lib, cfg, n_gen, seed, check_every=1):
+def run_pair(gpu_lib, oracle_lib, cfg, n_gen, seed, check_every=1, stitch_mode=0, family=None):
     """same seeded synthetic scenario through the HIP library and the oracle"""
     g = gpu_lib.create(1, cfg.nchr, cfg.nphen)
+    g.set_stitch_mode(stitch_mode)
     o = oracle_lib.create(1, cfg.nchr, cfg.nphen)
     cfg.apply_static(g); cfg.apply_static(o)
     nh = 2 * cfg.n_ind
@@ -100,6 +101,10 @@ def run_pair(gpu_lib, oracle_lib, cfg, n_gen, seed, check_every=1):
     rng = np.random.default_rng(seed)
     for gen in range(1, n_gen + 1):
         couples = synthetic_random_mate(sg.sex[0], cfg.n_ind, rng)
+        if family:                                   # few couples with `family` offspring each: many gametes per parent
+            couples = couples[:max(cfg.n_ind // family, 1)]
+            couples["num_offspring"] = family
+            couples["num_offspring"][0] += cfg.n_ind - family * len(couples)
         sg.couples[0] = couples; so.couples[0] = couples
         sx_g = sg.reproduce(0, gen); sx_o = so.reproduce(0, gen)
         assert np.array_equal(sx_g, sx_o), f"sex differs at generation {gen}"
@@ -124,6 +129,17 @@ def test_gpu_vs_oracle_task_parallel_mode(gpu_lib, oracle_lib):
     cfg = SyntheticConfig(300, 5000, nchr=2, chrom_bp=2_000_000, map_step=1000, rec_per_row=5e-3, mut_per_row=5e-3,
                           n_cv=300, nphen=2, seed=11, vd=0.4)
     run_pair(gpu_lib, oracle_lib, cfg, n_gen=5, seed=2024)
+
+
+def test_gamete_major_stitch_kernel_gives_the_same_state(gpu_lib, oracle_lib):
+    cfg = SyntheticConfig(300, 5000, nchr=2, chrom_bp=2_000_000, map_step=1000, rec_per_row=5e-3, mut_per_row=5e-3, n_cv=100, seed=12)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=3, seed=31, stitch_mode=1)
+
+
+def test_large_families_many_gametes_per_parent(gpu_lib, oracle_lib):
+    # 40 offspring per couple: 40 gametes per parent -> several PM_GMAX batches in the parent-major kernel
+    cfg = SyntheticConfig(240, 20000, nchr=1, chrom_bp=2_000_000, map_step=1000, rec_per_row=4e-3, mut_per_row=2e-3, n_cv=50, seed=13)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=3, seed=32, family=40)
 
 
 def test_gpu_vs_oracle_serial_chain_mode(gpu_lib, oracle_lib):
