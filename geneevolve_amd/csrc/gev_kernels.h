@@ -49,7 +49,17 @@ struct SampleDev {
     uint8_t* sex;    // [n_people] (:2472)
     const u32* father;  // [n_people] position of the father in the parent generation (:2438)
     const u32* mother;  // [n_people]
+    // Records are written in ONE pass: gamete G owns slots [G*GEV_BK_CAP, +GEV_BK_CAP) of bk and task t
+    // owns [t*GEV_NM_CAP, +GEV_NM_CAP) of nm_pos/nm_side; a gamete/task with more entries gets a range of the
+    // overflow region (bump-allocated with one atomic), bk_off/nm_off point at whichever was used.
+    u32 bk_ovf_base, bk_ovf_cap, nm_ovf_base, nm_ovf_cap;
+    u32* status;     // GenStatus words (below)
 };
+#define GEV_BK_CAP 8
+#define GEV_NM_CAP 8
+// status words written by the kernels of one generation, read back once at its end
+enum { ST_BK_OVF_USED = 0, ST_NM_OVF_USED = 1, ST_FLAGS = 2, ST_TOTALS = 4 /* then per chr: mut_total, parts_total */ };
+enum { FLAG_BK_OVF = 1, FLAG_NM_OVF = 2, FLAG_MUT_CAP = 4, FLAG_PARTS_CAP = 8 };
 
 // ------------------------------------------------------------------------------------------
 // exclusive scan of u32 counts (CSR offsets); n+1 outputs
@@ -183,19 +193,26 @@ __global__ void __launch_bounds__(64) k_sex_sequence(const GevRngTables* __restr
 // K2: mutation sampling  == Simulation::ras_add_mutation (src/Simulation.cpp:2497-2552)
 // one wave per (offspring, chromosome) task
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_mut_count(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
-                                                   const u32* __restrict__ mut_seeds, size_t n_tasks, u32* __restrict__ nmut)
+// one scan of the mutation map; the first `cap` hits are resolved (position, side) into `pos/side`
+template <class G>
+__device__ __forceinline__ u32 mut_scan_write(const GevRngTables* __restrict__ T, const ChrDev& C, u32 S, G& g, u64* __restrict__ pos, uint8_t* __restrict__ side, u32 cap)
 {
-    const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= n_tasks) return;
-    const ChrDev& C = chrs[t % nchr];
-    const u32 S = mut_seeds[t];
-    u32 n = 0;
-    if (C.M >= 2) n = wave_scan_hits(T, S + 2u, C.mthr, 1, C.M - 1, [](u32) {});      // generator_u(seed+2), i = 1..M-1
-    if ((threadIdx.x & 63) == 0) nmut[t] = n;
+    const u32 lane = threadIdx.x & 63;
+    u32 xg = minstd_seed(S + 1u);                                // generator(seed+1), :2503
+    u32 h = 0;
+    if (C.M >= 2)
+        wave_scan_hits(T, S + 2u, C.mthr, 1, C.M - 1, [&](u32 row) {                       // generator_u(seed+2), i = 1..M-1
+            if (h < cap) {
+                const u64 bp_mut = uniform_int_fallback(xg, C.mbp[row - 1], C.mbp[row]);    // :2516-2520
+                const u32 sd_ = g.out(T, h) & 1u;                                            // rand()%2, :2522
+                if (lane == 0) { pos[h] = bp_mut; side[h] = (uint8_t)sd_; }
+            }
+            h++;
+        });
+    return h;
 }
-__global__ void __launch_bounds__(256) k_mut_fill(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
-                                                  const u32* __restrict__ mut_seeds, size_t n_tasks, SampleDev sd)
+__global__ void __launch_bounds__(256) k_mut_sample(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
+                                                    const u32* __restrict__ mut_seeds, size_t n_tasks, SampleDev sd)
 {
     const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_tasks) return;
@@ -204,20 +221,23 @@ __global__ void __launch_bounds__(256) k_mut_fill(const GevRngTables* __restrict
     const ChrDev& C = chrs[c];
     const u32 S = mut_seeds[t];
     GlibcWave g; g.seed(T, S);                                   // srand(seed), :2501
-    u32 xg = minstd_seed(S + 1u);                                // generator(seed+1), :2503
-    const u32 off = sd.nm_off[t];
-    u32 h = 0;
-    if (C.M >= 2)
-        wave_scan_hits(T, S + 2u, C.mthr, 1, C.M - 1, [&](u32 row) {
-            const u64 bp_mut = uniform_int_fallback(xg, C.mbp[row - 1], C.mbp[row]);    // :2516-2520
-            const u32 side = g.out(T, h) & 1u;                                           // rand()%2, :2522
-            if (lane == 0) { sd.nm_pos[off + h] = bp_mut; sd.nm_side[off + h] = (uint8_t)side; }
-            h++;
-        });
-    u32 n = h;
+    u32 off = (u32)t * GEV_NM_CAP;
+    u32 n = mut_scan_write(T, C, S, g, sd.nm_pos + off, sd.nm_side + off, GEV_NM_CAP);
+    u32 n_store = n;
+    if (n > GEV_NM_CAP) {                                        // rare: take a range of the overflow region and redo the scan
+        u32 o = 0;
+        if (lane == 0) o = atomicAdd(&sd.status[ST_NM_OVF_USED], n);
+        o = __shfl(o, 0);
+        if (o + n <= sd.nm_ovf_cap) {
+            off = sd.nm_ovf_base + o;
+            g.seed(T, S);
+            mut_scan_write(T, C, S, g, sd.nm_pos + off, sd.nm_side + off, n);
+        } else { if (lane == 0) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_NM_OVF); n_store = 0; }     // host grows the region and redoes the generation
+    }
+    if (lane == 0) { sd.nmut[t] = n_store; sd.nm_off[t] = off; }
     if (c == nchr - 1) {                                         // sex = rand()%2+1 after the last chromosome, :2472
-        const u32 s = (g.out(T, n) & 1u) + 1u;
-        if (lane == 0) sd.sex[t / nchr] = (uint8_t)s;
+        const u32 sx = (g.out(T, n) & 1u) + 1u;
+        if (lane == 0) sd.sex[t / nchr] = (uint8_t)sx;
         n++;
     }
     const u32 nxt = g.out(T, n);                                 // seed_loc of the next task, :2447
@@ -228,38 +248,70 @@ __global__ void __launch_bounds__(256) k_mut_fill(const GevRngTables* __restrict
 // K1/K3: crossover sampling == Simulation::ras_sim_loc_rec (:2973-2995) and the rand() chain of
 // Simulation::reproduce (:2447-2455)
 // ------------------------------------------------------------------------------------------
-struct PairOut { u32 seed_mat, k_pat, k_mat, start_pat, start_mat; };
-// leaves g seeded with seed_mat; the next rand() of the reference is g.out(k_mat+1)
-__device__ __forceinline__ PairOut gamete_pair_pass1(const GevRngTables* __restrict__ T, const ChrDev& C, u32 seed_pat, GlibcWave& g)
+// one scan of the recombination map for one gamete; the first `cap` breakpoints bp[j] + rand()%dist (:2990) go to `out`
+__device__ __forceinline__ u32 rec_scan_write(const GevRngTables* __restrict__ T, const ChrDev& C, u32 seed, GlibcWave& g, u64* __restrict__ out, u32 cap)
 {
-    PairOut o;
-    o.k_pat = wave_scan_hits(T, seed_pat + 1u, C.rthr, 0, C.R, [](u32) {});
-    g.seed(T, seed_pat);
-    o.start_pat = g.out(T, o.k_pat) & 1u;         // rand()%2 after k_pat position draws, :2449
-    o.seed_mat = g.out(T, o.k_pat + 1);           // :2453
-    o.k_mat = wave_scan_hits(T, o.seed_mat + 1u, C.rthr, 0, C.R, [](u32) {});
-    g.seed(T, o.seed_mat);
-    o.start_mat = g.out(T, o.k_mat) & 1u;         // :2455
-    return o;
+    const u32 lane = threadIdx.x & 63;
+    u32 h = 0;
+    wave_scan_hits(T, seed + 1u, C.rthr, 0, C.R, [&](u32 row) {
+        if (h < cap) {
+            const u64 v = C.rbp[row] + (u64)g.out(T, h) % C.bp_dist;
+            if (lane == 0) out[h] = v;
+        }
+        h++;
+    });
+    return h;
+}
+// ras_sim_loc_rec for gamete G: srand(seed), scan, breakpoints; returns k (the true crossover count) with g
+// positioned so that g.out(k) is the rand() that follows the call (:2449 / :2455)
+__device__ __forceinline__ u32 gamete_sample(const GevRngTables* __restrict__ T, const ChrDev& C, u32 seed, size_t G, GlibcWave& g, const SampleDev& sd)
+{
+    const u32 lane = threadIdx.x & 63;
+    g.seed(T, seed);
+    u32 off = (u32)G * GEV_BK_CAP;
+    const u32 k = rec_scan_write(T, C, seed, g, sd.bk + off, GEV_BK_CAP);
+    u32 k_store = k;
+    if (k > GEV_BK_CAP) {
+        u32 o = 0;
+        if (lane == 0) o = atomicAdd(&sd.status[ST_BK_OVF_USED], k);
+        o = __shfl(o, 0);
+        if (o + k <= sd.bk_ovf_cap) {
+            off = sd.bk_ovf_base + o;
+            g.seed(T, seed);
+            rec_scan_write(T, C, seed, g, sd.bk + off, k);
+        } else { if (lane == 0) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_BK_OVF); k_store = 0; }
+    }
+    if (lane == 0) { sd.k[G] = k_store; sd.bk_off[G] = off; }
+    return k;
+}
+// one (offspring, chromosome) task: paternal then maternal gamete (:2447-2456); leaves g seeded with seed_mat,
+// the next rand() of the reference is g.out(k_mat + 1)
+__device__ __forceinline__ u32 task_sample(const GevRngTables* __restrict__ T, const ChrDev& C, u32 seed_pat, size_t t, GlibcWave& g, const SampleDev& sd)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u32 k_pat = gamete_sample(T, C, seed_pat, 2 * t, g, sd);
+    const u32 start_pat = g.out(T, k_pat) & 1u;       // rand()%2 after k_pat position draws, :2449
+    const u32 seed_mat = g.out(T, k_pat + 1);         // :2453
+    const u32 k_mat = gamete_sample(T, C, seed_mat, 2 * t + 1, g, sd);
+    const u32 start_mat = g.out(T, k_mat) & 1u;       // :2455
+    if (lane == 0) {
+        sd.seed_pat[t] = seed_pat; sd.seed_mat[t] = seed_mat;
+        sd.start[2 * t] = (uint8_t)start_pat; sd.start[2 * t + 1] = (uint8_t)start_mat;
+    }
+    return k_mat;
 }
 // task-parallel form (a mutation map is loaded: every task's chain restarts at srand(S), see
-// SURVEY.md section 7.2-1).  seed_pat[t] for t>0 was written by k_mut_fill.
-__global__ void __launch_bounds__(256) k_rec_pass1(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
-                                                   u32 seed_reproduce, size_t n_tasks, SampleDev sd)
+// SURVEY.md section 7.2-1).  seed_pat[t] for t>0 was written by k_mut_sample.
+__global__ void __launch_bounds__(256) k_rec_sample(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
+                                                    u32 seed_reproduce, size_t n_tasks, SampleDev sd)
 {
     const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_tasks) return;
-    const u32 lane = threadIdx.x & 63;
     GlibcWave g;
     u32 seed_pat;
     if (t == 0) { g.seed(T, seed_reproduce); seed_pat = g.out(T, 0); }     // srand(seed) :2400, first rand() :2447
     else seed_pat = sd.seed_pat[t];
-    const PairOut o = gamete_pair_pass1(T, chrs[t % nchr], seed_pat, g);
-    if (lane == 0) {
-        sd.seed_pat[t] = seed_pat; sd.seed_mat[t] = o.seed_mat;
-        sd.k[2 * t] = o.k_pat; sd.k[2 * t + 1] = o.k_mat;
-        sd.start[2 * t] = (uint8_t)o.start_pat; sd.start[2 * t + 1] = (uint8_t)o.start_mat;
-    }
+    task_sample(T, chrs[t % nchr], seed_pat, t, g, sd);
 }
 // serial form (no mutation map): every gamete's seed depends on the previous gamete's crossover
 // count, so one wave walks the chain; each link is still a wave-parallel scan.
@@ -271,13 +323,8 @@ __global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict
     u32 seed = g.out(T, 0);
     for (size_t t = 0; t < n_tasks; t++) {
         const int c = (int)(t % nchr);
-        const PairOut o = gamete_pair_pass1(T, chrs[c], seed, g);
-        if (lane == 0) {
-            sd.seed_pat[t] = seed; sd.seed_mat[t] = o.seed_mat;
-            sd.k[2 * t] = o.k_pat; sd.k[2 * t + 1] = o.k_mat;
-            sd.start[2 * t] = (uint8_t)o.start_pat; sd.start[2 * t + 1] = (uint8_t)o.start_mat;
-        }
-        u32 n = o.k_mat + 1;
+        const u32 k_mat = task_sample(T, chrs[c], seed, t, g, sd);
+        u32 n = k_mat + 1;
         if (c == nchr - 1) {                                       // :2472
             const u32 s = (g.out(T, n) & 1u) + 1u;
             if (lane == 0) sd.sex[t / nchr] = (uint8_t)s;
@@ -285,26 +332,6 @@ __global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict
         }
         seed = g.out(T, n);
     }
-}
-// pass 2: one wave per gamete re-scans and writes the breakpoints bp[j] + rand()%dist (:2990)
-__global__ void __launch_bounds__(256) k_rec_pass2(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
-                                                   size_t n_gametes, SampleDev sd)
-{
-    const size_t G = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (G >= n_gametes) return;
-    const u32 lane = threadIdx.x & 63;
-    const size_t t = G >> 1;
-    if (sd.k[G] == 0) return;
-    const ChrDev& C = chrs[t % nchr];
-    const u32 seed = (G & 1) ? sd.seed_mat[t] : sd.seed_pat[t];
-    GlibcWave g; g.seed(T, seed);
-    const u32 off = sd.bk_off[G];
-    u32 h = 0;
-    wave_scan_hits(T, seed + 1u, C.rthr, 0, C.R, [&](u32 row) {
-        const u64 v = C.rbp[row] + (u64)g.out(T, h) % C.bp_dist;
-        if (lane == 0) sd.bk[off + h] = v;
-        h++;
-    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -572,10 +599,11 @@ template <bool FILL>
 __global__ void __launch_bounds__(256) k_mutlist(
     const u32* __restrict__ p_off, const u64* __restrict__ p_pos,    // parent generation CSR
     u32* __restrict__ o_cnt, const u32* __restrict__ o_off, u64* __restrict__ o_pos,
-    size_t n_rows_out, int chr, int nchr, u64 bp0, u64 bp_end, int has_mut, SampleDev sd)
+    size_t n_rows_out, int chr, int nchr, u64 bp0, u64 bp_end, int has_mut, u32 cap, SampleDev sd)
 {
     const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows_out) return;
+    if (FILL && o_off[row + 1] > cap) { if (o_off[row] <= cap) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_MUT_CAP); return; }   // host grows and redoes
     const u32 i = (u32)(row >> 1), s = (u32)(row & 1);
     const size_t t = (size_t)i * nchr + chr, G = 2 * t + s;
     const u32 parent = s ? sd.mother[i] : sd.father[i];
@@ -584,7 +612,7 @@ __global__ void __launch_bounds__(256) k_mutlist(
     const u32 a0 = p_off[2 * parent], a1 = p_off[2 * parent + 1], b1 = p_off[2 * parent + 2];   // hap0 = [a0,a1), hap1 = [a1,b1)
     u32 ia = a0, ib = a1, in = 0, nn = 0;
     const u64* npos = nullptr; const uint8_t* nside = nullptr;
-    if (has_mut) { in = sd.nm_off[t]; nn = sd.nm_off[t + 1]; npos = sd.nm_pos; nside = sd.nm_side; }
+    if (has_mut) { in = sd.nm_off[t]; nn = in + sd.nmut[t]; npos = sd.nm_pos; nside = sd.nm_side; }
     u32 n = 0;
     u64* out = FILL ? o_pos + o_off[row] : nullptr;
     const u64 INF = ~0ull;
@@ -610,10 +638,11 @@ template <bool FILL>
 __global__ void __launch_bounds__(256) k_parts(
     const u32* __restrict__ p_off, const gev_part* __restrict__ p_parts,
     u32* __restrict__ o_cnt, const u32* __restrict__ o_off, gev_part* __restrict__ o_parts,
-    size_t n_rows_out, int chr, int nchr, u64 bp0, u64 bp_end, SampleDev sd)
+    size_t n_rows_out, int chr, int nchr, u64 bp0, u64 bp_end, u32 cap, SampleDev sd)
 {
     const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows_out) return;
+    if (FILL && o_off[row + 1] > cap) { if (o_off[row] <= cap) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_PARTS_CAP); return; }
     const u32 i = (u32)(row >> 1), s = (u32)(row & 1);
     const size_t G = 2 * ((size_t)i * nchr + chr) + s;
     const u32 parent = s ? sd.mother[i] : sd.father[i];
@@ -650,6 +679,8 @@ __global__ void __launch_bounds__(256) k_parts(
     }
     if (!FILL) o_cnt[row] = n;
 }
+
+__global__ void k_collect_total(const u32* __restrict__ off, size_t n_rows, u32* __restrict__ dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = off[n_rows]; }
 
 // ------------------------------------------------------------------------------------------
 // K6/K7: ras_find_cv + ras_compute_AD (src/Simulation.cpp:2624-2815)

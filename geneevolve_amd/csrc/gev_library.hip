@@ -78,6 +78,8 @@ struct CvStatic {                        // one population x phenotype x chromos
 };
 struct ChrState {
     DevBuf plane[2], moff[2], mpos[2], poff[2], parts[2];
+    size_t mut_total[2] = {0, 0}, parts_total[2] = {0, 0};   // list sizes of the two buffers (known to the host after each generation)
+    size_t mut_need = 0, parts_need = 0;                     // exact capacity demand after an overflowed attempt
 };
 struct PopState {
     std::vector<ChrStatic> cs;                         // [chr]
@@ -101,7 +103,9 @@ struct gev_ctx {
     DevBuf d_tables;
     // per-generation scratch
     DevBuf d_father, d_mother, d_mutseeds, d_seed_pat, d_seed_mat, d_k, d_bk_off, d_bk, d_start, d_nmut, d_nm_off, d_nm_pos, d_nm_side, d_sex;
-    DevBuf d_ghist, d_goff, d_glist;
+    DevBuf d_ghist, d_goff, d_glist, d_status;
+    size_t bk_ovf_cap = 1 << 16, nm_ovf_cap = 1 << 16;       // overflow regions of the breakpoint / new-mutation records
+    void* h_stage = nullptr; size_t h_stage_bytes = 0;       // pinned host staging
     int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
     DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
     std::map<double, GevThr> thr_cache;
@@ -222,6 +226,7 @@ void gev_destroy(gev_ctx* c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     hipStream_t s = c->stream;
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     delete c;
     if (s) (void)hipStreamDestroy(s);
 }
@@ -514,111 +519,83 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     KCHECK();
     if (sex_out) HIPC(hipMemcpyAsync(sex_out, c->d_sex.p, n_people, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = rows; }
     P.n_people = n_people; P.gen0 = true;
     return GEV_OK;
 }
 
 // ---- Simulation::reproduce ----------------------------------------------------------------
-int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_couples, uint32_t seed_reproduce,
-                  const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people, uint8_t* sex_out)
+// Everything of one generation is enqueued without a host round trip: variable-length outputs go
+// to capacity-checked buffers sized from the previous generation's totals, and one status block
+// is read back at the end.  If a capacity was too small the buffers are grown from the exact
+// totals the count passes produced and the generation is enqueued again (inputs are untouched:
+// all results go to the alternate buffers until the final flip).
+static int enqueue_generation(gev_ctx* c, int pop, size_t n_people, bool has_mut, u32 seed_reproduce)
 {
-    GEVC(check_idx(c, pop, 0));
     PopState& P = c->pop[pop];
-    if (!P.gen0) return fail(GEV_ESTATE, "reproduce: population %d has no current generation (call gev_init_gen0)", pop);
-    if (n_couples && !couples) return fail(GEV_EINVAL, "reproduce: null couples");
-    HIPC(hipSetDevice(c->device));
-    const int nchr = c->nchr;
-    // offspring enumeration order of the couple loop (src/Simulation.cpp:2433-2443)
-    std::vector<u32> father, mother;
-    father.reserve(n_people); mother.reserve(n_people);
-    for (size_t it = 0; it < n_couples; it++) {
-        if (couples[it].inbreed) continue;
-        if (couples[it].num_offspring < 0) return fail(GEV_EINVAL, "reproduce: couple %zu has negative num_offspring", it);
-        if (couples[it].num_offspring && (couples[it].pos_male >= P.n_people || couples[it].pos_female >= P.n_people))
-            return fail(GEV_EINVAL, "reproduce: couple %zu references position beyond the population (%zu people)", it, P.n_people);
-        for (int ns = 0; ns < couples[it].num_offspring; ns++) { father.push_back((u32)couples[it].pos_male); mother.push_back((u32)couples[it].pos_female); }
-    }
-    if (father.size() != n_people) return fail(GEV_EINVAL, "reproduce: n_people=%zu but the couples list yields %zu offspring", n_people, father.size());
-    if (n_people == 0) return fail(GEV_EINVAL, "reproduce: no offspring");
-    const size_t T = n_people * (size_t)nchr;
-    if (2 * T >= 0xffffffffull) return fail(GEV_EINVAL, "reproduce: too many gametes");
-    const bool has_mut = mut_seeds != nullptr;
-    if (has_mut && n_mut_seeds != T) return fail(GEV_EINVAL, "reproduce: n_mut_seeds=%zu, expected n_people*nchr=%zu", n_mut_seeds, T);
-    GEVC(finalize_static(c, pop));
-    GEVC(ensure_capacity(c, pop, n_people));
     hipStream_t st = c->stream;
+    const int nchr = c->nchr;
+    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
     const GevRngTables* Tb = c->d_tables.as<GevRngTables>();
     const ChrDev* chrs = P.d_chrdev.as<ChrDev>();
-
-    GEVC(h2d(c, c->d_father, father.data(), n_people * sizeof(u32)));
-    GEVC(h2d(c, c->d_mother, mother.data(), n_people * sizeof(u32)));
-    GEVC(c->d_seed_pat.ensure((T + 1) * sizeof(u32), st)); GEVC(c->d_seed_mat.ensure(T * sizeof(u32), st));
-    GEVC(c->d_k.ensure(2 * T * sizeof(u32), st)); GEVC(c->d_bk_off.ensure((2 * T + 1) * sizeof(u32), st));
-    GEVC(c->d_start.ensure(2 * T, st)); GEVC(c->d_sex.ensure(n_people, st));
-    GEVC(c->d_nmut.ensure(T * sizeof(u32), st)); GEVC(c->d_nm_off.ensure((T + 1) * sizeof(u32), st));
-    GEVC(c->d_bk.ensure(16, st)); GEVC(c->d_nm_pos.ensure(16, st)); GEVC(c->d_nm_side.ensure(16, st));
-    if (has_mut) GEVC(h2d(c, c->d_mutseeds, mut_seeds, T * sizeof(u32)));
-
+    const size_t bk_fixed = 2 * T * GEV_BK_CAP, nm_fixed = T * GEV_NM_CAP;
+    if (bk_fixed + c->bk_ovf_cap >= 0xffffffffull || nm_fixed + c->nm_ovf_cap >= 0xffffffffull) return fail(GEV_EINVAL, "reproduce: breakpoint/mutation record space exceeds 32-bit offsets");
+    GEVC(c->d_bk.ensure((bk_fixed + c->bk_ovf_cap) * sizeof(u64), st));
+    if (has_mut) { GEVC(c->d_nm_pos.ensure((nm_fixed + c->nm_ovf_cap) * sizeof(u64), st)); GEVC(c->d_nm_side.ensure(nm_fixed + c->nm_ovf_cap, st)); }
+    const size_t n_status = ST_TOTALS + 2 * (size_t)nchr;
+    GEVC(c->d_status.ensure(n_status * sizeof(u32), st));
+    HIPC(hipMemsetAsync(c->d_status.p, 0, n_status * sizeof(u32), st));
     SampleDev sd;
-    auto fill_sd = [&]() {
-        sd.seed_pat = c->d_seed_pat.as<u32>(); sd.seed_mat = c->d_seed_mat.as<u32>(); sd.k = c->d_k.as<u32>();
-        sd.bk_off = c->d_bk_off.as<u32>(); sd.bk = c->d_bk.as<u64>(); sd.start = c->d_start.as<uint8_t>();
-        sd.nmut = c->d_nmut.as<u32>(); sd.nm_off = c->d_nm_off.as<u32>(); sd.nm_pos = c->d_nm_pos.as<u64>();
-        sd.nm_side = c->d_nm_side.as<uint8_t>(); sd.sex = c->d_sex.as<uint8_t>();
-        sd.father = c->d_father.as<u32>(); sd.mother = c->d_mother.as<u32>();
-    };
-    fill_sd();
+    sd.seed_pat = c->d_seed_pat.as<u32>(); sd.seed_mat = c->d_seed_mat.as<u32>(); sd.k = c->d_k.as<u32>();
+    sd.bk_off = c->d_bk_off.as<u32>(); sd.bk = c->d_bk.as<u64>(); sd.start = c->d_start.as<uint8_t>();
+    sd.nmut = c->d_nmut.as<u32>(); sd.nm_off = c->d_nm_off.as<u32>(); sd.nm_pos = c->d_nm_pos.as<u64>();
+    sd.nm_side = c->d_nm_side.as<uint8_t>(); sd.sex = c->d_sex.as<uint8_t>();
+    sd.father = c->d_father.as<u32>(); sd.mother = c->d_mother.as<u32>();
+    sd.bk_ovf_base = (u32)bk_fixed; sd.bk_ovf_cap = (u32)c->bk_ovf_cap; sd.nm_ovf_base = (u32)nm_fixed; sd.nm_ovf_cap = (u32)c->nm_ovf_cap;
+    sd.status = c->d_status.as<u32>();
+
     HIPC(hipEventRecord(c->ev[0], st));
-    // ---- sampling
+    // ---- sampling: one map scan per gamete / per mutation task
     const unsigned task_blocks = (unsigned)ceil_div(T, 4);
     if (has_mut) {
-        hipLaunchKernelGGL(k_mut_count, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, c->d_mutseeds.as<u32>(), T, sd.nmut);
-        KCHECK();
-        u32 tot = 0;
-        GEVC(scan_u32(c, sd.nmut, T, sd.nm_off, &tot));
-        GEVC(c->d_nm_pos.ensure(std::max<size_t>(tot, 2) * sizeof(u64), st, false, 1.25));
-        GEVC(c->d_nm_side.ensure(std::max<size_t>(tot, 16), st, false, 1.25));
-        fill_sd();
-        hipLaunchKernelGGL(k_mut_fill, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, c->d_mutseeds.as<u32>(), T, sd);
-        hipLaunchKernelGGL(k_rec_pass1, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, (u32)seed_reproduce, T, sd);
+        hipLaunchKernelGGL(k_mut_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, c->d_mutseeds.as<u32>(), T, sd);
+        hipLaunchKernelGGL(k_rec_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd);
     } else {
-        hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, (u32)seed_reproduce, T, sd);
+        hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd);
     }
     KCHECK();
-    {
-        u32 tot = 0;
-        GEVC(scan_u32(c, sd.k, 2 * T, sd.bk_off, &tot));
-        GEVC(c->d_bk.ensure(std::max<size_t>(tot, 2) * sizeof(u64), st, false, 1.25));
-        fill_sd();
-        hipLaunchKernelGGL(k_rec_pass2, dim3((unsigned)ceil_div(2 * T, 4)), dim3(256), 0, st, Tb, chrs, nchr, 2 * T, sd);
-        KCHECK();
-    }
     HIPC(hipEventRecord(c->ev[1], st));
-    // ---- sparse state: mutation lists + ancestry intervals
+    // ---- sparse state: mutation lists + ancestry intervals + CV planes
     const int cur = P.cur, alt = P.cur ^ 1;
-    const size_t rows = 2 * n_people;
     GEVC(c->d_cnt.ensure((rows + 1) * sizeof(u32), st));
     const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
+    const double grow = (double)rows / (double)std::max<size_t>(2 * P.n_people, 1);
     for (int k = 0; k < nchr; k++) {
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         const u64 bp0 = S.rbp.front(), bpe = S.rbp.back();
-        u32 tot = 0;
+        // capacity guess: last generation's total scaled to the new size, plus room for this generation's events
+        size_t want = std::max<size_t>(cs.mut_need, (size_t)(cs.mut_total[cur] * grow * 1.5) + rows * 4 + 4096);
+        GEVC(cs.mpos[alt].ensure(want * sizeof(u64), st));
+        const u32 mcap = (u32)std::min<size_t>(cs.mpos[alt].bytes / sizeof(u64), 0xfffffff0u);
         hipLaunchKernelGGL((k_mutlist<false>), dim3(row_blocks), dim3(256), 0, st, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
-                           c->d_cnt.as<u32>(), (const u32*)nullptr, (u64*)nullptr, rows, k, nchr, bp0, bpe, (int)has_mut, sd);
+                           c->d_cnt.as<u32>(), (const u32*)nullptr, (u64*)nullptr, rows, k, nchr, bp0, bpe, (int)has_mut, 0u, sd);
         KCHECK();
-        GEVC(scan_u32(c, c->d_cnt.as<u32>(), rows, cs.moff[alt].as<u32>(), &tot));
-        GEVC(cs.mpos[alt].ensure(std::max<size_t>(tot, 2) * sizeof(u64), st, false, 1.25));
+        GEVC(scan_u32(c, c->d_cnt.as<u32>(), rows, cs.moff[alt].as<u32>(), nullptr));
         hipLaunchKernelGGL((k_mutlist<true>), dim3(row_blocks), dim3(256), 0, st, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
-                           (u32*)nullptr, cs.moff[alt].as<u32>(), cs.mpos[alt].as<u64>(), rows, k, nchr, bp0, bpe, (int)has_mut, sd);
+                           (u32*)nullptr, cs.moff[alt].as<u32>(), cs.mpos[alt].as<u64>(), rows, k, nchr, bp0, bpe, (int)has_mut, mcap, sd);
+        hipLaunchKernelGGL(k_collect_total, dim3(1), dim3(64), 0, st, cs.moff[alt].as<u32>(), rows, sd.status + ST_TOTALS + 2 * k);
         KCHECK();
         if (c->track_intervals) {
+            want = std::max<size_t>(cs.parts_need, (size_t)(cs.parts_total[cur] * grow * 1.5) + rows * 4 + 4096);
+            GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), st));
+            const u32 pcap = (u32)std::min<size_t>(cs.parts[alt].bytes / sizeof(gev_part), 0xfffffff0u);
             hipLaunchKernelGGL((k_parts<false>), dim3(row_blocks), dim3(256), 0, st, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
-                               c->d_cnt.as<u32>(), (const u32*)nullptr, (gev_part*)nullptr, rows, k, nchr, bp0, bpe, sd);
+                               c->d_cnt.as<u32>(), (const u32*)nullptr, (gev_part*)nullptr, rows, k, nchr, bp0, bpe, 0u, sd);
             KCHECK();
-            GEVC(scan_u32(c, c->d_cnt.as<u32>(), rows, cs.poff[alt].as<u32>(), &tot));
-            GEVC(cs.parts[alt].ensure(std::max<size_t>(tot, 1) * sizeof(gev_part), st, false, 1.25));
+            GEVC(scan_u32(c, c->d_cnt.as<u32>(), rows, cs.poff[alt].as<u32>(), nullptr));
             hipLaunchKernelGGL((k_parts<true>), dim3(row_blocks), dim3(256), 0, st, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
-                               (u32*)nullptr, cs.poff[alt].as<u32>(), cs.parts[alt].as<gev_part>(), rows, k, nchr, bp0, bpe, sd);
+                               (u32*)nullptr, cs.poff[alt].as<u32>(), cs.parts[alt].as<gev_part>(), rows, k, nchr, bp0, bpe, pcap, sd);
+            hipLaunchKernelGGL(k_collect_total, dim3(1), dim3(64), 0, st, cs.poff[alt].as<u32>(), rows, sd.status + ST_TOTALS + 2 * k + 1);
             KCHECK();
         }
         for (int p = 0; p < c->nphen; p++) {
@@ -628,7 +605,6 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
                                P.cvp[p][k][alt].as<u32>(), P.cvp[p][k][cur].as<u32>(), V.stride_w32, V.sub_w32, nsub, rows,
                                V.d_pos_sorted.as<u64>(), V.C, k, nchr, sd);
             KCHECK();
-            V.frq_valid = false;
         }
     }
     HIPC(hipEventRecord(c->ev[2], st));
@@ -667,8 +643,80 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
         KCHECK();
     }
     HIPC(hipEventRecord(c->ev[3], st));
-    if (sex_out) HIPC(hipMemcpyAsync(sex_out, c->d_sex.p, n_people, hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
+    return GEV_OK;
+}
+
+int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_couples, uint32_t seed_reproduce,
+                  const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people, uint8_t* sex_out)
+{
+    GEVC(check_idx(c, pop, 0));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "reproduce: population %d has no current generation (call gev_init_gen0)", pop);
+    if (n_couples && !couples) return fail(GEV_EINVAL, "reproduce: null couples");
+    HIPC(hipSetDevice(c->device));
+    const int nchr = c->nchr;
+    const size_t T = n_people * (size_t)nchr;
+    if (n_people == 0) return fail(GEV_EINVAL, "reproduce: no offspring");
+    if (2 * T * GEV_BK_CAP >= 0xf0000000ull) return fail(GEV_EINVAL, "reproduce: too many gametes");
+    const bool has_mut = mut_seeds != nullptr;
+    if (has_mut && n_mut_seeds != T) return fail(GEV_EINVAL, "reproduce: n_mut_seeds=%zu, expected n_people*nchr=%zu", n_mut_seeds, T);
+    // pinned staging: [father | mother | mut_seeds | status], written by the host, copied asynchronously
+    const size_t n_status = ST_TOTALS + 2 * (size_t)nchr;
+    const size_t stage_words = 2 * n_people + (has_mut ? T : 0) + n_status;
+    if (c->h_stage_bytes < stage_words * 4) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr; c->h_stage_bytes = 0;
+        HIPC(hipHostMalloc(&c->h_stage, stage_words * 4 * 5 / 4 + 4096, hipHostMallocDefault));
+        c->h_stage_bytes = stage_words * 4 * 5 / 4 + 4096;
+    }
+    u32* father = (u32*)c->h_stage; u32* mother = father + n_people; u32* hseeds = mother + n_people; u32* hstatus = hseeds + (has_mut ? T : 0);
+    // offspring enumeration order of the couple loop (src/Simulation.cpp:2433-2443)
+    size_t ip = 0;
+    for (size_t it = 0; it < n_couples; it++) {
+        if (couples[it].inbreed) continue;
+        if (couples[it].num_offspring < 0) return fail(GEV_EINVAL, "reproduce: couple %zu has negative num_offspring", it);
+        if (couples[it].num_offspring && (couples[it].pos_male >= P.n_people || couples[it].pos_female >= P.n_people))
+            return fail(GEV_EINVAL, "reproduce: couple %zu references position beyond the population (%zu people)", it, P.n_people);
+        for (int ns = 0; ns < couples[it].num_offspring; ns++) {
+            if (ip >= n_people) return fail(GEV_EINVAL, "reproduce: n_people=%zu but the couples list yields more offspring", n_people);
+            father[ip] = (u32)couples[it].pos_male; mother[ip] = (u32)couples[it].pos_female; ip++;
+        }
+    }
+    if (ip != n_people) return fail(GEV_EINVAL, "reproduce: n_people=%zu but the couples list yields %zu offspring", n_people, ip);
+    if (has_mut) memcpy(hseeds, mut_seeds, T * sizeof(u32));
+    GEVC(finalize_static(c, pop));
+    GEVC(ensure_capacity(c, pop, n_people));
+    hipStream_t st = c->stream;
+    GEVC(c->d_father.ensure(n_people * sizeof(u32), st)); GEVC(c->d_mother.ensure(n_people * sizeof(u32), st));
+    GEVC(c->d_seed_pat.ensure((T + 1) * sizeof(u32), st)); GEVC(c->d_seed_mat.ensure(T * sizeof(u32), st));
+    GEVC(c->d_k.ensure(2 * T * sizeof(u32), st)); GEVC(c->d_bk_off.ensure((2 * T + 1) * sizeof(u32), st));
+    GEVC(c->d_start.ensure(2 * T, st)); GEVC(c->d_sex.ensure(n_people, st));
+    GEVC(c->d_nmut.ensure(T * sizeof(u32), st)); GEVC(c->d_nm_off.ensure((T + 1) * sizeof(u32), st));
+    GEVC(c->d_nm_pos.ensure(16, st)); GEVC(c->d_nm_side.ensure(16, st));
+    if (has_mut) GEVC(c->d_mutseeds.ensure(T * sizeof(u32), st));
+    HIPC(hipMemcpyAsync(c->d_father.p, father, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(c->d_mother.p, mother, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
+    if (has_mut) HIPC(hipMemcpyAsync(c->d_mutseeds.p, hseeds, T * sizeof(u32), hipMemcpyHostToDevice, st));
+
+    const int alt = P.cur ^ 1;
+    for (int attempt = 0;; attempt++) {
+        GEVC(enqueue_generation(c, pop, n_people, has_mut, (u32)seed_reproduce));
+        HIPC(hipMemcpyAsync(hstatus, c->d_status.p, n_status * sizeof(u32), hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        const u32 flags = hstatus[ST_FLAGS];
+        for (int k = 0; k < nchr; k++) { P.st[k].mut_total[alt] = hstatus[ST_TOTALS + 2 * k]; P.st[k].parts_total[alt] = hstatus[ST_TOTALS + 2 * k + 1]; }
+        if (!flags) break;
+        if (attempt == 3) return fail(GEV_EDEVICE, "reproduce: buffers still too small after %d attempts (flags %u)", attempt + 1, flags);
+        if (flags & FLAG_BK_OVF) c->bk_ovf_cap = std::max<size_t>(2 * c->bk_ovf_cap, (size_t)hstatus[ST_BK_OVF_USED] * 5 / 4 + 1024);
+        if (flags & FLAG_NM_OVF) c->nm_ovf_cap = std::max<size_t>(2 * c->nm_ovf_cap, (size_t)hstatus[ST_NM_OVF_USED] * 5 / 4 + 1024);
+        for (int k = 0; k < nchr; k++) {     // exact needs from the count passes (valid unless a record overflow zeroed some counts: then next attempt refines)
+            P.st[k].mut_need = (size_t)P.st[k].mut_total[alt] * 5 / 4 + 1024;
+            P.st[k].parts_need = (size_t)P.st[k].parts_total[alt] * 5 / 4 + 1024;
+        }
+    }
+    for (int k = 0; k < nchr; k++) { P.st[k].mut_need = 0; P.st[k].parts_need = 0; }
+    for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = false;
+    if (sex_out) HIPC(hipMemcpy(sex_out, c->d_sex.p, n_people, hipMemcpyDeviceToHost));
     float t;
     HIPC(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); c->last_ms[0] = t;
     HIPC(hipEventElapsedTime(&t, c->ev[4], c->ev[3])); c->last_ms[1] = t;
@@ -787,8 +835,8 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
             u32 tot = 0;
             u32* doff = pass == 0 ? ds.moff[alt].as<u32>() : ds.poff[alt].as<u32>();
             GEVC(scan_u32(c, c->d_cnt.as<u32>(), rows_new, doff, &tot));
-            if (pass == 0) GEVC(ds.mpos[alt].ensure(std::max<size_t>(tot, 2) * sizeof(u64), st, false, 1.25));
-            else GEVC(ds.parts[alt].ensure(std::max<size_t>(tot, 1) * sizeof(gev_part), st, false, 1.25));
+            if (pass == 0) { GEVC(ds.mpos[alt].ensure(std::max<size_t>(tot, 2) * sizeof(u64), st, false, 1.25)); ds.mut_total[alt] = tot; }
+            else { GEVC(ds.parts[alt].ensure(std::max<size_t>(tot, 1) * sizeof(gev_part), st, false, 1.25)); ds.parts_total[alt] = tot; }
             row0 = 0;
             for (const Seg& sg : segs) {                // fill
                 if (sg.people.empty()) continue;
