@@ -10,7 +10,10 @@ One process per GPU; each rank advances its OWN population of the full config-2 
 scaling: populations shard across GPUs); no data-path collective is
 needed without migration.  A step = one generation: host makes the couples list from the
 returned sexes (mating is outside the hot path), then Simulation::reproduce and
-Simulation::ras_compute_AD run on the GPU through the C-ABI.  The founder panel is generated on
+Simulation::ras_compute_AD run on the GPU through the C-ABI.  gev_reproduce returns once the
+small per-generation work is done; the HBM-bound dense stitch continues on the library's second
+stream and overlaps A/D, host mating and the next generation's sampling (every generation's
+stitch is complete before the timed region ends: the closing barrier synchronises the device).  The founder panel is generated on
 the device before the timed region, so genotype state is resident in HBM throughout.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_parent):
@@ -119,29 +122,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    stitch_ms, sample_ms, sparse_ms, ad_ms, mate_ms, repro_ms = [], [], [], [], [], []
+    ad_ms, mate_ms, repro_ms = [], [], []
 
     def step(i):
         t0 = time.perf_counter()
-        sim.couples[0] = synthetic_random_mate(sim.sex[0], args.n_ind, rng)     # host mating (outside the hot path)
+        sim.couples[0] = synthetic_random_mate(sim.sex[0], args.n_ind, rng, out=sim.couples.get(0))   # host mating (outside the hot path)
         t1 = time.perf_counter()
-        sim.reproduce(0, i + 1, seeds=seeds[i])                                  # Simulation::reproduce
+        sim.reproduce(0, i + 1, seeds=seeds[i], n_people=args.n_ind)             # Simulation::reproduce
         t2 = time.perf_counter()
         sim.ras_compute_AD(0, i + 1)                                             # Simulation::ras_compute_AD
         t3 = time.perf_counter()
         mate_ms.append((t1 - t0) * 1e3); repro_ms.append((t2 - t1) * 1e3); ad_ms.append((t3 - t2) * 1e3)
-        ms = ctx.last_reproduce_ms()
-        sample_ms.append(ms[0]); stitch_ms.append(ms[1]); sparse_ms.append(ms[2])
 
     for i in range(args.warmup):
         step(i)
-    del stitch_ms[:], sample_ms[:], sparse_ms[:], ad_ms[:], mate_ms[:], repro_ms[:]
+    del ad_ms[:], mate_ms[:], repro_ms[:]
+    tot0, n0 = ctx.timing_totals()                       # (implies a sync of both library streams)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
-    barrier()
+    barrier()                                            # torch.cuda.synchronize() waits for the last dense stitch too
     dt = time.perf_counter() - t0
+    tot1, n1 = ctx.timing_totals()
+    assert n1 - n0 == args.steps
+    sample_ms = [(tot1[0] - tot0[0]) / args.steps]; stitch_ms = [(tot1[1] - tot0[1]) / args.steps]; sparse_ms = [(tot1[2] - tot0[2]) / args.steps]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

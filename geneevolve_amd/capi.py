@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "compute_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_cv", "download_intervals", "download_mutations",
-    "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode",
+    "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -183,14 +183,15 @@ class GevContext:
         self._call("init_gen0", C.c_int(pop), C.c_size_t(n_people), C.c_uint32(int(seed_gen0)), _p(sex))
         return sex
 
-    def reproduce(self, pop, couples, seed_reproduce, mut_seeds=None, want_sex=True):
+    def reproduce(self, pop, couples, seed_reproduce, mut_seeds=None, want_sex=True, n_people=None):
         """couples: int array [n,4] (pos_male,pos_female,inbreed,num_offspring) or COUPLE_DTYPE array"""
         if couples.dtype != COUPLE_DTYPE:
             c = np.zeros(len(couples), dtype=COUPLE_DTYPE)
             c["pos_male"], c["pos_female"], c["inbreed"], c["num_offspring"] = couples[:, 0], couples[:, 1], couples[:, 2], couples[:, 3]
             couples = c
         couples = np.ascontiguousarray(couples)
-        n_people = int(couples["num_offspring"][couples["inbreed"] == 0].sum())
+        if n_people is None:
+            n_people = int(couples["num_offspring"][couples["inbreed"] == 0].sum())
         ms = None if mut_seeds is None else _arr(mut_seeds, np.uint32)
         sex = np.zeros(n_people, dtype=np.uint8) if want_sex else None
         self._call("reproduce", C.c_int(pop), _p(couples), C.c_size_t(len(couples)), C.c_uint32(int(seed_reproduce)),
@@ -274,6 +275,14 @@ class GevContext:
         ms = (C.c_float * 4)()
         self._call("last_reproduce_ms", ms)
         return [float(x) for x in ms]
+
+    def sync(self):
+        self._call("sync")
+
+    def timing_totals(self):
+        ms = (C.c_double * 4)(); n = C.c_ulonglong()
+        self._call("timing_totals", ms, C.byref(n))
+        return [float(x) for x in ms], n.value
 
     def set_stitch_mode(self, mode):
         self._call("set_stitch_mode", C.c_int(mode))

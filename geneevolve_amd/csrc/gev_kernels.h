@@ -32,6 +32,7 @@ struct ChrDev {
     u64 bp_dist;          // rMap::bp_dist_in_rmap
     u64 bp0, bp_end;      // rmap.bp[0], rmap.bp[R-1]: every haplotype covers [bp0, bp_end)
     u32 R, M;
+    u32 r_amax, m_amax;   // largest a_hi of the recombination / mutation thresholds (scan prefilter)
 };
 
 // per-generation sampling results (all chromosomes; task t = offspring*nchr + chr, gamete G = 2t+s)
@@ -60,6 +61,18 @@ struct SampleDev {
 // status words written by the kernels of one generation, read back once at its end
 enum { ST_BK_OVF_USED = 0, ST_NM_OVF_USED = 1, ST_FLAGS = 2, ST_TOTALS = 4 /* then per chr: mut_total, parts_total */ };
 enum { FLAG_BK_OVF = 1, FLAG_NM_OVF = 2, FLAG_MUT_CAP = 4, FLAG_PARTS_CAP = 8 };
+
+// The RNG tables (16 KB) are read 31 words at a time for every srand(); under a concurrently
+// running HBM-saturating stitch a dependent global read costs microseconds, so every sampling
+// workgroup stages them into LDS once and loops over many tasks (persistent grid).
+__device__ __forceinline__ const GevRngTables* stage_tables(const GevRngTables* __restrict__ g, GevRngTables* s)
+{
+    const uint4* src = (const uint4*)g; uint4* dst = (uint4*)s;
+    for (u32 i = threadIdx.x; i < sizeof(GevRngTables) / 16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return s;
+}
+#define SAMPLE_GRID_MAX 2048      // 256 CUs x 8 workgroups of 4 waves
 
 // ------------------------------------------------------------------------------------------
 // exclusive scan of u32 counts (CSR offsets); n+1 outputs
@@ -179,8 +192,10 @@ __global__ void k_init_parts(gev_part* __restrict__ parts, u32* __restrict__ off
     if (r < nrows) parts[r] = gev_part{bp0, bp_end, (u64)r, pop, 0};
 }
 // sex[i] = rand()%2+1 for i = 0..n-1 after srand(seed) (src/Simulation.cpp:3005, 3036). One wave.
-__global__ void __launch_bounds__(64) k_sex_sequence(const GevRngTables* __restrict__ T, u32 seed, size_t n, uint8_t* __restrict__ sex)
+__global__ void __launch_bounds__(64) k_sex_sequence(const GevRngTables* __restrict__ Tg, u32 seed, size_t n, uint8_t* __restrict__ sex)
 {
+    __shared__ __attribute__((aligned(16))) GevRngTables s_T;
+    const GevRngTables* T = stage_tables(Tg, &s_T);
     GlibcWave g; g.seed(T, seed);
     const u32 lane = threadIdx.x;
     for (size_t base = 0; base < n; base += 64) {
@@ -201,7 +216,7 @@ __device__ __forceinline__ u32 mut_scan_write(const GevRngTables* __restrict__ T
     u32 xg = minstd_seed(S + 1u);                                // generator(seed+1), :2503
     u32 h = 0;
     if (C.M >= 2)
-        wave_scan_hits(T, S + 2u, C.mthr, 1, C.M - 1, [&](u32 row) {                       // generator_u(seed+2), i = 1..M-1
+        wave_scan_hits(T, S + 2u, C.mthr, C.m_amax, 1, C.M - 1, [&](u32 row) {                       // generator_u(seed+2), i = 1..M-1
             if (h < cap) {
                 const u64 bp_mut = uniform_int_fallback(xg, C.mbp[row - 1], C.mbp[row]);    // :2516-2520
                 const u32 sd_ = g.out(T, h) & 1u;                                            // rand()%2, :2522
@@ -211,12 +226,14 @@ __device__ __forceinline__ u32 mut_scan_write(const GevRngTables* __restrict__ T
         });
     return h;
 }
-__global__ void __launch_bounds__(256) k_mut_sample(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
+__global__ void __launch_bounds__(256) k_mut_sample(const GevRngTables* __restrict__ Tg, const ChrDev* __restrict__ chrs, int nchr,
                                                     const u32* __restrict__ mut_seeds, size_t n_tasks, SampleDev sd)
 {
-    const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= n_tasks) return;
+    __shared__ __attribute__((aligned(16))) GevRngTables s_T;
+    const GevRngTables* T = stage_tables(Tg, &s_T);
     const u32 lane = threadIdx.x & 63;
+    for (size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < n_tasks; t += (size_t)gridDim.x * 4) {
+    asm volatile("" : "+v"(T));          // keep the 62 table words of this lane out of registers across tasks (occupancy)
     const int c = (int)(t % nchr);
     const ChrDev& C = chrs[c];
     const u32 S = mut_seeds[t];
@@ -242,6 +259,7 @@ __global__ void __launch_bounds__(256) k_mut_sample(const GevRngTables* __restri
     }
     const u32 nxt = g.out(T, n);                                 // seed_loc of the next task, :2447
     if (lane == 0) sd.seed_pat[t + 1] = nxt;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -253,7 +271,7 @@ __device__ __forceinline__ u32 rec_scan_write(const GevRngTables* __restrict__ T
 {
     const u32 lane = threadIdx.x & 63;
     u32 h = 0;
-    wave_scan_hits(T, seed + 1u, C.rthr, 0, C.R, [&](u32 row) {
+    wave_scan_hits(T, seed + 1u, C.rthr, C.r_amax, 0, C.R, [&](u32 row) {
         if (h < cap) {
             const u64 v = C.rbp[row] + (u64)g.out(T, h) % C.bp_dist;
             if (lane == 0) out[h] = v;
@@ -302,22 +320,27 @@ __device__ __forceinline__ u32 task_sample(const GevRngTables* __restrict__ T, c
 }
 // task-parallel form (a mutation map is loaded: every task's chain restarts at srand(S), see
 // SURVEY.md section 7.2-1).  seed_pat[t] for t>0 was written by k_mut_sample.
-__global__ void __launch_bounds__(256) k_rec_sample(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
+__global__ void __launch_bounds__(256) k_rec_sample(const GevRngTables* __restrict__ Tg, const ChrDev* __restrict__ chrs, int nchr,
                                                     u32 seed_reproduce, size_t n_tasks, SampleDev sd)
 {
-    const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= n_tasks) return;
-    GlibcWave g;
-    u32 seed_pat;
-    if (t == 0) { g.seed(T, seed_reproduce); seed_pat = g.out(T, 0); }     // srand(seed) :2400, first rand() :2447
-    else seed_pat = sd.seed_pat[t];
-    task_sample(T, chrs[t % nchr], seed_pat, t, g, sd);
+    __shared__ __attribute__((aligned(16))) GevRngTables s_T;
+    const GevRngTables* T = stage_tables(Tg, &s_T);
+    for (size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < n_tasks; t += (size_t)gridDim.x * 4) {
+        asm volatile("" : "+v"(T));      // keep the 62 table words of this lane out of registers across tasks (occupancy)
+        GlibcWave g;
+        u32 seed_pat;
+        if (t == 0) { g.seed(T, seed_reproduce); seed_pat = g.out(T, 0); }     // srand(seed) :2400, first rand() :2447
+        else seed_pat = sd.seed_pat[t];
+        task_sample(T, chrs[t % nchr], seed_pat, t, g, sd);
+    }
 }
 // serial form (no mutation map): every gamete's seed depends on the previous gamete's crossover
 // count, so one wave walks the chain; each link is still a wave-parallel scan.
-__global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict__ T, const ChrDev* __restrict__ chrs, int nchr,
+__global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict__ Tg, const ChrDev* __restrict__ chrs, int nchr,
                                                   u32 seed_reproduce, size_t n_tasks, SampleDev sd)
 {
+    __shared__ __attribute__((aligned(16))) GevRngTables s_T;
+    const GevRngTables* T = stage_tables(Tg, &s_T);
     const u32 lane = threadIdx.x;
     GlibcWave g; g.seed(T, seed_reproduce);
     u32 seed = g.out(T, 0);
@@ -477,6 +500,8 @@ __global__ void __launch_bounds__(256) k_stitch_parent(
     const u64* __restrict__ pos, u32 L, int chr, int nchr, const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd)
 {
     __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big;
+    // Launched with a block of unused dynamic LDS: it caps the workgroups per CU so that wave slots stay free
+    // for the small kernels of the next generation running concurrently on the other stream.
     const u32 parent = blockIdx.x / blocks_per_parent, span = blockIdx.x % blocks_per_parent;
     const u32 g0 = goff[parent], g1 = goff[parent + 1];
     if (g0 == g1) return;

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -48,7 +49,7 @@ struct DevBuf {
         if (e != hipSuccess) return fail(GEV_EDEVICE, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
         if (p) {
             if (keep && bytes) { HIPC(hipMemcpyAsync(q, p, bytes, hipMemcpyDeviceToDevice, st)); }
-            HIPC(hipStreamSynchronize(st));
+            HIPC(hipDeviceSynchronize());      // the old buffer may still be in use on the other stream
             (void)hipFree(p);
         }
         p = q; bytes = want;
@@ -64,6 +65,7 @@ struct ChrStatic {                       // one population x one chromosome
     DevBuf d_rthr, d_rbp, d_mthr, d_mbp, d_pos;
     size_t L = 0, stride = 0;            // plane row stride in bytes (multiple of 128)
     u32 idx_lo = 0, idx_hi = 0;          // loci inside [bp0, bp_end)
+    u32 r_amax = 0, m_amax = 0;
     size_t founder_rows = 0;
 };
 struct CvStatic {                        // one population x phenotype x chromosome
@@ -101,12 +103,27 @@ struct gev_ctx {
     bool track_intervals = true;
     std::vector<PopState> pop;
     DevBuf d_tables;
-    // per-generation scratch
-    DevBuf d_father, d_mother, d_mutseeds, d_seed_pat, d_seed_mat, d_k, d_bk_off, d_bk, d_start, d_nmut, d_nm_off, d_nm_pos, d_nm_side, d_sex;
-    DevBuf d_ghist, d_goff, d_glist, d_status;
+    // per-generation scratch: two sets, because the dense stitch of generation g (stream_big) still reads set g%2
+    // while sampling / sparse state of generation g+1 (stream) fill the other one
+    struct Scratch {
+        DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, start, nmut, nm_off, nm_pos, nm_side, sex, ghist, goff, glist, status;
+        hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        bool timing_pending = false, stitch_pending = false;
+    } sc[2];
+    unsigned gen_counter = 0;
+    hipStream_t stream_big = nullptr;
+    bool planes_pending = false;            // a stitch may still be writing the current planes (stream_big)
+    hipEvent_t ev_planes = nullptr;         // recorded after the most recent stitch
+    double ms_sum[4] = {0, 0, 0, 0}; unsigned long long ms_count = 0;
     size_t bk_ovf_cap = 1 << 16, nm_ovf_cap = 1 << 16;       // overflow regions of the breakpoint / new-mutation records
     void* h_stage = nullptr; size_t h_stage_bytes = 0;       // pinned host staging
+    void* h_ad = nullptr; size_t h_ad_bytes = 0;             // pinned A/D result cache
+    int ad_cached_pop = -1;                                  // population whose current-generation A/D sits in h_ad
+    bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
     int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
+    bool serialize = false;        // GEV_SERIALIZE=1: wait for every stitch (diagnostic, measures the phases without overlap)
+    unsigned stitch_lds_pad = 0;   // unused dynamic LDS per stitch workgroup: limits workgroups per CU (160 KiB / CU)
+    DevBuf d_sex0;
     DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
     std::map<double, GevThr> thr_cache;
 };
@@ -206,8 +223,19 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     std::unique_ptr<gev_ctx> c(new gev_ctx());
     c->device = device; c->n_pop = n_pop; c->nchr = nchr; c->nphen = nphen;
     while ((1u << c->rp_bits) < (u32)n_pop) c->rp_bits++;
-    HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // small latency-critical kernels get the high-priority queue, the long HBM-bound stitch the low one:
+    // stitch workgroups are short-lived, so freed CU slots go to the small kernels first
+    int prio_least = 0, prio_greatest = 0;
+    HIPC(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIPC(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
     for (auto& ev : c->ev) HIPC(hipEventCreate(&ev));
+    HIPC(hipStreamCreateWithPriority(&c->stream_big, hipStreamNonBlocking, prio_least));
+    HIPC(hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming));
+    for (auto& sc : c->sc) {
+        HIPC(hipEventCreateWithFlags(&sc.ev_small_done, hipEventDisableTiming));
+        HIPC(hipEventCreateWithFlags(&sc.ev_stitch_done, hipEventDisableTiming));
+        for (auto& e : sc.t) HIPC(hipEventCreate(&e));
+    }
     c->pop.resize(n_pop);
     for (auto& P : c->pop) {
         P.cs.resize(nchr); P.st.resize(nchr);
@@ -216,6 +244,11 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     }
     GevRngTables T; gev_build_rng_tables(T);
     GEVC(h2d(c.get(), c->d_tables, &T, sizeof T));
+    if (const char* e = getenv("GEV_SERIALIZE")) c->serialize = atoi(e) != 0;
+    if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // tuning knob: stitch workgroups per CU (default: unlimited = 8)
+        const int occ = atoi(e);
+        if (occ >= 1 && occ < 8) c->stitch_lds_pad = (unsigned)std::min(160 * 1024 / occ - 3 * 1024, 64 * 1024 - 2048);
+    }
     *out = c.release();
     return GEV_OK;
 }
@@ -224,9 +257,13 @@ void gev_destroy(gev_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    if (c->stream_big) { (void)hipStreamSynchronize(c->stream_big); (void)hipStreamDestroy(c->stream_big); }
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
+    for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
     hipStream_t s = c->stream;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_ad) (void)hipHostFree(c->h_ad);
     delete c;
     if (s) (void)hipStreamDestroy(s);
 }
@@ -245,6 +282,7 @@ int gev_set_rmap(gev_ctx* c, int pop, int chr, const u64* bp, const double* prob
     S.rbp.assign(bp, bp + R); S.rprob.assign(prob, prob + R); S.bp_dist = bp_dist;
     std::vector<GevThr> thr;
     GEVC(make_thresholds(c, S.rprob, thr));
+    S.r_amax = 0; for (const GevThr& t : thr) S.r_amax = std::max(S.r_amax, t.a_hi);
     HIPC(hipSetDevice(c->device));
     GEVC(h2d(c, S.d_rthr, thr.data(), R * sizeof(GevThr)));
     GEVC(h2d(c, S.d_rbp, bp, R * sizeof(u64)));
@@ -264,6 +302,7 @@ int gev_set_mutmap(gev_ctx* c, int pop, int chr, const u64* bp, const double* ra
     S.mbp.assign(bp, bp + M); S.mrate.assign(rate, rate + M); S.mut_set = true;
     std::vector<GevThr> thr;
     GEVC(make_thresholds(c, S.mrate, thr));
+    S.m_amax = 0; for (size_t i = 1; i < M; i++) S.m_amax = std::max(S.m_amax, thr[i].a_hi);
     HIPC(hipSetDevice(c->device));
     GEVC(h2d(c, S.d_mthr, thr.data(), M * sizeof(GevThr)));
     GEVC(h2d(c, S.d_mbp, bp, M * sizeof(u64)));
@@ -311,6 +350,7 @@ int gev_set_cvs(gev_ctx* c, int pop, int phen, int chr, const u64* bp, const dou
     GEVC(V.d_frq.ensure(std::max<size_t>(C, 1) * sizeof(double), c->stream));
     GEVC(V.d_counts.ensure(std::max<size_t>(C, 1) * sizeof(u32), c->stream));
     V.frq_valid = false;
+    c->ad_cached_pop = -1;
     c->pop[pop].finalized = false;
     return GEV_OK;
 }
@@ -351,6 +391,7 @@ int gev_upload_founders(gev_ctx* c, int pop, int chr, const u64* bits, size_t ro
     if (L != S.L) return fail(GEV_EINVAL, "upload_founders: L=%zu but set_snps gave %zu loci", L, S.L);
     if (row_stride_words * 64 < L) return fail(GEV_EINVAL, "upload_founders: row stride too small");
     HIPC(hipSetDevice(c->device));
+    GEVC(gev_sync(c));
     GEVC(P.st[chr].plane[P.cur].ensure(nhap * S.stride, c->stream));
     HIPC(hipMemsetAsync(P.st[chr].plane[P.cur].p, 0, nhap * S.stride, c->stream));
     HIPC(hipMemcpy2DAsync(P.st[chr].plane[P.cur].p, S.stride, bits, row_stride_words * 8, ceil_div(L, 8), nhap, hipMemcpyHostToDevice, c->stream));
@@ -370,6 +411,7 @@ int gev_synth_founders(gev_ctx* c, int pop, int chr, size_t nhap, u64 seed)
     if (nhap < 2 || (nhap & 1)) return fail(GEV_EINVAL, "synth_founders: need an even number of haplotypes");
     if (!S.L) return fail(GEV_ESTATE, "synth_founders: set_snps first");
     HIPC(hipSetDevice(c->device));
+    GEVC(gev_sync(c));
     GEVC(P.st[chr].plane[P.cur].ensure(nhap * S.stride, c->stream));
     HIPC(hipMemsetAsync(P.st[chr].plane[P.cur].p, 0, nhap * S.stride, c->stream));
     GEVC(c->d_thr32.ensure(S.L * sizeof(u32), c->stream));
@@ -395,6 +437,7 @@ static int cv_founders_from_tmp(gev_ctx* c, int pop, int phen, int chr, size_t n
         KCHECK();
     }
     HIPC(hipStreamSynchronize(c->stream));
+    c->ad_cached_pop = -1;
     V.founder_rows = nhap; P.gen0 = false;
     return GEV_OK;
 }
@@ -442,7 +485,7 @@ static int finalize_static(gev_ctx* c, int pop)
         S.idx_lo = (u32)(std::lower_bound(S.pos.begin(), S.pos.end(), bp0) - S.pos.begin());
         S.idx_hi = (u32)(std::lower_bound(S.pos.begin(), S.pos.end(), bpe) - S.pos.begin());
         cd[k] = ChrDev{S.d_rthr.as<GevThr>(), S.d_rbp.as<u64>(), S.d_mthr.as<GevThr>(), S.d_mbp.as<u64>(), S.bp_dist, bp0, bpe,
-                       (u32)S.rbp.size(), (u32)S.mbp.size()};
+                       (u32)S.rbp.size(), (u32)S.mbp.size(), S.r_amax, S.m_amax};
         for (int p = 0; p < c->nphen; p++) {
             CvStatic& V = P.cv[p][k];
             if (!V.set) continue;
@@ -486,6 +529,7 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     if (n_people < 1) return fail(GEV_EINVAL, "init_gen0: n_people must be >= 1");
     if (2 * n_people >= 0xffffffffull) return fail(GEV_EINVAL, "init_gen0: too many people");
     HIPC(hipSetDevice(c->device));
+    GEVC(gev_sync(c));
     PopState& P = c->pop[pop];
     GEVC(finalize_static(c, pop));
     const size_t rows = 2 * n_people;
@@ -514,23 +558,62 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
             V.frq_valid = false;
         }
     }
-    GEVC(c->d_sex.ensure(n_people, c->stream));
-    hipLaunchKernelGGL(k_sex_sequence, dim3(1), dim3(64), 0, c->stream, c->d_tables.as<GevRngTables>(), (u32)seed_gen0, n_people, c->d_sex.as<uint8_t>());
+    GEVC(c->d_sex0.ensure(n_people, c->stream));
+    hipLaunchKernelGGL(k_sex_sequence, dim3(1), dim3(64), 0, c->stream, c->d_tables.as<GevRngTables>(), (u32)seed_gen0, n_people, c->d_sex0.as<uint8_t>());
     KCHECK();
-    if (sex_out) HIPC(hipMemcpyAsync(sex_out, c->d_sex.p, n_people, hipMemcpyDeviceToHost, c->stream));
+    if (sex_out) HIPC(hipMemcpyAsync(sex_out, c->d_sex0.p, n_people, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = rows; }
+    c->ad_cached_pop = -1;
     P.n_people = n_people; P.gen0 = true;
     return GEV_OK;
 }
 
 // ---- Simulation::reproduce ----------------------------------------------------------------
-// Everything of one generation is enqueued without a host round trip: variable-length outputs go
-// to capacity-checked buffers sized from the previous generation's totals, and one status block
-// is read back at the end.  If a capacity was too small the buffers are grown from the exact
-// totals the count passes produced and the generation is enqueued again (inputs are untouched:
-// all results go to the alternate buffers until the final flip).
-static int enqueue_generation(gev_ctx* c, int pop, size_t n_people, bool has_mut, u32 seed_reproduce)
+// Two HIP streams.  `stream` carries the small kernels of generation g (sampling, sparse lists,
+// CV planes, gamete grouping) and the status/sex read-back the host waits for; `stream_big`
+// carries the HBM-bound dense stitch, which the host does NOT wait for: gev_reproduce returns as
+// soon as the small work is done, so A/D of generation g, host mating and the small work of
+// generation g+1 overlap the stitch of generation g.  Order on stream_big serialises consecutive
+// stitches (each reads the plane the previous one wrote); the scratch set a stitch reads (g%2)
+// is not reused before that stitch has finished (stream waits on its event).
+// No host round trip inside a generation: variable-length outputs go to capacity-checked buffers
+// sized from the previous totals; if one was too small the buffers are grown from the exact totals
+// of the count passes and the small work is enqueued again (inputs are untouched until the flip).
+static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n);
+static int wait_planes(gev_ctx* c)
+{
+    if (c->planes_pending) HIPC(hipStreamWaitEvent(c->stream, c->ev_planes, 0));
+    return GEV_OK;
+}
+static int harvest_timing(gev_ctx* c, gev_ctx::Scratch& sc)
+{
+    if (!sc.timing_pending) return GEV_OK;
+    HIPC(hipEventSynchronize(sc.t[3]));
+    float t; float ms[4];
+    HIPC(hipEventElapsedTime(&t, sc.t[0], sc.t[1])); ms[0] = t;
+    HIPC(hipEventElapsedTime(&t, sc.t[4], sc.t[3])); ms[1] = t;
+    HIPC(hipEventElapsedTime(&t, sc.t[1], sc.t[2])); ms[2] = t;
+    ms[3] = ms[0] + ms[1] + ms[2];
+    for (int i = 0; i < 4; i++) { c->last_ms[i] = ms[i]; c->ms_sum[i] += ms[i]; }
+    c->ms_count++;
+    sc.timing_pending = false;
+    return GEV_OK;
+}
+static SampleDev make_sd(gev_ctx* c, gev_ctx::Scratch& sc, size_t T)
+{
+    SampleDev sd;
+    sd.seed_pat = sc.seed_pat.as<u32>(); sd.seed_mat = sc.seed_mat.as<u32>(); sd.k = sc.k.as<u32>();
+    sd.bk_off = sc.bk_off.as<u32>(); sd.bk = sc.bk.as<u64>(); sd.start = sc.start.as<uint8_t>();
+    sd.nmut = sc.nmut.as<u32>(); sd.nm_off = sc.nm_off.as<u32>(); sd.nm_pos = sc.nm_pos.as<u64>();
+    sd.nm_side = sc.nm_side.as<uint8_t>(); sd.sex = sc.sex.as<uint8_t>();
+    sd.father = sc.father.as<u32>(); sd.mother = sc.mother.as<u32>();
+    sd.bk_ovf_base = (u32)(2 * T * GEV_BK_CAP); sd.bk_ovf_cap = (u32)c->bk_ovf_cap;
+    sd.nm_ovf_base = (u32)(T * GEV_NM_CAP); sd.nm_ovf_cap = (u32)c->nm_ovf_cap;
+    sd.status = sc.status.as<u32>();
+    return sd;
+}
+static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut, u32 seed_reproduce)
 {
     PopState& P = c->pop[pop];
     hipStream_t st = c->stream;
@@ -540,31 +623,23 @@ static int enqueue_generation(gev_ctx* c, int pop, size_t n_people, bool has_mut
     const ChrDev* chrs = P.d_chrdev.as<ChrDev>();
     const size_t bk_fixed = 2 * T * GEV_BK_CAP, nm_fixed = T * GEV_NM_CAP;
     if (bk_fixed + c->bk_ovf_cap >= 0xffffffffull || nm_fixed + c->nm_ovf_cap >= 0xffffffffull) return fail(GEV_EINVAL, "reproduce: breakpoint/mutation record space exceeds 32-bit offsets");
-    GEVC(c->d_bk.ensure((bk_fixed + c->bk_ovf_cap) * sizeof(u64), st));
-    if (has_mut) { GEVC(c->d_nm_pos.ensure((nm_fixed + c->nm_ovf_cap) * sizeof(u64), st)); GEVC(c->d_nm_side.ensure(nm_fixed + c->nm_ovf_cap, st)); }
+    GEVC(sc.bk.ensure((bk_fixed + c->bk_ovf_cap) * sizeof(u64), st));
+    if (has_mut) { GEVC(sc.nm_pos.ensure((nm_fixed + c->nm_ovf_cap) * sizeof(u64), st)); GEVC(sc.nm_side.ensure(nm_fixed + c->nm_ovf_cap, st)); }
     const size_t n_status = ST_TOTALS + 2 * (size_t)nchr;
-    GEVC(c->d_status.ensure(n_status * sizeof(u32), st));
-    HIPC(hipMemsetAsync(c->d_status.p, 0, n_status * sizeof(u32), st));
-    SampleDev sd;
-    sd.seed_pat = c->d_seed_pat.as<u32>(); sd.seed_mat = c->d_seed_mat.as<u32>(); sd.k = c->d_k.as<u32>();
-    sd.bk_off = c->d_bk_off.as<u32>(); sd.bk = c->d_bk.as<u64>(); sd.start = c->d_start.as<uint8_t>();
-    sd.nmut = c->d_nmut.as<u32>(); sd.nm_off = c->d_nm_off.as<u32>(); sd.nm_pos = c->d_nm_pos.as<u64>();
-    sd.nm_side = c->d_nm_side.as<uint8_t>(); sd.sex = c->d_sex.as<uint8_t>();
-    sd.father = c->d_father.as<u32>(); sd.mother = c->d_mother.as<u32>();
-    sd.bk_ovf_base = (u32)bk_fixed; sd.bk_ovf_cap = (u32)c->bk_ovf_cap; sd.nm_ovf_base = (u32)nm_fixed; sd.nm_ovf_cap = (u32)c->nm_ovf_cap;
-    sd.status = c->d_status.as<u32>();
+    HIPC(hipMemsetAsync(sc.status.p, 0, n_status * sizeof(u32), st));
+    SampleDev sd = make_sd(c, sc, T);
 
-    HIPC(hipEventRecord(c->ev[0], st));
+    HIPC(hipEventRecord(sc.t[0], st));
     // ---- sampling: one map scan per gamete / per mutation task
-    const unsigned task_blocks = (unsigned)ceil_div(T, 4);
+    const unsigned task_blocks = (unsigned)std::min<size_t>(ceil_div(T, 4), SAMPLE_GRID_MAX);
     if (has_mut) {
-        hipLaunchKernelGGL(k_mut_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, c->d_mutseeds.as<u32>(), T, sd);
+        hipLaunchKernelGGL(k_mut_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, sc.mutseeds.as<u32>(), T, sd);
         hipLaunchKernelGGL(k_rec_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd);
     } else {
         hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd);
     }
     KCHECK();
-    HIPC(hipEventRecord(c->ev[1], st));
+    HIPC(hipEventRecord(sc.t[1], st));
     // ---- sparse state: mutation lists + ancestry intervals + CV planes
     const int cur = P.cur, alt = P.cur ^ 1;
     GEVC(c->d_cnt.ensure((rows + 1) * sizeof(u32), st));
@@ -607,22 +682,33 @@ static int enqueue_generation(gev_ctx* c, int pop, size_t n_people, bool has_mut
             KCHECK();
         }
     }
-    HIPC(hipEventRecord(c->ev[2], st));
-    // ---- dense stitch of the genotype planes (the HBM-bound kernel)
-    const size_t n_parent = P.n_people;
+    // ---- gamete grouping by source individual for the parent-major stitch (same for every chromosome)
     if (c->stitch_mode == 0) {
-        // group the gametes by source individual (same grouping for every chromosome)
-        GEVC(c->d_ghist.ensure((n_parent + 1) * sizeof(u32), st)); GEVC(c->d_goff.ensure((n_parent + 1) * sizeof(u32), st));
-        GEVC(c->d_glist.ensure(rows * sizeof(u32), st));
-        HIPC(hipMemsetAsync(c->d_ghist.p, 0, (n_parent + 1) * sizeof(u32), st));
-        hipLaunchKernelGGL(k_group_hist, dim3(row_blocks), dim3(256), 0, st, sd.father, sd.mother, rows, c->d_ghist.as<u32>());
+        const size_t n_parent = P.n_people;
+        GEVC(sc.ghist.ensure((n_parent + 1) * sizeof(u32), st)); GEVC(sc.goff.ensure((n_parent + 1) * sizeof(u32), st));
+        GEVC(sc.glist.ensure(rows * sizeof(u32), st));
+        HIPC(hipMemsetAsync(sc.ghist.p, 0, (n_parent + 1) * sizeof(u32), st));
+        hipLaunchKernelGGL(k_group_hist, dim3(row_blocks), dim3(256), 0, st, sd.father, sd.mother, rows, sc.ghist.as<u32>());
         KCHECK();
-        GEVC(scan_u32(c, c->d_ghist.as<u32>(), n_parent, c->d_goff.as<u32>(), nullptr));
-        HIPC(hipMemsetAsync(c->d_ghist.p, 0, (n_parent + 1) * sizeof(u32), st));
-        hipLaunchKernelGGL(k_group_fill, dim3(row_blocks), dim3(256), 0, st, sd.father, sd.mother, rows, c->d_goff.as<u32>(), c->d_ghist.as<u32>(), c->d_glist.as<u32>());
+        GEVC(scan_u32(c, sc.ghist.as<u32>(), n_parent, sc.goff.as<u32>(), nullptr));
+        HIPC(hipMemsetAsync(sc.ghist.p, 0, (n_parent + 1) * sizeof(u32), st));
+        hipLaunchKernelGGL(k_group_fill, dim3(row_blocks), dim3(256), 0, st, sd.father, sd.mother, rows, sc.goff.as<u32>(), sc.ghist.as<u32>(), sc.glist.as<u32>());
         KCHECK();
     }
-    HIPC(hipEventRecord(c->ev[4], st));
+    HIPC(hipEventRecord(sc.t[2], st));
+    return GEV_OK;
+}
+// the HBM-bound part, on stream_big, after the small work of the same generation
+static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people)
+{
+    PopState& P = c->pop[pop];
+    const int nchr = c->nchr, cur = P.cur, alt = P.cur ^ 1;
+    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people, n_parent = P.n_people;
+    hipStream_t sb = c->stream_big;
+    SampleDev sd = make_sd(c, sc, T);
+    HIPC(hipEventRecord(sc.ev_small_done, c->stream));
+    HIPC(hipStreamWaitEvent(sb, sc.ev_small_done, 0));
+    HIPC(hipEventRecord(sc.t[4], sb));
     for (int k = 0; k < nchr; k++) {
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         const u32 chunks = (u32)(S.stride / 16);
@@ -633,16 +719,20 @@ static int enqueue_generation(gev_ctx* c, int pop, size_t n_people, bool has_mut
         const size_t nblk = units * bpr;
         if (nblk > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
         if (c->stitch_mode == 0)
-            hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)nblk), dim3(256), 0, st,
+            hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)nblk), dim3(256), c->stitch_lds_pad, sb,
                                cs.plane[alt].as<uint8_t>(), cs.plane[cur].as<uint8_t>(), S.stride, chunks, bpr,
-                               S.d_pos.as<u64>(), (u32)S.L, k, nchr, c->d_goff.as<u32>(), c->d_glist.as<u32>(), sd);
+                               S.d_pos.as<u64>(), (u32)S.L, k, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd);
         else
-            hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)nblk), dim3(STITCH_THREADS), 0, st,
+            hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)nblk), dim3(STITCH_THREADS), 0, sb,
                                cs.plane[alt].as<uint8_t>(), cs.plane[cur].as<uint8_t>(), S.stride, chunks, bpr,
                                S.d_pos.as<u64>(), (u32)S.L, k, nchr, sd);
         KCHECK();
     }
-    HIPC(hipEventRecord(c->ev[3], st));
+    HIPC(hipEventRecord(sc.t[3], sb));
+    HIPC(hipEventRecord(sc.ev_stitch_done, sb));
+    HIPC(hipEventRecord(c->ev_planes, sb));
+    sc.timing_pending = true; sc.stitch_pending = true; c->planes_pending = true;
+    if (c->serialize) HIPC(hipStreamSynchronize(sb));      // diagnostic: no overlap between generations
     return GEV_OK;
 }
 
@@ -664,6 +754,7 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     const size_t n_status = ST_TOTALS + 2 * (size_t)nchr;
     const size_t stage_words = 2 * n_people + (has_mut ? T : 0) + n_status;
     if (c->h_stage_bytes < stage_words * 4) {
+        HIPC(hipDeviceSynchronize());
         if (c->h_stage) (void)hipHostFree(c->h_stage);
         c->h_stage = nullptr; c->h_stage_bytes = 0;
         HIPC(hipHostMalloc(&c->h_stage, stage_words * 4 * 5 / 4 + 4096, hipHostMallocDefault));
@@ -687,21 +778,28 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     GEVC(finalize_static(c, pop));
     GEVC(ensure_capacity(c, pop, n_people));
     hipStream_t st = c->stream;
-    GEVC(c->d_father.ensure(n_people * sizeof(u32), st)); GEVC(c->d_mother.ensure(n_people * sizeof(u32), st));
-    GEVC(c->d_seed_pat.ensure((T + 1) * sizeof(u32), st)); GEVC(c->d_seed_mat.ensure(T * sizeof(u32), st));
-    GEVC(c->d_k.ensure(2 * T * sizeof(u32), st)); GEVC(c->d_bk_off.ensure((2 * T + 1) * sizeof(u32), st));
-    GEVC(c->d_start.ensure(2 * T, st)); GEVC(c->d_sex.ensure(n_people, st));
-    GEVC(c->d_nmut.ensure(T * sizeof(u32), st)); GEVC(c->d_nm_off.ensure((T + 1) * sizeof(u32), st));
-    GEVC(c->d_nm_pos.ensure(16, st)); GEVC(c->d_nm_side.ensure(16, st));
-    if (has_mut) GEVC(c->d_mutseeds.ensure(T * sizeof(u32), st));
-    HIPC(hipMemcpyAsync(c->d_father.p, father, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(c->d_mother.p, mother, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
-    if (has_mut) HIPC(hipMemcpyAsync(c->d_mutseeds.p, hseeds, T * sizeof(u32), hipMemcpyHostToDevice, st));
+    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    // the stitch that last read this scratch set must be over before the set is refilled
+    GEVC(harvest_timing(c, sc));
+    if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); sc.stitch_pending = false; }
+    GEVC(sc.father.ensure(n_people * sizeof(u32), st)); GEVC(sc.mother.ensure(n_people * sizeof(u32), st));
+    GEVC(sc.seed_pat.ensure((T + 1) * sizeof(u32), st)); GEVC(sc.seed_mat.ensure(T * sizeof(u32), st));
+    GEVC(sc.k.ensure(2 * T * sizeof(u32), st)); GEVC(sc.bk_off.ensure((2 * T + 1) * sizeof(u32), st));
+    GEVC(sc.start.ensure(2 * T, st)); GEVC(sc.sex.ensure(n_people, st));
+    GEVC(sc.nmut.ensure(T * sizeof(u32), st)); GEVC(sc.nm_off.ensure((T + 1) * sizeof(u32), st));
+    GEVC(sc.nm_pos.ensure(16, st)); GEVC(sc.nm_side.ensure(16, st));
+    GEVC(sc.status.ensure(n_status * sizeof(u32), st));
+    if (has_mut) GEVC(sc.mutseeds.ensure(T * sizeof(u32), st));
+    HIPC(hipMemcpyAsync(sc.father.p, father, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(sc.mother.p, mother, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
+    if (has_mut) HIPC(hipMemcpyAsync(sc.mutseeds.p, hseeds, T * sizeof(u32), hipMemcpyHostToDevice, st));
 
     const int alt = P.cur ^ 1;
     for (int attempt = 0;; attempt++) {
-        GEVC(enqueue_generation(c, pop, n_people, has_mut, (u32)seed_reproduce));
-        HIPC(hipMemcpyAsync(hstatus, c->d_status.p, n_status * sizeof(u32), hipMemcpyDeviceToHost, st));
+        GEVC(enqueue_small(c, sc, pop, n_people, has_mut, (u32)seed_reproduce));
+        c->ad_cached_pop = -1;
+        if (c->eager_ad && c->pop[pop].cv[0][0].d_aptr.p) GEVC(enqueue_ad(c, pop, alt, n_people));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
+        HIPC(hipMemcpyAsync(hstatus, sc.status.p, n_status * sizeof(u32), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
         const u32 flags = hstatus[ST_FLAGS];
         for (int k = 0; k < nchr; k++) { P.st[k].mut_total[alt] = hstatus[ST_TOTALS + 2 * k]; P.st[k].parts_total[alt] = hstatus[ST_TOTALS + 2 * k + 1]; }
@@ -715,27 +813,42 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
         }
     }
     for (int k = 0; k < nchr; k++) { P.st[k].mut_need = 0; P.st[k].parts_need = 0; }
-    for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = false;
-    if (sex_out) HIPC(hipMemcpy(sex_out, c->d_sex.p, n_people, hipMemcpyDeviceToHost));
-    float t;
-    HIPC(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); c->last_ms[0] = t;
-    HIPC(hipEventElapsedTime(&t, c->ev[4], c->ev[3])); c->last_ms[1] = t;
-    HIPC(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); c->last_ms[2] = t;
-    HIPC(hipEventElapsedTime(&t, c->ev[0], c->ev[3])); c->last_ms[3] = t;
+    const bool ad_done = c->eager_ad && c->pop[pop].cv[0][0].d_aptr.p;
+    for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = ad_done;
+    if (ad_done) c->ad_cached_pop = pop;
+    if (sex_out) { HIPC(hipMemcpyAsync(sex_out, sc.sex.p, n_people, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st)); }
+    GEVC(enqueue_stitch(c, sc, pop, n_people));          // not waited for
     P.cur = alt; P.n_people = n_people;
+    c->gen_counter++;
+    return GEV_OK;
+}
+// wait for all device work of the context (both streams) and collect pending kernel timings
+int gev_sync(gev_ctx* c)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipStreamSynchronize(c->stream)); HIPC(hipStreamSynchronize(c->stream_big));
+    for (auto& sc : c->sc) { GEVC(harvest_timing(c, sc)); sc.stitch_pending = false; }
+    c->planes_pending = false;
+    return GEV_OK;
+}
+// cumulative kernel time per phase over all harvested generations: sampling, dense stitch, sparse, sum
+int gev_timing_totals(gev_ctx* c, double ms_sum[4], unsigned long long* n_generations)
+{
+    if (!c || !ms_sum || !n_generations) return fail(GEV_EINVAL, "null");
+    GEVC(gev_sync(c));
+    for (int i = 0; i < 4; i++) ms_sum[i] = c->ms_sum[i];
+    *n_generations = c->ms_count;
     return GEV_OK;
 }
 
 // ---- Simulation::ras_compute_AD -----------------------------------------------------------
-int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, double* add_chr, double* dom_chr)
+// kernels of ras_compute_AD on buffer set `buf` (current generation, or the one being produced)
+static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
 {
-    GEVC(check_idx(c, pop, 0));
     PopState& P = c->pop[pop];
-    if (!P.gen0) return fail(GEV_ESTATE, "compute_ad: population %d has no current generation", pop);
-    HIPC(hipSetDevice(c->device));
-    if (!c->pop[pop].cv[0][0].d_aptr.p) GEVC(check_multipop(c));
     hipStream_t st = c->stream;
-    const size_t n = P.n_people, rows = 2 * n;
+    const size_t rows = 2 * n;
     const int nchr = c->nchr, nphen = c->nphen;
     GEVC(c->d_addchr.ensure(n * nchr * nphen * sizeof(double), st)); GEVC(c->d_domchr.ensure(n * nchr * nphen * sizeof(double), st));
     GEVC(c->d_add.ensure(n * nphen * sizeof(double), st)); GEVC(c->d_dom.ensure(n * nphen * sizeof(double), st));
@@ -748,8 +861,8 @@ int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, dou
             double* dout = c->d_domchr.as<double>() + (size_t)k * nphen + p;
             GEVC(c->d_cvm.ensure(std::max<size_t>(rows * V.sub_w32 * sizeof(u32), 16), st));
             hipLaunchKernelGGL(k_cv_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st,
-                               P.cvp[p][k][P.cur].as<u32>(), V.stride_w32, V.sub_w32, c->d_cvm.as<u32>(), rows,
-                               cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), V.d_pos_sorted.as<u64>(), V.C);
+                               P.cvp[p][k][buf].as<u32>(), V.stride_w32, V.sub_w32, c->d_cvm.as<u32>(), rows,
+                               cs.moff[buf].as<u32>(), cs.mpos[buf].as<u64>(), V.d_pos_sorted.as<u64>(), V.C);
             HIPC(hipMemsetAsync(V.d_counts.p, 0, std::max<size_t>(V.C, 1) * sizeof(u32), st));
             if (V.C) {
                 const unsigned gy = (unsigned)std::min<size_t>(std::max<size_t>(rows / 512, 1), 256);
@@ -771,23 +884,55 @@ int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, dou
             } else {
                 if (V.C) hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, st, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n, V.d_frq.as<double>());
                 hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
-                                   c->d_cvm.as<u32>(), V.sub_w32, P.cvp[p][k][P.cur].as<u32>(), V.stride_w32, c->rp_bits,
+                                   c->d_cvm.as<u32>(), V.sub_w32, P.cvp[p][k][buf].as<u32>(), V.stride_w32, c->rp_bits,
                                    V.d_col_of_icv.as<u32>(), V.d_frq.as<double>(), V.d_aptr.as<const double*>(), V.d_dptr.as<const double*>(), pop,
                                    V.d_pos_file.as<u64>(), S.rbp.front(), S.rbp.back(), V.vd, V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
             }
             KCHECK();
-            V.frq_valid = true;
         }
     hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_addchr.as<double>(), c->d_add.as<double>(), n, nchr, nphen);
     hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_domchr.as<double>(), c->d_dom.as<double>(), n, nchr, nphen);
     KCHECK();
-    u32 flag = 0;
-    HIPC(hipMemcpyAsync(&flag, c->d_flag.p, 4, hipMemcpyDeviceToHost, st));
-    if (additive) HIPC(hipMemcpyAsync(additive, c->d_add.p, n * nphen * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (dominance) HIPC(hipMemcpyAsync(dominance, c->d_dom.p, n * nphen * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (add_chr) HIPC(hipMemcpyAsync(add_chr, c->d_addchr.p, n * nchr * nphen * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (dom_chr) HIPC(hipMemcpyAsync(dom_chr, c->d_domchr.p, n * nchr * nphen * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
+    // results to the pinned host cache: [flag | additive | dominance | add_chr | dom_chr]
+    const size_t nd = n * nphen, ndc = n * (size_t)nchr * nphen;
+    const size_t bytes = 16 + (2 * nd + 2 * ndc) * sizeof(double);
+    if (c->h_ad_bytes < bytes) {
+        HIPC(hipDeviceSynchronize());
+        if (c->h_ad) (void)hipHostFree(c->h_ad);
+        c->h_ad = nullptr; c->h_ad_bytes = 0;
+        HIPC(hipHostMalloc(&c->h_ad, bytes * 5 / 4 + 4096, hipHostMallocDefault));
+        c->h_ad_bytes = bytes * 5 / 4 + 4096;
+    }
+    uint8_t* h = (uint8_t*)c->h_ad;
+    HIPC(hipMemcpyAsync(h, c->d_flag.p, 4, hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(h + 16, c->d_add.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(h + 16 + nd * 8, c->d_dom.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(h + 16 + 2 * nd * 8, c->d_addchr.p, ndc * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(h + 16 + (2 * nd + ndc) * 8, c->d_domchr.p, ndc * sizeof(double), hipMemcpyDeviceToHost, st));
+    return GEV_OK;
+}
+int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, double* add_chr, double* dom_chr)
+{
+    GEVC(check_idx(c, pop, 0));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "compute_ad: population %d has no current generation", pop);
+    HIPC(hipSetDevice(c->device));
+    if (!c->pop[pop].cv[0][0].d_aptr.p) GEVC(check_multipop(c));
+    const size_t n = P.n_people;
+    const int nchr = c->nchr, nphen = c->nphen;
+    if (c->ad_cached_pop != pop) {          // not computed eagerly by the last gev_reproduce of this population
+        GEVC(enqueue_ad(c, pop, P.cur, n));
+        HIPC(hipStreamSynchronize(c->stream));
+        c->ad_cached_pop = pop;
+        for (int p = 0; p < nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = true;
+    }
+    const uint8_t* h = (const uint8_t*)c->h_ad;
+    const size_t nd = n * nphen, ndc = n * (size_t)nchr * nphen;
+    const u32 flag = *(const u32*)h;
+    if (additive) memcpy(additive, h + 16, nd * sizeof(double));
+    if (dominance) memcpy(dominance, h + 16 + nd * 8, nd * sizeof(double));
+    if (add_chr) memcpy(add_chr, h + 16 + 2 * nd * 8, ndc * sizeof(double));
+    if (dom_chr) memcpy(dom_chr, h + 16 + (2 * nd + ndc) * 8, ndc * sizeof(double));
     if (flag != 0xffffffffu) return fail(GEV_ENAN, "Error: A or D is nan for human %u", flag);
     return GEV_OK;
 }
@@ -887,6 +1032,7 @@ int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
     if (!c) return fail(GEV_EINVAL, "null context");
     if (n_moves && !moves) return fail(GEV_EINVAL, "migrate: null moves");
     HIPC(hipSetDevice(c->device));
+    GEVC(gev_sync(c));
     if (c->n_pop > 1 && !c->pop[0].cv[0][0].d_aptr.p) GEVC(check_multipop(c));
     std::vector<std::vector<uint8_t>> gone(c->n_pop);
     for (int p = 0; p < c->n_pop; p++) {
@@ -921,6 +1067,7 @@ int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
     for (int p = 0; p < c->n_pop; p++) if (n_new[p] > c->pop[p].cap_people) GEVC(ensure_capacity(c, p, n_new[p]));
     for (int p = 0; p < c->n_pop; p++) GEVC(gather_population(c, p, plan[p], n_new[p]));
     for (int p = 0; p < c->n_pop; p++) { c->pop[p].cur ^= 1; c->pop[p].n_people = n_new[p]; }
+    c->ad_cached_pop = -1;
     return GEV_OK;
 }
 int gev_export_size(gev_ctx*, int, const uint64_t*, size_t, size_t*) { return fail(GEV_EUNSUPPORTED, "gev_export_size: cross-GPU row exchange is not implemented yet"); }
@@ -937,6 +1084,7 @@ int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_r
     if (row_begin + n_rows > 2 * P.n_people) return fail(GEV_EINVAL, "download_haps: rows [%zu,%zu) beyond 2*n_people=%zu", row_begin, row_begin + n_rows, 2 * P.n_people);
     if (n_rows && (!bits || row_stride_words * 64 < S.L)) return fail(GEV_EINVAL, "download_haps: bad output buffer");
     HIPC(hipSetDevice(c->device));
+    GEVC(wait_planes(c));
     hipStream_t st = c->stream;
     const size_t max_rows = std::max<size_t>((64u << 20) / S.stride, 1);
     GEVC(c->d_stage.ensure(std::min(max_rows, std::max<size_t>(n_rows, 1)) * S.stride, st));
@@ -1023,6 +1171,7 @@ int gev_pop_size(gev_ctx* c, int pop, size_t* n) { GEVC(check_idx(c, pop, 0)); i
 int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows)
 {
     GEVC(check_idx(c, pop, chr));
+    GEVC(gev_sync(c));
     PopState& P = c->pop[pop];
     if (dptr) *dptr = P.st[chr].plane[P.cur].p;
     if (row_stride_bytes) *row_stride_bytes = P.cs[chr].stride;
@@ -1030,7 +1179,7 @@ int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_
     return GEV_OK;
 }
 int gev_stream(gev_ctx* c, void** s) { if (!c || !s) return fail(GEV_EINVAL, "null"); *s = (void*)c->stream; return GEV_OK; }
-int gev_last_reproduce_ms(gev_ctx* c, float ms[4]) { if (!c || !ms) return fail(GEV_EINVAL, "null"); for (int i = 0; i < 4; i++) ms[i] = c->last_ms[i]; return GEV_OK; }
+int gev_last_reproduce_ms(gev_ctx* c, float ms[4]) { if (!c || !ms) return fail(GEV_EINVAL, "null"); GEVC(gev_sync(c)); for (int i = 0; i < 4; i++) ms[i] = c->last_ms[i]; return GEV_OK; }
 int gev_set_track_intervals(gev_ctx* c, int on) { if (!c) return fail(GEV_EINVAL, "null"); c->track_intervals = on != 0; return GEV_OK; }
 int gev_set_stitch_mode(gev_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return fail(GEV_EINVAL, "stitch mode must be 0 (parent-major) or 1 (gamete-major)"); c->stitch_mode = mode; return GEV_OK; }
 
@@ -1047,7 +1196,7 @@ __global__ void __launch_bounds__(64) k_dbg_sim_loc_rec(const GevRngTables* __re
     const ChrDev& C = chrs[chr];
     GlibcWave g; g.seed(T, seed);
     u32 h = 0;
-    wave_scan_hits(T, seed + 1u, C.rthr, 0, C.R, [&](u32 row) {
+    wave_scan_hits(T, seed + 1u, C.rthr, C.r_amax, 0, C.R, [&](u32 row) {
         const u64 v = C.rbp[row] + (u64)g.out(T, h) % C.bp_dist;
         if (threadIdx.x == 0 && h < cap) locs[h] = v;
         h++;

@@ -29,19 +29,23 @@
 struct GevThr { uint32_t a_lo, a_hi, b0, b1; };
 
 struct GevRngTables {
-    uint32_t pow_odd[64];     // 16807^(2l+1) mod M31 : lane l's first engine output index 2l+1
+    uint32_t pow_even[64];    // 16807^(2l+2) mod M31 : lane l's first HIGH-digit engine output (index 2l+2)
     uint32_t pow128;          // 16807^128 mod M31    : 64 draws = 128 engine steps
+    uint32_t inv16807;        // 16807^-1 mod M31     : low-digit output x1 = x2 * inv (only needed for candidates)
     uint32_t pow_lcg[31];     // 16807^(i-1) mod M31, i = 1..30 (glibc seeding), [0] unused
     uint32_t w_init[31 * 64]; // x_{344+k} = sum_i w_init[i*64+k] * r_i  (mod 2^32); lane k reads a coalesced row
     uint32_t w_next[31 * 64]; // x_{n+31+k} = sum_i w_next[i*64+k] * x_{n+i}
+    uint32_t pad[3];          // sizeof % 16 == 0: the tables are staged into LDS with 16-byte copies
 };
+static_assert(sizeof(GevRngTables) % 16 == 0, "GevRngTables must be a multiple of 16 bytes");
 
+// a*b mod (2^31-1) for a, b < 2^31, in 32-bit operations: p = hi*2^32 + lo, 2^32 = 2 and 2^31 = 1 (mod M)
 __device__ __forceinline__ uint32_t mulmod31(uint32_t a, uint32_t b)
 {
-    uint64_t p = (uint64_t)a * b;
-    uint64_t s = (p & GEV_M31) + (p >> 31);          // < 2^32
-    uint32_t t = (uint32_t)((s & GEV_M31) + (s >> 31));
-    return t >= GEV_M31 ? t - GEV_M31 : t;
+    const uint32_t lo = a * b, hi = __umulhi(a, b);                  // hi < 2^30
+    uint32_t r = (hi << 1) + (lo >> 31) + (lo & GEV_M31);            // <= 2^32 - 2
+    r = (r & GEV_M31) + (r >> 31);                                   // <= M + 1
+    return r >= GEV_M31 ? r - GEV_M31 : r;
 }
 
 // std::minstd_rand0::seed(s): state = s mod (2^31-1), 0 -> 1.  `s` is the unsigned expression the
@@ -61,23 +65,26 @@ __device__ __forceinline__ bool thr_hit(const GevThr t, uint32_t x1, uint32_t x2
 }
 
 // Wave-cooperative Bernoulli scan: draw d (0-based) tests map row first_row+d and consumes engine
-// outputs 2d+1, 2d+2.  Calls on_hit(row) wave-uniformly for every hit, in row order.
-// Returns the number of hits.  All 64 lanes must call it.
+// outputs 2d+1 (low digit x1), 2d+2 (high digit x2).  Only the high digit is generated per draw
+// (one modular multiply by 16807^128); a draw can hit only if a = x2-1 is below `amax`, the
+// largest a_hi of the map, so the threshold row and the low digit (x1 = x2 * 16807^-1) are
+// fetched for those rare candidates alone.  Calls on_hit(row) wave-uniformly for every hit, in
+// row order.  Returns the number of hits.  All 64 lanes must call it.
 template <class F>
 __device__ __forceinline__ uint32_t wave_scan_hits(const GevRngTables* __restrict__ T, uint32_t engine_seed,
-                                                   const GevThr* __restrict__ thr, uint32_t first_row,
+                                                   const GevThr* __restrict__ thr, uint32_t amax, uint32_t first_row,
                                                    uint32_t n_draws, F on_hit)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t s0 = minstd_seed(engine_seed);
-    uint32_t x1 = mulmod31(T->pow_odd[lane], s0);
-    const uint32_t p128 = T->pow128;
+    uint32_t x2 = mulmod31(T->pow_even[lane], s0);
+    const uint32_t p128 = T->pow128, inv = T->inv16807;
     uint32_t n_hits = 0;
     for (uint32_t base = 0; base < n_draws; base += 64) {
         const uint32_t d = base + lane;
         bool hit = false;
-        if (d < n_draws) {
-            const uint32_t x2 = mulmod31(x1, 16807u);
+        if (d < n_draws && x2 - 1 < amax) {
+            const uint32_t x1 = mulmod31(x2, inv);
             const GevThr t = thr[first_row + d];
             hit = thr_hit(t, x1, x2);
         }
@@ -88,7 +95,7 @@ __device__ __forceinline__ uint32_t wave_scan_hits(const GevRngTables* __restric
             on_hit(first_row + base + l);
             m &= m - 1;
         }
-        x1 = mulmod31(x1, p128);
+        x2 = mulmod31(x2, p128);
     }
     return n_hits;
 }
@@ -114,7 +121,7 @@ struct GlibcWave {
         else if (lane < 31) r = mulmod31(T->pow_lcg[lane], r1);      // 16807^(lane-1) * r1
         uint32_t acc = 0;
         const uint32_t* wcol = T->w_init + lane;
-#pragma unroll
+#pragma unroll 4
         for (int i = 0; i < 31; i++) acc += wcol[i * 64] * __shfl(r, i);
         x = acc; block = 0;
     }
@@ -123,7 +130,7 @@ struct GlibcWave {
         const uint32_t lane = threadIdx.x & 63;
         uint32_t acc = 0;
         const uint32_t* wcol = T->w_next + lane;
-#pragma unroll
+#pragma unroll 4
         for (int i = 0; i < 31; i++) acc += wcol[i * 64] * __shfl(x, 33 + i);
         x = acc; block++;
     }
@@ -163,8 +170,9 @@ static inline uint32_t h_powmod31(uint32_t a, uint64_t e)
 
 static inline void gev_build_rng_tables(GevRngTables& T)
 {
-    for (int l = 0; l < 64; l++) T.pow_odd[l] = h_powmod31(16807u, 2 * l + 1);
+    for (int l = 0; l < 64; l++) T.pow_even[l] = h_powmod31(16807u, 2 * l + 2);
     T.pow128 = h_powmod31(16807u, 128);
+    T.inv16807 = h_powmod31(16807u, (uint64_t)GEV_M31 - 2);
     T.pow_lcg[0] = 0;
     for (int i = 1; i < 31; i++) T.pow_lcg[i] = h_powmod31(16807u, i - 1);
     // z_m = z_{m-31} + z_{m-3} (m >= 34), z_{31..33} = z_{0..2}; output k = z_{344+k}.

@@ -67,7 +67,7 @@ def couples_array(pos_male, pos_female, num_offspring=1, inbreed=0):
     return c
 
 
-def synthetic_random_mate(sex, pop_size, rng):
+def synthetic_random_mate(sex, pop_size, rng, out=None):
     """Shape of Simulation::random_mate (src/Simulation.cpp:2090-2157): pop_size couples, one
     offspring each, father drawn uniformly from the males and mother from the females.
     Draws come from `rng` (numpy), NOT from the reference's minstd streams: mating is outside
@@ -77,7 +77,11 @@ def synthetic_random_mate(sex, pop_size, rng):
     females = np.flatnonzero(sex == 2)
     if len(males) == 0 or len(females) == 0:
         raise RuntimeError("Error: No one can marry")
-    return couples_array(males[rng.integers(0, len(males), pop_size)], females[rng.integers(0, len(females), pop_size)])
+    if out is None or len(out) != pop_size:
+        out = couples_array(np.zeros(pop_size, dtype=np.uint64), np.zeros(pop_size, dtype=np.uint64))
+    out["pos_male"] = males[rng.integers(0, len(males), pop_size)]
+    out["pos_female"] = females[rng.integers(0, len(females), pop_size)]
+    return out
 
 
 class SyntheticConfig:
@@ -134,12 +138,13 @@ class Simulation:
         self.sex[ipop] = self.ctx.init_gen0(ipop, n_people, int(self.ras_glob_seed()[0]))
         return True
 
-    def reproduce(self, ipop, gen_num=0, seeds=None):           # :2394
+    def reproduce(self, ipop, gen_num=0, seeds=None, n_people=None):   # :2394 (n_people: known offspring count, skips a host pass)
         c = self.couples[ipop]
-        n_people = int(c["num_offspring"][c["inbreed"] == 0].sum())
+        if n_people is None:
+            n_people = int(c["num_offspring"][c["inbreed"] == 0].sum())
         if seeds is None:                                       # 1 + n_people*nchr ras_glob_seed() draws (:2398, :2500)
             seeds = self.ras_glob_seed(1 + (n_people * self.nchr if self.has_mut else 0))
-        self.sex[ipop] = self.ctx.reproduce(ipop, c, int(seeds[0]), seeds[1:] if self.has_mut else None)
+        self.sex[ipop] = self.ctx.reproduce(ipop, c, int(seeds[0]), seeds[1:] if self.has_mut else None, n_people=n_people)
         return self.sex[ipop]
 
     def ras_compute_AD(self, ipop, gen_num=0, per_chr=False):   # :2624

@@ -184,10 +184,16 @@ int gev_plane_ptr(gev_ctx*, int pop, int chr, void** dptr, size_t* row_stride_by
 int gev_reserve(gev_ctx*, int pop, size_t max_people);
 /* HIP stream the context launches on (hipStream_t as void*), for event timing by the caller */
 int gev_stream(gev_ctx*, void** stream);
-/* timing of the kernels of the last gev_reproduce measured with HIP events on that stream:
- * ms[0] = sampling (crossover + mutation + seed chain), ms[1] = dense stitch (genotype planes),
- * ms[2] = sparse state (mutation lists, intervals, CV planes), ms[3] = total. */
+/* gev_reproduce returns when the small per-generation work is done; the dense stitch of the
+ * genotype planes keeps running on a second HIP stream and every later call is ordered after it
+ * where it needs the planes.  gev_sync waits for all device work of the context. */
+int gev_sync(gev_ctx*);
+/* kernel timing measured with HIP events on the library's own streams: ms[0] = sampling
+ * (crossover + mutation + seed chain), ms[1] = dense stitch (genotype planes), ms[2] = sparse state
+ * (mutation lists, intervals, CV planes, grouping), ms[3] = sum.  _last = most recent generation
+ * (implies gev_sync); _totals = cumulative sums over all generations so far (implies gev_sync). */
 int gev_last_reproduce_ms(gev_ctx*, float ms[4]);
+int gev_timing_totals(gev_ctx*, double ms_sum[4], unsigned long long* n_generations);
 /* enable/disable keeping the ancestry interval state on the device (default on) */
 int gev_set_track_intervals(gev_ctx*, int on);
 /* dense-stitch kernel: 0 = parent-major k_stitch_parent (default), 1 = gamete-major k_stitch_rows.

@@ -122,26 +122,21 @@ int main(int argc, char** argv)
     std::vector<Var> vars;
 #define ADD(name, ...) vars.push_back({name, [&]() { __VA_ARGS__; }, {}})
     ADD("prod k_stitch_rows", hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)rows), dim3(256), 0, 0, dst, src, stride, chunks, 1u, dpos, (u32)L, 0, 1, sd));
-    ADD("v U1", hipLaunchKernelGGL((stitch_v<1, false, false, false, 256>), dim3((unsigned)rows), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
-    ADD("v U2", hipLaunchKernelGGL((stitch_v<2, false, false, false, 256>), dim3((unsigned)rows), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
     ADD("v U4", hipLaunchKernelGGL((stitch_v<4, false, false, false, 256>), dim3((unsigned)rows), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
-    ADD("v U8", hipLaunchKernelGGL((stitch_v<8, false, false, false, 256>), dim3((unsigned)rows), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
-    ADD("v U4 ntS", hipLaunchKernelGGL((stitch_v<4, false, true, false, 256>), dim3((unsigned)rows), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
     ADD("v U4 ntLS", hipLaunchKernelGGL((stitch_v<4, true, true, false, 256>), dim3((unsigned)rows), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
-    ADD("v U4 persist2048", hipLaunchKernelGGL((stitch_v<4, false, false, true, 256>), dim3(2048), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
     ADD("v U4 ntLS persist2048", hipLaunchKernelGGL((stitch_v<4, true, true, true, 256>), dim3(2048), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
-    ADD("v U4 T512", hipLaunchKernelGGL((stitch_v<4, false, false, false, 512>), dim3((unsigned)rows), dim3(512), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
-    ADD("v U2 T1024", hipLaunchKernelGGL((stitch_v<2, false, false, false, 1024>), dim3((unsigned)rows), dim3(1024), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
-    ADD("parent-major U1", hipLaunchKernelGGL((k_stitch_parent<1, false>), dim3((unsigned)N), dim3(256), 0, 0, dst, src, stride, chunks, 1u, dpos, (u32)L, 0, 1, dgoff, dglist, sd));
-    ADD("parent-major U2", hipLaunchKernelGGL((k_stitch_parent<2, false>), dim3((unsigned)N), dim3(256), 0, 0, dst, src, stride, chunks, 1u, dpos, (u32)L, 0, 1, dgoff, dglist, sd));
-    ADD("parent-major U2 nt", hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)N), dim3(256), 0, 0, dst, src, stride, chunks, 1u, dpos, (u32)L, 0, 1, dgoff, dglist, sd));
-    ADD("parent-major U4", hipLaunchKernelGGL((k_stitch_parent<4, false>), dim3((unsigned)N), dim3(256), 0, 0, dst, src, stride, chunks, 1u, dpos, (u32)L, 0, 1, dgoff, dglist, sd));
-    ADD("parent-major U4 nt", hipLaunchKernelGGL((k_stitch_parent<4, true>), dim3((unsigned)N), dim3(256), 0, 0, dst, src, stride, chunks, 1u, dpos, (u32)L, 0, 1, dgoff, dglist, sd));
-    ADD("parent-major U2 nt bpp2", hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)N * 2), dim3(256), 0, 0, dst, src, stride, chunks, 2u, dpos, (u32)L, 0, 1, dgoff, dglist, sd));
-    ADD("copy U4 g2048", hipLaunchKernelGGL((copy_rows<4, false>), dim3(2048), dim3(256), 0, 0, (v4u*)dst, (const v4u*)src, rows * stride / 16));
+#define PM(name, U, NT, occ) ADD(name, hipLaunchKernelGGL((k_stitch_parent<U, NT>), dim3((unsigned)N), dim3(256), (occ) >= 8 ? 0 : std::min(160 * 1024 / (occ) - 3 * 1024, 64 * 1024 - 2048), 0, dst, src, stride, chunks, 1u, dpos, (u32)L, 0, 1, dgoff, dglist, sd))
+    PM("pm U2 nt occ8", 2, true, 8);
+    PM("pm U2 nt occ6", 2, true, 6);
+    PM("pm U4 nt occ8", 4, true, 8);
+    PM("pm U4 nt occ6", 4, true, 6);
+    PM("pm U4 nt occ5", 4, true, 5);
+    PM("pm U4 nt occ4", 4, true, 4);
+    PM("pm U8 nt occ8", 8, true, 8);
+    PM("pm U8 nt occ4", 8, true, 4);
+    PM("pm U8 nt occ3", 8, true, 3);
     ADD("copy U4 nt g2048", hipLaunchKernelGGL((copy_rows<4, true>), dim3(2048), dim3(256), 0, 0, (v4u*)dst, (const v4u*)src, rows * stride / 16));
     ADD("copy U8 g8192", hipLaunchKernelGGL((copy_rows<8, false>), dim3(8192), dim3(256), 0, 0, (v4u*)dst, (const v4u*)src, rows * stride / 16));
-    ADD("hipMemcpyDtoD", CK(hipMemcpyAsync(dst, src, rows * stride, hipMemcpyDeviceToDevice, 0)));
     for (int round = 0; round < 6; round++)
         for (auto& v : vars) {
             CK(hipEventRecord(e0, 0)); v.run(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
