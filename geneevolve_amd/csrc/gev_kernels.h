@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) k_mut_sample(const GevRngTables* __restri
     if (n > GEV_NM_CAP) {                                        // rare: take a range of the overflow region and redo the scan
         u32 o = 0;
         if (lane == 0) o = atomicAdd(&sd.status[ST_NM_OVF_USED], n);
-        o = __shfl(o, 0);
+        o = rl_u32(o, 0);
         if (o + n <= sd.nm_ovf_cap) {
             off = sd.nm_ovf_base + o;
             g.seed(T, S);
@@ -292,7 +292,7 @@ __device__ __forceinline__ u32 gamete_sample(const GevRngTables* __restrict__ T,
     if (k > GEV_BK_CAP) {
         u32 o = 0;
         if (lane == 0) o = atomicAdd(&sd.status[ST_BK_OVF_USED], k);
-        o = __shfl(o, 0);
+        o = rl_u32(o, 0);
         if (o + k <= sd.bk_ovf_cap) {
             off = sd.bk_ovf_base + o;
             g.seed(T, seed);
@@ -737,8 +737,18 @@ __global__ void __launch_bounds__(256) k_cv_count(const u32* __restrict__ cvm, u
     const size_t rows_per = (n_rows + gridDim.y - 1) / gridDim.y;
     const size_t r0 = (size_t)blockIdx.y * rows_per, r1 = min(r0 + rows_per, n_rows);
     if (c >= Cn) return;
+    const u32* col = cvm + (c >> 5);
+    const u32 sh = c & 31;
     u32 n = 0;
-    for (size_t r = r0; r < r1; r++) n += (cvm[r * sub_w32 + (c >> 5)] >> (c & 31)) & 1u;
+    size_t r = r0;
+    for (; r + 8 <= r1; r += 8) {                      // 8 independent loads in flight
+        u32 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = col[(r + j) * sub_w32];
+#pragma unroll
+        for (int j = 0; j < 8; j++) n += (v[j] >> sh) & 1u;
+    }
+    for (; r < r1; r++) n += (col[r * sub_w32] >> sh) & 1u;
     if (n) atomicAdd(&counts[c], n);
 }
 // frq[icv] = f / (2*n_human) in FILE order (:2655)
@@ -840,18 +850,30 @@ __global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(
         s_rows[((row & 1u) * IPB + (row >> 1)) * S1 + w] = src[e];
     }
     __syncthreads();
-    if (threadIdx.x >= n_here) return;
+    const bool live = threadIdx.x < n_here;                      // idle lanes still take part in the broadcasts
     const u32* r0 = s_rows + (size_t)threadIdx.x * S1;
     const u32* r1 = s_rows + ((size_t)IPB + threadIdx.x) * S1;
     double A_chr = 0, D_chr = 0;
-    for (u32 icv = 0; icv < Cn; icv++) {
-        const u32 c = col_of_icv[icv];
-        const u32 t = ((r0[c >> 5] >> (c & 31)) & 1u) + ((r1[c >> 5] >> (c & 31)) & 1u);
-        const double a0 = tab[6 * icv + 0], a1 = tab[6 * icv + 1], a2 = tab[6 * icv + 2];
-        const double d0 = tab[6 * icv + 3], d1 = tab[6 * icv + 4], d2 = tab[6 * icv + 5];
-        A_chr += (t == 0) ? a0 : (t == 1 ? a1 : a2);
-        D_chr += (t == 0) ? d0 : (t == 1 ? d1 : d2);
+    // col_of_icv / tab are the same for every lane: lane j of the wave fetches CV (base+j)'s entries with one
+    // coalesced load and the inner loop broadcasts them (no dependent scalar load per CV)
+    const u32 lane = threadIdx.x & 63;
+    for (u32 base = 0; base < Cn; base += 64) {
+        const u32 mine = min(base + lane, Cn - 1);
+        const u32 c_l = col_of_icv[mine];
+        double tb[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) tb[e] = tab[6 * (size_t)mine + e];
+        const u32 nj = min(64u, Cn - base);
+        for (u32 j = 0; j < nj; j++) {
+            const u32 c = rl_u32(c_l, j);
+            const u32 t = ((r0[c >> 5] >> (c & 31)) & 1u) + ((r1[c >> 5] >> (c & 31)) & 1u);
+            const double a0 = rl_f64(tb[0], j), a1 = rl_f64(tb[1], j), a2 = rl_f64(tb[2], j);
+            const double d0 = rl_f64(tb[3], j), d1 = rl_f64(tb[4], j), d2 = rl_f64(tb[5], j);
+            A_chr += (t == 0) ? a0 : (t == 1 ? a1 : a2);
+            D_chr += (t == 0) ? d0 : (t == 1 ? d1 : d2);
+        }
     }
+    if (!live) return;
     const size_t ih = ih0 + threadIdx.x;
     add_out[ih * out_stride] = A_chr;
     dom_out[ih * out_stride] = D_chr;

@@ -31,11 +31,12 @@ struct GevThr { uint32_t a_lo, a_hi, b0, b1; };
 struct GevRngTables {
     uint32_t pow_even[64];    // 16807^(2l+2) mod M31 : lane l's first HIGH-digit engine output (index 2l+2)
     uint32_t pow128;          // 16807^128 mod M31    : 64 draws = 128 engine steps
+    uint32_t pow512;          // 16807^512 mod M31    : 256 draws
     uint32_t inv16807;        // 16807^-1 mod M31     : low-digit output x1 = x2 * inv (only needed for candidates)
     uint32_t pow_lcg[31];     // 16807^(i-1) mod M31, i = 1..30 (glibc seeding), [0] unused
     uint32_t w_init[31 * 64]; // x_{344+k} = sum_i w_init[i*64+k] * r_i  (mod 2^32); lane k reads a coalesced row
     uint32_t w_next[31 * 64]; // x_{n+31+k} = sum_i w_next[i*64+k] * x_{n+i}
-    uint32_t pad[3];          // sizeof % 16 == 0: the tables are staged into LDS with 16-byte copies
+    uint32_t pad[2];          // sizeof % 16 == 0: the tables are staged into LDS with 16-byte copies
 };
 static_assert(sizeof(GevRngTables) % 16 == 0, "GevRngTables must be a multiple of 16 bytes");
 
@@ -77,27 +78,47 @@ __device__ __forceinline__ uint32_t wave_scan_hits(const GevRngTables* __restric
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t s0 = minstd_seed(engine_seed);
-    uint32_t x2 = mulmod31(T->pow_even[lane], s0);
     const uint32_t p128 = T->pow128, inv = T->inv16807;
+    // four independent LCG chains per lane (draws d, d+64, d+128, d+192; step 16807^512) hide the
+    // latency of the dependent modular multiply
+    uint32_t xa = mulmod31(T->pow_even[lane], s0);
+    uint32_t xb = mulmod31(xa, p128), xc = mulmod31(xb, p128), xd = mulmod31(xc, p128);
+    const uint32_t p512 = T->pow512;
     uint32_t n_hits = 0;
-    for (uint32_t base = 0; base < n_draws; base += 64) {
-        const uint32_t d = base + lane;
-        bool hit = false;
+    auto test = [&](uint32_t x2, uint32_t d) -> bool {
         if (d < n_draws && x2 - 1 < amax) {
             const uint32_t x1 = mulmod31(x2, inv);
             const GevThr t = thr[first_row + d];
-            hit = thr_hit(t, x1, x2);
+            return thr_hit(t, x1, x2);
         }
-        unsigned long long m = __ballot(hit);
+        return false;
+    };
+    auto drain = [&](unsigned long long m, uint32_t base) {
         n_hits += __popcll(m);
         while (m) {
             const uint32_t l = __ffsll((long long)m) - 1;
             on_hit(first_row + base + l);
             m &= m - 1;
         }
-        x2 = mulmod31(x2, p128);
+    };
+    for (uint32_t base = 0; base < n_draws; base += 256) {
+        const unsigned long long ma = __ballot(test(xa, base + lane));
+        const unsigned long long mb = __ballot(test(xb, base + 64 + lane));
+        const unsigned long long mc = __ballot(test(xc, base + 128 + lane));
+        const unsigned long long md = __ballot(test(xd, base + 192 + lane));
+        if (ma | mb | mc | md) { drain(ma, base); drain(mb, base + 64); drain(mc, base + 128); drain(md, base + 192); }
+        xa = mulmod31(xa, p512); xb = mulmod31(xb, p512); xc = mulmod31(xc, p512); xd = mulmod31(xd, p512);
     }
     return n_hits;
+}
+
+// wave-uniform lane index -> v_readlane_b32 (SGPR broadcast) instead of the LDS crossbar (ds_bpermute) of __shfl
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ double rl_f64(double v, uint32_t lane)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = rl_u32((uint32_t)b, lane), hi = rl_u32((uint32_t)(b >> 32), lane);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
 // glibc srand()/rand(): lane k of the wave holds raw word x of output (64*block + k); rand() = x >> 1.
@@ -122,7 +143,7 @@ struct GlibcWave {
         uint32_t acc = 0;
         const uint32_t* wcol = T->w_init + lane;
 #pragma unroll 4
-        for (int i = 0; i < 31; i++) acc += wcol[i * 64] * __shfl(r, i);
+        for (int i = 0; i < 31; i++) acc += wcol[i * 64] * rl_u32(r, i);
         x = acc; block = 0;
     }
     __device__ __forceinline__ void next_block(const GevRngTables* __restrict__ T)
@@ -131,14 +152,14 @@ struct GlibcWave {
         uint32_t acc = 0;
         const uint32_t* wcol = T->w_next + lane;
 #pragma unroll 4
-        for (int i = 0; i < 31; i++) acc += wcol[i * 64] * __shfl(x, 33 + i);
+        for (int i = 0; i < 31; i++) acc += wcol[i * 64] * rl_u32(x, 33 + i);
         x = acc; block++;
     }
     // n-th output (0-based) of the stream; n must not decrease between calls.  Wave-uniform.
     __device__ __forceinline__ uint32_t out(const GevRngTables* __restrict__ T, uint32_t n)
     {
         while ((n >> 6) > block) next_block(T);
-        return __shfl(x, n & 63) >> 1;
+        return rl_u32(x, n & 63) >> 1;
     }
 };
 
@@ -172,6 +193,7 @@ static inline void gev_build_rng_tables(GevRngTables& T)
 {
     for (int l = 0; l < 64; l++) T.pow_even[l] = h_powmod31(16807u, 2 * l + 2);
     T.pow128 = h_powmod31(16807u, 128);
+    T.pow512 = h_powmod31(16807u, 512);
     T.inv16807 = h_powmod31(16807u, (uint64_t)GEV_M31 - 2);
     T.pow_lcg[0] = 0;
     for (int i = 1; i < 31; i++) T.pow_lcg[i] = h_powmod31(16807u, i - 1);

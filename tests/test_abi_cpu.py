@@ -69,14 +69,14 @@ def test_threshold_tables_match_exact_canonical(gpu_lib, oracle_lib):
 def test_glibc_linear_tables_reproduce_rand(gpu_lib, oracle_lib):
     """x_{344+k} = sum_i W[i][k] r_i (mod 2^32): emulate the device GlibcWave in numpy."""
     class T(C.Structure):
-        _fields_ = [("pow_even", C.c_uint32 * 64), ("pow128", C.c_uint32), ("inv16807", C.c_uint32), ("pow_lcg", C.c_uint32 * 31),
-                    ("w_init", C.c_uint32 * (31 * 64)), ("w_next", C.c_uint32 * (31 * 64))]
+        _fields_ = [("pow_even", C.c_uint32 * 64), ("pow128", C.c_uint32), ("pow512", C.c_uint32), ("inv16807", C.c_uint32), ("pow_lcg", C.c_uint32 * 31),
+                    ("w_init", C.c_uint32 * (31 * 64)), ("w_next", C.c_uint32 * (31 * 64)), ("pad", C.c_uint32 * 2)]
     t = T()
     assert gpu_lib.lib.gev_dbg_tables(C.byref(t), C.c_size_t(C.sizeof(t))) == 0
     M = 2147483647
     assert [int(x) for x in t.pow_even][:3] == [pow(16807, 2, M), pow(16807, 4, M), pow(16807, 6, M)]
     assert (int(t.inv16807) * 16807) % M == 1
-    assert int(t.pow128) == pow(16807, 128, M)
+    assert int(t.pow128) == pow(16807, 128, M) and int(t.pow512) == pow(16807, 512, M)
     w_init = np.array(t.w_init, dtype=np.uint64).reshape(31, 64)
     w_next = np.array(t.w_next, dtype=np.uint64).reshape(31, 64)
     for seed in [0, 1, 12345, 2147483646, 2147483647, 2147483648, 4294967295, 987654321]:
