@@ -91,6 +91,12 @@ struct PopState {
     DevBuf d_chrdev;
     int cur = 0;
     size_t n_people = 0, cap_people = 0;
+    // After a cross-GPU migration the individuals of the current generation are not moved physically:
+    // `logical[i]` = physical individual index of logical position i (empty = identity).  The next
+    // gev_reproduce maps parent positions through it and writes a dense generation again; anything
+    // else that needs the dense order calls materialize_order() first.
+    std::vector<u32> logical;
+    size_t n_phys = 0;
     bool finalized = false, gen0 = false;
 };
 
@@ -565,7 +571,7 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     HIPC(hipStreamSynchronize(c->stream));
     for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = rows; }
     c->ad_cached_pop = -1;
-    P.n_people = n_people; P.gen0 = true;
+    P.n_people = n_people; P.n_phys = n_people; P.logical.clear(); P.gen0 = true;
     return GEV_OK;
 }
 
@@ -581,6 +587,7 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
 // sized from the previous totals; if one was too small the buffers are grown from the exact totals
 // of the count passes and the small work is enqueued again (inputs are untouched until the flip).
 static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n);
+static int materialize_order(gev_ctx* c, int pop);
 static int wait_planes(gev_ctx* c)
 {
     if (c->planes_pending) HIPC(hipStreamWaitEvent(c->stream, c->ev_planes, 0));
@@ -684,7 +691,7 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
     }
     // ---- gamete grouping by source individual for the parent-major stitch (same for every chromosome)
     if (c->stitch_mode == 0) {
-        const size_t n_parent = P.n_people;
+        const size_t n_parent = P.n_phys;
         GEVC(sc.ghist.ensure((n_parent + 1) * sizeof(u32), st)); GEVC(sc.goff.ensure((n_parent + 1) * sizeof(u32), st));
         GEVC(sc.glist.ensure(rows * sizeof(u32), st));
         HIPC(hipMemsetAsync(sc.ghist.p, 0, (n_parent + 1) * sizeof(u32), st));
@@ -703,7 +710,7 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
 {
     PopState& P = c->pop[pop];
     const int nchr = c->nchr, cur = P.cur, alt = P.cur ^ 1;
-    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people, n_parent = P.n_people;
+    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people, n_parent = P.n_phys;
     hipStream_t sb = c->stream_big;
     SampleDev sd = make_sd(c, sc, T);
     HIPC(hipEventRecord(sc.ev_small_done, c->stream));
@@ -763,6 +770,7 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     u32* father = (u32*)c->h_stage; u32* mother = father + n_people; u32* hseeds = mother + n_people; u32* hstatus = hseeds + (has_mut ? T : 0);
     // offspring enumeration order of the couple loop (src/Simulation.cpp:2433-2443)
     size_t ip = 0;
+    const u32* lg = P.logical.empty() ? nullptr : P.logical.data();
     for (size_t it = 0; it < n_couples; it++) {
         if (couples[it].inbreed) continue;
         if (couples[it].num_offspring < 0) return fail(GEV_EINVAL, "reproduce: couple %zu has negative num_offspring", it);
@@ -770,7 +778,8 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
             return fail(GEV_EINVAL, "reproduce: couple %zu references position beyond the population (%zu people)", it, P.n_people);
         for (int ns = 0; ns < couples[it].num_offspring; ns++) {
             if (ip >= n_people) return fail(GEV_EINVAL, "reproduce: n_people=%zu but the couples list yields more offspring", n_people);
-            father[ip] = (u32)couples[it].pos_male; mother[ip] = (u32)couples[it].pos_female; ip++;
+            father[ip] = lg ? lg[couples[it].pos_male] : (u32)couples[it].pos_male;
+            mother[ip] = lg ? lg[couples[it].pos_female] : (u32)couples[it].pos_female; ip++;
         }
     }
     if (ip != n_people) return fail(GEV_EINVAL, "reproduce: n_people=%zu but the couples list yields %zu offspring", n_people, ip);
@@ -818,7 +827,7 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     if (ad_done) c->ad_cached_pop = pop;
     if (sex_out) { HIPC(hipMemcpyAsync(sex_out, sc.sex.p, n_people, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st)); }
     GEVC(enqueue_stitch(c, sc, pop, n_people));          // not waited for
-    P.cur = alt; P.n_people = n_people;
+    P.cur = alt; P.n_people = n_people; P.n_phys = n_people; P.logical.clear();
     c->gen_counter++;
     return GEV_OK;
 }
@@ -918,6 +927,7 @@ int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, dou
     if (!P.gen0) return fail(GEV_ESTATE, "compute_ad: population %d has no current generation", pop);
     HIPC(hipSetDevice(c->device));
     if (!c->pop[pop].cv[0][0].d_aptr.p) GEVC(check_multipop(c));
+    GEVC(materialize_order(c, pop));
     const size_t n = P.n_people;
     const int nchr = c->nchr, nphen = c->nphen;
     if (c->ad_cached_pop != pop) {          // not computed eagerly by the last gev_reproduce of this population
@@ -1027,12 +1037,25 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
     }
     return GEV_OK;
 }
+// bring the current generation back to dense logical order (no-op unless rows were removed/imported)
+static int materialize_order(gev_ctx* c, int pop)
+{
+    PopState& P = c->pop[pop];
+    if (P.logical.empty()) return GEV_OK;
+    GEVC(gev_sync(c));
+    Seg all; all.src_pop = pop; all.people = P.logical;
+    std::vector<Seg> segs; segs.push_back(std::move(all));
+    GEVC(gather_population(c, pop, segs, P.n_people));
+    P.cur ^= 1; P.n_phys = P.n_people; P.logical.clear(); c->ad_cached_pop = -1;
+    return GEV_OK;
+}
 int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
 {
     if (!c) return fail(GEV_EINVAL, "null context");
     if (n_moves && !moves) return fail(GEV_EINVAL, "migrate: null moves");
     HIPC(hipSetDevice(c->device));
     GEVC(gev_sync(c));
+    for (int p = 0; p < c->n_pop; p++) if (c->pop[p].gen0) GEVC(materialize_order(c, p));
     if (c->n_pop > 1 && !c->pop[0].cv[0][0].d_aptr.p) GEVC(check_multipop(c));
     std::vector<std::vector<uint8_t>> gone(c->n_pop);
     for (int p = 0; p < c->n_pop; p++) {
@@ -1066,14 +1089,200 @@ int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
     // grow every destination first (capacity growth copies the current buffers), then gather
     for (int p = 0; p < c->n_pop; p++) if (n_new[p] > c->pop[p].cap_people) GEVC(ensure_capacity(c, p, n_new[p]));
     for (int p = 0; p < c->n_pop; p++) GEVC(gather_population(c, p, plan[p], n_new[p]));
-    for (int p = 0; p < c->n_pop; p++) { c->pop[p].cur ^= 1; c->pop[p].n_people = n_new[p]; }
+    for (int p = 0; p < c->n_pop; p++) { c->pop[p].cur ^= 1; c->pop[p].n_people = n_new[p]; c->pop[p].n_phys = n_new[p]; }
     c->ad_cached_pop = -1;
     return GEV_OK;
 }
-int gev_export_size(gev_ctx*, int, const uint64_t*, size_t, size_t*) { return fail(GEV_EUNSUPPORTED, "gev_export_size: cross-GPU row exchange is not implemented yet"); }
-int gev_export_rows(gev_ctx*, int, const uint64_t*, size_t, void*, size_t) { return fail(GEV_EUNSUPPORTED, "gev_export_rows: cross-GPU row exchange is not implemented yet"); }
-int gev_remove_rows(gev_ctx*, int, const uint64_t*, size_t) { return fail(GEV_EUNSUPPORTED, "gev_remove_rows: cross-GPU row exchange is not implemented yet"); }
-int gev_import_rows(gev_ctx*, int, const void*, size_t, size_t) { return fail(GEV_EUNSUPPORTED, "gev_import_rows: cross-GPU row exchange is not implemented yet"); }
+// ---- cross-GPU form of the migration step ---------------------------------------------------
+// Packed record buffer (all offsets 16-byte aligned), for n individuals:
+//   [counts]  u32[n][nchr][2 haps][2] = (n_mut, n_parts) per haplotype row
+//   [planes]  per chr: 2n rows x stride bytes          [cv] per (phen, chr): 2n rows x stride_w32*4 bytes
+//   [muts]    per chr: u64 lists concatenated in row order   [parts] per chr: gev_part lists likewise
+struct PackLayout { size_t counts, planes, cv, muts, parts, total; std::vector<size_t> mut_chr, parts_chr; };
+static size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+static PackLayout pack_layout(gev_ctx* c, PopState& P, size_t n, const std::vector<u32>& counts)
+{
+    PackLayout L; const int nchr = c->nchr;
+    size_t off = 0;
+    L.counts = off; off = al16(off + n * nchr * 4 * sizeof(u32));
+    L.planes = off; for (int k = 0; k < nchr; k++) off = al16(off + 2 * n * P.cs[k].stride);
+    L.cv = off; for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) off = al16(off + 2 * n * P.cv[p][k].stride_w32 * sizeof(u32));
+    L.mut_chr.assign(nchr, 0); L.parts_chr.assign(nchr, 0);
+    for (size_t i = 0; i < n; i++) for (int k = 0; k < nchr; k++) for (int h = 0; h < 2; h++) {
+        L.mut_chr[k] += counts[((i * nchr + k) * 2 + h) * 2]; L.parts_chr[k] += counts[((i * nchr + k) * 2 + h) * 2 + 1];
+    }
+    L.muts = off; for (int k = 0; k < nchr; k++) off = al16(off + L.mut_chr[k] * sizeof(u64));
+    L.parts = off; for (int k = 0; k < nchr; k++) off = al16(off + L.parts_chr[k] * sizeof(gev_part));
+    L.total = off;
+    return L;
+}
+// per-row list lengths of the selected individuals (device count kernels, one small D2H)
+static int export_counts(gev_ctx* c, int pop, const uint64_t* positions, size_t n, std::vector<u32>& counts, std::vector<u32>& map)
+{
+    PopState& P = c->pop[pop];
+    const int nchr = c->nchr;
+    map.resize(2 * n);
+    for (size_t i = 0; i < n; i++) {
+        if (positions[i] >= P.n_people) return fail(GEV_EINVAL, "export: position %llu beyond the population (%zu people)", (unsigned long long)positions[i], P.n_people);
+        const u32 ph = P.logical.empty() ? (u32)positions[i] : P.logical[positions[i]];
+        map[2 * i] = 2 * ph; map[2 * i + 1] = 2 * ph + 1;
+    }
+    counts.assign(n * nchr * 4, 0);
+    if (!n) return GEV_OK;
+    GEVC(h2d(c, c->d_map, map.data(), map.size() * sizeof(u32)));
+    GEVC(c->d_cnt.ensure(2 * n * sizeof(u32) * 2 + 16, c->stream));
+    std::vector<u32> tmp(2 * n);
+    for (int k = 0; k < nchr; k++)
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1 && !c->track_intervals) continue;
+            const u32* soff = pass == 0 ? P.st[k].moff[P.cur].as<u32>() : P.st[k].poff[P.cur].as<u32>();
+            hipLaunchKernelGGL(k_csr_gather_count, dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, c->stream, soff, c->d_map.as<u32>(), 2 * n, c->d_cnt.as<u32>());
+            KCHECK();
+            HIPC(hipMemcpyAsync(tmp.data(), c->d_cnt.p, 2 * n * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipStreamSynchronize(c->stream));
+            for (size_t i = 0; i < n; i++) for (int h = 0; h < 2; h++) counts[((i * nchr + k) * 2 + h) * 2 + pass] = tmp[2 * i + h];
+        }
+    return GEV_OK;
+}
+int gev_export_size(gev_ctx* c, int pop, const uint64_t* positions, size_t n, size_t* bytes)
+{
+    GEVC(check_idx(c, pop, 0));
+    if (!bytes || (n && !positions)) return fail(GEV_EINVAL, "export_size: null argument");
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "export_size: population %d has no current generation", pop);
+    HIPC(hipSetDevice(c->device));
+    std::vector<u32> counts, map;
+    GEVC(export_counts(c, pop, positions, n, counts, map));
+    *bytes = pack_layout(c, P, n, counts).total;
+    return GEV_OK;
+}
+int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, void* device_buf, size_t bytes)
+{
+    GEVC(check_idx(c, pop, 0));
+    if (n && (!positions || !device_buf)) return fail(GEV_EINVAL, "export_rows: null argument");
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "export_rows: population %d has no current generation", pop);
+    HIPC(hipSetDevice(c->device));
+    GEVC(gev_sync(c));
+    std::vector<u32> counts, map;
+    GEVC(export_counts(c, pop, positions, n, counts, map));
+    const PackLayout L = pack_layout(c, P, n, counts);
+    if (bytes < L.total) return fail(GEV_EINVAL, "export_rows: buffer of %zu bytes, %zu needed", bytes, L.total);
+    if (!n) return GEV_OK;
+    hipStream_t st = c->stream;
+    uint8_t* out = (uint8_t*)device_buf;
+    const int nchr = c->nchr;
+    HIPC(hipMemcpyAsync(out + L.counts, counts.data(), counts.size() * sizeof(u32), hipMemcpyHostToDevice, st));
+    size_t po = L.planes, co = L.cv, mo = L.muts, pa = L.parts;
+    GEVC(c->d_cnt.ensure((2 * n + 1) * sizeof(u32) * 2, st));
+    u32* d_off = c->d_cnt.as<u32>() + 2 * n + 1;
+    for (int k = 0; k < nchr; k++) {
+        ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
+        const u32 chunks = (u32)(S.stride / 16);
+        hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, (uint4*)(out + po), S.stride / 16,
+                           (const uint4*)cs.plane[P.cur].p, S.stride / 16, c->d_map.as<u32>(), 2 * n, chunks);
+        po = al16(po + 2 * n * S.stride);
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1 && !c->track_intervals) continue;
+            const u32* soff = pass == 0 ? cs.moff[P.cur].as<u32>() : cs.poff[P.cur].as<u32>();
+            hipLaunchKernelGGL(k_csr_gather_count, dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, st, soff, c->d_map.as<u32>(), 2 * n, c->d_cnt.as<u32>());
+            KCHECK();
+            GEVC(scan_u32(c, c->d_cnt.as<u32>(), 2 * n, d_off, nullptr));
+            if (pass == 0) hipLaunchKernelGGL((k_csr_gather_fill<u64>), dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, st, soff, cs.mpos[P.cur].as<u64>(), c->d_map.as<u32>(), 2 * n, d_off, (u64*)(out + mo));
+            else hipLaunchKernelGGL((k_csr_gather_fill<gev_part>), dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, st, soff, cs.parts[P.cur].as<gev_part>(), c->d_map.as<u32>(), 2 * n, d_off, (gev_part*)(out + pa));
+            KCHECK();
+        }
+        mo = al16(mo + L.mut_chr[k] * sizeof(u64)); pa = al16(pa + L.parts_chr[k] * sizeof(gev_part));
+    }
+    for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) {
+        CvStatic& V = P.cv[p][k];
+        const u32 cch = V.stride_w32 / 4;
+        hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(2 * n * cch, 256)), dim3(256), 0, st, (uint4*)(out + co), (size_t)cch,
+                           (const uint4*)P.cvp[p][k][P.cur].p, (size_t)cch, c->d_map.as<u32>(), 2 * n, cch);
+        co = al16(co + 2 * n * V.stride_w32 * sizeof(u32));
+    }
+    KCHECK();
+    HIPC(hipStreamSynchronize(st));
+    return GEV_OK;
+}
+int gev_remove_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n)
+{
+    GEVC(check_idx(c, pop, 0));
+    if (n && !positions) return fail(GEV_EINVAL, "remove_rows: null positions");
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "remove_rows: population %d has no current generation", pop);
+    std::vector<uint8_t> gone(P.n_people, 0);
+    for (size_t i = 0; i < n; i++) {
+        if (positions[i] >= P.n_people || gone[positions[i]]) return fail(GEV_EINVAL, "remove_rows: position out of range or listed twice");
+        gone[positions[i]] = 1;
+    }
+    if (n >= P.n_people) return fail(GEV_EINVAL, "remove_rows: population %d would become empty", pop);
+    // no row moves: only the logical order changes; stayers keep their order (src/Simulation.cpp:960-966)
+    std::vector<u32> keep; keep.reserve(P.n_people - n);
+    for (size_t i = 0; i < P.n_people; i++) if (!gone[i]) keep.push_back(P.logical.empty() ? (u32)i : P.logical[i]);
+    P.logical.swap(keep); P.n_people = P.logical.size(); c->ad_cached_pop = -1;
+    return GEV_OK;
+}
+int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, size_t n)
+{
+    GEVC(check_idx(c, pop, 0));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "import_rows: population %d has no current generation", pop);
+    if (!n) return GEV_OK;
+    if (!device_buf) return fail(GEV_EINVAL, "import_rows: null buffer");
+    HIPC(hipSetDevice(c->device));
+    GEVC(gev_sync(c));
+    hipStream_t st = c->stream;
+    const int nchr = c->nchr;
+    const uint8_t* in = (const uint8_t*)device_buf;
+    if (bytes < n * nchr * 4 * sizeof(u32)) return fail(GEV_EINVAL, "import_rows: buffer too small for its own header");
+    std::vector<u32> counts(n * nchr * 4);
+    HIPC(hipMemcpyAsync(counts.data(), in, counts.size() * sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    const PackLayout L = pack_layout(c, P, n, counts);
+    if (bytes < L.total) return fail(GEV_EINVAL, "import_rows: buffer of %zu bytes, %zu expected from its header", bytes, L.total);
+    const size_t n_old = P.n_phys, n_new = n_old + n, r_old = 2 * n_old;     // physical append behind every existing row
+    if (n_new * 2 >= 0xffffffffull) return fail(GEV_EINVAL, "import_rows: too many rows");
+    GEVC(ensure_capacity(c, pop, n_new));                              // keeps the current buffers' content
+    size_t po = L.planes, co = L.cv, mo = L.muts, pa = L.parts;
+    for (int k = 0; k < nchr; k++) {
+        ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
+        HIPC(hipMemcpyAsync(cs.plane[P.cur].as<uint8_t>() + r_old * S.stride, in + po, 2 * n * S.stride, hipMemcpyDeviceToDevice, st));
+        po = al16(po + 2 * n * S.stride);
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1 && !c->track_intervals) continue;
+            size_t& total = pass == 0 ? cs.mut_total[P.cur] : cs.parts_total[P.cur];
+            std::vector<u32> off(2 * n + 1);
+            off[0] = (u32)total;
+            for (size_t i = 0; i < n; i++) for (int h = 0; h < 2; h++) off[2 * i + h + 1] = off[2 * i + h] + counts[((i * nchr + k) * 2 + h) * 2 + pass];
+            const size_t add = off[2 * n] - off[0];
+            DevBuf& doff = pass == 0 ? cs.moff[P.cur] : cs.poff[P.cur];
+            // offsets of the appended rows: entries r_old .. r_old + 2n (entry r_old already equals the old total)
+            HIPC(hipMemcpyAsync(doff.as<u32>() + r_old, off.data(), (2 * n + 1) * sizeof(u32), hipMemcpyHostToDevice, st));
+            HIPC(hipStreamSynchronize(st));
+            if (pass == 0) {
+                GEVC(cs.mpos[P.cur].ensure(std::max<size_t>(total + add, 2) * sizeof(u64), st, /*keep=*/true, 1.25));
+                if (add) HIPC(hipMemcpyAsync(cs.mpos[P.cur].as<u64>() + total, in + mo, add * sizeof(u64), hipMemcpyDeviceToDevice, st));
+            } else {
+                GEVC(cs.parts[P.cur].ensure(std::max<size_t>(total + add, 1) * sizeof(gev_part), st, true, 1.25));
+                if (add) HIPC(hipMemcpyAsync(cs.parts[P.cur].as<gev_part>() + total, in + pa, add * sizeof(gev_part), hipMemcpyDeviceToDevice, st));
+            }
+            total += add;
+        }
+        mo = al16(mo + L.mut_chr[k] * sizeof(u64)); pa = al16(pa + L.parts_chr[k] * sizeof(gev_part));
+    }
+    for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) {
+        CvStatic& V = P.cv[p][k];
+        HIPC(hipMemcpyAsync(P.cvp[p][k][P.cur].as<u32>() + r_old * V.stride_w32, in + co, 2 * n * V.stride_w32 * sizeof(u32), hipMemcpyDeviceToDevice, st));
+        co = al16(co + 2 * n * V.stride_w32 * sizeof(u32));
+        V.frq_valid = false;
+    }
+    HIPC(hipStreamSynchronize(st));
+    if (P.logical.empty()) { P.logical.resize(P.n_people); for (size_t i = 0; i < P.n_people; i++) P.logical[i] = (u32)i; }
+    for (size_t i = 0; i < n; i++) P.logical.push_back((u32)(n_old + i));
+    P.n_phys = n_new; P.n_people = P.logical.size(); c->ad_cached_pop = -1;
+    return GEV_OK;
+}
 
 // ---- output materialisation ---------------------------------------------------------------
 int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, u64* bits, size_t row_stride_words)
@@ -1081,6 +1290,7 @@ int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_r
     GEVC(check_idx(c, pop, chr));
     PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_haps: population %d has no current generation", pop);
+    GEVC(materialize_order(c, pop));
     if (row_begin + n_rows > 2 * P.n_people) return fail(GEV_EINVAL, "download_haps: rows [%zu,%zu) beyond 2*n_people=%zu", row_begin, row_begin + n_rows, 2 * P.n_people);
     if (n_rows && (!bits || row_stride_words * 64 < S.L)) return fail(GEV_EINVAL, "download_haps: bad output buffer");
     HIPC(hipSetDevice(c->device));
@@ -1108,6 +1318,7 @@ int gev_download_cv(gev_ctx* c, int pop, int phen, int chr, u64* bits, size_t ro
     GEVC(check_idx(c, pop, chr, phen));
     PopState& P = c->pop[pop]; CvStatic& V = P.cv[phen][chr]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_cv: population %d has no current generation", pop);
+    GEVC(materialize_order(c, pop));
     if (!bits || row_stride_words * 64 < V.C) return fail(GEV_EINVAL, "download_cv: bad output buffer");
     HIPC(hipSetDevice(c->device));
     hipStream_t st = c->stream;
@@ -1131,6 +1342,7 @@ int gev_download_intervals(gev_ctx* c, int pop, int chr, gev_part* out, u64* hap
     GEVC(check_idx(c, pop, chr));
     PopState& P = c->pop[pop]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_intervals: population %d has no current generation", pop);
+    GEVC(materialize_order(c, pop));
     if (!c->track_intervals) return fail(GEV_ESTATE, "download_intervals: interval tracking is disabled");
     if (!n_parts) return fail(GEV_EINVAL, "download_intervals: n_parts is null");
     HIPC(hipSetDevice(c->device));
@@ -1151,6 +1363,7 @@ int gev_download_mutations(gev_ctx* c, int pop, int chr, u64* out, u64* hap_offs
     GEVC(check_idx(c, pop, chr));
     PopState& P = c->pop[pop]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_mutations: population %d has no current generation", pop);
+    GEVC(materialize_order(c, pop));
     if (!n_mut) return fail(GEV_EINVAL, "download_mutations: n_mut is null");
     HIPC(hipSetDevice(c->device));
     const size_t rows = 2 * P.n_people;
@@ -1172,6 +1385,7 @@ int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_
 {
     GEVC(check_idx(c, pop, chr));
     GEVC(gev_sync(c));
+    if (c->pop[pop].gen0) GEVC(materialize_order(c, pop));
     PopState& P = c->pop[pop];
     if (dptr) *dptr = P.st[chr].plane[P.cur].p;
     if (row_stride_bytes) *row_stride_bytes = P.cs[chr].stride;

@@ -1,0 +1,63 @@
+"""Cross-GPU migration: one process per GPU, one population per process, variable-count
+all-to-all of complete individual records over torch.distributed (backend "nccl" = RCCL over
+xGMI on a multi-GPU node; "gloo" for CPU rehearsal).
+
+Reference semantics (Simulation::ras_do_migration, reference src/Simulation.cpp:877-989): the
+HOST decides who moves; migrants are erased from their origin (stayers keep their order,
+:960-966) and appended to their destination in (origin ascending, sample order) order (:971-981).
+This module only moves the rows: `outgoing[j]` = positions (in the reference's order) of the
+individuals of THIS rank's population that move to population j.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def migrate_all_to_all(ctx, outgoing, local_pop, device=None, group=None):
+    """ctx: GevContext whose population `local_pop` lives on this rank.  outgoing: list (len = world)
+    of uint64 position arrays (entry [rank] must be empty).  Collective: every rank must call it."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    outgoing = [np.ascontiguousarray(o, dtype=np.uint64) for o in outgoing]
+    assert len(outgoing) == world and len(outgoing[rank]) == 0
+    # 1. sizes and counts, exchanged first (variable-length records)
+    send_bytes = [ctx.export_size(local_pop, o) if len(o) else 0 for o in outgoing]
+    meta_dev = torch.device(device) if (on_gpu and backend == "nccl") else torch.device("cpu")
+    meta_out = torch.tensor([[send_bytes[j], len(outgoing[j])] for j in range(world)], dtype=torch.int64, device=meta_dev)
+    meta_in = torch.empty_like(meta_out)
+    dist.all_to_all_single(meta_in, meta_out, group=group)
+    meta_in = meta_in.cpu().numpy()
+    recv_bytes = [int(x) for x in meta_in[:, 0]]; recv_n = [int(x) for x in meta_in[:, 1]]
+    # 2. pack every destination's records into one send buffer (device memory for the HIP library)
+    buf_dev = torch.device(device) if on_gpu else torch.device("cpu")
+    send = torch.empty(max(sum(send_bytes), 16), dtype=torch.uint8, device=buf_dev)
+    recv = torch.empty(max(sum(recv_bytes), 16), dtype=torch.uint8, device=buf_dev)
+    off = 0
+    for j in range(world):
+        if send_bytes[j]:
+            ctx.export_rows(local_pop, outgoing[j], send.data_ptr() + off, send_bytes[j])
+        off += send_bytes[j]
+    # 3. the exchange; gloo cannot move device memory, so a CPU rehearsal of the GPU path stages through the host
+    if on_gpu and backend != "nccl":
+        send_x, recv_x = send.cpu(), torch.empty(recv.shape, dtype=torch.uint8)
+    else:
+        send_x, recv_x = send, recv
+    if sum(send_bytes) or sum(recv_bytes):
+        dist.all_to_all_single(recv_x[:sum(recv_bytes)] if sum(recv_bytes) else recv_x[:0],
+                               send_x[:sum(send_bytes)] if sum(send_bytes) else send_x[:0],
+                               output_split_sizes=recv_bytes, input_split_sizes=send_bytes, group=group)
+    if recv_x is not recv:
+        recv.copy_(recv_x)
+        if on_gpu:
+            torch.cuda.synchronize()
+    # 4. erase the emigrants, then append immigrants origin by origin (ascending)
+    gone = np.concatenate([o for o in outgoing]) if sum(len(o) for o in outgoing) else np.empty(0, dtype=np.uint64)
+    if len(gone):
+        ctx.remove_rows(local_pop, gone)
+    off = 0
+    for i in range(world):
+        if recv_n[i]:
+            ctx.import_rows(local_pop, recv.data_ptr() + off, recv_bytes[i], recv_n[i])
+        off += recv_bytes[i]
+    return recv_n

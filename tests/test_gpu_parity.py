@@ -208,3 +208,12 @@ def test_full_row_properties_at_scale(gpu_lib):
             row = kids[2 * i + s]
             assert np.array_equal(row, parents[2 * par]) or np.array_equal(row, parents[2 * par + 1])
     g.close()
+
+
+def test_two_rank_migration_on_gpu_matches_reference_fixture():
+    """two processes share the GPU; packed records are produced/consumed by the HIP library
+    (gev_export_rows / gev_remove_rows / gev_import_rows) and exchanged with all_to_all over gloo"""
+    from tests import dist_worker
+    res = dist_worker.launch("gpu")
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
