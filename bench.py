@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--cpu-sample-ind", type=int, default=20000)
     ap.add_argument("--cpu-sample-gens", type=int, default=4)
     ap.add_argument("--no-intervals", action="store_true", help="do not keep the ancestry interval state on the device")
+    ap.add_argument("--migration-rate", type=float, default=0.0,
+                    help="N>1 only: fraction of each population that moves to EACH other population every generation "
+                         "(BASELINE config 3 uses 0.01); rows travel by all_to_all over RCCL")
+    ap.add_argument("--isolated-steps", type=int, default=3, help="extra untimed generations without stream overlap for roofline.isolated")
     args = ap.parse_args()
 
     import torch
@@ -102,15 +106,19 @@ def main():
     from geneevolve_amd.capi import GevLibrary
     from geneevolve_amd.host import Simulation, SyntheticConfig, synthetic_random_mate
     lib = GevLibrary()                                   # the HIP library or nothing
-    cfg = SyntheticConfig(args.n_ind, args.n_loci, n_cv=args.n_cv, seed=12345 + rank)
-    ctx = lib.create(1, 1, 1, local_rank)
+    cfg = SyntheticConfig(args.n_ind, args.n_loci, n_cv=args.n_cv, seed=12345)      # same grids / maps / CV effects on every rank
+    migrate = world > 1 and args.migration_rate > 0
+    n_pop_ctx, my_pop = (world, rank) if migrate else (1, 0)   # with migration every rank knows all populations' static tables
+    ctx = lib.create(n_pop_ctx, 1, 1, local_rank)
     if args.no_intervals:
         ctx.set_track_intervals(False)
-    cfg.apply_static(ctx)
-    ctx.synth_founders(0, 0, 2 * args.n_ind, 1000 + rank)
-    ctx.synth_cv_founders(0, 0, 0, 2 * args.n_ind, 2000 + rank)
+    for p in range(n_pop_ctx):
+        cfg.apply_static(ctx, p)
+    P = my_pop
+    ctx.synth_founders(P, 0, 2 * args.n_ind, 1000 + rank)
+    ctx.synth_cv_founders(P, 0, 0, 2 * args.n_ind, 2000 + rank)
     sim = Simulation(ctx, 12345 + rank, 1, True)
-    sim.ras_initial_human_gen0(0, args.n_ind)
+    sim.ras_initial_human_gen0(P, args.n_ind)
     rng = np.random.default_rng(rank)
     total = args.warmup + args.steps
     # the ras_glob_seed() stream is a pure function of --seed and of counts known in advance
@@ -122,21 +130,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ad_ms, mate_ms, repro_ms = [], [], []
+    ad_ms, mate_ms, repro_ms, mig_ms = [], [], [], []
+    if migrate:
+        from geneevolve_amd.distributed import migrate_all_to_all
 
     def step(i):
         t0 = time.perf_counter()
-        sim.couples[0] = synthetic_random_mate(sim.sex[0], args.n_ind, rng, out=sim.couples.get(0))   # host mating (outside the hot path)
+        sim.couples[P] = synthetic_random_mate(sim.sex[P], args.n_ind, rng, out=sim.couples.get(P))   # host mating (outside the hot path)
         t1 = time.perf_counter()
-        sim.reproduce(0, i + 1, seeds=seeds[i], n_people=args.n_ind)             # Simulation::reproduce
+        sim.reproduce(P, i + 1, seeds=seeds[i], n_people=args.n_ind)             # Simulation::reproduce
         t2 = time.perf_counter()
-        sim.ras_compute_AD(0, i + 1)                                             # Simulation::ras_compute_AD
+        sim.ras_compute_AD(P, i + 1)                                             # Simulation::ras_compute_AD
         t3 = time.perf_counter()
+        if migrate:                                                              # Simulation::ras_do_migration: host picks WHO, rows go by all_to_all
+            k = int(round(args.migration_rate * args.n_ind))
+            sample = np.sort(rng.choice(args.n_ind, size=k * (world - 1), replace=False))[::-1].astype(np.uint64)   # :921-922
+            outgoing, o = [], 0
+            for j in range(world):
+                outgoing.append(np.empty(0, dtype=np.uint64) if j == rank else sample[o:o + k])
+                o += 0 if j == rank else k
+            sex = sim.sex[P]
+            gone = np.zeros(args.n_ind, dtype=bool); gone[sample.astype(np.int64)] = True
+            sent_sex = [sex[outgoing[j].astype(np.int64)] for j in range(world)]
+            migrate_all_to_all(ctx, outgoing, P, device=f"cuda:{local_rank}")
+            # host bookkeeping the reference does on its Human records: sexes follow the rows
+            recv_sex = [None] * world
+            dist.all_gather_object(recv_sex, sent_sex)
+            sim.sex[P] = np.concatenate([sex[~gone]] + [recv_sex[i][rank] for i in range(world) if i != rank])
+            mig_ms.append((time.perf_counter() - t3) * 1e3)
         mate_ms.append((t1 - t0) * 1e3); repro_ms.append((t2 - t1) * 1e3); ad_ms.append((t3 - t2) * 1e3)
 
     for i in range(args.warmup):
         step(i)
-    del ad_ms[:], mate_ms[:], repro_ms[:]
+    del ad_ms[:], mate_ms[:], repro_ms[:], mig_ms[:]
     tot0, n0 = ctx.timing_totals()                       # (implies a sync of both library streams)
     barrier()
     t0 = time.perf_counter()
@@ -152,12 +178,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # a few extra, untimed generations with the two library streams serialised: the stitch kernel alone on the GPU
+    iso = None
+    if args.isolated_steps > 0 and not migrate:
+        ctx.set_overlap(False)
+        more = [sim.ras_glob_seed(1 + args.n_ind) for _ in range(args.isolated_steps)]
+        ta, na = ctx.timing_totals()
+        for j in range(args.isolated_steps):
+            sim.couples[P] = synthetic_random_mate(sim.sex[P], args.n_ind, rng, out=sim.couples.get(P))
+            sim.reproduce(P, total + j + 1, seeds=more[j], n_people=args.n_ind)
+        tb, nb = ctx.timing_totals()
+        iso = (tb[1] - ta[1]) / max(nb - na, 1)
+        ctx.set_overlap(True)
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         gens_per_s = world * args.steps / dt
         alg_bytes = args.n_ind * args.n_loci / 2.0          # per stitch launch (1 chromosome)
         stitch = float(np.mean(stitch_ms))
         achieved = alg_bytes / (stitch * 1e-3) / 1e9
+        traffic = None                                      # HBM bytes per launch from the committed PMC passes (same workload only)
+        pmc = os.path.join(ROOT, "profiles", "r01_final_config2_pmc_hbm.json")
+        if os.path.exists(pmc) and (args.n_ind, args.n_loci) == (100_000, 1_000_000):
+            traffic = json.load(open(pmc))["k_stitch_parent_summary"]["hbm_traffic_bytes_per_launch"]
         out = {
             "metric": "generations/sec", "value": gens_per_s,
             "unit": f"generations/s of {args.n_ind} individuals x {args.n_loci} loci populations (summed over GPUs)",
@@ -166,15 +209,20 @@ def main():
             "data": "synthetic (device-generated founder panel, uniform maps, SURVEY.md 8(d) config C2)",
             "config": {"workload": "BASELINE config 2: 100k individuals x 1M SNPs, 1 population per GPU, 1 chromosome (100 Mb), "
                                    "uniform recombination map 2001 rows @ 5e-4, mutation 1e-8/bp, 1000 CVs, random mating",
-                       "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU",
+                       "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
                        "interval_state_tracked": not args.no_intervals},
             "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci / dt,
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
                          "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
-                         "gev_compute_ad_wall": float(np.mean(ad_ms))},
+                         "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None},
             "roofline": {"bound": "hbm", "kernel": "k_stitch_parent", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": stitch},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": stitch,
+                         "note": "kernel time measured live with HIP events on the library's stitch stream inside the timed region, where the "
+                                 "kernel shares the GPU with the next generation's sampling/A-D kernels; isolated_* = same kernel with the two "
+                                 "streams serialised (extra untimed generations); traffic = rocprofv3 PMC measurement committed under profiles/",
+                         "isolated_kernel_ms": iso, "isolated_achieved": (alg_bytes / (iso * 1e-3) / 1e9) if iso else None,
+                         "isolated_frac": (alg_bytes / (iso * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso else None},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.n_loci)

@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "compute_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_cv", "download_intervals", "download_mutations",
-    "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals",
+    "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -283,6 +283,9 @@ class GevContext:
         ms = (C.c_double * 4)(); n = C.c_ulonglong()
         self._call("timing_totals", ms, C.byref(n))
         return [float(x) for x in ms], n.value
+
+    def set_overlap(self, on):
+        self._call("set_overlap", C.c_int(1 if on else 0))
 
     def set_stitch_mode(self, mode):
         self._call("set_stitch_mode", C.c_int(mode))

@@ -1395,6 +1395,7 @@ int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_
 int gev_stream(gev_ctx* c, void** s) { if (!c || !s) return fail(GEV_EINVAL, "null"); *s = (void*)c->stream; return GEV_OK; }
 int gev_last_reproduce_ms(gev_ctx* c, float ms[4]) { if (!c || !ms) return fail(GEV_EINVAL, "null"); GEVC(gev_sync(c)); for (int i = 0; i < 4; i++) ms[i] = c->last_ms[i]; return GEV_OK; }
 int gev_set_track_intervals(gev_ctx* c, int on) { if (!c) return fail(GEV_EINVAL, "null"); c->track_intervals = on != 0; return GEV_OK; }
+int gev_set_overlap(gev_ctx* c, int on) { if (!c) return fail(GEV_EINVAL, "null"); GEVC(gev_sync(c)); c->serialize = on == 0; return GEV_OK; }
 int gev_set_stitch_mode(gev_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return fail(GEV_EINVAL, "stitch mode must be 0 (parent-major) or 1 (gamete-major)"); c->stitch_mode = mode; return GEV_OK; }
 
 // ---- diagnostics (tests only; no simulation state involved) --------------------------------

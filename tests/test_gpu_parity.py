@@ -217,3 +217,48 @@ def test_two_rank_migration_on_gpu_matches_reference_fixture():
     res = dist_worker.launch("gpu")
     for r, msg in res:
         assert msg == "ok", f"rank {r}: {msg}"
+
+
+def test_baseline_config2_full_size_dense_state_equals_interval_state(gpu_lib):
+    """BASELINE config 2 at FULL size (100k individuals x 1M SNPs; the oracle would need hours):
+    after two generations the dense genotype rows produced by the stitch kernel must equal what the
+    reference's materialisation rule (ras_convert_interval_to_hap_matrix, src/Simulation.cpp:1186-1230)
+    gives from the device's own ancestry intervals + mutation sets + the founder panel -- checked
+    on sampled rows, founder rows regenerated independently by tests/synth.py."""
+    from tests.synth import synth_bits
+    n, L = 100_000, 1_000_000
+    cfg = SyntheticConfig(n, L, seed=12345)
+    g = gpu_lib.create(1, 1, 1)
+    cfg.apply_static(g)
+    g.synth_founders(0, 0, 2 * n, 4711); g.synth_cv_founders(0, 0, 0, 2 * n, 4712)
+    sim = Simulation(g, 2024, 1, True)
+    sim.ras_initial_human_gen0(0, n)
+    rng = np.random.default_rng(5)
+    for gen in (1, 2):
+        sim.couples[0] = synthetic_random_mate(sim.sex[0], n, rng)
+        sim.reproduce(0, gen)
+        add, dom, _, _ = sim.ras_compute_AD(0, gen)
+        assert np.isfinite(add).all() and add.std() > 0
+    parts, off = g.download_intervals(0, 0)
+    muts, moff = g.download_mutations(0, 0)
+    assert off[-1] > 2 * n * 1.5                                  # recombination happened
+    assert moff[-1] > n * 0.5                                     # mutations accumulated
+    pos = cfg.snp_pos
+    bp0, bpe = int(cfg.rmap_bp[0]), int(cfg.rmap_bp[-1])
+    rows = rng.choice(2 * n, size=24, replace=False)
+    for r in rows:
+        got = capi.unpack_rows(g.download_haps(0, 0, int(r), 1), L)[0]
+        want = np.zeros(L, dtype=np.uint8)
+        cover = np.zeros(L, dtype=bool)
+        for p in parts[int(off[r]):int(off[r + 1])]:
+            lo, hi = np.searchsorted(pos, int(p["st"])), np.searchsorted(pos, int(p["en"]))
+            f = synth_bits(4711, 1, L, row_begin=int(p["hap_index"]))[0]
+            want[lo:hi] = f[lo:hi]; cover[lo:hi] = True
+        assert cover[np.searchsorted(pos, bp0):np.searchsorted(pos, bpe)].all()
+        flipped = set()
+        for x in muts[int(moff[r]):int(moff[r + 1])]:
+            j = int(np.searchsorted(pos, int(x)))
+            if j < L and pos[j] == x and j not in flipped:       # set semantics: one flip per position however often it was hit
+                want[j] = 1 - want[j]; flipped.add(j)
+        assert np.array_equal(got, want), f"row {r}: dense state != interval state"
+    g.close()
