@@ -71,6 +71,67 @@ def cpu_baseline(args, n_loci_unused):
                       f"(generation cost is independent of the SNP count); host has {os.cpu_count()} cores, 1 used"}
 
 
+def write_bits_text(path, bits_rows_by_cols):
+    """rows x cols 0/1 matrix -> the reference's .hap text ('0 1 0 ...' per line) without Python loops"""
+    r, c = bits_rows_by_cols.shape
+    buf = np.full((r, 2 * c), ord(" "), dtype=np.uint8)
+    buf[:, 0::2] = bits_rows_by_cols + ord("0")
+    buf[:, -1] = ord("\n")
+    buf.tofile(path)
+
+
+def cpu_baseline_reference(args):
+    """The REAL reference (oracle/_ref/ref_harness: unmodified GeneEvolve objects + a timing/dump driver, built
+    in the build container by oracle/Makefile.ref) on a bounded sample of the same workload: wall time of its
+    Simulation::reproduce + Simulation::ras_compute_AD calls, scaled linearly in N."""
+    import subprocess
+    import tempfile
+    from geneevolve_amd.host import SyntheticConfig
+    from tests.synth import synth_bits
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not os.path.exists(exe):
+        return None
+    ns, gens, nsnp = args.ref_sample_ind, args.ref_sample_gens, 64
+    cfg = SyntheticConfig(ns, nsnp, seed=12345)
+    with tempfile.TemporaryDirectory(prefix="gev_ref_") as wd:
+        j = lambda f: os.path.join(wd, f)
+        write_bits_text(j("ref.hap"), np.ascontiguousarray(synth_bits(1, 2 * ns, nsnp).T))         # .hap is SNP-major
+        with open(j("ref.legend"), "w") as f:
+            f.write("id pos al0 al1\n" + "".join(f"rs{i+1} {int(p)} A C\n" for i, p in enumerate(cfg.snp_pos)))
+        with open(j("ref.indv"), "w") as f:
+            f.write("".join(f"id{i+1}\n" for i in range(ns)))
+        with open(j("hapaddr.txt"), "w") as f:
+            f.write("chr hap legend sample\n" + f"1 {j('ref.hap')} {j('ref.legend')} {j('ref.indv')}\n")
+        cM = 1e-6 * (cfg.rmap_bp - cfg.rmap_bp[0]).astype(np.float64)                                # 1 cM/Mb -> 5e-4 per 50 kb row
+        with open(j("rmap.txt"), "w") as f:
+            f.write("chr bp cM\n" + "".join(f"1 {int(b)} {float(c)!r}\n" for b, c in zip(cfg.rmap_bp, cM)))
+        with open(j("mmap.txt"), "w") as f:
+            f.write("chr bp mutation_rate\n" + "".join(f"1 {int(b)} {float(r)!r}\n" for b, r in zip(cfg.mut_bp, cfg.mut_rate)))
+        bp, a, d = cfg.cv[0][0]
+        with open(j("cvinfo.txt"), "w") as f:
+            f.write("chr pos a d\n" + "".join(f"1 {int(b)} {float(x)!r} {float(y)!r}\n" for b, x, y in zip(bp, a, d)))
+        write_bits_text(j("cv.hap"), np.ascontiguousarray(synth_bits(2, 2 * ns, len(bp)).T))
+        with open(j("cvaddr.txt"), "w") as f:
+            f.write(f"1 {j('cv.hap')}\n")
+        with open(j("popinfo.txt"), "w") as f:
+            f.write("pop_size mat_cor offspring_dist selection_func selection_func_par1 selection_func_par2\n" + f"{ns} 0 p thr 1 1\n" * gens)
+        cmd = [exe, "--file_gen_info", j("popinfo.txt"), "--file_hap_name", j("hapaddr.txt"), "--file_recom_map", j("rmap.txt"),
+               "--file_mutation_map", j("mmap.txt"), "--file_cv_info", j("cvinfo.txt"), "--file_cvs", j("cvaddr.txt"),
+               "--va", "0.5", "--vd", "0", "--ve", "0.5", "--RM", "--seed", "12345", "--prefix", j("out")]
+        env = dict(os.environ, GEV_DUMP=j("d"), GEV_DUMP_GENS="9999")
+        try:
+            subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=600)
+            t = np.loadtxt(j("d.timing.txt")).reshape(-1, 5)
+        except Exception:  # noqa: BLE001  (binary missing its runtime, timeout ...): fall back to the port
+            return None
+    per_gen = float((t[:, 3] + t[:, 4]).mean())
+    return {"value": (1.0 / per_gen) * ns / args.n_ind, "unit": "generations/s", "cores": 1, "kind": "reference",
+            "sample": f"unmodified reference objects (oracle/_ref/ref_harness) on {ns} individuals x {gens} generations: "
+                      f"Simulation::reproduce {t[:,3].mean():.2f} s + ras_compute_AD {t[:,4].mean():.2f} s per generation, same maps/CVs/mutation "
+                      f"rate, --RM; scaled linearly in N to {args.n_ind} individuals (the reference's generation cost is independent "
+                      f"of the SNP count); host has {os.cpu_count()} cores, 1 used (the reference is single threaded)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +143,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ind", type=int, default=20000)
     ap.add_argument("--cpu-sample-gens", type=int, default=4)
+    ap.add_argument("--ref-sample-ind", type=int, default=8000)
+    ap.add_argument("--ref-sample-gens", type=int, default=3)
     ap.add_argument("--no-intervals", action="store_true", help="do not keep the ancestry interval state on the device")
     ap.add_argument("--migration-rate", type=float, default=0.0,
                     help="N>1 only: fraction of each population that moves to EACH other population every generation "
@@ -225,7 +288,10 @@ def main():
                          "isolated_frac": (alg_bytes / (iso * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso else None},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, args.n_loci)
+            port = cpu_baseline(args, args.n_loci)
+            ref = cpu_baseline_reference(args)
+            out["cpu_baseline"] = ref if ref is not None else port
+            out["cpu_baseline_port"] = port
             out["gpu_over_cpu"] = (gens_per_s / world) / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     ctx.close()

@@ -1,0 +1,82 @@
+// gev_host.hpp -- C++ host-side mirror of the reference's seam (header only, no HIP, no torch).
+//
+// The reference host is C++ (`class Simulation`, reference src/Simulation.h:64-144).  This class keeps
+// what the reference keeps on the host -- the ras_glob_seed() stream (src/Simulation.cpp:17-21), the
+// couples list, sexes -- and forwards the seam functions, under their reference names, to the C-ABI
+// of include/geneevolve_amd.h.  INTEGRATION.md shows the same calls as a patch to the reference.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/geneevolve_amd.h"
+
+namespace gev {
+
+// std::default_random_engine (minstd_rand0) + std::uniform_int_distribution<unsigned>(1,1000000):
+// libstdc++ down-scaling branch, scaling = 2147483645/1000000, reject engine()-1 >= 1000000*scaling
+class GlobSeed {
+    uint64_t x_;
+public:
+    explicit GlobSeed(unsigned seed) { x_ = seed % 2147483647ull; if (!x_) x_ = 1; }   // glob_generator.seed(par._seed), :75-76
+    unsigned operator()()                                                            // Simulation::ras_glob_seed, :17-21
+    {
+        const uint64_t scaling = 2147483645ull / 1000000ull, past = 1000000ull * scaling;
+        uint64_t r;
+        do { x_ = x_ * 16807ull % 2147483647ull; r = x_ - 1; } while (r >= past);
+        return (unsigned)(r / scaling + 1);
+    }
+};
+
+inline void check(int rc) { if (rc != GEV_OK) throw std::runtime_error(std::string(gev_last_error())); }
+
+class Simulation {
+public:
+    gev_ctx* ctx = nullptr;
+    int n_pop, nchr, nphen;
+    bool has_mutation_map;
+    GlobSeed glob;
+    std::vector<std::vector<gev_couple>> couples;     // population[ipop]._couples_info
+    std::vector<std::vector<uint8_t>> sex;            // Human::sex of the current generation
+
+    Simulation(int device, int n_pop_, int nchr_, int nphen_, unsigned seed, bool has_mut)
+        : n_pop(n_pop_), nchr(nchr_), nphen(nphen_), has_mutation_map(has_mut), glob(seed), couples(n_pop_), sex(n_pop_)
+    { check(gev_create(&ctx, device, n_pop, nchr, nphen)); }
+    ~Simulation() { gev_destroy(ctx); }
+    Simulation(const Simulation&) = delete;
+
+    unsigned ras_glob_seed() { return glob(); }
+
+    bool ras_initial_human_gen0(int ipop, size_t n_people)                      // src/Simulation.cpp:3000
+    {
+        sex[ipop].resize(n_people);
+        check(gev_init_gen0(ctx, ipop, n_people, ras_glob_seed(), sex[ipop].data()));
+        return true;
+    }
+    // src/Simulation.cpp:2394: draws 1 + n_people*nchr glob seeds exactly as the reference would (:2398, :2500)
+    const std::vector<uint8_t>& reproduce(int ipop)
+    {
+        size_t n_people = 0;
+        for (const gev_couple& c : couples[ipop]) if (!c.inbreed) n_people += c.num_offspring;
+        const unsigned seed = ras_glob_seed();
+        std::vector<uint32_t> mut_seeds;
+        if (has_mutation_map) { mut_seeds.resize(n_people * nchr); for (auto& s : mut_seeds) s = ras_glob_seed(); }
+        std::vector<uint8_t> s(n_people);
+        check(gev_reproduce(ctx, ipop, couples[ipop].data(), couples[ipop].size(), seed,
+                            has_mutation_map ? mut_seeds.data() : nullptr, mut_seeds.size(), n_people, s.data()));
+        sex[ipop].swap(s);
+        return sex[ipop];
+    }
+    bool ras_compute_AD(int ipop, std::vector<double>& additive, std::vector<double>& dominance)   // :2624
+    {
+        size_t n = 0; check(gev_pop_size(ctx, ipop, &n));
+        additive.resize(n * nphen); dominance.resize(n * nphen);
+        const int rc = gev_compute_ad(ctx, ipop, additive.data(), dominance.data(), nullptr, nullptr);
+        if (rc != GEV_OK) { printf("%s\n", gev_last_error()); return false; }                         // error convention of the reference: message + false
+        return true;
+    }
+    bool ras_do_migration(const std::vector<gev_move>& moves) { check(gev_migrate(ctx, moves.data(), moves.size())); return true; }   // :877
+};
+
+} // namespace gev

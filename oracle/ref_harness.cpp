@@ -18,6 +18,8 @@
 //       Simulation::sim_next_generation (src/Simulation.cpp:1890-2082), and dumps the
 //       inputs (couples, ras_glob_seed() values) and outputs (sex, interval lists,
 //       mutation lists, raw A/D, dense haplotype matrix) of the hot path.
+//       <prefix>.timing.txt receives the wall time of every reproduce / ras_compute_AD call (the
+//       CPU baseline of bench.py when this binary is present).
 //       The driver order is validated by comparing the .info files it writes with the
 //       ones the stock CLI build (oracle/_ref/GeneEvolve_ref) writes for the same seed.
 // Standard headers first (they must not see the macro below), then open the reference's
@@ -25,6 +27,7 @@
 // layout or symbol names, so this TU links against the reference objects compiled
 // without any such define.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -46,6 +49,7 @@
 #undef private
 
 static FILE* g_out = nullptr;
+static FILE* g_timing = nullptr;   // <GEV_DUMP>.timing.txt: gen pop n_people reproduce_seconds compute_AD_seconds
 
 static void dump_humans(Simulation& sim, int ipop, const char* tag)
 {
@@ -121,6 +125,7 @@ static int run_sim(int argc, char** argv)
         while (p < t.size()) { gens.insert(atoi(t.c_str() + p)); p = t.find(',', p); if (p == std::string::npos) break; p++; }
     }
     bool dense = getenv("GEV_DUMP_DENSE") != nullptr;
+    g_timing = fopen((std::string(prefix) + ".timing.txt").c_str(), "w");
     std::set<int> dense_gens;
     if (const char* s = getenv("GEV_DENSE_GENS")) {
         std::string t(s); size_t p = 0;
@@ -182,7 +187,9 @@ static int run_sim(int argc, char** argv)
             int nchr = (int)P.h[0].chr.size();
             bool has_mut = P._mutation_map.size() > 0;
             std::default_random_engine snap = sim.glob_generator;       // state before reproduce
+            const auto t_r0 = std::chrono::steady_clock::now();
             P.h = sim.reproduce(ipop, gen_num);                          // :1929
+            const auto t_r1 = std::chrono::steady_clock::now();
             // replay the ras_glob_seed() draws reproduce made (1 + n_people*nchr with a mutation map)
             {
                 std::uniform_int_distribution<unsigned> d(1, 1000000);   // ras_glob_seed, :17-21
@@ -193,7 +200,12 @@ static int run_sim(int argc, char** argv)
                 for (unsigned long i = 0; i < nm; i++) fprintf(g_out, "S %u\n", d(snap));
                 if (!(snap == sim.glob_generator)) { fprintf(stderr, "harness: glob_generator replay mismatch\n"); return 6; }
             }
+            const auto t_a0 = std::chrono::steady_clock::now();
             if (!sim.ras_compute_AD(ipop, gen_num)) return 7;            // :1935
+            const auto t_a1 = std::chrono::steady_clock::now();
+            if (g_timing)                                                // wall time of the two hot-path calls of the REAL reference
+                fprintf(g_timing, "%d %d %lu %.6f %.6f\n", gen_num, ipop, (unsigned long)P.h.size(),
+                        std::chrono::duration<double>(t_r1 - t_r0).count(), std::chrono::duration<double>(t_a1 - t_a0).count());
             dump_humans(sim, ipop, "OFFSPRING");
             dump_ad(sim, ipop);                                          // raw A/D (before scaling)
             for (int iphen = 0; iphen < nphen; iphen++)                  // :1943-1946
@@ -222,7 +234,9 @@ static int run_sim(int argc, char** argv)
             sim.population[ipop].ras_save_human_info(gen_num);
         if (w && dense && want_gen(dense_gens, gen_num)) dump_dense(sim);
         fclose(g_out);
+        if (g_timing) fflush(g_timing);
     }
+    if (g_timing) fclose(g_timing);
     return 0;
 }
 

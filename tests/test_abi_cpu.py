@@ -98,3 +98,16 @@ def test_glibc_linear_tables_reproduce_rand(gpu_lib, oracle_lib):
             out += list(x >> 1)
         want = oracle_api.kat_rand(oracle_lib, seed, 192)
         assert [int(v) for v in out] == [int(v) for v in want], f"seed {seed}"
+
+
+def test_cpp_host_fails_loudly_without_gpu():
+    """error convention of the reference's seam: message on stdout, failure status, no exception across the ABI"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "tools", "host_demo")
+    if not os.path.exists(exe):
+        pytest.skip("tools/host_demo not built (run __graft_entry__.build())")
+    r = subprocess.run([exe, "10", "100", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stdout

@@ -262,3 +262,45 @@ def test_baseline_config2_full_size_dense_state_equals_interval_state(gpu_lib):
                 want[j] = 1 - want[j]; flipped.add(j)
         assert np.array_equal(got, want), f"row {r}: dense state != interval state"
     g.close()
+
+
+def test_cpp_host_drives_the_c_abi_like_the_python_host(gpu_lib):
+    """tools/host_demo.cpp (C++ host, geneevolve_amd/host/gev_host.hpp, no Python) and the ctypes host
+    run the same scenario through the same C-ABI: identical genotype / A / sex checksums."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(helpers.GOLDEN), "..", "tools", "host_demo")
+    N, L, G, R, C = 500, 5000, 4, 201, 64
+    out = subprocess.run([exe, str(N), str(L), str(G)], capture_output=True, text=True, check=True).stdout
+    want = dict(l.split() for l in out.strip().splitlines())
+
+    def fnv(b):
+        h = 1469598103934665603
+        for x in bytes(b):
+            h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % h
+    g = gpu_lib.create(1, 1, 1)
+    bp = (1000 + 10000 * np.arange(R)).astype(np.uint64)
+    prob = np.r_[0.0, np.full(R - 1, 5e-3)]
+    g.set_rmap(0, 0, bp, prob, 10000); g.set_mutmap(0, 0, bp, prob)
+    g.set_snps(0, 0, (1000 + (2000000 // L) * np.arange(L)).astype(np.uint64))
+    a = np.array([float((i * 37) % 11) - 5.0 for i in range(C)])
+    g.set_cvs(0, 0, 0, (1500 + 31000 * np.arange(C)).astype(np.uint64), a, np.zeros(C), 0.0)
+    g.synth_founders(0, 0, 2 * N, 77); g.synth_cv_founders(0, 0, 0, 2 * N, 78)
+    sim = Simulation(g, 12345, 1, True)
+    sim.ras_initial_human_gen0(0, N)
+    lcg = 4242
+    M = (1 << 64) - 1
+    for gen in range(1, G + 1):
+        males = np.flatnonzero(sim.sex[0] == 1); females = np.flatnonzero(sim.sex[0] == 2)
+        c = np.zeros((N, 4), dtype=np.int64); c[:, 3] = 1
+        for i in range(N):
+            lcg = (lcg * 6364136223846793005 + 1442695040888963407) & M; c[i, 0] = males[(lcg >> 33) % len(males)]
+            lcg = (lcg * 6364136223846793005 + 1442695040888963407) & M; c[i, 1] = females[(lcg >> 33) % len(females)]
+        sim.couples[0] = c
+        seeds = sim.ras_glob_seed(1 + N)
+        sim.sex[0] = g.reproduce(0, c, int(seeds[0]), seeds[1:])
+        add, dom, _, _ = g.compute_ad(0, per_chr=False)
+    assert fnv(np.ascontiguousarray(g.download_haps(0, 0)).tobytes()) == want["HAPS"]
+    assert fnv(np.ascontiguousarray(add).tobytes()) == want["ADD"]
+    assert fnv(sim.sex[0].tobytes()) == want["SEX"]
+    g.close()
