@@ -159,12 +159,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    # rehearsal knob for a ONE-GPU box: all ranks share device 0 and talk over gloo (RCCL refuses two ranks on one GPU)
+    one_gpu = os.environ.get("GEV_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from geneevolve_amd.capi import GevLibrary
     from geneevolve_amd.host import Simulation, SyntheticConfig, synthetic_random_mate
@@ -237,7 +244,7 @@ def main():
     assert n1 - n0 == args.steps
     sample_ms = [(tot1[0] - tot0[0]) / args.steps]; stitch_ms = [(tot1[1] - tot0[1]) / args.steps]; sparse_ms = [(tot1[2] - tot0[2]) / args.steps]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -287,7 +294,7 @@ def main():
                          "isolated_kernel_ms": iso, "isolated_achieved": (alg_bytes / (iso * 1e-3) / 1e9) if iso else None,
                          "isolated_frac": (alg_bytes / (iso * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso else None},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N=1 only
             port = cpu_baseline(args, args.n_loci)
             ref = cpu_baseline_reference(args)
             out["cpu_baseline"] = ref if ref is not None else port
@@ -296,6 +303,7 @@ def main():
         print(json.dumps(out))
     ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
