@@ -304,3 +304,75 @@ def test_cpp_host_drives_the_c_abi_like_the_python_host(gpu_lib):
     assert fnv(np.ascontiguousarray(add).tobytes()) == want["ADD"]
     assert fnv(sim.sex[0].tobytes()) == want["SEX"]
     g.close()
+
+
+def test_inbred_couples_zero_row_mutation_map_and_heterogeneous_chromosomes(gpu_lib, oracle_lib):
+    """3 chromosomes with different lengths / map densities / SNP counts; chromosome 1 has an EMPTY mutation map
+    (the reference still draws its ras_glob_seed and calls srand for it, src/Simulation.cpp:2459-2462, 2509);
+    couples flagged inbreed are skipped (:2440); 2 phenotypes with different CV counts per chromosome."""
+    rs = np.random.RandomState(21)
+    nchr, nphen, n = 3, 2, 150
+    g = gpu_lib.create(1, nchr, nphen); o = oracle_lib.create(1, nchr, nphen)
+    Ls = [3000, 777, 64]
+    for c in range(nchr):
+        R = [301, 41, 9][c]; step = [1000, 5000, 200][c]
+        bp = (500 + step * np.arange(R)).astype(np.uint64)
+        prob = np.r_[0.0, rs.uniform(0, [4e-3, 3e-2, 0.2][c], R - 1)]
+        pos = np.sort(rs.randint(0, int(bp[-1]) + 3 * step, Ls[c])).astype(np.uint64)          # duplicates and loci outside the map range
+        rate = np.r_[0.0, rs.uniform(0, 0.02, R - 1)]
+        for ctx in (g, o):
+            ctx.set_rmap(0, c, bp, prob, step)
+            if c == 1:
+                ctx.set_mutmap(0, c, np.empty(0, dtype=np.uint64), np.empty(0))
+            else:
+                ctx.set_mutmap(0, c, bp, rate)
+            ctx.set_snps(0, c, pos)
+        g.synth_founders(0, c, 2 * n, 50 + c); o.upload_founders(0, c, synth_packed(50 + c, 2 * n, Ls[c]), Ls[c])
+        for p in range(nphen):
+            C = [[40, 7, 3], [11, 0, 5]][p][c]
+            cvbp = rs.randint(int(bp[0]) - 100, int(bp[-1]) + 100, C).astype(np.uint64)              # unsorted, some outside the range
+            a, d = rs.randn(C), rs.randn(C)
+            for ctx in (g, o):
+                ctx.set_cvs(0, p, c, cvbp, a, d, [0.3, 0.0][p])
+            g.synth_cv_founders(0, p, c, 2 * n, 900 + 10 * p + c)
+            o.upload_cv_founders(0, p, c, synth_packed(900 + 10 * p + c, 2 * n, C) if C else np.zeros((2 * n, 1), dtype=np.uint64), C)
+    sg = Simulation(g, 5, nchr, True); so = Simulation(o, 5, nchr, True)
+    sg.ras_initial_human_gen0(0, n); so.ras_initial_human_gen0(0, n)
+    rng = np.random.default_rng(3)
+    for gen in range(1, 5):
+        c = synthetic_random_mate(sg.sex[0], n, rng)
+        c["num_offspring"] = rng.integers(0, 4, n)
+        c["inbreed"] = rng.integers(0, 5, n) == 0
+        if c["num_offspring"][c["inbreed"] == 0].sum() == 0:
+            c["num_offspring"][0] = 2; c["inbreed"][0] = 0
+        sg.couples[0] = c; so.couples[0] = c.copy()
+        assert np.array_equal(sg.reproduce(0, gen), so.reproduce(0, gen)), f"sex gen {gen}"
+        for x, y in zip(sg.ras_compute_AD(0, gen, per_chr=True), so.ras_compute_AD(0, gen, per_chr=True)):
+            assert helpers.bits_equal(x, y), f"A/D gen {gen}"
+        for k in range(nchr):
+            assert np.array_equal(g.download_haps(0, k), o.download_haps(0, k)), f"dense gen {gen} chr {k}"
+            pg, og = g.download_intervals(0, k); po, oo = o.download_intervals(0, k)
+            assert np.array_equal(og, oo) and np.array_equal(pg, po)
+            mg, mog = g.download_mutations(0, k); mo, moo = o.download_mutations(0, k)
+            assert np.array_equal(mog, moo) and np.array_equal(mg, mo)
+            for p in range(nphen):
+                assert np.array_equal(g.download_cv(0, p, k), o.download_cv(0, p, k))
+    g.close(); o.close()
+
+
+def test_unsupported_inputs_are_refused_not_miscomputed(gpu_lib):
+    g = gpu_lib.create(1, 1, 1)
+    bp = np.array([0, 1000, 1500, 3000], dtype=np.uint64)
+    with pytest.raises(capi.GevError) as e:                       # rows closer than bp_dist: the reference would emit unsorted breakpoints
+        g.set_rmap(0, 0, bp, np.zeros(4), 1000)
+    assert e.value.code == -5
+    with pytest.raises(capi.GevError) as e:
+        g.set_snps(0, 0, np.array([5, 4, 6], dtype=np.uint64))    # unsorted SNP grid
+    assert e.value.code == -5
+    with pytest.raises(capi.GevError) as e:
+        g.set_rmap(0, 0, bp[:2], np.zeros(2), 0)                  # rand() % 0
+    assert e.value.code == -1
+    with pytest.raises(capi.GevError) as e:                       # call order
+        g.reproduce(0, np.array([[0, 1, 0, 1]]), 1, None)
+    assert e.value.code == -2
+    g.close()
