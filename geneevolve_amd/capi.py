@@ -32,6 +32,11 @@ class gev_move(C.Structure):
     _fields_ = [("src_pop", C.c_int32), ("dst_pop", C.c_int32), ("src_pos", C.c_uint64)]
 
 
+class gev_gef_params(C.Structure):
+    _fields_ = [("va", C.c_double), ("vd", C.c_double), ("ve", C.c_double), ("vf", C.c_double), ("beta", C.c_double),
+                ("s2_a_gen0", C.c_double), ("s2_d_gen0", C.c_double), ("gen_num", C.c_int32), ("reserved", C.c_int32)]
+
+
 COUPLE_DTYPE = np.dtype([("pos_male", "<u8"), ("pos_female", "<u8"), ("inbreed", "<i4"), ("num_offspring", "<i4")])
 PART_DTYPE = np.dtype([("st", "<u8"), ("en", "<u8"), ("hap_index", "<u8"), ("root_population", "<i4"), ("reserved", "<i4")])
 MOVE_DTYPE = np.dtype([("src_pop", "<i4"), ("dst_pop", "<i4"), ("src_pos", "<u8")])
@@ -40,7 +45,7 @@ MOVE_DTYPE = np.dtype([("src_pop", "<i4"), ("dst_pop", "<i4"), ("src_pos", "<u8"
 ABI_SYMBOLS = [
     "last_error", "version", "create", "destroy", "set_rmap", "set_mutmap", "set_snps", "set_cvs",
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
-    "reproduce", "compute_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
+    "reproduce", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
@@ -205,6 +210,18 @@ class GevContext:
         domc = np.zeros((n, self.nchr, self.nphen)) if per_chr else None
         self._call("compute_ad", C.c_int(pop), _p(add), _p(dom), _p(addc), _p(domc))
         return add, dom, addc, domc
+
+    def scale_ad_compute_gef(self, pop, phen, gen_num, seed, va, vd, ve, vf, beta, s2_a_gen0, s2_d_gen0,
+                             common_sibling=None, f_father=None, f_mother=None):
+        """Simulation::ras_scale_AD_compute_GEF (reference src/Simulation.cpp:3075): -> dict of n-vectors"""
+        n = self.pop_size(pop)
+        par = gev_gef_params(va, vd, ve, vf, beta, s2_a_gen0, s2_d_gen0, gen_num, 0)
+        arr = lambda x: None if x is None else _arr(x, np.float64)
+        cs, ff, fm = arr(common_sibling), arr(f_father), arr(f_mother)
+        out = {k: np.zeros(n) for k in ("additive", "dominance", "bv", "e_noise", "parental_effect", "phen")}
+        self._call("scale_ad_compute_gef", C.c_int(pop), C.c_int(phen), C.byref(par), C.c_uint32(int(seed)), _p(cs), _p(ff), _p(fm),
+                   _p(out["additive"]), _p(out["dominance"]), _p(out["bv"]), _p(out["e_noise"]), _p(out["parental_effect"]), _p(out["phen"]))
+        return out
 
     def get_cv_freq(self, pop, phen, chr):
         ncv = self._ncv[(pop, phen, chr)]

@@ -935,3 +935,86 @@ __global__ void k_csr_gather_fill(const u32* __restrict__ s_off, const E* __rest
     const u32 a = s_off[map[r]], n = s_off[map[r] + 1] - a, o = d_off[r];
     for (u32 j = 0; j < n; j++) d_val[o + j] = s_val[a + j];
 }
+
+// ------------------------------------------------------------------------------------------
+// Simulation::ras_scale_AD_compute_GEF (src/Simulation.cpp:3075-3206)
+// std::normal_distribution<double> on minstd_rand0 = Marsaglia polar method with rejection
+// (libstdc++ bits/random.tcc:1802-1835): candidate pair j consumes engine outputs 4j+1..4j+4, the
+// k-th ACCEPTED pair yields normals 2k (= y*mult) and 2k+1 (= x*mult).  Candidates are evaluated in
+// parallel (LCG jump-ahead) and compacted with a scan.  u = generate_canonical is computed in FP64
+// exactly as libstdc++ does (no contraction); log() is the device libm (<= 1 ulp from glibc's).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 powmod31(u32 a, u64 e)
+{
+    u32 r = 1;
+    while (e) { if (e & 1) r = mulmod31(r, a); a = mulmod31(a, a); e >>= 1; }
+    return r;
+}
+__device__ __forceinline__ double canonical_f64(u32 x1, u32 x2)
+{
+    const double R = 2147483646.0, R2 = 0x1.fffffff000000p+61;
+    const double t = (double)(x2 - 1) * R;
+    const double sum = (double)(x1 - 1) + t;
+    double ret = sum / R2;
+    if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;       // nextafter(1, 0)
+    return ret;
+}
+__global__ void __launch_bounds__(256) k_polar_candidates(u32 engine_seed, size_t n_cand, u32* __restrict__ flag, double* __restrict__ first, double* __restrict__ second)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cand) return;
+    u32 x = mulmod31(powmod31(16807u, 4 * j + 1), minstd_seed(engine_seed));
+    const u32 x1 = x; x = mulmod31(x, 16807u); const u32 x2 = x; x = mulmod31(x, 16807u); const u32 x3 = x; x = mulmod31(x, 16807u); const u32 x4 = x;
+    const double xx = 2.0 * canonical_f64(x1, x2) - 1.0;
+    const double yy = 2.0 * canonical_f64(x3, x4) - 1.0;
+    const double r2 = xx * xx + yy * yy;
+    const bool ok = !(r2 > 1.0 || r2 == 0.0);
+    flag[j] = ok ? 1u : 0u;
+    if (ok) { const double mult = sqrt(-2 * log(r2) / r2); first[j] = yy * mult; second[j] = xx * mult; }
+}
+__global__ void __launch_bounds__(256) k_polar_emit(const u32* __restrict__ flag, const u32* __restrict__ off, const double* __restrict__ first, const double* __restrict__ second,
+                                                    size_t n_cand, size_t n, double sd, double* __restrict__ out)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cand || !flag[j]) return;
+    const size_t k = off[j];
+    if (2 * k < n) out[2 * k] = first[j] * sd + 0.0;          // ret * stddev + mean
+    if (2 * k + 1 < n) out[2 * k + 1] = second[j] * sd + 0.0;
+}
+// deterministic two-level sum of (x[i]-shift)^pw, pw in {1,2}
+__global__ void __launch_bounds__(256) k_sum_partial(const double* __restrict__ x, size_t n, double shift, int pw, double* __restrict__ partial)
+{
+    __shared__ double s[256];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const double v = x[i] - shift; acc += pw == 2 ? v * v : v; }
+    s[threadIdx.x] = acc; __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+__global__ void __launch_bounds__(256) k_sum_final(const double* __restrict__ partial, int nb, double* __restrict__ out)
+{
+    __shared__ double s[256];
+    s[threadIdx.x] = (int)threadIdx.x < nb ? partial[threadIdx.x] : 0.0; __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) *out = s[0];
+}
+// :3174-3203; raw a, d strided by nphen
+__global__ void __launch_bounds__(256) k_gef_apply(const double* __restrict__ a, const double* __restrict__ d, size_t stride, const double* __restrict__ e, const double* __restrict__ par_eff,
+                                                   const double* __restrict__ common, size_t n, double s_a, double s_d, double s_ev, double vf,
+                                                   double* __restrict__ o_add, double* __restrict__ o_dom, double* __restrict__ o_bv, double* __restrict__ o_e, double* __restrict__ o_par, double* __restrict__ o_phen)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double en = s_ev > 0 ? e[i] / s_ev : 0;
+    const double ad = a[i * stride] / s_a;
+    const double dm = s_d > 0 ? d[i * stride] / s_d : 0;
+    const double pe = vf > 0 ? par_eff[i] : 0;
+    const double cs = common ? common[i] : 0.0;
+    o_e[i] = en; o_add[i] = ad; o_dom[i] = dm; o_bv[i] = ad + dm; o_par[i] = pe;
+    o_phen[i] = ad + dm + cs + en + pe;
+}
+__global__ void __launch_bounds__(256) k_par_eff(const double* __restrict__ ff, const double* __restrict__ fm, size_t n, double beta, double* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = beta * ((ff ? ff[i] : 0.0) + (fm ? fm[i] : 0.0));
+}

@@ -129,7 +129,7 @@ struct gev_ctx {
     int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
     bool serialize = false;        // GEV_SERIALIZE=1: wait for every stitch (diagnostic, measures the phases without overlap)
     unsigned stitch_lds_pad = 0;   // unused dynamic LDS per stitch workgroup: limits workgroups per CU (160 KiB / CU)
-    DevBuf d_sex0;
+    DevBuf d_sex0, d_gef_flag, d_gef_first, d_gef_red, d_gef_io;
     DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
     std::map<double, GevThr> thr_cache;
 };
@@ -946,6 +946,90 @@ int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, dou
     if (flag != 0xffffffffu) return fail(GEV_ENAN, "Error: A or D is nan for human %u", flag);
     return GEV_OK;
 }
+// ---- Simulation::ras_scale_AD_compute_GEF ---------------------------------
+static int normal_stream(gev_ctx* c, u32 engine_seed, size_t n, double sd, double* d_out)
+{
+    hipStream_t st = c->stream;
+    size_t n_cand = (size_t)((n / 2 + 1) / 0.7) + 4096;           // acceptance = pi/4
+    for (int attempt = 0; attempt < 4; attempt++, n_cand *= 2) {
+        GEVC(c->d_gef_flag.ensure((n_cand + 1) * sizeof(u32) * 2, st)); GEVC(c->d_gef_first.ensure(n_cand * sizeof(double) * 2, st));
+        u32* flag = c->d_gef_flag.as<u32>(); u32* off = flag + n_cand + 1;
+        double* first = c->d_gef_first.as<double>(); double* second = first + n_cand;
+        hipLaunchKernelGGL(k_polar_candidates, dim3((unsigned)ceil_div(n_cand, 256)), dim3(256), 0, st, engine_seed, n_cand, flag, first, second);
+        KCHECK();
+        u32 accepted = 0;
+        GEVC(scan_u32(c, flag, n_cand, off, &accepted));
+        if ((size_t)accepted * 2 < n) continue;                     // (practically never) not enough accepted pairs: more candidates
+        hipLaunchKernelGGL(k_polar_emit, dim3((unsigned)ceil_div(n_cand, 256)), dim3(256), 0, st, flag, off, first, second, n_cand, n, sd, d_out);
+        KCHECK();
+        return GEV_OK;
+    }
+    return fail(GEV_EDEVICE, "normal_stream: acceptance far below pi/4");
+}
+static int device_sum(gev_ctx* c, const double* x, size_t n, double shift, int pw, double* host_out)
+{
+    hipStream_t st = c->stream;
+    GEVC(c->d_gef_red.ensure(512 * sizeof(double), st));
+    const int nb = (int)std::min<size_t>(ceil_div(n, 256), 256);
+    hipLaunchKernelGGL(k_sum_partial, dim3(nb), dim3(256), 0, st, x, n, shift, pw, c->d_gef_red.as<double>());
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, st, c->d_gef_red.as<double>(), nb, c->d_gef_red.as<double>() + 256);
+    KCHECK();
+    HIPC(hipMemcpyAsync(host_out, c->d_gef_red.as<double>() + 256, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    return GEV_OK;
+}
+int gev_scale_ad_compute_gef(gev_ctx* c, int pop, int phen, const gev_gef_params* par, uint32_t seed,
+                             const double* common_sibling, const double* f_father, const double* f_mother,
+                             double* additive, double* dominance, double* bv, double* e_noise, double* parental_effect, double* phen_out)
+{
+    GEVC(check_idx(c, pop, 0, phen));
+    if (!par) return fail(GEV_EINVAL, "scale_ad_compute_gef: null parameters");
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "scale_ad_compute_gef: population %d has no current generation", pop);
+    HIPC(hipSetDevice(c->device));
+    if (c->ad_cached_pop != pop) GEVC(gev_compute_ad(c, pop, nullptr, nullptr, nullptr, nullptr));      // raw A/D of this generation on the device
+    hipStream_t st = c->stream;
+    const size_t n = P.n_people;
+    GEVC(c->d_gef_io.ensure(10 * n * sizeof(double), st));
+    double* io = c->d_gef_io.as<double>();
+    double *d_e = io, *d_par = io + n, *d_cs = io + 2 * n, *d_ff = io + 3 * n, *d_out = io + 4 * n;     // d_out: 6 vectors
+    GEVC(normal_stream(c, seed, n, 1.0, d_e));                                                           // generator_e(seed), N(0,1), :3080-3102
+    const bool need_par = par->vf > 0;
+    if (par->gen_num == 0) { if (need_par) GEVC(normal_stream(c, seed + 1u, n, std::sqrt(par->vf), d_par)); }   // generator_f(seed+1), :3095-3114
+    else if (need_par) {
+        double* d_fm = d_out;                                                                             // staging before d_out is written
+        if (f_father) HIPC(hipMemcpyAsync(d_ff, f_father, n * sizeof(double), hipMemcpyHostToDevice, st));
+        if (f_mother) HIPC(hipMemcpyAsync(d_fm, f_mother, n * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_par_eff, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, f_father ? d_ff : (const double*)nullptr, f_mother ? d_fm : (const double*)nullptr, n, par->beta, d_par);
+        KCHECK();
+        HIPC(hipStreamSynchronize(st));
+    }
+    if (common_sibling) HIPC(hipMemcpyAsync(d_cs, common_sibling, n * sizeof(double), hipMemcpyHostToDevice, st));
+    double s_a = 1;
+    if (par->va > 0) s_a = std::sqrt(par->s2_a_gen0 / par->va);
+    double s_d = 0;
+    if (par->vd > 0) s_d = std::sqrt(par->s2_d_gen0 / par->vd); else if (par->vd == -1) s_d = 1;
+    double s_ev = 0;
+    if (par->ve > 0) {                                                                                    // CommFunc::var(e): two passes, n-1
+        double sum = 0, ss = 0, var_e = 0;
+        if (n > 1) {
+            GEVC(device_sum(c, d_e, n, 0.0, 1, &sum));
+            const double mu = sum / (double)n;
+            GEVC(device_sum(c, d_e, n, mu, 2, &ss));
+            var_e = ss / (double)(n - 1);
+        }
+        s_ev = std::sqrt(var_e / par->ve);
+    }
+    hipLaunchKernelGGL(k_gef_apply, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, c->d_add.as<double>() + phen, c->d_dom.as<double>() + phen, (size_t)c->nphen,
+                       d_e, d_par, common_sibling ? d_cs : (const double*)nullptr, n, s_a, s_d, s_ev, par->vf,
+                       d_out, d_out + n, d_out + 2 * n, d_out + 3 * n, d_out + 4 * n, d_out + 5 * n);
+    KCHECK();
+    double* outs[6] = {additive, dominance, bv, e_noise, parental_effect, phen_out};
+    for (int k = 0; k < 6; k++) if (outs[k]) HIPC(hipMemcpyAsync(outs[k], d_out + k * n, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    return GEV_OK;
+}
+
 int gev_get_cv_freq(gev_ctx* c, int pop, int phen, int chr, double* frq, size_t C)
 {
     GEVC(check_idx(c, pop, chr, phen));

@@ -141,6 +141,25 @@ int gev_reproduce(gev_ctx*, int pop, const gev_couple* couples, size_t n_couples
  * bv = additive + dominance is left to the host (:2715, :2744). */
 int gev_compute_ad(gev_ctx*, int pop, double* additive, double* dominance,
                    double* add_chr, double* dom_chr);
+/* ---- Simulation::ras_scale_AD_compute_GEF (src/Simulation.cpp:3075-3206)  [SURVEY 8(f) row 1] ----
+ * Scales the raw A/D of the last gev_compute_ad to the generation-0 variances, draws the noise term
+ * e ~ N(0,1) from std::normal_distribution on minstd_rand0(seed) (seed = the ras_glob_seed() value
+ * drawn at :3078), standardises it with CommFunc::var, and assembles phen = A + D + C + E + F.
+ * The host supplies what the reference reads from host-side records: common_sibling[i]
+ * (Human::common_sibling), and for gen_num > 0 the parents' values f_father[i], f_mother[i]
+ * (_Pop_info_prev_gen phen or parental_effect looked up by ID_Father / ID_Mother, :3118-3131); any may be
+ * NULL (= 0).  Outputs: n doubles each, any may be NULL.  Floats agree with the reference within 1e-12
+ * relative (device log() and parallel sums differ from glibc / sequential sums in the last bits). */
+typedef struct gev_gef_params {
+    double va, vd, ve, vf, beta;        /* Phenotype_scheme::_va,_vd,_ve,_vf,_beta                        */
+    double s2_a_gen0, s2_d_gen0;        /* Population::_var_a_gen0 / _var_d_gen0 of this phenotype        */
+    int32_t gen_num, reserved;
+} gev_gef_params;
+int gev_scale_ad_compute_gef(gev_ctx*, int pop, int phen, const gev_gef_params* par, uint32_t seed,
+                             const double* common_sibling, const double* f_father, const double* f_mother,
+                             double* additive, double* dominance, double* bv, double* e_noise,
+                             double* parental_effect, double* phen_out);
+
 /* population allele frequency frq[icv] of the last gev_compute_ad (:2647-2655), FILE order. */
 int gev_get_cv_freq(gev_ctx*, int pop, int phen, int chr, double* frq, size_t C);
 

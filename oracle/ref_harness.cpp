@@ -208,8 +208,25 @@ static int run_sim(int argc, char** argv)
                         std::chrono::duration<double>(t_r1 - t_r0).count(), std::chrono::duration<double>(t_a1 - t_a0).count());
             dump_humans(sim, ipop, "OFFSPRING");
             dump_ad(sim, ipop);                                          // raw A/D (before scaling)
-            for (int iphen = 0; iphen < nphen; iphen++)                  // :1943-1946
+            for (int iphen = 0; iphen < nphen; iphen++) {                // :1943-1946
+                // inputs of ras_scale_AD_compute_GEF (:3075): its ras_glob_seed() value, gen-0 variances, the parents' values it looks up
+                std::default_random_engine snap2 = sim.glob_generator;
+                std::uniform_int_distribution<unsigned> d2(1, 1000000);
+                fprintf(g_out, "GEF pop %d phen %d seed %u s2a %a s2d %a va %a vd %a ve %a vf %a beta %a vt %d\n", ipop, iphen, d2(snap2),
+                        P._var_a_gen0[iphen], P._var_d_gen0[iphen], P._pheno_scheme[iphen]._va, P._pheno_scheme[iphen]._vd,
+                        P._pheno_scheme[iphen]._ve, P._pheno_scheme[iphen]._vf, P._pheno_scheme[iphen]._beta, sim._vt_type);
+                for (unsigned long ih = 0; ih < P.h.size(); ih++) {
+                    const unsigned long f = P.h[ih].ID_Father, m = P.h[ih].ID_Mother;
+                    const double pf = sim._vt_type == 1 ? sim._Pop_info_prev_gen[ipop].phen[iphen][f] : (sim._vt_type == 2 ? sim._Pop_info_prev_gen[ipop].parental_effect[iphen][f] : 0.0);
+                    const double pm = sim._vt_type == 1 ? sim._Pop_info_prev_gen[ipop].phen[iphen][m] : (sim._vt_type == 2 ? sim._Pop_info_prev_gen[ipop].parental_effect[iphen][m] : 0.0);
+                    fprintf(g_out, "GI %lu %a %a %a\n", ih, P.h[ih].common_sibling[iphen], pf, pm);
+                }
                 if (!sim.ras_scale_AD_compute_GEF(gen_num, ipop, iphen, P._var_a_gen0[iphen], P._var_d_gen0[iphen])) return 8;
+                if (!(snap2 == sim.glob_generator)) { fprintf(stderr, "harness: GEF glob replay mismatch\n"); return 6; }
+                for (unsigned long ih = 0; ih < P.h.size(); ih++)
+                    fprintf(g_out, "GO %lu %a %a %a %a %a %a\n", ih, P.h[ih].additive[iphen], P.h[ih].dominance[iphen], P.h[ih].bv[iphen],
+                            P.h[ih].e_noise[iphen], P.h[ih].parental_effect[iphen], P.h[ih].phen[iphen]);
+            }
         }
         for (int iphen = 0; iphen < nphen; iphen++)                      // :1973-1977
             sim.sim_environmental_effects_specific_to_each_population(iphen);

@@ -139,6 +139,13 @@ def parse_dump(path):
                 cur = out.setdefault("postfp", {}).setdefault(int(t[2]), [])
             elif k == "J":
                 cur.append((int(t[1]), hexf(t[2])))
+            elif k == "GEF":
+                cur = {"pop": int(t[2]), "phen": int(t[4]), "seed": int(t[6]), "par": [hexf(t[i]) for i in (8, 10, 12, 14, 16, 18, 20)], "vt": int(t[22]), "GI": [], "GO": []}
+                out.setdefault("gef", []).append(cur)
+            elif k == "GI":
+                cur["GI"].append([hexf(x) for x in t[2:5]])
+            elif k == "GO":
+                cur["GO"].append([hexf(x) for x in t[2:8]])
             elif k == "GLOBSEQ":
                 out["globseq"] = [int(x) for x in t[1:]]
     return out
@@ -260,7 +267,7 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
                         arrs[f"{pre}ph{iph}_chr{ic}_cv_val"] = np.packbits(ph["val"][ic].astype(np.uint8), axis=1, bitorder="little")
             a += ["--file_cv_info", os.path.join(wd, f"p{ip}.ph{iph}.cvinfo.txt"), "--file_cvs", os.path.join(wd, f"p{ip}.ph{iph}.cvaddr.txt")]
             arrs[f"{pre}ph{iph}_vd"] = np.float64(ph.get("vd", -1.0))
-        for key in ("va", "vd", "ve"):
+        for key in ("va", "vd", "ve", "vf"):
             for ph in P["phens"]:
                 if key in ph:
                     a += [f"--{key}", repr(float(ph[key]))]
@@ -311,6 +318,10 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             pack_ad(d["ad"][ip], pre, arrs)
             if d["premig"]:
                 pack_humans(d["postmig"][ip], pre + "postmig_", arrs)
+        for ge in d.get("gef", []):       # ras_scale_AD_compute_GEF inputs / outputs
+            k = f"g{g}_pop{ge['pop']}_ph{ge['phen']}_gef_"
+            arrs[k + "seed"] = np.uint32(ge["seed"]); arrs[k + "par"] = np.array(ge["par"]); arrs[k + "vt"] = np.int64(ge["vt"])
+            arrs[k + "in"] = np.array(ge["GI"]).reshape(-1, 3); arrs[k + "out"] = np.array(ge["GO"]).reshape(-1, 6)
         if d["premig"]:
             # WHO moved (the host's decision in ras_do_migration, src/Simulation.cpp:899-937), recovered by
             # matching (ID, phenotype) fingerprints; listed in the reference's append order (:971-981):
@@ -421,7 +432,7 @@ def main():
         cvbp = rs.choice(np.arange(950, 21100), size=150, replace=False).astype(np.uint64)   # file order unsorted
         cvbp[:40] = rs.choice(snp, 40, replace=False)
         phens.append({"bp": [cvbp], "a": [rs.randn(150)], "d": [rs.randn(150) * 0.3],
-                      "val": [(rs.rand(nf, 150) < 0.3).astype(np.uint8)], "vd": 0.2 if k == 0 else 0.0, "va": 0.5, "ve": 0.3})
+                      "val": [(rs.rand(nf, 150) < 0.3).astype(np.uint8)], "vd": 0.2 if k == 0 else 0.0, "va": 0.5, "ve": 0.3, "vf": 0.15 if k == 0 else 0.0})
     c = Case("dense")
     c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=phens, RM=True,
               mut_bp=[rbp], mut_rate=[np.full(R, 0.02)], popinfo=["120 0 p thr 1 1"] * 6)

@@ -110,7 +110,7 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
 
 
-def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_lists=True, max_gen=None):
+def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_lists=True, max_gen=None, check_gef=False, gef_rtol=0.0):
     """Run the whole fixture through `lib` and compare every dumped quantity."""
     n_pop, nchr, nphen, ngen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"]), int(fx["n_gen"])
     if max_gen:
@@ -149,6 +149,18 @@ def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_l
             cmp_float(dom, fx[pre + "dominance"], f"dominance gen {g}")
             if check_lists:
                 compare_lists(ctx, fx, pre, ip, nchr, f"{label} gen {g} pop {ip}")
+            if check_gef:                      # ras_scale_AD_compute_GEF follows ras_compute_AD (src/Simulation.cpp:1943-1946)
+                for iph in range(nphen):
+                    k = f"g{g}_pop{ip}_ph{iph}_gef_"
+                    s2a, s2d, va, vd, ve, vf, beta = [float(x) for x in fx[k + "par"]]
+                    gi, want = fx[k + "in"], fx[k + "out"]
+                    got = ctx.scale_ad_compute_gef(ip, iph, g, int(fx[k + "seed"]), va, vd, ve, vf, beta, s2a, s2d,
+                                                   common_sibling=gi[:, 0], f_father=gi[:, 1], f_mother=gi[:, 2])
+                    for j, nm in enumerate(("additive", "dominance", "bv", "e_noise", "parental_effect", "phen")):
+                        if gef_rtol == 0.0:
+                            assert bits_equal(got[nm], want[:, j]), f"{label}: scaled {nm} not bit-identical (gen {g} phen {iph}), max diff {np.max(np.abs(got[nm]-want[:, j]))}"
+                        else:
+                            assert np.allclose(got[nm], want[:, j], rtol=gef_rtol, atol=1e-12), f"{label}: scaled {nm} differs by more than {gef_rtol} relative (gen {g} phen {iph}): max abs diff {np.max(np.abs(got[nm]-want[:, j]))}"
         if f"g{g}_moves" in fx:
             ctx.migrate(derive_moves(fx, g))
             for ip in range(n_pop):

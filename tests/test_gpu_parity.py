@@ -376,3 +376,12 @@ def test_unsupported_inputs_are_refused_not_miscomputed(gpu_lib):
         g.reproduce(0, np.array([[0, 1, 0, 1]]), 1, None)
     assert e.value.code == -2
     g.close()
+
+
+@pytest.mark.parametrize("case", ["dense", "ex1sub"])
+def test_gpu_scale_ad_compute_gef_matches_reference(gpu_lib, oracle_lib, case):
+    """SURVEY 8(f) row 1 on the device: phenotype floats within 1e-12 relative of the reference's hex-dumped values
+    (north star: 1e-6); e comes from the parallel polar-method normal stream, var(e) from parallel sums."""
+    fx = helpers.load_fixture(case)
+    seeds = helpers.find_gen0_seeds(fx, oracle_lib)
+    helpers.replay_case(gpu_lib, fx, seeds, f"gpu-gef/{case}", check_lists=False, check_gef=True, gef_rtol=1e-12)

@@ -117,3 +117,12 @@ def test_oracle_replays_reference_generations(oracle_lib, case):
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
     n_dense = helpers.replay_case(oracle_lib, fx, seeds, f"oracle/{case}")
     assert n_dense >= 2
+
+
+@pytest.mark.parametrize("case", ["dense", "ex1sub", "mig2"])
+def test_oracle_scale_ad_compute_gef_matches_reference(oracle_lib, case):
+    """ras_scale_AD_compute_GEF (src/Simulation.cpp:3075-3206) incl. libstdc++ normal_distribution."""
+    fx = helpers.load_fixture(case)
+    seeds = helpers.find_gen0_seeds(fx, oracle_lib)
+    checked = helpers.replay_case(oracle_lib, fx, seeds, f"oracle-gef/{case}", check_lists=False, check_gef=True)
+    assert checked >= 0
