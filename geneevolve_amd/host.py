@@ -61,6 +61,62 @@ class GlobSeedStream:
         return r
 
 
+class MinstdStream:
+    """std::default_random_engine seeded with the `unsigned` expression the reference passes (seed, seed+1, ...),
+    with vectorised draws of the two libstdc++ distributions the mating code uses."""
+
+    def __init__(self, seed):
+        x = (int(seed) & 0xFFFFFFFF) % M31
+        self.x = x if x else 1
+
+    def _outputs(self, m):
+        k = np.arange(1, m + 1, dtype=np.uint64)
+        return (GlobSeedStream._powmod(k) * np.uint64(self.x)) % np.uint64(M31)
+
+    def u01(self, n):
+        """n draws of uniform_real_distribution<double>(0,1) = generate_canonical<double,53> (2 engine calls each)"""
+        xs = self._outputs(2 * n)
+        self.x = int(xs[-1]) if n else self.x
+        lo = (xs[0::2] - np.uint64(1)).astype(np.float64); hi = (xs[1::2] - np.uint64(1)).astype(np.float64)
+        r = (lo + hi * 2147483646.0) / float(2147483646 ** 2)
+        return np.where(r >= 1.0, np.nextafter(1.0, 0.0), r)
+
+    def uniform_int(self, n, lo, hi):
+        """n draws of uniform_int_distribution<unsigned long>(lo,hi), down-scaling branch (hi-lo < 2147483645)"""
+        uerange = int(hi) - int(lo) + 1
+        assert 0 < uerange <= 2147483645
+        scaling = 2147483645 // uerange; past = uerange * scaling
+        out = np.empty(0, dtype=np.uint64)
+        while len(out) < n:
+            m = int((n - len(out)) * (2147483646.0 / past) * 1.01) + 16
+            xs = self._outputs(m)
+            ret = xs - np.uint64(1)
+            ok = ret < np.uint64(past)
+            vals = ret[ok] // np.uint64(scaling) + np.uint64(lo)
+            need = n - len(out)
+            if len(vals) >= need:
+                self.x = int(xs[np.flatnonzero(ok)[need - 1]])
+                out = np.concatenate([out, vals[:need]])
+            else:
+                self.x = int(xs[-1])
+                out = np.concatenate([out, vals])
+        return out
+
+
+def random_mate(sex, selection_value_func, pop_size, seed):
+    """Simulation::random_mate (reference src/Simulation.cpp:2090-2157), bit-exact: `seed` is the
+    ras_glob_seed() value drawn at :2092.  Returns the couples list (one offspring per couple)."""
+    n_h = len(sex)
+    r = MinstdStream(seed).u01(n_h)                                  # generator(seed), one draw per individual (:2112)
+    ok = r < np.asarray(selection_value_func, dtype=np.float64)
+    pos_male = np.flatnonzero(ok & (sex == 1)); pos_female = np.flatnonzero(ok & (sex == 2))
+    if len(pos_male) == 0 or len(pos_female) == 0:
+        raise RuntimeError(f"Error: No one can marry, num_males_mate={len(pos_male)}, num_females_mate={len(pos_female)}")
+    i_f = MinstdStream(int(seed) + 1).uniform_int(pop_size, 0, len(pos_male) - 1)      # g_uint_f(seed+1), :2132-2144
+    i_m = MinstdStream(int(seed) + 2).uniform_int(pop_size, 0, len(pos_female) - 1)    # g_uint_m(seed+2)
+    return couples_array(pos_male[i_f.astype(np.int64)], pos_female[i_m.astype(np.int64)])
+
+
 def couples_array(pos_male, pos_female, num_offspring=1, inbreed=0):
     c = np.zeros(len(pos_male), dtype=COUPLE_DTYPE)
     c["pos_male"], c["pos_female"], c["num_offspring"], c["inbreed"] = pos_male, pos_female, num_offspring, inbreed

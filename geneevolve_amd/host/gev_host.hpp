@@ -29,6 +29,47 @@ public:
     }
 };
 
+// std::default_random_engine + the two libstdc++ distributions Simulation::random_mate uses
+class Minstd {
+    uint64_t x_;
+public:
+    explicit Minstd(unsigned seed) { x_ = seed % 2147483647ull; if (!x_) x_ = 1; }
+    uint64_t operator()() { x_ = x_ * 16807ull % 2147483647ull; return x_; }
+    double u01()                                                      // generate_canonical<double,53>: first call = low digit
+    {
+        const double lo = (double)((*this)() - 1), hi = (double)((*this)() - 1);
+        const double R2 = (double)(2147483646.0L * 2147483646.0L);
+        double r = (lo + hi * 2147483646.0) / R2;
+        return r >= 1.0 ? 0x1.fffffffffffffp-1 : r;
+    }
+    uint64_t uniform_int(uint64_t lo, uint64_t hi)                     // down-scaling branch (hi-lo < 2147483645)
+    {
+        const uint64_t uerange = hi - lo + 1, scaling = 2147483645ull / uerange, past = uerange * scaling;
+        uint64_t r;
+        do r = (*this)() - 1; while (r >= past);
+        return r / scaling + lo;
+    }
+};
+// Simulation::random_mate (src/Simulation.cpp:2090-2157); seed = the ras_glob_seed() value drawn at :2092
+inline bool random_mate(const std::vector<uint8_t>& sex, const std::vector<double>& selection_value_func, size_t pop_size, unsigned seed,
+                        std::vector<gev_couple>& couples)
+{
+    Minstd generator(seed);
+    std::vector<uint64_t> pos_male, pos_female;
+    for (size_t i = 0; i < sex.size(); i++) {
+        const double r = generator.u01();
+        if (r < selection_value_func[i]) { if (sex[i] == 1) pos_male.push_back(i); else if (sex[i] == 2) pos_female.push_back(i); }
+    }
+    if (pos_male.empty() || pos_female.empty()) { printf("Error: No one can marry, num_males_mate=%zu, num_females_mate=%zu\n", pos_male.size(), pos_female.size()); return false; }
+    Minstd g_f(seed + 1), g_m(seed + 2);
+    couples.assign(pop_size, gev_couple{0, 0, 0, 1});
+    for (size_t i = 0; i < pop_size; i++) {
+        couples[i].pos_male = pos_male[g_f.uniform_int(0, pos_male.size() - 1)];
+        couples[i].pos_female = pos_female[g_m.uniform_int(0, pos_female.size() - 1)];
+    }
+    return true;
+}
+
 inline void check(int rc) { if (rc != GEV_OK) throw std::runtime_error(std::string(gev_last_error())); }
 
 class Simulation {

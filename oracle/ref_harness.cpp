@@ -174,6 +174,14 @@ static int run_sim(int argc, char** argv)
         // ---- Simulation::sim_next_generation, src/Simulation.cpp:1895-1966
         for (int ipop = 0; ipop < sim._n_pop; ipop++) {
             Population& P = sim.population[ipop];
+            // inputs of the mating step: sexes and selection_value_func of the parent generation,
+            // and, for random_mate (exactly one ras_glob_seed() draw, :2092), its seed
+            {
+                std::default_random_engine snapm = sim.glob_generator;
+                std::uniform_int_distribution<unsigned> dm(1, 1000000);
+                fprintf(g_out, "MATE pop %d rm %d seed %u popsize %lu n %zu\n", ipop, (int)P._RM, dm(snapm), (unsigned long)P._pop_size[gen_num - 1], P.h.size());
+                for (size_t i = 0; i < P.h.size(); i++) fprintf(g_out, "MS %d %a\n", P.h[i].sex, P.h[i].selection_value_func);
+            }
             bool ok = P._RM ? sim.random_mate(ipop, gen_num - 1) : sim.assort_mate(ipop, gen_num - 1);   // :1907-1918
             if (!ok) return 5;
             // inputs of the hot path

@@ -139,6 +139,11 @@ def parse_dump(path):
                 cur = out.setdefault("postfp", {}).setdefault(int(t[2]), [])
             elif k == "J":
                 cur.append((int(t[1]), hexf(t[2])))
+            elif k == "MATE":
+                cur = {"pop": int(t[2]), "rm": int(t[4]), "seed": int(t[6]), "popsize": int(t[8]), "MS": []}
+                out.setdefault("mate", []).append(cur)
+            elif k == "MS":
+                cur["MS"].append((int(t[1]), hexf(t[2])))
             elif k == "GEF":
                 cur = {"pop": int(t[2]), "phen": int(t[4]), "seed": int(t[6]), "par": [hexf(t[i]) for i in (8, 10, 12, 14, 16, 18, 20)], "vt": int(t[22]), "GI": [], "GO": []}
                 out.setdefault("gef", []).append(cur)
@@ -318,6 +323,10 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             pack_ad(d["ad"][ip], pre, arrs)
             if d["premig"]:
                 pack_humans(d["postmig"][ip], pre + "postmig_", arrs)
+        for ma in d.get("mate", []):      # mating inputs
+            k = f"g{g}_pop{ma['pop']}_mate_"
+            arrs[k + "rm"] = np.int64(ma["rm"]); arrs[k + "seed"] = np.uint32(ma["seed"]); arrs[k + "popsize"] = np.int64(ma["popsize"])
+            arrs[k + "sex"] = np.array([m[0] for m in ma["MS"]], dtype=np.uint8); arrs[k + "svf"] = np.array([m[1] for m in ma["MS"]])
         for ge in d.get("gef", []):       # ras_scale_AD_compute_GEF inputs / outputs
             k = f"g{g}_pop{ge['pop']}_ph{ge['phen']}_gef_"
             arrs[k + "seed"] = np.uint32(ge["seed"]); arrs[k + "par"] = np.array(ge["par"]); arrs[k + "vt"] = np.int64(ge["vt"])
@@ -464,7 +473,7 @@ def main():
           "va": 0.5, "vd": 0.0, "ve": 0.5}
     c = Case("syn1k")
     c.add_pop(chrs=[1], founders=[founders], founders_synth_seed=12345, snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph], RM=True,
-              mut_bp=[rbp], mut_rate=[np.r_[0.0, np.full(R - 1, 5e-4)]], popinfo=["1000 0 p thr 1 1"] * 10)
+              mut_bp=[rbp], mut_rate=[np.r_[0.0, np.full(R - 1, 5e-4)]], popinfo=["1000 0 p logit 0 1"] * 10)
     run_case(c, 12345, dense_gens={1, 5, 10}, hash_only_dense=True, keep_parts_gens={1, 10})
 
 

@@ -288,14 +288,9 @@ def test_cpp_host_drives_the_c_abi_like_the_python_host(gpu_lib):
     g.synth_founders(0, 0, 2 * N, 77); g.synth_cv_founders(0, 0, 0, 2 * N, 78)
     sim = Simulation(g, 12345, 1, True)
     sim.ras_initial_human_gen0(0, N)
-    lcg = 4242
-    M = (1 << 64) - 1
+    from geneevolve_amd.host import random_mate
     for gen in range(1, G + 1):
-        males = np.flatnonzero(sim.sex[0] == 1); females = np.flatnonzero(sim.sex[0] == 2)
-        c = np.zeros((N, 4), dtype=np.int64); c[:, 3] = 1
-        for i in range(N):
-            lcg = (lcg * 6364136223846793005 + 1442695040888963407) & M; c[i, 0] = males[(lcg >> 33) % len(males)]
-            lcg = (lcg * 6364136223846793005 + 1442695040888963407) & M; c[i, 1] = females[(lcg >> 33) % len(females)]
+        c = random_mate(sim.sex[0], np.ones(len(sim.sex[0])), N, int(sim.ras_glob_seed()[0]))     # same draws as gev::random_mate
         sim.couples[0] = c
         seeds = sim.ras_glob_seed(1 + N)
         sim.sex[0] = g.reproduce(0, c, int(seeds[0]), seeds[1:])

@@ -41,3 +41,22 @@ def test_synthetic_random_mate_shapes():
     assert len(c) == 1000 and (sex[c["pos_male"]] == 1).all() and (sex[c["pos_female"]] == 2).all()
     cfg = SyntheticConfig(100, 1000, n_cv=50)
     assert len(cfg.rmap_bp) == 2001 and cfg.rmap_prob[0] == 0 and len(cfg.snp_pos) == 1000
+
+
+def test_random_mate_restatement_reproduces_reference_couples():
+    """SURVEY 8(f) row 2: Simulation::random_mate (src/Simulation.cpp:2090-2157) restated in the host mirror, checked
+    against the couples the real reference formed (all --RM fixtures; syn1k has a non-constant selection function)."""
+    from geneevolve_amd.host import random_mate
+    n_checked = 0
+    for case in ("syn1k", "ex1mut", "dense", "mig2"):
+        fx = helpers.load_fixture(case)
+        for g in range(1, int(fx["n_gen"]) + 1):
+            for ip in range(int(fx["n_pop"])):
+                k = f"g{g}_pop{ip}_mate_"
+                assert int(fx[k + "rm"]) == 1
+                c = random_mate(fx[k + "sex"], fx[k + "svf"], int(fx[k + "popsize"]), int(fx[k + "seed"]))
+                want = fx[f"g{g}_pop{ip}_couples"]
+                assert np.array_equal(c["pos_male"].astype(np.int64), want[:, 0]) and np.array_equal(c["pos_female"].astype(np.int64), want[:, 1]), (case, g, ip)
+                assert (c["num_offspring"] == want[:, 3]).all() and (c["inbreed"] == want[:, 2]).all()
+                n_checked += 1
+    assert n_checked >= 20

@@ -34,17 +34,11 @@ int main(int argc, char** argv)
         gev::check(gev_synth_founders(sim.ctx, 0, 0, 2 * N, 77));
         gev::check(gev_synth_cv_founders(sim.ctx, 0, 0, 0, 2 * N, 78));
         sim.ras_initial_human_gen0(0, N);
-        uint64_t lcg = 4242;                                     // host-side mating stand-in (deterministic)
         std::vector<double> A, D;
         for (int g = 1; g <= G; g++) {
-            std::vector<uint32_t> males, females;
-            for (size_t i = 0; i < sim.sex[0].size(); i++) (sim.sex[0][i] == 1 ? males : females).push_back((uint32_t)i);
-            if (males.empty() || females.empty()) { printf("Error: No one can marry\n"); return 1; }
-            sim.couples[0].assign(N, gev_couple{0, 0, 0, 1});
-            for (size_t i = 0; i < N; i++) {
-                lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; sim.couples[0][i].pos_male = males[(lcg >> 33) % males.size()];
-                lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; sim.couples[0][i].pos_female = females[(lcg >> 33) % females.size()];
-            }
+            // Simulation::sim_next_generation order (src/Simulation.cpp:1907-1935): random_mate, reproduce, ras_compute_AD
+            const std::vector<double> svf(sim.sex[0].size(), 1.0);                    // selection_value_func: everybody may marry
+            if (!gev::random_mate(sim.sex[0], svf, N, sim.ras_glob_seed(), sim.couples[0])) return 1;
             sim.reproduce(0);
             if (!sim.ras_compute_AD(0, A, D)) return 1;
         }
