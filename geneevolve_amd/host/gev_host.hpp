@@ -5,6 +5,7 @@
 // couples list, sexes -- and forwards the seam functions, under their reference names, to the C-ABI
 // of include/geneevolve_amd.h.  INTEGRATION.md shows the same calls as a patch to the reference.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -40,7 +41,7 @@ public:
         const double lo = (double)((*this)() - 1), hi = (double)((*this)() - 1);
         const double R2 = (double)(2147483646.0L * 2147483646.0L);
         double r = (lo + hi * 2147483646.0) / R2;
-        return r >= 1.0 ? 0x1.fffffffffffffp-1 : r;
+        return r >= 1.0 ? std::nextafter(1.0, 0.0) : r;
     }
     uint64_t uniform_int(uint64_t lo, uint64_t hi)                     // down-scaling branch (hi-lo < 2147483645)
     {
