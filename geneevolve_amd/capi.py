@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "last_error", "version", "create", "destroy", "set_rmap", "set_mutmap", "set_snps", "set_cvs",
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
-    "import_rows", "download_haps", "download_cv", "download_intervals", "download_mutations",
+    "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
@@ -249,6 +249,31 @@ class GevContext:
         w = words_for(L)
         out = np.zeros((n_rows, w), dtype=np.uint64)
         self._call("download_haps", C.c_int(pop), C.c_int(chr), C.c_size_t(row_begin), C.c_size_t(n_rows), _p(out), C.c_size_t(w))
+        return out
+
+    def download_snp_major(self, pop, chr, snp_begin=0, n_snps=None):
+        L = self._nsnp[(pop, chr)]
+        n_snps = L - snp_begin if n_snps is None else n_snps
+        w = words_for(2 * self.pop_size(pop))
+        out = np.zeros((n_snps, w), dtype=np.uint64)
+        self._call("download_snp_major", C.c_int(pop), C.c_int(chr), C.c_size_t(snp_begin), C.c_size_t(n_snps), _p(out), C.c_size_t(w))
+        return out
+
+    def format_hap_text(self, pop, chr, snp_begin=0, n_snps=None):
+        """bytes of the reference's .hap file (format_hap::write_hap) for the given SNP lines"""
+        L = self._nsnp[(pop, chr)]
+        n_snps = L - snp_begin if n_snps is None else n_snps
+        nb = n_snps * (4 * self.pop_size(pop) + 1)
+        out = np.zeros(nb, dtype=np.uint8)
+        self._call("format_hap_text", C.c_int(pop), C.c_int(chr), C.c_size_t(snp_begin), C.c_size_t(n_snps), _p(out), C.c_size_t(nb))
+        return out
+
+    def format_bed(self, pop, chr, snp_begin=0, n_snps=None):
+        L = self._nsnp[(pop, chr)]
+        n_snps = L - snp_begin if n_snps is None else n_snps
+        nb = n_snps * ((self.pop_size(pop) + 3) // 4)
+        out = np.zeros(nb, dtype=np.uint8)
+        self._call("format_bed", C.c_int(pop), C.c_int(chr), C.c_size_t(snp_begin), C.c_size_t(n_snps), _p(out), C.c_size_t(nb))
         return out
 
     def download_cv(self, pop, phen, chr):

@@ -1018,3 +1018,80 @@ __global__ void __launch_bounds__(256) k_par_eff(const double* __restrict__ ff, 
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = beta * ((ff ? ff[i] : 0.0) + (fm ? fm[i] : 0.0));
 }
+
+// ------------------------------------------------------------------------------------------
+// K9: output packing.  The reference's .hap files are SNP-major text
+// (format_hap::write_hap, src/format_hap.cpp:6-30); PLINK .bed is SNP-major 2-bit.  The resident
+// plane is haplotype-major, so output = 64x64 bit-tile transposes (64 ballots per tile: lane b ends
+// up with SNP 64*sw+b across 64 haplotypes), then the sparse mutation overlay, then formatting.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_transpose_tiles(const u64* __restrict__ plane, size_t stride_w64, size_t n_rows, u32 L,
+                                                         u32 snp_begin, u32 n_snps, u64* __restrict__ out, size_t out_stride_w64, u32 words_per_wave)
+{
+    const u32 lane = threadIdx.x & 63;
+    const size_t hb = (size_t)blockIdx.x;                                   // block of 64 haplotype rows
+    const u32 wave = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const u32 sw_first = snp_begin >> 6, sw_last = (snp_begin + n_snps - 1) >> 6;
+    const u32 sw0 = sw_first + wave * words_per_wave;
+    const size_t row = hb * 64 + lane;
+    for (u32 sw = sw0; sw < sw0 + words_per_wave && sw <= sw_last; sw++) {
+        const u64 v = row < n_rows ? plane[row * stride_w64 + sw] : 0ull;
+        u64 mine = 0;
+#pragma unroll 8
+        for (u32 b = 0; b < 64; b++) {
+            const u64 m = __ballot((v >> b) & 1ull);
+            if (lane == b) mine = m;
+        }
+        const u32 snp = sw * 64 + lane;
+        if (snp >= snp_begin && snp < snp_begin + n_snps && snp < L) out[(size_t)(snp - snp_begin) * out_stride_w64 + hb] = mine;
+    }
+}
+// flip (snp, hap) where the SNP position is in the haplotype's mutation set: value = !founder (idempotent)
+__global__ void __launch_bounds__(256) k_snpmajor_apply_mut(const u32* __restrict__ plane, size_t stride_w32, size_t n_rows,
+                                                            const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ pos, u32 L,
+                                                            u32 snp_begin, u32 n_snps, unsigned long long* __restrict__ out, size_t out_stride_w64)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const u32* in = plane + r * stride_w32;
+    for (u32 j = m_off[r]; j < m_off[r + 1]; j++) {
+        const u64 x = m_pos[j];
+        u32 c = lower_bound_u64(pos, L, x);
+        for (; c < L && pos[c] == x; c++) {
+            if (c < snp_begin || c >= snp_begin + n_snps) continue;
+            const u32 f = (in[c >> 5] >> (c & 31)) & 1u;
+            unsigned long long* w = out + (size_t)(c - snp_begin) * out_stride_w64 + (r >> 6);
+            const unsigned long long bit = 1ull << (r & 63);
+            if (f) atomicAnd(w, ~bit); else atomicOr(w, bit);
+        }
+    }
+}
+// one .hap line per SNP: "b b b ... b \n" (digit + space per haplotype, then newline)
+__global__ void __launch_bounds__(256) k_format_hap_text(const u64* __restrict__ snpmajor, size_t stride_w64, size_t n_rows, u32 n_snps, char* __restrict__ out)
+{
+    const size_t line_len = 2 * n_rows + 1;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (size_t)n_snps * (n_rows + 1)) return;
+    const size_t j = q / (n_rows + 1), h = q % (n_rows + 1);
+    char* line = out + j * line_len;
+    if (h == n_rows) { line[2 * n_rows] = '\n'; return; }
+    const u32 b = (u32)((snpmajor[j * stride_w64 + (h >> 6)] >> (h & 63)) & 1ull);
+    line[2 * h] = (char)('0' + b); line[2 * h + 1] = ' ';
+}
+// PLINK .bed body, SNP-major: 2 bits per individual, A1 = allele 1: 00 = 1/1, 10 = heterozygous, 11 = 0/0, pad = 00
+__global__ void __launch_bounds__(256) k_format_bed(const u64* __restrict__ snpmajor, size_t stride_w64, size_t n_people, u32 n_snps, uint8_t* __restrict__ out)
+{
+    const size_t bpl = (n_people + 3) / 4;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (size_t)n_snps * bpl) return;
+    const size_t j = q / bpl, by = q % bpl;
+    const u32 bits = (u32)((snpmajor[j * stride_w64 + (by >> 3)] >> ((by & 7) * 8)) & 0xffull);     // haplotypes 8*by .. 8*by+7
+    u32 o = 0;
+    for (u32 i = 0; i < 4; i++) {
+        if (by * 4 + i >= n_people) break;
+        const u32 b0 = (bits >> (2 * i)) & 1u, b1 = (bits >> (2 * i + 1)) & 1u;
+        const u32 code = (b0 & b1) ? 0u : ((b0 ^ b1) ? 2u : 3u);
+        o |= code << (2 * i);
+    }
+    out[q] = (uint8_t)o;
+}

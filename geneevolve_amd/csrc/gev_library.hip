@@ -129,6 +129,7 @@ struct gev_ctx {
     int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
     bool serialize = false;        // GEV_SERIALIZE=1: wait for every stitch (diagnostic, measures the phases without overlap)
     unsigned stitch_lds_pad = 0;   // unused dynamic LDS per stitch workgroup: limits workgroups per CU (160 KiB / CU)
+    DevBuf d_snpmajor, d_text;
     DevBuf d_sex0, d_gef_flag, d_gef_first, d_gef_red, d_gef_io;
     DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
     std::map<double, GevThr> thr_cache;
@@ -1397,6 +1398,95 @@ int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_r
     }
     return GEV_OK;
 }
+// ---- K9: SNP-major outputs ---------------------------------------------------
+// SNP-major bit matrix of SNPs [s0, s0+ns) of the current generation (mutations applied) into c->d_snpmajor
+static int snp_major_device(gev_ctx* c, int pop, int chr, size_t s0, size_t ns, size_t& stride_w64)
+{
+    PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
+    hipStream_t st = c->stream;
+    const size_t rows = 2 * P.n_people;
+    stride_w64 = ceil_div(rows, 64);
+    GEVC(c->d_snpmajor.ensure(std::max<size_t>(ns * stride_w64 * 8, 16), st));
+    HIPC(hipMemsetAsync(c->d_snpmajor.p, 0, ns * stride_w64 * 8, st));
+    const u32 n_words = (u32)(((s0 + ns - 1) >> 6) - (s0 >> 6) + 1);
+    const u32 wpw = 16;                                              // 16 words = one 128-byte line of every row per wave
+    const unsigned gy = (unsigned)ceil_div(ceil_div(n_words, wpw), 4);
+    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)stride_w64, gy), dim3(256), 0, st, cs.plane[P.cur].as<u64>(), S.stride / 8, rows, (u32)S.L,
+                       (u32)s0, (u32)ns, c->d_snpmajor.as<u64>(), stride_w64, wpw);
+    hipLaunchKernelGGL(k_snpmajor_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, cs.plane[P.cur].as<u32>(), S.stride / 4, rows,
+                       cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)S.L, (u32)s0, (u32)ns,
+                       (unsigned long long*)c->d_snpmajor.p, stride_w64);
+    KCHECK();
+    return GEV_OK;
+}
+static int snp_range_check(gev_ctx* c, int pop, int chr, size_t s0, size_t ns, const char* who)
+{
+    GEVC(check_idx(c, pop, chr));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "%s: population %d has no current generation", who, pop);
+    if (s0 + ns > P.cs[chr].L) return fail(GEV_EINVAL, "%s: SNPs [%zu,%zu) beyond the %zu loci of chromosome %d", who, s0, s0 + ns, P.cs[chr].L, chr);
+    HIPC(hipSetDevice(c->device));
+    GEVC(materialize_order(c, pop));
+    GEVC(wait_planes(c));
+    return GEV_OK;
+}
+// SNPs per device chunk so that the staging buffers stay <= ~256 MB
+static size_t snp_chunk(size_t bytes_per_snp) { return std::max<size_t>((256u << 20) / std::max<size_t>(bytes_per_snp, 1), 64) & ~(size_t)63; }
+int gev_download_snp_major(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, u64* bits, size_t row_stride_words)
+{
+    GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "download_snp_major"));
+    PopState& P = c->pop[pop];
+    const size_t rows = 2 * P.n_people, w = ceil_div(rows, 64);
+    if (n_snps && (!bits || row_stride_words < w)) return fail(GEV_EINVAL, "download_snp_major: bad output buffer");
+    const size_t chunk = snp_chunk(w * 8);
+    for (size_t s = 0; s < n_snps; s += chunk) {
+        const size_t ns = std::min(chunk, n_snps - s); size_t stride;
+        GEVC(snp_major_device(c, pop, chr, snp_begin + s, ns, stride));
+        if (row_stride_words > w) for (size_t j = 0; j < ns; j++) memset(bits + (s + j) * row_stride_words + w, 0, (row_stride_words - w) * 8);
+        HIPC(hipMemcpy2DAsync(bits + s * row_stride_words, row_stride_words * 8, c->d_snpmajor.p, stride * 8, w * 8, ns, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    return GEV_OK;
+}
+// bytes of the reference's .hap file for SNP lines [snp_begin, snp_begin+n_snps): n_snps * (4*n_people + 1)
+int gev_format_hap_text(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes)
+{
+    GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "format_hap_text"));
+    PopState& P = c->pop[pop];
+    const size_t rows = 2 * P.n_people, line = 2 * rows + 1;
+    if (out_bytes < n_snps * line || (n_snps && !out)) return fail(GEV_EINVAL, "format_hap_text: buffer of %zu bytes, %zu needed", out_bytes, n_snps * line);
+    const size_t chunk = snp_chunk(line);
+    for (size_t s = 0; s < n_snps; s += chunk) {
+        const size_t ns = std::min(chunk, n_snps - s); size_t stride;
+        GEVC(snp_major_device(c, pop, chr, snp_begin + s, ns, stride));
+        GEVC(c->d_text.ensure(ns * line, c->stream));
+        hipLaunchKernelGGL(k_format_hap_text, dim3((unsigned)ceil_div(ns * (rows + 1), 256)), dim3(256), 0, c->stream, c->d_snpmajor.as<u64>(), stride, rows, (u32)ns, c->d_text.as<char>());
+        KCHECK();
+        HIPC(hipMemcpyAsync(out + s * line, c->d_text.p, ns * line, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    return GEV_OK;
+}
+// PLINK .bed body (SNP-major, without the 3 magic bytes 0x6c 0x1b 0x01): n_snps * ceil(n_people/4) bytes
+int gev_format_bed(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, uint8_t* out, size_t out_bytes)
+{
+    GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "format_bed"));
+    PopState& P = c->pop[pop];
+    const size_t bpl = ceil_div(P.n_people, 4);
+    if (out_bytes < n_snps * bpl || (n_snps && !out)) return fail(GEV_EINVAL, "format_bed: buffer of %zu bytes, %zu needed", out_bytes, n_snps * bpl);
+    const size_t chunk = snp_chunk(ceil_div(2 * P.n_people, 64) * 8);
+    for (size_t s = 0; s < n_snps; s += chunk) {
+        const size_t ns = std::min(chunk, n_snps - s); size_t stride;
+        GEVC(snp_major_device(c, pop, chr, snp_begin + s, ns, stride));
+        GEVC(c->d_text.ensure(ns * bpl, c->stream));
+        hipLaunchKernelGGL(k_format_bed, dim3((unsigned)ceil_div(ns * bpl, 256)), dim3(256), 0, c->stream, c->d_snpmajor.as<u64>(), stride, P.n_people, (u32)ns, c->d_text.as<uint8_t>());
+        KCHECK();
+        HIPC(hipMemcpyAsync(out + s * bpl, c->d_text.p, ns * bpl, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    return GEV_OK;
+}
+
 int gev_download_cv(gev_ctx* c, int pop, int phen, int chr, u64* bits, size_t row_stride_words)
 {
     GEVC(check_idx(c, pop, chr, phen));

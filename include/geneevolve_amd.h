@@ -182,6 +182,17 @@ int gev_import_rows(gev_ctx*, int pop, const void* device_buf, size_t bytes, siz
  * rows [row_begin, row_begin+n_rows) of the 2*n_people x L matrix, mutations applied. */
 int gev_download_haps(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_rows,
                       uint64_t* bits, size_t row_stride_words);
+/* ---- K9 output packing [SURVEY 8(f) row 3]: SNP-major forms of the same matrix, built on the device
+ * (64x64 bit-tile transposes + mutation overlay).
+ *  gev_download_snp_major : row = SNP (snp_begin + j), bit h = haplotype row h; ceil(2*n_people/64) words per row
+ *  gev_format_hap_text    : the exact bytes format_hap::write_hap (src/format_hap.cpp:6-30) writes for these SNP
+ *                           lines: per line "b b ... b \n", i.e. n_snps * (4*n_people + 1) bytes
+ *  gev_format_bed         : PLINK .bed body (SNP-major, 2 bits / individual, A1 = allele 1: 00 = 1/1, 10 = het,
+ *                           11 = 0/0, pad 00; without the 3 magic bytes): n_snps * ceil(n_people/4) bytes.  The
+ *                           reference has no .bed writer (BASELINE config 5 asks for one): checked by definition. */
+int gev_download_snp_major(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, uint64_t* bits, size_t row_stride_words);
+int gev_format_hap_text(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes);
+int gev_format_bed(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, uint8_t* out, size_t out_bytes);
 /* CV genotype matrix of ras_find_cv (the --debug .cvval dump, :2665-2683), FILE column order. */
 int gev_download_cv(gev_ctx*, int pop, int phen, int chr, uint64_t* bits, size_t row_stride_words);
 /* ancestry interval lists (the .int output, :1596-1633): hap_offsets has 2*n_people+1 entries;

@@ -286,7 +286,7 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
         sh([HARNESS] + args, env=env, stdout=log, stderr=subprocess.STDOUT)
     # validate the harness driver against the stock CLI on this very input
     wd2 = os.path.join(wd, "cli"); os.makedirs(wd2)
-    args2 = [x if x != os.path.join(wd, "out") else os.path.join(wd2, "out") for x in args]
+    args2 = [x if x != os.path.join(wd, "out") else os.path.join(wd2, "out") for x in args] + ["--out_hap"]
     with open(os.path.join(wd2, "log.txt"), "w") as log:
         sh([os.path.join(ORACLE, "_ref", "GeneEvolve_ref")] + args2, stdout=log, stderr=subprocess.STDOUT)
     ngen = len(case.pops[0]["popinfo"])
@@ -295,6 +295,13 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             fa = os.path.join(wd, f"out.info.pop{ip+1}.gen{g}.txt"); fb = os.path.join(wd2, f"out.info.pop{ip+1}.gen{g}.txt")
             assert open(fa, "rb").read() == open(fb, "rb").read(), f"harness != CLI at gen {g} pop {ip+1}"
     arrs["n_gen"] = np.int64(ngen)
+    # the reference's own .hap text of the last generation (format_hap::write_hap, src/format_hap.cpp:6-30): hash + head
+    for ip in range(len(case.pops)):
+        for ic, c in enumerate(case.pops[ip]["chrs"]):
+            raw = open(os.path.join(wd2, f"out.pop{ip+1}.gen{ngen}.chr{c}.hap"), "rb").read()
+            arrs[f"hapfile_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
+            arrs[f"hapfile_pop{ip}_chr{ic}_size"] = np.int64(len(raw))
+            arrs[f"hapfile_pop{ip}_chr{ic}_head"] = np.frombuffer(raw[:4096], dtype=np.uint8)
 
     # gen 0
     d0 = parse_dump(os.path.join(wd, "d.gen0.txt"))

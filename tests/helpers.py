@@ -169,5 +169,15 @@ def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_l
                     compare_lists(ctx, fx, f"g{g}_pop{ip}_postmig_", ip, nchr, f"{label} gen {g} post-migration pop {ip}")
         for ip in range(n_pop):
             n_dense += compare_dense(ctx, fx, g, ip, nchr, label)
+    # the reference's own .hap output file of the last generation (format_hap::write_hap)
+    if ngen == int(fx["n_gen"]) and lib.exports("format_hap_text"):
+        for ip in range(n_pop):
+            for ic in range(nchr):
+                k = f"hapfile_pop{ip}_chr{ic}_"
+                if k + "sha" in fx:
+                    txt = ctx.format_hap_text(ip, ic)
+                    assert len(txt) == int(fx[k + "size"]), f"{label}: .hap size"
+                    assert np.array_equal(txt[:4096], fx[k + "head"]), f"{label}: .hap head differs"
+                    assert np.array_equal(sha(txt), fx[k + "sha"]), f"{label}: .hap text differs from the reference's file (pop {ip} chr {ic})"
     ctx.close()
     return n_dense

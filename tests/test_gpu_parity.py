@@ -380,3 +380,35 @@ def test_gpu_scale_ad_compute_gef_matches_reference(gpu_lib, oracle_lib, case):
     fx = helpers.load_fixture(case)
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
     helpers.replay_case(gpu_lib, fx, seeds, f"gpu-gef/{case}", check_lists=False, check_gef=True, gef_rtol=1e-12)
+
+
+def test_snp_major_and_bed_packing_match_their_definition(gpu_lib):
+    """K9: SNP-major transpose / PLINK .bed against numpy on the downloaded haplotype-major matrix (mutations applied).
+    The reference has no .bed writer: checked by definition (parity unpinned); the .hap TEXT is pinned on the
+    reference's own output files in the golden replays."""
+    cfg = SyntheticConfig(333, 5000, chrom_bp=2_000_000, map_step=1000, rec_per_row=2e-3, mut_per_row=0.05, n_cv=10, seed=4)
+    g = gpu_lib.create(1, 1, 1)
+    cfg.apply_static(g)
+    g.synth_founders(0, 0, 666, 9); g.synth_cv_founders(0, 0, 0, 666, 10)
+    sim = Simulation(g, 77, 1, True)
+    sim.ras_initial_human_gen0(0, 333)
+    rng = np.random.default_rng(0)
+    for gen in (1, 2, 3):
+        sim.couples[0] = synthetic_random_mate(sim.sex[0], 333, rng)
+        sim.reproduce(0, gen)
+    L, n = 5000, 333
+    H = capi.unpack_rows(g.download_haps(0, 0), L)                       # [666][5000]
+    for (s0, ns) in ((0, L), (70, 999), (4937, 63)):
+        S = capi.unpack_rows(g.download_snp_major(0, 0, s0, ns), 2 * n)  # [ns][666]
+        assert np.array_equal(S, H[:, s0:s0 + ns].T), (s0, ns)
+        bed = g.format_bed(0, 0, s0, ns).reshape(ns, (n + 3) // 4)
+        a, b = H[0::2, s0:s0 + ns].T, H[1::2, s0:s0 + ns].T             # [ns][n]
+        code = np.where((a & b) == 1, 0, np.where((a ^ b) == 1, 2, 3)).astype(np.uint8)
+        pad = (-n) % 4
+        code = np.concatenate([code, np.zeros((ns, pad), dtype=np.uint8)], axis=1).reshape(ns, -1, 4)
+        want = code[:, :, 0] | (code[:, :, 1] << 2) | (code[:, :, 2] << 4) | (code[:, :, 3] << 6)
+        assert np.array_equal(bed, want), (s0, ns)
+        txt = g.format_hap_text(0, 0, s0, ns).reshape(ns, 4 * n + 1)
+        assert (txt[:, -1] == ord("\n")).all() and (txt[:, 1::2][:, :2 * n] == ord(" ")).all()
+        assert np.array_equal(txt[:, 0:4 * n:2] - ord("0"), H[:, s0:s0 + ns].T)
+    g.close()
