@@ -72,7 +72,7 @@ __device__ __forceinline__ const GevRngTables* stage_tables(const GevRngTables* 
     __syncthreads();
     return s;
 }
-#define SAMPLE_GRID_MAX 2048      // 256 CUs x 8 workgroups of 4 waves
+#define SAMPLE_GRID_MAX 1024      // persistent sampling workgroups (4 waves each): half the wave slots, the rest stays with the concurrent stitch
 
 // ------------------------------------------------------------------------------------------
 // exclusive scan of u32 counts (CSR offsets); n+1 outputs

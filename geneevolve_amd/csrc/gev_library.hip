@@ -127,6 +127,7 @@ struct gev_ctx {
     int ad_cached_pop = -1;                                  // population whose current-generation A/D sits in h_ad
     bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
     int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
+    unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels (GEV_SAMPLE_GRID)
     bool serialize = false;        // GEV_SERIALIZE=1: wait for every stitch (diagnostic, measures the phases without overlap)
     unsigned stitch_lds_pad = 0;   // unused dynamic LDS per stitch workgroup: limits workgroups per CU (160 KiB / CU)
     DevBuf d_snpmajor, d_text;
@@ -252,6 +253,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     GevRngTables T; gev_build_rng_tables(T);
     GEVC(h2d(c.get(), c->d_tables, &T, sizeof T));
     if (const char* e = getenv("GEV_SERIALIZE")) c->serialize = atoi(e) != 0;
+    if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = (unsigned)g; }
     if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // tuning knob: stitch workgroups per CU (default: unlimited = 8)
         const int occ = atoi(e);
         if (occ >= 1 && occ < 8) c->stitch_lds_pad = (unsigned)std::min(160 * 1024 / occ - 3 * 1024, 64 * 1024 - 2048);
@@ -639,7 +641,7 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
 
     HIPC(hipEventRecord(sc.t[0], st));
     // ---- sampling: one map scan per gamete / per mutation task
-    const unsigned task_blocks = (unsigned)std::min<size_t>(ceil_div(T, 4), SAMPLE_GRID_MAX);
+    const unsigned task_blocks = (unsigned)std::min<size_t>(ceil_div(T, 4), c->sample_grid);
     if (has_mut) {
         hipLaunchKernelGGL(k_mut_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, sc.mutseeds.as<u32>(), T, sd);
         hipLaunchKernelGGL(k_rec_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd);
