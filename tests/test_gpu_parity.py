@@ -412,3 +412,61 @@ def test_snp_major_and_bed_packing_match_their_definition(gpu_lib):
         assert (txt[:, -1] == ord("\n")).all() and (txt[:, 1::2][:, :2 * n] == ord(" ")).all()
         assert np.array_equal(txt[:, 0:4 * n:2] - ord("0"), H[:, s0:s0 + ns].T)
     g.close()
+
+
+def test_randomised_small_configurations_against_oracle(gpu_lib, oracle_lib):
+    """40 random tiny scenarios (1-3 chromosomes, 2-60 individuals, 1-300 loci, 2-40 map rows, hot maps, ragged families,
+    with/without mutation map, both stitch kernels): every quantity bit-identical to the oracle."""
+    rs = np.random.RandomState(20241004)
+    for trial in range(40):
+        nchr = int(rs.randint(1, 4)); nphen = int(rs.randint(1, 3)); n = int(rs.randint(2, 61))
+        has_mut = bool(rs.randint(0, 2))
+        g = gpu_lib.create(1, nchr, nphen); o = oracle_lib.create(1, nchr, nphen)
+        g.set_stitch_mode(int(rs.randint(0, 2)))
+        for c in range(nchr):
+            R = int(rs.randint(2, 41)); step = int(rs.choice([1, 3, 10, 1000]))
+            bp = (int(rs.randint(0, 50)) + step * np.arange(R) * int(rs.randint(1, 4))).astype(np.uint64)
+            prob = np.r_[0.0, rs.uniform(0, rs.choice([0.01, 0.3, 1.0]), R - 1)]
+            L = int(rs.randint(1, 301))
+            pos = np.sort(rs.randint(0, int(bp[-1]) + 2 * step + 2, L)).astype(np.uint64)
+            rate = np.r_[0.0, rs.uniform(0, rs.choice([0.01, 0.5]), R - 1)]
+            for ctx in (g, o):
+                ctx.set_rmap(0, c, bp, prob, step)
+                if has_mut:
+                    ctx.set_mutmap(0, c, bp, rate)
+                ctx.set_snps(0, c, pos)
+            F = synth_packed(1000 * trial + c, 2 * n, L)
+            g.upload_founders(0, c, F, L); o.upload_founders(0, c, F, L)
+            for p in range(nphen):
+                C = int(rs.randint(0, 40))
+                cvbp = rs.randint(0, int(bp[-1]) + 5, C).astype(np.uint64)
+                a, d = rs.randn(C), rs.randn(C)
+                vd = float(rs.choice([0.0, 0.5, -1.0]))
+                V = synth_packed(7000 * trial + 10 * p + c, 2 * n, C) if C else np.zeros((2 * n, 1), dtype=np.uint64)
+                for ctx in (g, o):
+                    ctx.set_cvs(0, p, c, cvbp, a, d, vd)
+                    ctx.upload_cv_founders(0, p, c, V, C)
+        seed0 = int(rs.randint(1, 1000001))
+        assert np.array_equal(g.init_gen0(0, n, seed0), o.init_gen0(0, n, seed0))
+        npop = n
+        for gen in range(1, 4):
+            ncp = int(rs.randint(1, 2 * npop + 1))
+            c = np.stack([rs.randint(0, npop, ncp), rs.randint(0, npop, ncp), (rs.rand(ncp) < 0.15).astype(np.int64), rs.randint(0, 4, ncp)], axis=1)
+            if c[c[:, 2] == 0, 3].sum() == 0:
+                c[0, 2] = 0; c[0, 3] = 1
+            n_off = int(c[c[:, 2] == 0, 3].sum())
+            sd = int(rs.randint(1, 1000001)); ms = rs.randint(1, 1000001, n_off * nchr).astype(np.uint32) if has_mut else None
+            assert np.array_equal(g.reproduce(0, c, sd, ms), o.reproduce(0, c, sd, ms)), f"trial {trial} gen {gen}: sex"
+            for x, y in zip(g.compute_ad(0), o.compute_ad(0)):
+                assert helpers.bits_equal(x, y), f"trial {trial} gen {gen}: A/D"
+            for k in range(nchr):
+                assert np.array_equal(g.download_haps(0, k), o.download_haps(0, k)), f"trial {trial} gen {gen} chr {k}: dense"
+                pg, og = g.download_intervals(0, k); po, oo = o.download_intervals(0, k)
+                assert np.array_equal(og, oo) and np.array_equal(pg, po), f"trial {trial} gen {gen} chr {k}: intervals"
+                mg, mog = g.download_mutations(0, k); mo, moo = o.download_mutations(0, k)
+                assert np.array_equal(mog, moo) and np.array_equal(mg, mo), f"trial {trial} gen {gen} chr {k}: mutations"
+                for p in range(nphen):
+                    assert np.array_equal(g.download_cv(0, p, k), o.download_cv(0, p, k)), f"trial {trial} gen {gen} chr {k}: CV matrix"
+                assert np.array_equal(g.format_hap_text(0, k), o.format_hap_text(0, k))
+            npop = n_off
+        g.close(); o.close()
