@@ -412,8 +412,21 @@ def example1_inputs(n_founder_ind=300):
     return dict(chrs=chrs, founders=founders, snp_pos=snp_pos, rmap_bp=rmap_bp, rmap_cM=rmap_cM, phens=[ph])
 
 
+def genetic_map_fixture():
+    """Recom_Map.zip:Recom.Map.b37.50KbDiff (a DATA file of the reference: 22 autosomes, 55 657 rows at 50 kb) as arrays --
+    the genetic map BASELINE config 4 names."""
+    d = os.path.join(WORK, "rmap")
+    with zipfile.ZipFile(os.path.join(REF, "Recom_Map.zip")) as z:
+        z.extract("Recom.Map.b37.50KbDiff", d)
+    m = np.loadtxt(os.path.join(d, "Recom.Map.b37.50KbDiff"), skiprows=1)
+    out = os.path.join(HERE, "recom_map_b37_50kb.npz")
+    np.savez_compressed(out, chr=m[:, 0].astype(np.uint8), bp=m[:, 1].astype(np.uint64), cM=m[:, 2])
+    print(f"wrote {out}: {os.path.getsize(out)/1e6:.2f} MB")
+
+
 def main():
     os.makedirs(WORK, exist_ok=True)
+    genetic_map_fixture()
     sh(["make", "-f", "Makefile.ref", "-j8"], cwd=ORACLE, stdout=subprocess.DEVNULL)
     # ---- KAT
     kat = os.path.join(WORK, "kat.txt")

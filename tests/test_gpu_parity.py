@@ -470,3 +470,41 @@ def test_randomised_small_configurations_against_oracle(gpu_lib, oracle_lib):
                 assert np.array_equal(g.format_hap_text(0, k), o.format_hap_text(0, k))
             npop = n_off
         g.close(); o.close()
+
+
+def test_whole_genome_22_chromosomes_on_the_reference_genetic_map(gpu_lib, oracle_lib):
+    """BASELINE config 4's map: Recom_Map.zip:Recom.Map.b37.50KbDiff (22 autosomes, 55 657 rows, 35.9 Morgans) with a
+    mutation map on the same rows; synthetic founders; ragged families.  GPU == oracle on every chromosome."""
+    z = np.load(os.path.join(helpers.GOLDEN, "recom_map_b37_50kb.npz"))
+    nchr, n, L, C = 22, 60, 400, 20
+    g = gpu_lib.create(1, nchr, 1); o = oracle_lib.create(1, nchr, 1)
+    rs = np.random.RandomState(8)
+    for c in range(nchr):
+        bp = z["bp"][z["chr"] == c + 1]; cM = z["cM"][z["chr"] == c + 1]
+        prob = np.zeros(len(bp)); prob[1:] = (cM[1:] - cM[:-1]) * .01          # Population::ras_compute_recom_prob
+        pos = np.sort(rs.randint(int(bp[0]), int(bp[-1]), L)).astype(np.uint64)
+        cvbp = np.sort(rs.randint(int(bp[0]), int(bp[-1]), C)).astype(np.uint64)
+        a, d = rs.randn(C), rs.randn(C) * 0.2
+        F = synth_packed(300 + c, 2 * n, L); V = synth_packed(600 + c, 2 * n, C)
+        for ctx in (g, o):
+            ctx.set_rmap(0, c, bp, prob, int(bp[1] - bp[0]))
+            ctx.set_mutmap(0, c, bp, np.r_[0.0, np.full(len(bp) - 1, 2e-4)])
+            ctx.set_snps(0, c, pos)
+            ctx.set_cvs(0, 0, c, cvbp, a, d, -1.0)
+            ctx.upload_founders(0, c, F, L); ctx.upload_cv_founders(0, 0, c, V, C)
+    sg = Simulation(g, 31, nchr, True); so = Simulation(o, 31, nchr, True)
+    sg.ras_initial_human_gen0(0, n); so.ras_initial_human_gen0(0, n)
+    rng = np.random.default_rng(2)
+    for gen in (1, 2, 3):
+        c = synthetic_random_mate(sg.sex[0], n // 2, rng); c["num_offspring"] = 2
+        sg.couples[0] = c; so.couples[0] = c.copy()
+        assert np.array_equal(sg.reproduce(0, gen), so.reproduce(0, gen))
+        for x, y in zip(sg.ras_compute_AD(0, gen, per_chr=True), so.ras_compute_AD(0, gen, per_chr=True)):
+            assert helpers.bits_equal(x, y), f"A/D gen {gen}"
+        for k in range(nchr):
+            assert np.array_equal(g.download_haps(0, k), o.download_haps(0, k)), f"dense gen {gen} chr {k + 1}"
+            pg, og = g.download_intervals(0, k); po, oo = o.download_intervals(0, k)
+            assert np.array_equal(og, oo) and np.array_equal(pg, po)
+    total_parts = sum(len(g.download_intervals(0, k)[0]) for k in range(nchr))
+    assert total_parts > 2 * n * nchr * 1.5          # ~36 crossovers per gamete set per generation
+    g.close(); o.close()
