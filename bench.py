@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--n-ind", type=int, default=100_000)
     ap.add_argument("--n-loci", type=int, default=1_000_000)
     ap.add_argument("--n-cv", type=int, default=1000)
+    ap.add_argument("--nchr", type=int, default=1, help="chromosomes (each of --n-loci SNPs and 100 Mb; config 2 has 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ind", type=int, default=20000)
     ap.add_argument("--cpu-sample-gens", type=int, default=4)
@@ -176,24 +177,25 @@ def main():
     from geneevolve_amd.capi import GevLibrary
     from geneevolve_amd.host import Simulation, SyntheticConfig, synthetic_random_mate
     lib = GevLibrary()                                   # the HIP library or nothing
-    cfg = SyntheticConfig(args.n_ind, args.n_loci, n_cv=args.n_cv, seed=12345)      # same grids / maps / CV effects on every rank
+    cfg = SyntheticConfig(args.n_ind, args.n_loci, nchr=args.nchr, n_cv=args.n_cv, seed=12345)   # same grids / maps / CV effects on every rank
     migrate = world > 1 and args.migration_rate > 0
     n_pop_ctx, my_pop = (world, rank) if migrate else (1, 0)   # with migration every rank knows all populations' static tables
-    ctx = lib.create(n_pop_ctx, 1, 1, local_rank)
+    ctx = lib.create(n_pop_ctx, args.nchr, 1, local_rank)
     if args.no_intervals:
         ctx.set_track_intervals(False)
     for p in range(n_pop_ctx):
         cfg.apply_static(ctx, p)
     P = my_pop
-    ctx.synth_founders(P, 0, 2 * args.n_ind, 1000 + rank)
-    ctx.synth_cv_founders(P, 0, 0, 2 * args.n_ind, 2000 + rank)
-    sim = Simulation(ctx, 12345 + rank, 1, True)
+    for c in range(args.nchr):
+        ctx.synth_founders(P, c, 2 * args.n_ind, 1000 + 100 * c + rank)
+        ctx.synth_cv_founders(P, 0, c, 2 * args.n_ind, 2000 + 100 * c + rank)
+    sim = Simulation(ctx, 12345 + rank, args.nchr, True)
     sim.ras_initial_human_gen0(P, args.n_ind)
     rng = np.random.default_rng(rank)
     total = args.warmup + args.steps
     # the ras_glob_seed() stream is a pure function of --seed and of counts known in advance
     # (1 + N*nchr draws per generation): draw it before the timed region
-    seeds = [sim.ras_glob_seed(1 + args.n_ind) for _ in range(total)]
+    seeds = [sim.ras_glob_seed(1 + args.n_ind * args.nchr) for _ in range(total)]
 
     def barrier():
         if dist is not None:
@@ -252,24 +254,24 @@ def main():
     iso = None
     if args.isolated_steps > 0 and not migrate:
         ctx.set_overlap(False)
-        more = [sim.ras_glob_seed(1 + args.n_ind) for _ in range(args.isolated_steps)]
+        more = [sim.ras_glob_seed(1 + args.n_ind * args.nchr) for _ in range(args.isolated_steps)]
         ta, na = ctx.timing_totals()
         for j in range(args.isolated_steps):
             sim.couples[P] = synthetic_random_mate(sim.sex[P], args.n_ind, rng, out=sim.couples.get(P))
             sim.reproduce(P, total + j + 1, seeds=more[j], n_people=args.n_ind)
         tb, nb = ctx.timing_totals()
         iso = (tb[1] - ta[1]) / max(nb - na, 1)
-        ctx.set_overlap(True)
+        ctx.set_overlap(None)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         gens_per_s = world * args.steps / dt
-        alg_bytes = args.n_ind * args.n_loci / 2.0          # per stitch launch (1 chromosome)
+        alg_bytes = args.n_ind * args.n_loci / 2.0 * args.nchr   # per generation: one stitch launch per chromosome, N*L/2 bytes each
         stitch = float(np.mean(stitch_ms))
         achieved = alg_bytes / (stitch * 1e-3) / 1e9
         traffic = None                                      # HBM bytes per launch from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r01_final_config2_pmc_hbm.json")
-        if os.path.exists(pmc) and (args.n_ind, args.n_loci) == (100_000, 1_000_000):
+        if os.path.exists(pmc) and (args.n_ind, args.n_loci, args.nchr) == (100_000, 1_000_000, 1):
             traffic = json.load(open(pmc))["k_stitch_parent_summary"]["hbm_traffic_bytes_per_launch"]
         out = {
             "metric": "generations/sec", "value": gens_per_s,
@@ -277,11 +279,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 bit-planes + f64 A/D",
             "data": "synthetic (device-generated founder panel, uniform maps, SURVEY.md 8(d) config C2)",
-            "config": {"workload": "BASELINE config 2: 100k individuals x 1M SNPs, 1 population per GPU, 1 chromosome (100 Mb), "
-                                   "uniform recombination map 2001 rows @ 5e-4, mutation 1e-8/bp, 1000 CVs, random mating",
-                       "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
+            "config": {"workload": ("BASELINE config 2: 100k individuals x 1M SNPs, 1 population per GPU, 1 chromosome (100 Mb), "
+                                    "uniform recombination map 2001 rows @ 5e-4, mutation 1e-8/bp, 1000 CVs, random mating")
+                       if (args.n_ind, args.n_loci, args.nchr) == (100_000, 1_000_000, 1) else
+                       f"config-2 family, non-default size: {args.n_ind} individuals x {args.nchr} chromosome(s) x {args.n_loci} SNPs",
+                       "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_chromosomes": args.nchr, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
                        "interval_state_tracked": not args.no_intervals},
-            "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci / dt,
+            "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci * args.nchr / dt,
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
                          "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
                          "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None},

@@ -327,7 +327,8 @@ class GevContext:
         return [float(x) for x in ms], n.value
 
     def set_overlap(self, on):
-        self._call("set_overlap", C.c_int(1 if on else 0))
+        """True/False, or None for the automatic choice (default)"""
+        self._call("set_overlap", C.c_int(-1 if on is None else (1 if on else 0)))
 
     def set_stitch_mode(self, mode):
         self._call("set_stitch_mode", C.c_int(mode))

@@ -128,7 +128,9 @@ struct gev_ctx {
     bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
     int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
     unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels (GEV_SAMPLE_GRID)
-    bool serialize = false;        // GEV_SERIALIZE=1: wait for every stitch (diagnostic, measures the phases without overlap)
+    bool serialize = false;        // wait for every stitch (no overlap between the two streams)
+    int overlap_mode = -1;         // -1 auto (decide after two serialised generations), 0 never, 1 always
+    int auto_gens = 0; double auto_small_ms = 0, auto_stitch_ms = 0;
     unsigned stitch_lds_pad = 0;   // unused dynamic LDS per stitch workgroup: limits workgroups per CU (160 KiB / CU)
     DevBuf d_snpmajor, d_text;
     DevBuf d_sex0, d_gef_flag, d_gef_first, d_gef_red, d_gef_io;
@@ -252,7 +254,8 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     }
     GevRngTables T; gev_build_rng_tables(T);
     GEVC(h2d(c.get(), c->d_tables, &T, sizeof T));
-    if (const char* e = getenv("GEV_SERIALIZE")) c->serialize = atoi(e) != 0;
+    if (const char* e = getenv("GEV_SERIALIZE")) c->overlap_mode = atoi(e) != 0 ? 0 : 1;
+    c->serialize = c->overlap_mode != 1;                             // auto starts serialised
     if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = (unsigned)g; }
     if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // tuning knob: stitch workgroups per CU (default: unlimited = 8)
         const int occ = atoi(e);
@@ -607,6 +610,12 @@ static int harvest_timing(gev_ctx* c, gev_ctx::Scratch& sc)
     ms[3] = ms[0] + ms[1] + ms[2];
     for (int i = 0; i < 4; i++) { c->last_ms[i] = ms[i]; c->ms_sum[i] += ms[i]; }
     c->ms_count++;
+    // overlap pays when the small kernels are a small fraction of the stitch (config 2: ~0.2); when they are
+    // comparable (many chromosomes, short rows) the starved small stream only delays everything: stay serialised
+    if (c->overlap_mode < 0 && c->serialize && c->auto_gens < 2) {
+        c->auto_small_ms += ms[0] + ms[2]; c->auto_stitch_ms += ms[1];
+        if (++c->auto_gens == 2) c->serialize = !(c->auto_small_ms < 0.35 * c->auto_stitch_ms);
+    }
     sc.timing_pending = false;
     return GEV_OK;
 }
@@ -660,7 +669,7 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
         const u64 bp0 = S.rbp.front(), bpe = S.rbp.back();
         // capacity guess: last generation's total scaled to the new size, plus room for this generation's events
         size_t want = std::max<size_t>(cs.mut_need, (size_t)(cs.mut_total[cur] * grow * 1.5) + rows * 4 + 4096);
-        GEVC(cs.mpos[alt].ensure(want * sizeof(u64), st));
+        GEVC(cs.mpos[alt].ensure(want * sizeof(u64), st, false, 2.0));        // grow geometrically: lists lengthen every generation
         const u32 mcap = (u32)std::min<size_t>(cs.mpos[alt].bytes / sizeof(u64), 0xfffffff0u);
         hipLaunchKernelGGL((k_mutlist<false>), dim3(row_blocks), dim3(256), 0, st, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
                            c->d_cnt.as<u32>(), (const u32*)nullptr, (u64*)nullptr, rows, k, nchr, bp0, bpe, (int)has_mut, 0u, sd);
@@ -672,7 +681,7 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
         KCHECK();
         if (c->track_intervals) {
             want = std::max<size_t>(cs.parts_need, (size_t)(cs.parts_total[cur] * grow * 1.5) + rows * 4 + 4096);
-            GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), st));
+            GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), st, false, 2.0));
             const u32 pcap = (u32)std::min<size_t>(cs.parts[alt].bytes / sizeof(gev_part), 0xfffffff0u);
             hipLaunchKernelGGL((k_parts<false>), dim3(row_blocks), dim3(256), 0, st, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
                                c->d_cnt.as<u32>(), (const u32*)nullptr, (gev_part*)nullptr, rows, k, nchr, bp0, bpe, 0u, sd);
@@ -742,7 +751,7 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     HIPC(hipEventRecord(sc.ev_stitch_done, sb));
     HIPC(hipEventRecord(c->ev_planes, sb));
     sc.timing_pending = true; sc.stitch_pending = true; c->planes_pending = true;
-    if (c->serialize) HIPC(hipStreamSynchronize(sb));      // diagnostic: no overlap between generations
+    if (c->serialize) { HIPC(hipStreamSynchronize(sb)); GEVC(harvest_timing(c, sc)); sc.stitch_pending = false; }   // no overlap: timings are final right away
     return GEV_OK;
 }
 
@@ -1571,7 +1580,14 @@ int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_
 int gev_stream(gev_ctx* c, void** s) { if (!c || !s) return fail(GEV_EINVAL, "null"); *s = (void*)c->stream; return GEV_OK; }
 int gev_last_reproduce_ms(gev_ctx* c, float ms[4]) { if (!c || !ms) return fail(GEV_EINVAL, "null"); GEVC(gev_sync(c)); for (int i = 0; i < 4; i++) ms[i] = c->last_ms[i]; return GEV_OK; }
 int gev_set_track_intervals(gev_ctx* c, int on) { if (!c) return fail(GEV_EINVAL, "null"); c->track_intervals = on != 0; return GEV_OK; }
-int gev_set_overlap(gev_ctx* c, int on) { if (!c) return fail(GEV_EINVAL, "null"); GEVC(gev_sync(c)); c->serialize = on == 0; return GEV_OK; }
+int gev_set_overlap(gev_ctx* c, int on)
+{
+    if (!c) return fail(GEV_EINVAL, "null");
+    GEVC(gev_sync(c));
+    c->overlap_mode = on < 0 ? -1 : (on ? 1 : 0);
+    if (c->overlap_mode >= 0) c->serialize = c->overlap_mode == 0; else { c->serialize = true; c->auto_gens = 0; c->auto_small_ms = c->auto_stitch_ms = 0; }
+    return GEV_OK;
+}
 int gev_set_stitch_mode(gev_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return fail(GEV_EINVAL, "stitch mode must be 0 (parent-major) or 1 (gamete-major)"); c->stitch_mode = mode; return GEV_OK; }
 
 // ---- diagnostics (tests only; no simulation state involved) --------------------------------

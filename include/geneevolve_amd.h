@@ -218,8 +218,9 @@ int gev_stream(gev_ctx*, void** stream);
  * genotype planes keeps running on a second HIP stream and every later call is ordered after it
  * where it needs the planes.  gev_sync waits for all device work of the context. */
 int gev_sync(gev_ctx*);
-/* on (default): the stitch overlaps later work as described above; off: gev_reproduce waits for it
- * (diagnostic: kernel timings without interference between the two streams). */
+/* on > 0: the stitch always overlaps later work as described above; on == 0: gev_reproduce waits for it (kernel
+ * timings without interference between the two streams); on < 0 (default): automatic -- two serialised
+ * generations are timed and overlap is switched on if the small kernels take < 0.35 of the stitch time. */
 int gev_set_overlap(gev_ctx*, int on);
 /* kernel timing measured with HIP events on the library's own streams: ms[0] = sampling
  * (crossover + mutation + seed chain), ms[1] = dense stitch (genotype planes), ms[2] = sparse state
