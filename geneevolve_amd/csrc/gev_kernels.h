@@ -33,6 +33,8 @@ struct ChrDev {
     u64 bp0, bp_end;      // rmap.bp[0], rmap.bp[R-1]: every haplotype covers [bp0, bp_end)
     u32 R, M;
     u32 r_amax, m_amax;   // largest a_hi of the recombination / mutation thresholds (scan prefilter)
+    const u64* snp_pos;   // [L] Legend.pos of the genotype plane
+    u32 L, pad_;
 };
 
 // per-generation sampling results (all chromosomes; task t = offspring*nchr + chr, gamete G = 2t+s)
@@ -42,6 +44,7 @@ struct SampleDev {
     u32* k;          // [2T]  crossover count of gamete G
     u32* bk_off;     // [2T+1] exclusive scan of k
     u64* bk;         // breakpoints, ascending per gamete (:2990)
+    u32* bk_idx;     // same layout: first locus index of the genotype plane at or after each breakpoint
     uint8_t* start;  // [2T]  starting haplotype (:2449, :2455)
     u32* nmut;       // [T]   new mutations of task t (:2513)
     u32* nm_off;     // [T+1]
@@ -470,6 +473,16 @@ __global__ void __launch_bounds__(256) k_group_fill(const u32* __restrict__ fath
     const u32 p = (r & 1) ? mother[r >> 1] : father[r >> 1];
     glist[goff[p] + atomicAdd(&cursor[p], 1u)] = (u32)r;      // order inside a group is irrelevant: every gamete owns its output row
 }
+// breakpoint (base pairs) -> first locus index >= it, for every gamete of every chromosome: one fully parallel pass,
+// so that no stitch workgroup has to walk a 20-step dependent binary search before it can start streaming
+__global__ void __launch_bounds__(256) k_bk_to_idx(const ChrDev* __restrict__ chrs, int nchr, size_t n_gametes, SampleDev sd)
+{
+    const size_t G = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (G >= n_gametes) return;
+    const ChrDev& C = chrs[(G >> 1) % nchr];
+    const u32 k = sd.k[G], off = sd.bk_off[G];
+    for (u32 m = 0; m < k; m++) sd.bk_idx[off + m] = lower_bound_u64(C.snp_pos, C.L, sd.bk[off + m]);
+}
 #define PM_GMAX 16           // gametes of one parent handled per pass
 #define PM_KTOT 256          // their boundaries staged in LDS
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -484,8 +497,8 @@ __device__ __forceinline__ v4u mask_from(u32 rel)           // ones at bit posit
 }
 // boundary m of a staged gamete as a locus index: from LDS, or (one oversize gamete) from global memory
 struct PmIdx {
-    const u32* lds; const u64* bk; const u64* pos; u32 L; bool big;
-    __device__ __forceinline__ u32 at(u32 m) const { return big ? lower_bound_u64(pos, L, bk[m]) : lds[m]; }
+    const u32* lds; const u32* glob; bool big;
+    __device__ __forceinline__ u32 at(u32 m) const { return big ? glob[m] : lds[m]; }
 };
 // #{boundaries <= bit0} and the first boundary after them
 __device__ __forceinline__ void pm_locate(const PmIdx& I, u32 k, u32 bit0, u32& cnt, u32& nxt)
@@ -512,15 +525,20 @@ __global__ void __launch_bounds__(256) k_stitch_parent(
     u32 gb = g0;
     while (gb < g1) {
         __syncthreads();                                   // previous batch consumed
+        // descriptors of up to PM_GMAX gametes, one thread each (parallel loads), then a short serial prefix in LDS
+        const u32 cand = min(g1 - gb, (u32)PM_GMAX);
+        if (threadIdx.x < cand) {
+            const u32 row = glist[gb + threadIdx.x];
+            const size_t G = 2 * ((size_t)(row >> 1) * nchr + chr) + (row & 1);
+            s_row[threadIdx.x] = row; s_start[threadIdx.x] = sd.start[G]; s_k[threadIdx.x] = sd.k[G]; s_bkoff[threadIdx.x] = sd.bk_off[G];
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
             u32 n = 0, kt = 0, big = 0;
-            while (gb + n < g1 && n < PM_GMAX) {
-                const u32 row = glist[gb + n];
-                const size_t G = 2 * ((size_t)(row >> 1) * nchr + chr) + (row & 1);
-                const u32 k = sd.k[G];
-                if (kt + k > PM_KTOT) { if (n == 0) { big = 1; } else break; }
-                s_row[n] = row; s_start[n] = sd.start[G]; s_k[n] = k; s_kb[n] = kt; s_bkoff[n] = sd.bk_off[G];
-                kt += k; n++;
+            while (n < cand) {
+                const u32 k = s_k[n];
+                if (kt + k > PM_KTOT) { if (n == 0) big = 1; else break; }
+                s_kb[n] = kt; kt += k; n++;
                 if (big) break;
             }
             s_n = n; s_big = big;
@@ -529,7 +547,7 @@ __global__ void __launch_bounds__(256) k_stitch_parent(
         const u32 n = s_n; const bool big = s_big != 0;
         if (!big)
             for (u32 j = 0; j < n; j++)
-                for (u32 m = threadIdx.x; m < s_k[j]; m += 256) s_idx[s_kb[j] + m] = lower_bound_u64(pos, L, sd.bk[s_bkoff[j] + m]);
+                for (u32 m = threadIdx.x; m < s_k[j]; m += 256) s_idx[s_kb[j] + m] = sd.bk_idx[s_bkoff[j] + m];
         __syncthreads();
         for (u32 q = q0 + threadIdx.x; q < q1; q += 256 * UNROLL) {
             bool need0[UNROLL], need1[UNROLL];
@@ -541,7 +559,7 @@ __global__ void __launch_bounds__(256) k_stitch_parent(
                 if (qq >= q1) continue;
                 const u32 bit0 = qq * 128u, bit1 = bit0 + 128u;
                 for (u32 j = 0; j < n; j++) {
-                    const PmIdx I{s_idx + s_kb[j], sd.bk + s_bkoff[j], pos, L, big};
+                    const PmIdx I{s_idx + s_kb[j], sd.bk_idx + s_bkoff[j], big};
                     u32 cnt, nxt; pm_locate(I, s_k[j], bit0, cnt, nxt);
                     const u32 sel = s_start[j] ^ (cnt & 1u);
                     const bool mixed = nxt < bit1;
@@ -560,7 +578,7 @@ __global__ void __launch_bounds__(256) k_stitch_parent(
                 if (qq >= q1) continue;
                 const u32 bit0 = qq * 128u, bit1 = bit0 + 128u;
                 for (u32 j = 0; j < n; j++) {
-                    const PmIdx I{s_idx + s_kb[j], sd.bk + s_bkoff[j], pos, L, big};
+                    const PmIdx I{s_idx + s_kb[j], sd.bk_idx + s_bkoff[j], big};
                     const u32 k = s_k[j];
                     u32 cnt, nxt; pm_locate(I, k, bit0, cnt, nxt);
                     const u32 sel = s_start[j] ^ (cnt & 1u);

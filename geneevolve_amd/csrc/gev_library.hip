@@ -112,7 +112,7 @@ struct gev_ctx {
     // per-generation scratch: two sets, because the dense stitch of generation g (stream_big) still reads set g%2
     // while sampling / sparse state of generation g+1 (stream) fill the other one
     struct Scratch {
-        DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, start, nmut, nm_off, nm_pos, nm_side, sex, ghist, goff, glist, status;
+        DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, ghist, goff, glist, status;
         hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         bool timing_pending = false, stitch_pending = false;
     } sc[2];
@@ -497,7 +497,7 @@ static int finalize_static(gev_ctx* c, int pop)
         S.idx_lo = (u32)(std::lower_bound(S.pos.begin(), S.pos.end(), bp0) - S.pos.begin());
         S.idx_hi = (u32)(std::lower_bound(S.pos.begin(), S.pos.end(), bpe) - S.pos.begin());
         cd[k] = ChrDev{S.d_rthr.as<GevThr>(), S.d_rbp.as<u64>(), S.d_mthr.as<GevThr>(), S.d_mbp.as<u64>(), S.bp_dist, bp0, bpe,
-                       (u32)S.rbp.size(), (u32)S.mbp.size(), S.r_amax, S.m_amax};
+                       (u32)S.rbp.size(), (u32)S.mbp.size(), S.r_amax, S.m_amax, S.d_pos.as<u64>(), (u32)S.L, 0u};
         for (int p = 0; p < c->nphen; p++) {
             CvStatic& V = P.cv[p][k];
             if (!V.set) continue;
@@ -623,7 +623,7 @@ static SampleDev make_sd(gev_ctx* c, gev_ctx::Scratch& sc, size_t T)
 {
     SampleDev sd;
     sd.seed_pat = sc.seed_pat.as<u32>(); sd.seed_mat = sc.seed_mat.as<u32>(); sd.k = sc.k.as<u32>();
-    sd.bk_off = sc.bk_off.as<u32>(); sd.bk = sc.bk.as<u64>(); sd.start = sc.start.as<uint8_t>();
+    sd.bk_off = sc.bk_off.as<u32>(); sd.bk = sc.bk.as<u64>(); sd.bk_idx = sc.bk_idx.as<u32>(); sd.start = sc.start.as<uint8_t>();
     sd.nmut = sc.nmut.as<u32>(); sd.nm_off = sc.nm_off.as<u32>(); sd.nm_pos = sc.nm_pos.as<u64>();
     sd.nm_side = sc.nm_side.as<uint8_t>(); sd.sex = sc.sex.as<uint8_t>();
     sd.father = sc.father.as<u32>(); sd.mother = sc.mother.as<u32>();
@@ -643,6 +643,7 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
     const size_t bk_fixed = 2 * T * GEV_BK_CAP, nm_fixed = T * GEV_NM_CAP;
     if (bk_fixed + c->bk_ovf_cap >= 0xffffffffull || nm_fixed + c->nm_ovf_cap >= 0xffffffffull) return fail(GEV_EINVAL, "reproduce: breakpoint/mutation record space exceeds 32-bit offsets");
     GEVC(sc.bk.ensure((bk_fixed + c->bk_ovf_cap) * sizeof(u64), st));
+    GEVC(sc.bk_idx.ensure((bk_fixed + c->bk_ovf_cap) * sizeof(u32), st));
     if (has_mut) { GEVC(sc.nm_pos.ensure((nm_fixed + c->nm_ovf_cap) * sizeof(u64), st)); GEVC(sc.nm_side.ensure(nm_fixed + c->nm_ovf_cap, st)); }
     const size_t n_status = ST_TOTALS + 2 * (size_t)nchr;
     HIPC(hipMemsetAsync(sc.status.p, 0, n_status * sizeof(u32), st));
@@ -657,6 +658,7 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
     } else {
         hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd);
     }
+    hipLaunchKernelGGL(k_bk_to_idx, dim3((unsigned)ceil_div(2 * T, 256)), dim3(256), 0, st, chrs, nchr, 2 * T, sd);
     KCHECK();
     HIPC(hipEventRecord(sc.t[1], st));
     // ---- sparse state: mutation lists + ancestry intervals + CV planes

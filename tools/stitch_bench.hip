@@ -108,6 +108,8 @@ int main(int argc, char** argv)
     CK(hipMemcpy(df, father.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dm, mother.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dbk, bk.data(), bk.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dpos, pos.data(), L * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dst_, start.data(), rows, hipMemcpyHostToDevice));
+    { std::vector<u32> bi(bk.begin(), bk.end()); bi.push_back(0); u32* dbi; CK(hipMalloc(&dbi, bi.size() * 4));   // pos[i] = i: index == base pair
+      CK(hipMemcpy(dbi, bi.data(), bi.size() * 4, hipMemcpyHostToDevice)); sd.bk_idx = dbi; }
     sd.k = dk; sd.bk_off = doff; sd.bk = dbk; sd.start = dst_; sd.father = df; sd.mother = dm;
     // grouping by source individual for the parent-major kernel
     std::vector<u32> goff(N + 1, 0), glist(rows);
