@@ -135,8 +135,8 @@ def cpu_baseline_reference(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n-ind", type=int, default=100_000)
     ap.add_argument("--n-loci", type=int, default=1_000_000)
     ap.add_argument("--n-cv", type=int, default=1000)

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "last_error", "version", "create", "destroy", "set_rmap", "set_mutmap", "set_snps", "set_cvs",
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
-    "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "download_cv", "download_intervals", "download_mutations",
+    "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
@@ -274,6 +274,28 @@ class GevContext:
         nb = n_snps * ((self.pop_size(pop) + 3) // 4)
         out = np.zeros(nb, dtype=np.uint8)
         self._call("format_bed", C.c_int(pop), C.c_int(chr), C.c_size_t(snp_begin), C.c_size_t(n_snps), _p(out), C.c_size_t(nb))
+        return out
+
+    def download_plink_matrix(self, pop, chr, ind_begin=0, n_ind=None):
+        """matrix_plink_ped rows (bit 2*snp + hap) of ras_convert_interval_to_format_plink"""
+        L = self._nsnp[(pop, chr)]
+        n_ind = self.pop_size(pop) - ind_begin if n_ind is None else n_ind
+        w = words_for(2 * L)
+        out = np.zeros((n_ind, w), dtype=np.uint64)
+        self._call("download_plink_matrix", C.c_int(pop), C.c_int(chr), C.c_size_t(ind_begin), C.c_size_t(n_ind), _p(out), C.c_size_t(w))
+        return out
+
+    def format_ped_text(self, pop, chr, al0=None, al1=None, ind_begin=0, n_ind=None):
+        """genotype columns of the reference's .ped lines (format_plink::write_ped_map; write_ped01_map when al0 is None)"""
+        L = self._nsnp[(pop, chr)]
+        n_ind = self.pop_size(pop) - ind_begin if n_ind is None else n_ind
+        if al0 is not None:
+            al0 = _arr(al0, np.uint8); al1 = _arr(al1, np.uint8)
+            if len(al0) != L or len(al1) != L:
+                raise ValueError("format_ped_text: one allele letter per SNP expected")
+        nb = n_ind * (4 * L + 1)
+        out = np.zeros(nb, dtype=np.uint8)
+        self._call("format_ped_text", C.c_int(pop), C.c_int(chr), C.c_size_t(ind_begin), C.c_size_t(n_ind), _p(al0), _p(al1), _p(out), C.c_size_t(nb))
         return out
 
     def download_cv(self, pop, phen, chr):

@@ -1085,16 +1085,77 @@ __global__ void __launch_bounds__(256) k_snpmajor_apply_mut(const u32* __restric
     }
 }
 // one .hap line per SNP: "b b b ... b \n" (digit + space per haplotype, then newline)
+// The text is produced as a flat byte stream: thread t owns the aligned 16 bytes [16t, 16t+16) of the output (lines have odd
+// lengths, so line-relative ownership would make every store misaligned), one 16-byte store per thread.
 __global__ void __launch_bounds__(256) k_format_hap_text(const u64* __restrict__ snpmajor, size_t stride_w64, size_t n_rows, u32 n_snps, char* __restrict__ out)
 {
-    const size_t line_len = 2 * n_rows + 1;
+    const size_t line_len = 2 * n_rows + 1, total = (size_t)n_snps * line_len;
+    const size_t o = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (o >= total) return;
+    size_t j = o / line_len, p = o % line_len;
+    union { char ch[16]; uint4 v; } u;
+    u64 word = 0; size_t word_at = ~(size_t)0;
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        char ch = ' ';
+        if (o + b >= total) ch = 0;
+        else if (p == 2 * n_rows) ch = '\n';
+        else if (!(p & 1)) {
+            const size_t h = p >> 1, at = j * stride_w64 + (h >> 6);
+            if (at != word_at) { word = snpmajor[at]; word_at = at; }
+            ch = (char)('0' + (int)((word >> (h & 63)) & 1ull));
+        }
+        u.ch[b] = ch;
+        if (++p == line_len) { p = 0; j++; }
+    }
+    if (o + 16 <= total) *reinterpret_cast<uint4*>(out + o) = u.v;
+    else for (int b = 0; b < 16 && o + b < total; b++) out[o + b] = u.ch[b];
+}
+// PLINK .ped genotype columns (format_plink::write_ped_map / write_ped01_map, src/format_plink.cpp:42-49 / :114-121):
+// per individual  L x " a b"  then '\n', a/b = allele letters of haplotype 0/1 (al1 if the bit is set else al0; "1"/"0"
+// when al0 == NULL).  `rows` = staged hap-major rows (mutations applied) of individuals [0, n_ind); same flat-stream layout.
+__global__ void __launch_bounds__(256) k_format_ped_text(const u32* __restrict__ rows, size_t stride_w32, size_t n_ind, u32 L,
+                                                         const char* __restrict__ al0, const char* __restrict__ al1, char* __restrict__ out)
+{
+    const size_t line_len = 4 * (size_t)L + 1, total = n_ind * line_len;
+    const size_t o = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (o >= total) return;
+    size_t i = o / line_len, p = o % line_len;
+    union { char ch[16]; uint4 v; } u;
+    u32 w0 = 0, w1 = 0; size_t word_at = ~(size_t)0;
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        char ch = ' ';
+        if (o + b >= total) ch = 0;
+        else if (p == 4 * (size_t)L) ch = '\n';
+        else if (p & 1) {
+            const u32 s = (u32)(p >> 2), hap = (u32)(p >> 1) & 1u;
+            const size_t at = 2 * i * stride_w32 + (s >> 5);
+            if (at != word_at) { w0 = rows[at]; w1 = rows[at + stride_w32]; word_at = at; }
+            const u32 bit = ((hap ? w1 : w0) >> (s & 31)) & 1u;
+            ch = al0 ? (bit ? al1[s] : al0[s]) : (char)('0' + bit);
+        }
+        u.ch[b] = ch;
+        if (++p == line_len) { p = 0; i++; }
+    }
+    if (o + 16 <= total) *reinterpret_cast<uint4*>(out + o) = u.v;
+    else for (int b = 0; b < 16 && o + b < total; b++) out[o + b] = u.ch[b];
+}
+// matrix_plink_ped of ras_convert_interval_to_format_plink (src/Simulation.cpp:1308-1362): bit 2*ii+ihap of row ih
+__device__ __forceinline__ u64 spread_bits(u32 x)
+{
+    u64 v = x;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffull; v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
+    v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0full;  v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+__global__ void __launch_bounds__(256) k_interleave_haps(const u32* __restrict__ rows, size_t stride_w32, size_t n_ind, u32 words, u64* __restrict__ out, size_t out_stride_w64)
+{
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (size_t)n_snps * (n_rows + 1)) return;
-    const size_t j = q / (n_rows + 1), h = q % (n_rows + 1);
-    char* line = out + j * line_len;
-    if (h == n_rows) { line[2 * n_rows] = '\n'; return; }
-    const u32 b = (u32)((snpmajor[j * stride_w64 + (h >> 6)] >> (h & 63)) & 1ull);
-    line[2 * h] = (char)('0' + b); line[2 * h + 1] = ' ';
+    if (q >= n_ind * words) return;
+    const size_t i = q / words, w = q % words;
+    out[i * out_stride_w64 + w] = spread_bits(rows[2 * i * stride_w32 + w]) | (spread_bits(rows[(2 * i + 1) * stride_w32 + w]) << 1);
 }
 // PLINK .bed body, SNP-major: 2 bits per individual, A1 = allele 1: 00 = 1/1, 10 = heterozygous, 11 = 0/0, pad = 00
 __global__ void __launch_bounds__(256) k_format_bed(const u64* __restrict__ snpmajor, size_t stride_w64, size_t n_people, u32 n_snps, uint8_t* __restrict__ out)

@@ -1473,10 +1473,85 @@ int gev_format_hap_text(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n
         const size_t ns = std::min(chunk, n_snps - s); size_t stride;
         GEVC(snp_major_device(c, pop, chr, snp_begin + s, ns, stride));
         GEVC(c->d_text.ensure(ns * line, c->stream));
-        hipLaunchKernelGGL(k_format_hap_text, dim3((unsigned)ceil_div(ns * (rows + 1), 256)), dim3(256), 0, c->stream, c->d_snpmajor.as<u64>(), stride, rows, (u32)ns, c->d_text.as<char>());
+        hipLaunchKernelGGL(k_format_hap_text, dim3((unsigned)ceil_div(ceil_div(ns * line, 16), 256)), dim3(256), 0, c->stream, c->d_snpmajor.as<u64>(), stride, rows, (u32)ns, c->d_text.as<char>());
         KCHECK();
         HIPC(hipMemcpyAsync(out + s * line, c->d_text.p, ns * line, hipMemcpyDeviceToHost, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
+    }
+    return GEV_OK;
+}
+// hap-major rows (mutations applied) of individuals [ind0, ind0+n) into c->d_stage
+static int stage_individuals(gev_ctx* c, int pop, int chr, size_t ind0, size_t n)
+{
+    PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
+    hipStream_t st = c->stream;
+    GEVC(c->d_stage.ensure(std::max<size_t>(2 * n * S.stride, 16), st));
+    if (!n) return GEV_OK;
+    HIPC(hipMemcpyAsync(c->d_stage.p, cs.plane[P.cur].as<uint8_t>() + 2 * ind0 * S.stride, 2 * n * S.stride, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_snp_apply_mut, dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, st,
+                       cs.plane[P.cur].as<u32>(), S.stride / 4, c->d_stage.as<u32>(), S.stride / 4, 2 * ind0, 2 * n,
+                       cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)S.L);
+    KCHECK();
+    return GEV_OK;
+}
+static int ind_range_check(gev_ctx* c, int pop, int chr, size_t ind0, size_t n, const char* what)
+{
+    GEVC(check_idx(c, pop, chr));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "%s: population %d has no current generation", what, pop);
+    GEVC(materialize_order(c, pop));
+    if (ind0 + n > P.n_people) return fail(GEV_EINVAL, "%s: individuals [%zu,%zu) beyond n_people=%zu", what, ind0, ind0 + n, P.n_people);
+    HIPC(hipSetDevice(c->device));
+    GEVC(wait_planes(c));
+    return GEV_OK;
+}
+// genotype columns of the PLINK .ped text, one line per individual (the caller writes the six id columns in front)
+int gev_format_ped_text(gev_ctx* c, int pop, int chr, size_t ind_begin, size_t n_ind, const char* al0, const char* al1, char* out, size_t out_bytes)
+{
+    GEVC(ind_range_check(c, pop, chr, ind_begin, n_ind, "format_ped_text"));
+    ChrStatic& S = c->pop[pop].cs[chr];
+    const size_t line = 4 * S.L + 1;
+    if ((al0 == nullptr) != (al1 == nullptr)) return fail(GEV_EINVAL, "format_ped_text: al0 and al1 must both be given or both be NULL");
+    if (out_bytes < n_ind * line || (n_ind && !out)) return fail(GEV_EINVAL, "format_ped_text: buffer of %zu bytes, %zu needed", out_bytes, n_ind * line);
+    hipStream_t st = c->stream;
+    const char *d_al0 = nullptr, *d_al1 = nullptr;
+    if (al0) {
+        GEVC(c->d_tmp.ensure(std::max<size_t>(2 * S.L, 16), st));
+        HIPC(hipMemcpyAsync(c->d_tmp.p, al0, S.L, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(c->d_tmp.as<char>() + S.L, al1, S.L, hipMemcpyHostToDevice, st));
+        d_al0 = c->d_tmp.as<char>(); d_al1 = d_al0 + S.L;
+    }
+    const size_t chunk = std::max<size_t>((256u << 20) / line, 1);
+    for (size_t i = 0; i < n_ind; i += chunk) {
+        const size_t n = std::min(chunk, n_ind - i);
+        GEVC(stage_individuals(c, pop, chr, ind_begin + i, n));
+        GEVC(c->d_text.ensure(n * line, st));
+        hipLaunchKernelGGL(k_format_ped_text, dim3((unsigned)ceil_div(ceil_div(n * line, 16), 256)), dim3(256), 0, st, c->d_stage.as<u32>(), S.stride / 4, n, (u32)S.L, d_al0, d_al1, c->d_text.as<char>());
+        KCHECK();
+        HIPC(hipMemcpyAsync(out + i * line, c->d_text.p, n * line, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+    }
+    return GEV_OK;
+}
+// matrix_plink_ped rows (bit 2*snp + hap), ceil(2L/64) words per individual
+int gev_download_plink_matrix(gev_ctx* c, int pop, int chr, size_t ind_begin, size_t n_ind, u64* bits, size_t row_stride_words)
+{
+    GEVC(ind_range_check(c, pop, chr, ind_begin, n_ind, "download_plink_matrix"));
+    ChrStatic& S = c->pop[pop].cs[chr];
+    const size_t w32 = ceil_div(S.L, 32);                  // one source word -> one 64-bit output word
+    if (n_ind && (!bits || row_stride_words < w32)) return fail(GEV_EINVAL, "download_plink_matrix: bad output buffer (need %zu words per row)", w32);
+    hipStream_t st = c->stream;
+    const size_t chunk = std::max<size_t>((256u << 20) / std::max<size_t>(w32 * 8, 1), 1);
+    for (size_t i = 0; i < n_ind; i += chunk) {
+        const size_t n = std::min(chunk, n_ind - i);
+        GEVC(stage_individuals(c, pop, chr, ind_begin + i, n));
+        GEVC(c->d_text.ensure(std::max<size_t>(n * w32 * 8, 16), st));
+        if (w32) hipLaunchKernelGGL(k_interleave_haps, dim3((unsigned)ceil_div(n * w32, 256)), dim3(256), 0, st, c->d_stage.as<u32>(), S.stride / 4, n, (u32)w32, c->d_text.as<u64>(), w32);
+        KCHECK();
+        if (row_stride_words > w32)
+            for (size_t r = 0; r < n; r++) memset(bits + (i + r) * row_stride_words + w32, 0, (row_stride_words - w32) * 8);
+        if (w32) HIPC(hipMemcpy2DAsync(bits + i * row_stride_words, row_stride_words * 8, c->d_text.p, w32 * 8, w32 * 8, n, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
     }
     return GEV_OK;
 }

@@ -193,6 +193,16 @@ int gev_download_haps(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_row
 int gev_download_snp_major(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, uint64_t* bits, size_t row_stride_words);
 int gev_format_hap_text(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes);
 int gev_format_bed(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, uint8_t* out, size_t out_bytes);
+/* ---- PLINK siblings of the dense assembly (src/Simulation.cpp:1308-1416, src/format_plink.cpp:5-141), individual-major:
+ *  gev_download_plink_matrix : matrix_plink_ped of ras_convert_interval_to_format_plink (:1335-1362): row = individual
+ *                              ind_begin + i, bit 2*snp + hap; ceil(L/32) words per row
+ *  gev_format_ped_text       : the genotype columns format_plink::write_ped_map (:42-49) / write_ped01_map (:114-121) append
+ *                              to each line: L x " a b" then '\n' = 4*L + 1 bytes per individual.  al0/al1 = one allele
+ *                              letter per SNP (Legend.al0/al1, plink_map.al0/al1), or both NULL for "0"/"1" (--out_plink01).
+ *                              The six id columns (FID IID PID MID sex phen, :1391-1402) are host pedigree strings: the caller
+ *                              writes them in front of each line. */
+int gev_download_plink_matrix(gev_ctx*, int pop, int chr, size_t ind_begin, size_t n_ind, uint64_t* bits, size_t row_stride_words);
+int gev_format_ped_text(gev_ctx*, int pop, int chr, size_t ind_begin, size_t n_ind, const char* al0, const char* al1, char* out, size_t out_bytes);
 /* CV genotype matrix of ras_find_cv (the --debug .cvval dump, :2665-2683), FILE column order. */
 int gev_download_cv(gev_ctx*, int pop, int phen, int chr, uint64_t* bits, size_t row_stride_words);
 /* ancestry interval lists (the .int output, :1596-1633): hap_offsets has 2*n_people+1 entries;

@@ -52,11 +52,20 @@ def write_hap(path, bits):  # bits [nhap][L]; file is SNP-major text (format_hap
             f.write(" ".join("1" if b else "0" for b in bits[:, i]) + "\n")
 
 
+def legend_alleles(n):
+    """allele letters of the synthetic legends (they only matter to the PLINK .ped writer)"""
+    i = np.arange(n)
+    al0 = np.frombuffer(b"ACGT", dtype=np.uint8)[i % 4]
+    al1 = np.frombuffer(b"CGTA", dtype=np.uint8)[(i + i // 4) % 4]
+    return al0, al1
+
+
 def write_legend(path, pos):
+    al0, al1 = legend_alleles(len(pos))
     with open(path, "w") as f:
         f.write("id pos al0 al1\n")
         for i, p in enumerate(pos):
-            f.write(f"rs{i+1} {int(p)} A C\n")
+            f.write(f"rs{i+1} {int(p)} {chr(al0[i])} {chr(al1[i])}\n")
 
 
 def write_indv(path, n, prefix="id"):
@@ -302,6 +311,30 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             arrs[f"hapfile_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
             arrs[f"hapfile_pop{ip}_chr{ic}_size"] = np.int64(len(raw))
             arrs[f"hapfile_pop{ip}_chr{ic}_head"] = np.frombuffer(raw[:4096], dtype=np.uint8)
+    # the reference's PLINK text of the last generation (format_plink::write_ped_map / write_ped01_map, src/format_plink.cpp):
+    # both flags write the same <prefix>.ped, so one CLI run each.  Stored: hash of the whole file, hash of the genotype
+    # columns alone (each line after its six id columns = what gev_format_ped_text produces) and the id columns.
+    for tag, flag in (("ped", "--out_plink"), ("ped01", "--out_plink01")):
+        wd3 = os.path.join(wd, "cli_" + tag); os.makedirs(wd3)
+        args3 = [x if x != os.path.join(wd, "out") else os.path.join(wd3, "out") for x in args] + [flag]
+        with open(os.path.join(wd3, "log.txt"), "w") as log:
+            sh([os.path.join(ORACLE, "_ref", "GeneEvolve_ref")] + args3, stdout=log, stderr=subprocess.STDOUT)
+        for ip in range(len(case.pops)):
+            for ic, c in enumerate(case.pops[ip]["chrs"]):
+                raw = open(os.path.join(wd3, f"out.pop{ip+1}.gen{ngen}.chr{c}.ped"), "rb").read()
+                geno, ids = hashlib.sha256(), []
+                for line in raw.split(b"\n")[:-1]:
+                    tok = line.split(b" ", 6)
+                    ids.append([int(t) for t in tok[:6]])
+                    geno.update(b" " + tok[6] + b"\n")
+                k = f"{tag}file_pop{ip}_chr{ic}_"
+                arrs[k + "sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
+                arrs[k + "size"] = np.int64(len(raw))
+                arrs[k + "geno_sha"] = np.frombuffer(geno.digest(), dtype=np.uint8)
+                arrs[k + "ids"] = np.array(ids, dtype=np.int64)
+                if tag == "ped":
+                    al0, al1 = legend_alleles(len(case.pops[ip]["snp_pos"][ic]))
+                    arrs[f"pop{ip}_chr{ic}_al0"] = al0; arrs[f"pop{ip}_chr{ic}_al1"] = al1
 
     # gen 0
     d0 = parse_dump(os.path.join(wd, "d.gen0.txt"))

@@ -179,5 +179,45 @@ def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_l
                     assert len(txt) == int(fx[k + "size"]), f"{label}: .hap size"
                     assert np.array_equal(txt[:4096], fx[k + "head"]), f"{label}: .hap head differs"
                     assert np.array_equal(sha(txt), fx[k + "sha"]), f"{label}: .hap text differs from the reference's file (pop {ip} chr {ic})"
+    # the reference's own .ped files of the last generation (format_plink::write_ped_map / write_ped01_map)
+    if ngen == int(fx["n_gen"]) and lib.exports("format_ped_text"):
+        for ip in range(n_pop):
+            for ic in range(nchr):
+                check_ped_files(ctx, fx, ngen, ip, ic, label)
     ctx.close()
     return n_dense
+
+
+def interleave_haps(bits, L):
+    """numpy statement of matrix_plink_ped (src/Simulation.cpp:1335-1362): bit 2*ii+ihap of row ih, from the hap-major matrix"""
+    u = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, :L]
+    n = u.shape[0] // 2
+    m = np.zeros((n, 2 * L), dtype=np.uint8)
+    m[:, 0::2] = u[0::2]; m[:, 1::2] = u[1::2]
+    w = (2 * L + 63) // 64
+    out = np.zeros((n, w * 64), dtype=np.uint8); out[:, :2 * L] = m
+    return np.packbits(out, axis=1, bitorder="little").view(np.uint64)
+
+
+def check_ped_files(ctx, fx, ngen, ip, ic, label):
+    L = len(fx[f"pop{ip}_chr{ic}_snp_pos"])
+    n = ctx.pop_size(ip)
+    assert np.array_equal(ctx.download_plink_matrix(ip, ic), interleave_haps(ctx.download_haps(ip, ic), L)), f"{label}: matrix_plink_ped differs (pop {ip} chr {ic})"
+    for tag in ("ped", "ped01"):
+        k = f"{tag}file_pop{ip}_chr{ic}_"
+        if k + "sha" not in fx:
+            continue
+        al0 = fx[f"pop{ip}_chr{ic}_al0"] if tag == "ped" else None
+        al1 = fx[f"pop{ip}_chr{ic}_al1"] if tag == "ped" else None
+        txt = ctx.format_ped_text(ip, ic, al0, al1)
+        assert np.array_equal(sha(txt), fx[k + "geno_sha"]), f"{label}: .{tag} genotype columns differ from the reference's file (pop {ip} chr {ic})"
+        # whole file = the host's six id columns (FID IID PID MID sex phen, src/Simulation.cpp:1391-1402) + the device text
+        pre = f"g{ngen}_pop{ip}_postmig_" if f"g{ngen}_pop{ip}_postmig_ids" in fx else f"g{ngen}_pop{ip}_"
+        ids, sex = fx[pre + "ids"], fx[pre + "sex"]
+        cols = np.stack([ids[:, 1] + 1, ids[:, 0] + 1, ids[:, 1] + 1, ids[:, 2] + 1, sex.astype(np.int64), np.full(n, -9)], axis=1)
+        assert np.array_equal(cols, fx[k + "ids"]), f"{label}: .{tag} id columns"
+        lines = txt.reshape(n, 4 * L + 1)
+        h = hashlib.sha256()
+        for i in range(n):
+            h.update(" ".join(str(int(v)) for v in cols[i]).encode()); h.update(lines[i].tobytes())
+        assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), fx[k + "sha"]), f"{label}: .{tag} file differs from the reference's (pop {ip} chr {ic})"

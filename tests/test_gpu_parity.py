@@ -411,6 +411,20 @@ def test_snp_major_and_bed_packing_match_their_definition(gpu_lib):
         txt = g.format_hap_text(0, 0, s0, ns).reshape(ns, 4 * n + 1)
         assert (txt[:, -1] == ord("\n")).all() and (txt[:, 1::2][:, :2 * n] == ord(" ")).all()
         assert np.array_equal(txt[:, 0:4 * n:2] - ord("0"), H[:, s0:s0 + ns].T)
+    # PLINK individual-major siblings (ranges that start / end inside the population; L = 5000 is not a multiple of 32 or 64)
+    full = helpers.interleave_haps(g.download_haps(0, 0), L)
+    al0 = np.frombuffer(b"ACGT", dtype=np.uint8)[np.arange(L) % 4]; al1 = np.frombuffer(b"TGCA", dtype=np.uint8)[(np.arange(L) // 3) % 4]
+    for (i0, ni) in ((0, n), (1, 7), (330, 3), (5, 0)):
+        assert np.array_equal(g.download_plink_matrix(0, 0, i0, ni), full[i0:i0 + ni]), (i0, ni)
+        for letters in (False, True):
+            txt = g.format_ped_text(0, 0, al0 if letters else None, al1 if letters else None, i0, ni).reshape(ni, 4 * L + 1)
+            assert (txt[:, -1] == ord("\n")).all() and (txt[:, 0:4 * L:2] == ord(" ")).all()
+            for hp in (0, 1):
+                bits = H[2 * i0 + hp:2 * (i0 + ni):2, :]
+                want = np.where(bits == 1, al1, al0) if letters else bits + ord("0")
+                assert np.array_equal(txt[:, 1 + 2 * hp:4 * L:4], want), (i0, ni, letters, hp)
+    with pytest.raises(capi.GevError):
+        g.format_ped_text(0, 0, None, None, n - 1, 2)
     g.close()
 
 
