@@ -261,7 +261,7 @@ def main():
             sim.reproduce(P, total + j + 1, seeds=more[j], n_people=args.n_ind)
         tb, nb = ctx.timing_totals()
         iso = (tb[1] - ta[1]) / max(nb - na, 1)
-        ctx.set_overlap(None)
+        ctx.set_overlap(True)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "last_error", "version", "create", "destroy", "set_rmap", "set_mutmap", "set_snps", "set_cvs",
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
-    "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
+    "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
@@ -276,6 +276,15 @@ class GevContext:
         self._call("format_bed", C.c_int(pop), C.c_int(chr), C.c_size_t(snp_begin), C.c_size_t(n_snps), _p(out), C.c_size_t(nb))
         return out
 
+    def format_vcf_gt(self, pop, chr, snp_begin=0, n_snps=None):
+        """sample columns ("\\ta|b" per individual + newline) of the reference's VCF data lines (format_vcf::write_vcf_file)"""
+        L = self._nsnp[(pop, chr)]
+        n_snps = L - snp_begin if n_snps is None else n_snps
+        nb = n_snps * (4 * self.pop_size(pop) + 1)
+        out = np.zeros(nb, dtype=np.uint8)
+        self._call("format_vcf_gt", C.c_int(pop), C.c_int(chr), C.c_size_t(snp_begin), C.c_size_t(n_snps), _p(out), C.c_size_t(nb))
+        return out
+
     def download_plink_matrix(self, pop, chr, ind_begin=0, n_ind=None):
         """matrix_plink_ped rows (bit 2*snp + hap) of ras_convert_interval_to_format_plink"""
         L = self._nsnp[(pop, chr)]
@@ -349,8 +358,8 @@ class GevContext:
         return [float(x) for x in ms], n.value
 
     def set_overlap(self, on):
-        """True/False, or None for the automatic choice (default)"""
-        self._call("set_overlap", C.c_int(-1 if on is None else (1 if on else 0)))
+        """True (default) / False / 2 (sampling-only overlap), or None: decide from two timed serialised generations"""
+        self._call("set_overlap", C.c_int(-1 if on is None else int(on)))
 
     def set_stitch_mode(self, mode):
         self._call("set_stitch_mode", C.c_int(mode))

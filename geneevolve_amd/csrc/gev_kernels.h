@@ -1111,6 +1111,34 @@ __global__ void __launch_bounds__(256) k_format_hap_text(const u64* __restrict__
     if (o + 16 <= total) *reinterpret_cast<uint4*>(out + o) = u.v;
     else for (int b = 0; b < 16 && o + b < total; b++) out[o + b] = u.ch[b];
 }
+// VCF genotype columns of one data line (format_vcf::write_vcf_file, src/format_vcf.cpp:55-59): per individual "\ta|b"
+// (a, b = haplotype rows 2i, 2i+1 at this SNP), then '\n'; flat-stream layout as above
+__global__ void __launch_bounds__(256) k_format_vcf_gt(const u64* __restrict__ snpmajor, size_t stride_w64, size_t n_ind, u32 n_snps, char* __restrict__ out)
+{
+    const size_t line_len = 4 * n_ind + 1, total = (size_t)n_snps * line_len;
+    const size_t o = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (o >= total) return;
+    size_t j = o / line_len, p = o % line_len;
+    union { char ch[16]; uint4 v; } u;
+    u64 word = 0; size_t word_at = ~(size_t)0;
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        char ch;
+        if (o + b >= total) ch = 0;
+        else if (p == 4 * n_ind) ch = '\n';
+        else if ((p & 3) == 0) ch = '\t';
+        else if ((p & 3) == 2) ch = '|';
+        else {
+            const size_t h = p >> 1, at = j * stride_w64 + (h >> 6);      // p = 4i+1 -> row 2i, p = 4i+3 -> row 2i+1
+            if (at != word_at) { word = snpmajor[at]; word_at = at; }
+            ch = (char)('0' + (int)((word >> (h & 63)) & 1ull));
+        }
+        u.ch[b] = ch;
+        if (++p == line_len) { p = 0; j++; }
+    }
+    if (o + 16 <= total) *reinterpret_cast<uint4*>(out + o) = u.v;
+    else for (int b = 0; b < 16 && o + b < total; b++) out[o + b] = u.ch[b];
+}
 // PLINK .ped genotype columns (format_plink::write_ped_map / write_ped01_map, src/format_plink.cpp:42-49 / :114-121):
 // per individual  L x " a b"  then '\n', a/b = allele letters of haplotype 0/1 (al1 if the bit is set else al0; "1"/"0"
 // when al0 == NULL).  `rows` = staged hap-major rows (mutations applied) of individuals [0, n_ind); same flat-stream layout.

@@ -33,6 +33,30 @@ static int fail(int code, const char* fmt, ...)
 static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 static inline size_t round_up(size_t a, size_t b) { return ceil_div(a, b) * b; }
 
+// Device buffers that were outgrown while kernels may still be reading them: freeing (hipFree waits for the whole device)
+// would stall the host behind the running stitch, so they are parked here and released at the next point where the
+// device is idle anyway (gev_sync, serialised generations, gev_destroy) or when too much has piled up.
+struct Graveyard {
+    struct Item { void* p; size_t bytes; int device; };
+    std::vector<Item> items; size_t bytes = 0;
+    void park(void* p, size_t n) { int d = 0; (void)hipGetDevice(&d); items.push_back({p, n, d}); bytes += n; }
+    void drain(int device, bool device_is_idle)
+    {
+        bool any = false;
+        for (auto& it : items) any |= it.device == device;
+        if (!any) return;
+        int cur = 0; (void)hipGetDevice(&cur);
+        (void)hipSetDevice(device);
+        if (!device_is_idle) (void)hipDeviceSynchronize();
+        size_t w = 0;
+        for (auto& it : items) { if (it.device == device) { (void)hipFree(it.p); bytes -= it.bytes; } else items[w++] = it; }
+        items.resize(w);
+        (void)hipSetDevice(cur);
+    }
+};
+static Graveyard g_graveyard;                 // one host thread calls the seam
+static const size_t GRAVEYARD_LIMIT = (size_t)4 << 30;
+
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -45,12 +69,17 @@ struct DevBuf {
         size_t want = std::max<size_t>((size_t)(need * slack), 256);
         void* q = nullptr;
         hipError_t e = hipMalloc(&q, want);
-        if (e != hipSuccess && want > need) { want = std::max<size_t>(need, 256); e = hipMalloc(&q, want); }
+        if (e != hipSuccess && g_graveyard.bytes) {                      // out of memory with parked buffers: release them and retry
+            (void)hipGetLastError();
+            int d = 0; (void)hipGetDevice(&d); g_graveyard.drain(d, false);
+            e = hipMalloc(&q, want);
+        }
+        if (e != hipSuccess && want > need) { (void)hipGetLastError(); want = std::max<size_t>(need, 256); e = hipMalloc(&q, want); }
         if (e != hipSuccess) return fail(GEV_EDEVICE, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
         if (p) {
             if (keep && bytes) { HIPC(hipMemcpyAsync(q, p, bytes, hipMemcpyDeviceToDevice, st)); }
-            HIPC(hipDeviceSynchronize());      // the old buffer may still be in use on the other stream
-            (void)hipFree(p);
+            g_graveyard.park(p, bytes);        // the old buffer may still be in use on either stream
+            if (g_graveyard.bytes > GRAVEYARD_LIMIT) { int d = 0; (void)hipGetDevice(&d); g_graveyard.drain(d, false); }
         }
         p = q; bytes = want;
         return GEV_OK;
@@ -129,7 +158,8 @@ struct gev_ctx {
     int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
     unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels (GEV_SAMPLE_GRID)
     bool serialize = false;        // wait for every stitch (no overlap between the two streams)
-    int overlap_mode = -1;         // -1 auto (decide after two serialised generations), 0 never, 1 always
+    int overlap_mode = 1;          // 1 everything (default), 0 never, 2 sampling only, -1 decide after two serialised generations
+    bool sparse_after_stitch = false;   // mode 2: the memory-bound sparse/CV/A-D kernels wait for the running stitch, only the ALU-bound sampling shares the GPU with it
     int auto_gens = 0; double auto_small_ms = 0, auto_stitch_ms = 0;
     unsigned stitch_lds_pad = 0;   // unused dynamic LDS per stitch workgroup: limits workgroups per CU (160 KiB / CU)
     DevBuf d_snpmajor, d_text;
@@ -255,7 +285,9 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     GevRngTables T; gev_build_rng_tables(T);
     GEVC(h2d(c.get(), c->d_tables, &T, sizeof T));
     if (const char* e = getenv("GEV_SERIALIZE")) c->overlap_mode = atoi(e) != 0 ? 0 : 1;
-    c->serialize = c->overlap_mode != 1;                             // auto starts serialised
+    if (const char* e = getenv("GEV_OVERLAP")) { const int v = atoi(e); c->overlap_mode = v < 0 ? -1 : std::min(v, 2); }
+    c->serialize = c->overlap_mode <= 0;                             // auto starts serialised
+    c->sparse_after_stitch = c->overlap_mode == 2;
     if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = (unsigned)g; }
     if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // tuning knob: stitch workgroups per CU (default: unlimited = 8)
         const int occ = atoi(e);
@@ -270,6 +302,7 @@ void gev_destroy(gev_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     if (c->stream_big) { (void)hipStreamSynchronize(c->stream_big); (void)hipStreamDestroy(c->stream_big); }
+    if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
     for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
@@ -614,7 +647,7 @@ static int harvest_timing(gev_ctx* c, gev_ctx::Scratch& sc)
     // comparable (many chromosomes, short rows) the starved small stream only delays everything: stay serialised
     if (c->overlap_mode < 0 && c->serialize && c->auto_gens < 2) {
         c->auto_small_ms += ms[0] + ms[2]; c->auto_stitch_ms += ms[1];
-        if (++c->auto_gens == 2) c->serialize = !(c->auto_small_ms < 0.35 * c->auto_stitch_ms);
+        if (++c->auto_gens == 2) c->serialize = !(c->auto_small_ms < 4.0 * c->auto_stitch_ms);   // overlap unless the stitch is negligible
     }
     sc.timing_pending = false;
     return GEV_OK;
@@ -661,6 +694,7 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
     hipLaunchKernelGGL(k_bk_to_idx, dim3((unsigned)ceil_div(2 * T, 256)), dim3(256), 0, st, chrs, nchr, 2 * T, sd);
     KCHECK();
     HIPC(hipEventRecord(sc.t[1], st));
+    if (c->sparse_after_stitch && c->planes_pending) HIPC(hipStreamWaitEvent(st, c->ev_planes, 0));
     // ---- sparse state: mutation lists + ancestry intervals + CV planes
     const int cur = P.cur, alt = P.cur ^ 1;
     GEVC(c->d_cnt.ensure((rows + 1) * sizeof(u32), st));
@@ -753,7 +787,10 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     HIPC(hipEventRecord(sc.ev_stitch_done, sb));
     HIPC(hipEventRecord(c->ev_planes, sb));
     sc.timing_pending = true; sc.stitch_pending = true; c->planes_pending = true;
-    if (c->serialize) { HIPC(hipStreamSynchronize(sb)); GEVC(harvest_timing(c, sc)); sc.stitch_pending = false; }   // no overlap: timings are final right away
+    if (c->serialize) {                                  // no overlap: timings are final right away
+        HIPC(hipStreamSynchronize(sb)); GEVC(harvest_timing(c, sc)); sc.stitch_pending = false;
+        if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
+    }
     return GEV_OK;
 }
 
@@ -853,6 +890,7 @@ int gev_sync(gev_ctx* c)
     HIPC(hipStreamSynchronize(c->stream)); HIPC(hipStreamSynchronize(c->stream_big));
     for (auto& sc : c->sc) { GEVC(harvest_timing(c, sc)); sc.stitch_pending = false; }
     c->planes_pending = false;
+    if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
     return GEV_OK;
 }
 // cumulative kernel time per phase over all harvested generations: sampling, dense stitch, sparse, sum
@@ -1555,6 +1593,25 @@ int gev_download_plink_matrix(gev_ctx* c, int pop, int chr, size_t ind_begin, si
     }
     return GEV_OK;
 }
+// GT columns of the VCF data lines: n_snps * (4*n_people + 1) bytes; the caller writes the nine fixed columns in front
+int gev_format_vcf_gt(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes)
+{
+    GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "format_vcf_gt"));
+    PopState& P = c->pop[pop];
+    const size_t line = 4 * P.n_people + 1;
+    if (out_bytes < n_snps * line || (n_snps && !out)) return fail(GEV_EINVAL, "format_vcf_gt: buffer of %zu bytes, %zu needed", out_bytes, n_snps * line);
+    const size_t chunk = snp_chunk(line);
+    for (size_t s = 0; s < n_snps; s += chunk) {
+        const size_t ns = std::min(chunk, n_snps - s); size_t stride;
+        GEVC(snp_major_device(c, pop, chr, snp_begin + s, ns, stride));
+        GEVC(c->d_text.ensure(ns * line, c->stream));
+        hipLaunchKernelGGL(k_format_vcf_gt, dim3((unsigned)ceil_div(ceil_div(ns * line, 16), 256)), dim3(256), 0, c->stream, c->d_snpmajor.as<u64>(), stride, P.n_people, (u32)ns, c->d_text.as<char>());
+        KCHECK();
+        HIPC(hipMemcpyAsync(out + s * line, c->d_text.p, ns * line, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    return GEV_OK;
+}
 // PLINK .bed body (SNP-major, without the 3 magic bytes 0x6c 0x1b 0x01): n_snps * ceil(n_people/4) bytes
 int gev_format_bed(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, uint8_t* out, size_t out_bytes)
 {
@@ -1661,7 +1718,8 @@ int gev_set_overlap(gev_ctx* c, int on)
 {
     if (!c) return fail(GEV_EINVAL, "null");
     GEVC(gev_sync(c));
-    c->overlap_mode = on < 0 ? -1 : (on ? 1 : 0);
+    c->overlap_mode = on < 0 ? -1 : std::min(on, 2);
+    c->sparse_after_stitch = c->overlap_mode == 2;
     if (c->overlap_mode >= 0) c->serialize = c->overlap_mode == 0; else { c->serialize = true; c->auto_gens = 0; c->auto_small_ms = c->auto_stitch_ms = 0; }
     return GEV_OK;
 }

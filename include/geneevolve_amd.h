@@ -189,10 +189,16 @@ int gev_download_haps(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_row
  *                           lines: per line "b b ... b \n", i.e. n_snps * (4*n_people + 1) bytes
  *  gev_format_bed         : PLINK .bed body (SNP-major, 2 bits / individual, A1 = allele 1: 00 = 1/1, 10 = het,
  *                           11 = 0/0, pad 00; without the 3 magic bytes): n_snps * ceil(n_people/4) bytes.  The
- *                           reference has no .bed writer (BASELINE config 5 asks for one): checked by definition. */
+ *                           reference has no .bed writer (BASELINE config 5 asks for one): checked by definition.
+ *  gev_format_vcf_gt      : the sample columns format_vcf::write_vcf_file (src/format_vcf.cpp:55-59) appends to each data
+ *                           line: per individual "\ta|b", then '\n' = n_snps * (4*n_people + 1) bytes; the nine fixed
+ *                           columns (CHROM..FORMAT, host strings of the input VCF) are the caller's.  The reference's
+ *                           VCF-panel path cannot run here (format_vcf.cpp:367-389 falls off a bool function; crashes
+ *                           under g++ 11 -O3): checked by definition and against the oracle -- parity unpinned. */
 int gev_download_snp_major(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, uint64_t* bits, size_t row_stride_words);
 int gev_format_hap_text(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes);
 int gev_format_bed(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, uint8_t* out, size_t out_bytes);
+int gev_format_vcf_gt(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes);
 /* ---- PLINK siblings of the dense assembly (src/Simulation.cpp:1308-1416, src/format_plink.cpp:5-141), individual-major:
  *  gev_download_plink_matrix : matrix_plink_ped of ras_convert_interval_to_format_plink (:1335-1362): row = individual
  *                              ind_begin + i, bit 2*snp + hap; ceil(L/32) words per row
@@ -228,9 +234,11 @@ int gev_stream(gev_ctx*, void** stream);
  * genotype planes keeps running on a second HIP stream and every later call is ordered after it
  * where it needs the planes.  gev_sync waits for all device work of the context. */
 int gev_sync(gev_ctx*);
-/* on > 0: the stitch always overlaps later work as described above; on == 0: gev_reproduce waits for it (kernel
- * timings without interference between the two streams); on < 0 (default): automatic -- two serialised
- * generations are timed and overlap is switched on if the small kernels take < 0.35 of the stitch time. */
+/* on == 1 (default): the stitch overlaps later work as described above; on == 0: gev_reproduce waits for it (kernel
+ * timings without interference between the two streams); on == 2: only the ALU-bound sampling of the next generation
+ * shares the GPU with the stitch, its memory-bound sparse/A-D kernels wait for it; on < 0: two serialised generations
+ * are timed first and overlap is switched on unless the stitch is negligible (< 1/4 of the small kernels).
+ * Environment: GEV_OVERLAP=<on> sets the initial mode. */
 int gev_set_overlap(gev_ctx*, int on);
 /* kernel timing measured with HIP events on the library's own streams: ms[0] = sampling
  * (crossover + mutation + seed chain), ms[1] = dense stitch (genotype planes), ms[2] = sparse state

@@ -68,6 +68,19 @@ def write_legend(path, pos):
             f.write(f"rs{i+1} {int(p)} {chr(al0[i])} {chr(al1[i])}\n")
 
 
+def write_vcf(path, chrom, founders, pos, prefix):
+    """phased biallelic VCF of a founder panel [nhap][L] with the same sample ids / alleles as the .indv / .legend files"""
+    al0, al1 = legend_alleles(len(pos))
+    n = founders.shape[0] // 2
+    F = founders.astype(np.uint8)
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"{prefix}{i+1}" for i in range(n)) + "\n")
+        for j, p in enumerate(pos):
+            gts = "\t".join(f"{F[2*i, j]}|{F[2*i+1, j]}" for i in range(n))
+            f.write(f"{chrom}\t{int(p)}\trs{j+1}\t{chr(al0[j])}\t{chr(al1[j])}\t.\tPASS\t.\tGT\t{gts}\n")
+
+
 def write_indv(path, n, prefix="id"):
     with open(path, "w") as f:
         for i in range(n):
@@ -222,7 +235,7 @@ class Case:
         self.pops.append(kw)
 
 
-def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_parts_gens=None):
+def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_parts_gens=None, vcf=False):
     wd = os.path.join(WORK, case.name)
     shutil.rmtree(wd, ignore_errors=True)
     os.makedirs(wd)
@@ -335,6 +348,50 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
                 if tag == "ped":
                     al0, al1 = legend_alleles(len(case.pops[ip]["snp_pos"][ic]))
                     arrs[f"pop{ip}_chr{ic}_al0"] = al0; arrs[f"pop{ip}_chr{ic}_al1"] = al1
+
+    # the reference's VCF output (format_vcf::write_vcf_file, src/format_vcf.cpp:44-61): it only exists for a VCF reference
+    # panel, so the same founders are also written as phased VCF and the stock CLI is run on them with --out_vcf; the
+    # run is the same simulation (identical .info files are asserted).  Stored: hash of the GT columns of every data line
+    # ("\ta|b" per individual + newline = what gev_format_vcf_gt produces), hash of the whole data section.
+    # NOT USED (vcf=False everywhere): built with its own flags (-O3) by g++ 11 the reference crashes on every VCF
+    # reference panel -- format_vcf::read_vcf_header_sample (src/format_vcf.cpp:367-389) has no return statement
+    # (undefined behaviour) -- so gev_format_vcf_gt is checked by definition and against the oracle only.
+    if vcf:
+        wd4 = os.path.join(wd, "cli_vcf"); os.makedirs(wd4)
+        args4 = [x if x != os.path.join(wd, "out") else os.path.join(wd4, "out") for x in args] + ["--out_vcf"]
+        for ip, P in enumerate(case.pops):
+            addr = os.path.join(wd4, f"p{ip}.vcfaddr.txt")
+            with open(addr, "w") as f:
+                f.write("chr vcf\n")
+                for ic, c in enumerate(P["chrs"]):
+                    fn = os.path.join(wd4, f"p{ip}.chr{c}.vcf")
+                    write_vcf(fn, c, P["founders"][ic], P["snp_pos"][ic], f"p{ip}i")
+                    f.write(f"{c} {fn}\n")
+            k = args4.index(os.path.join(wd, f"p{ip}.hapaddr.txt"))
+            args4[k - 1] = "--file_ref_vcf"; args4[k] = addr
+        with open(os.path.join(wd4, "log.txt"), "w") as log:
+            sh([os.path.join(ORACLE, "_ref", "GeneEvolve_ref")] + args4, stdout=log, stderr=subprocess.STDOUT)
+        for g in range(ngen + 1):
+            for ip in range(len(case.pops)):
+                fa = os.path.join(wd, f"out.info.pop{ip+1}.gen{g}.txt"); fb = os.path.join(wd4, f"out.info.pop{ip+1}.gen{g}.txt")
+                assert open(fa, "rb").read() == open(fb, "rb").read(), f"VCF-reference run != hap-reference run at gen {g} pop {ip+1}"
+        for ip in range(len(case.pops)):
+            for ic, c in enumerate(case.pops[ip]["chrs"]):
+                raw = open(os.path.join(wd4, f"out.pop{ip+1}.gen{ngen}.chr{c}.vcf"), "rb").read()
+                gt, body, samples = hashlib.sha256(), hashlib.sha256(), None
+                for line in raw.split(b"\n")[:-1]:
+                    if line.startswith(b"##"):
+                        continue
+                    if line.startswith(b"#"):
+                        samples = line.split(b"\t")[9:]
+                        continue
+                    tok = line.split(b"\t", 9)
+                    gt.update(b"\t" + tok[9] + b"\n"); body.update(line + b"\n")
+                k = f"vcffile_pop{ip}_chr{ic}_"
+                arrs[k + "gt_sha"] = np.frombuffer(gt.digest(), dtype=np.uint8)
+                arrs[k + "body_sha"] = np.frombuffer(body.digest(), dtype=np.uint8)
+                arrs[k + "n_samples"] = np.int64(len(samples))
+                arrs[k + "first_sample"] = np.frombuffer(samples[0], dtype=np.uint8)
 
     # gen 0
     d0 = parse_dump(os.path.join(wd, "d.gen0.txt"))

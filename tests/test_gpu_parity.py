@@ -411,6 +411,9 @@ def test_snp_major_and_bed_packing_match_their_definition(gpu_lib):
         txt = g.format_hap_text(0, 0, s0, ns).reshape(ns, 4 * n + 1)
         assert (txt[:, -1] == ord("\n")).all() and (txt[:, 1::2][:, :2 * n] == ord(" ")).all()
         assert np.array_equal(txt[:, 0:4 * n:2] - ord("0"), H[:, s0:s0 + ns].T)
+        gt = g.format_vcf_gt(0, 0, s0, ns).reshape(ns, 4 * n + 1)            # "\ta|b" per individual (format_vcf.cpp:55-59)
+        assert (gt[:, -1] == ord("\n")).all() and (gt[:, 0:4 * n:4] == ord("\t")).all() and (gt[:, 2:4 * n:4] == ord("|")).all()
+        assert np.array_equal(gt[:, 1:4 * n:4] - ord("0"), H[0::2, s0:s0 + ns].T) and np.array_equal(gt[:, 3:4 * n:4] - ord("0"), H[1::2, s0:s0 + ns].T)
     # PLINK individual-major siblings (ranges that start / end inside the population; L = 5000 is not a multiple of 32 or 64)
     full = helpers.interleave_haps(g.download_haps(0, 0), L)
     al0 = np.frombuffer(b"ACGT", dtype=np.uint8)[np.arange(L) % 4]; al1 = np.frombuffer(b"TGCA", dtype=np.uint8)[(np.arange(L) // 3) % 4]
@@ -482,6 +485,8 @@ def test_randomised_small_configurations_against_oracle(gpu_lib, oracle_lib):
                 for p in range(nphen):
                     assert np.array_equal(g.download_cv(0, p, k), o.download_cv(0, p, k)), f"trial {trial} gen {gen} chr {k}: CV matrix"
                 assert np.array_equal(g.format_hap_text(0, k), o.format_hap_text(0, k))
+                assert np.array_equal(g.format_vcf_gt(0, k), o.format_vcf_gt(0, k)) and np.array_equal(g.format_ped_text(0, k), o.format_ped_text(0, k))
+                assert np.array_equal(g.download_plink_matrix(0, k), o.download_plink_matrix(0, k))
             npop = n_off
         g.close(); o.close()
 
