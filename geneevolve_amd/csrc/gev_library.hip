@@ -165,18 +165,30 @@ struct gev_ctx {
     DevBuf d_snpmajor, d_text;
     DevBuf d_sex0, d_gef_flag, d_gef_first, d_gef_red, d_gef_io;
     DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
+    // chromosome lanes: the per-chromosome chains of the sparse / A-D phases (row-parallel, latency-bound kernels) are
+    // independent, so chromosome k runs on lane k % n_lanes; lane 0 is `stream`, the others fork from / join into it
+    static const int MAX_LANES = 4;
+    struct Lane { hipStream_t st = nullptr; hipEvent_t done = nullptr; DevBuf d_cnt, d_sums, d_cvm; };
+    Lane lane[MAX_LANES];
+    int n_lanes = 1;
+    hipEvent_t ev_fork = nullptr;
     std::map<double, GevThr> thr_cache;
 };
 
 // ------------------------------------------------------------------------------------------
-static int scan_u32(gev_ctx* c, const u32* in, size_t n, u32* out /*n+1*/, u32* total_host)
+static int scan_u32_on(hipStream_t st, DevBuf& sums, const u32* in, size_t n, u32* out /*n+1*/)
 {
     const size_t nb = ceil_div(n + 1, SCAN_ITEMS);
-    GEVC(c->d_sums.ensure(nb * sizeof(u32), c->stream));
-    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(256), 0, c->stream, in, n, c->d_sums.as<u32>());
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, c->stream, c->d_sums.as<u32>(), nb);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(256), 0, c->stream, in, n, c->d_sums.as<u32>(), out);
+    GEVC(sums.ensure(nb * sizeof(u32), st));
+    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums.as<u32>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, sums.as<u32>(), nb);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums.as<u32>(), out);
     KCHECK();
+    return GEV_OK;
+}
+static int scan_u32(gev_ctx* c, const u32* in, size_t n, u32* out /*n+1*/, u32* total_host)
+{
+    GEVC(scan_u32_on(c->stream, c->d_sums, in, n, out));
     if (total_host) {
         HIPC(hipMemcpyAsync(total_host, out + n, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
@@ -271,6 +283,14 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     for (auto& ev : c->ev) HIPC(hipEventCreate(&ev));
     HIPC(hipStreamCreateWithPriority(&c->stream_big, hipStreamNonBlocking, prio_least));
     HIPC(hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming));
+    c->n_lanes = std::max(1, std::min(nchr, (int)gev_ctx::MAX_LANES));
+    if (const char* e = getenv("GEV_LANES")) c->n_lanes = std::max(1, std::min(atoi(e), (int)gev_ctx::MAX_LANES));
+    c->lane[0].st = c->stream;
+    for (int l = 1; l < c->n_lanes; l++) {
+        HIPC(hipStreamCreateWithPriority(&c->lane[l].st, hipStreamNonBlocking, prio_greatest));
+        HIPC(hipEventCreateWithFlags(&c->lane[l].done, hipEventDisableTiming));
+    }
+    HIPC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (auto& sc : c->sc) {
         HIPC(hipEventCreateWithFlags(&sc.ev_small_done, hipEventDisableTiming));
         HIPC(hipEventCreateWithFlags(&sc.ev_stitch_done, hipEventDisableTiming));
@@ -305,6 +325,11 @@ void gev_destroy(gev_ctx* c)
     if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int l = 1; l < gev_ctx::MAX_LANES; l++) {
+        if (c->lane[l].st) { (void)hipStreamSynchronize(c->lane[l].st); (void)hipStreamDestroy(c->lane[l].st); }
+        if (c->lane[l].done) (void)hipEventDestroy(c->lane[l].done);
+    }
     for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
     hipStream_t s = c->stream;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -652,6 +677,22 @@ static int harvest_timing(gev_ctx* c, gev_ctx::Scratch& sc)
     sc.timing_pending = false;
     return GEV_OK;
 }
+// side lanes start after everything enqueued on `stream` so far / `stream` continues after every lane has finished
+static int lanes_fork(gev_ctx* c)
+{
+    if (c->n_lanes < 2) return GEV_OK;
+    HIPC(hipEventRecord(c->ev_fork, c->stream));
+    for (int l = 1; l < c->n_lanes; l++) HIPC(hipStreamWaitEvent(c->lane[l].st, c->ev_fork, 0));
+    return GEV_OK;
+}
+static int lanes_join(gev_ctx* c)
+{
+    for (int l = 1; l < c->n_lanes; l++) {
+        HIPC(hipEventRecord(c->lane[l].done, c->lane[l].st));
+        HIPC(hipStreamWaitEvent(c->stream, c->lane[l].done, 0));
+    }
+    return GEV_OK;
+}
 static SampleDev make_sd(gev_ctx* c, gev_ctx::Scratch& sc, size_t T)
 {
     SampleDev sd;
@@ -697,46 +738,50 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
     if (c->sparse_after_stitch && c->planes_pending) HIPC(hipStreamWaitEvent(st, c->ev_planes, 0));
     // ---- sparse state: mutation lists + ancestry intervals + CV planes
     const int cur = P.cur, alt = P.cur ^ 1;
-    GEVC(c->d_cnt.ensure((rows + 1) * sizeof(u32), st));
+    for (int l = 0; l < c->n_lanes; l++) GEVC(c->lane[l].d_cnt.ensure((rows + 1) * sizeof(u32), st));
+    GEVC(lanes_fork(c));
     const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
     const double grow = (double)rows / (double)std::max<size_t>(2 * P.n_people, 1);
     for (int k = 0; k < nchr; k++) {
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
+        gev_ctx::Lane& ln = c->lane[k % c->n_lanes];
+        hipStream_t ls = ln.st;
         const u64 bp0 = S.rbp.front(), bpe = S.rbp.back();
         // capacity guess: last generation's total scaled to the new size, plus room for this generation's events
         size_t want = std::max<size_t>(cs.mut_need, (size_t)(cs.mut_total[cur] * grow * 1.5) + rows * 4 + 4096);
-        GEVC(cs.mpos[alt].ensure(want * sizeof(u64), st, false, 2.0));        // grow geometrically: lists lengthen every generation
+        GEVC(cs.mpos[alt].ensure(want * sizeof(u64), ls, false, 2.0));        // grow geometrically: lists lengthen every generation
         const u32 mcap = (u32)std::min<size_t>(cs.mpos[alt].bytes / sizeof(u64), 0xfffffff0u);
-        hipLaunchKernelGGL((k_mutlist<false>), dim3(row_blocks), dim3(256), 0, st, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
-                           c->d_cnt.as<u32>(), (const u32*)nullptr, (u64*)nullptr, rows, k, nchr, bp0, bpe, (int)has_mut, 0u, sd);
+        hipLaunchKernelGGL((k_mutlist<false>), dim3(row_blocks), dim3(256), 0, ls, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
+                           ln.d_cnt.as<u32>(), (const u32*)nullptr, (u64*)nullptr, rows, k, nchr, bp0, bpe, (int)has_mut, 0u, sd);
         KCHECK();
-        GEVC(scan_u32(c, c->d_cnt.as<u32>(), rows, cs.moff[alt].as<u32>(), nullptr));
-        hipLaunchKernelGGL((k_mutlist<true>), dim3(row_blocks), dim3(256), 0, st, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
+        GEVC(scan_u32_on(ls, ln.d_sums, ln.d_cnt.as<u32>(), rows, cs.moff[alt].as<u32>()));
+        hipLaunchKernelGGL((k_mutlist<true>), dim3(row_blocks), dim3(256), 0, ls, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
                            (u32*)nullptr, cs.moff[alt].as<u32>(), cs.mpos[alt].as<u64>(), rows, k, nchr, bp0, bpe, (int)has_mut, mcap, sd);
-        hipLaunchKernelGGL(k_collect_total, dim3(1), dim3(64), 0, st, cs.moff[alt].as<u32>(), rows, sd.status + ST_TOTALS + 2 * k);
+        hipLaunchKernelGGL(k_collect_total, dim3(1), dim3(64), 0, ls, cs.moff[alt].as<u32>(), rows, sd.status + ST_TOTALS + 2 * k);
         KCHECK();
         if (c->track_intervals) {
             want = std::max<size_t>(cs.parts_need, (size_t)(cs.parts_total[cur] * grow * 1.5) + rows * 4 + 4096);
-            GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), st, false, 2.0));
+            GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), ls, false, 2.0));
             const u32 pcap = (u32)std::min<size_t>(cs.parts[alt].bytes / sizeof(gev_part), 0xfffffff0u);
-            hipLaunchKernelGGL((k_parts<false>), dim3(row_blocks), dim3(256), 0, st, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
-                               c->d_cnt.as<u32>(), (const u32*)nullptr, (gev_part*)nullptr, rows, k, nchr, bp0, bpe, 0u, sd);
+            hipLaunchKernelGGL((k_parts<false>), dim3(row_blocks), dim3(256), 0, ls, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
+                               ln.d_cnt.as<u32>(), (const u32*)nullptr, (gev_part*)nullptr, rows, k, nchr, bp0, bpe, 0u, sd);
             KCHECK();
-            GEVC(scan_u32(c, c->d_cnt.as<u32>(), rows, cs.poff[alt].as<u32>(), nullptr));
-            hipLaunchKernelGGL((k_parts<true>), dim3(row_blocks), dim3(256), 0, st, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
+            GEVC(scan_u32_on(ls, ln.d_sums, ln.d_cnt.as<u32>(), rows, cs.poff[alt].as<u32>()));
+            hipLaunchKernelGGL((k_parts<true>), dim3(row_blocks), dim3(256), 0, ls, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
                                (u32*)nullptr, cs.poff[alt].as<u32>(), cs.parts[alt].as<gev_part>(), rows, k, nchr, bp0, bpe, pcap, sd);
-            hipLaunchKernelGGL(k_collect_total, dim3(1), dim3(64), 0, st, cs.poff[alt].as<u32>(), rows, sd.status + ST_TOTALS + 2 * k + 1);
+            hipLaunchKernelGGL(k_collect_total, dim3(1), dim3(64), 0, ls, cs.poff[alt].as<u32>(), rows, sd.status + ST_TOTALS + 2 * k + 1);
             KCHECK();
         }
         for (int p = 0; p < c->nphen; p++) {
             CvStatic& V = P.cv[p][k];
             const u32 nsub = 1 + c->rp_bits;
-            hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows * V.sub_w32 * nsub, 256)), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows * V.sub_w32 * nsub, 256)), dim3(256), 0, ls,
                                P.cvp[p][k][alt].as<u32>(), P.cvp[p][k][cur].as<u32>(), V.stride_w32, V.sub_w32, nsub, rows,
                                V.d_pos_sorted.as<u64>(), V.C, k, nchr, sd);
             KCHECK();
         }
     }
+    GEVC(lanes_join(c));
     // ---- gamete grouping by source individual for the parent-major stitch (same for every chromosome)
     if (c->stitch_mode == 0) {
         const size_t n_parent = P.n_phys;
@@ -915,42 +960,46 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
     GEVC(c->d_add.ensure(n * nphen * sizeof(double), st)); GEVC(c->d_dom.ensure(n * nphen * sizeof(double), st));
     GEVC(c->d_flag.ensure(16, st));
     HIPC(hipMemsetAsync(c->d_flag.p, 0xff, 4, st));
+    GEVC(lanes_fork(c));
     for (int p = 0; p < nphen; p++)
         for (int k = 0; k < nchr; k++) {
             CvStatic& V = P.cv[p][k]; ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
+            gev_ctx::Lane& ln = c->lane[k % c->n_lanes];
+            hipStream_t ls = ln.st;
             double* ao = c->d_addchr.as<double>() + (size_t)k * nphen + p;
             double* dout = c->d_domchr.as<double>() + (size_t)k * nphen + p;
-            GEVC(c->d_cvm.ensure(std::max<size_t>(rows * V.sub_w32 * sizeof(u32), 16), st));
-            hipLaunchKernelGGL(k_cv_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st,
-                               P.cvp[p][k][buf].as<u32>(), V.stride_w32, V.sub_w32, c->d_cvm.as<u32>(), rows,
+            GEVC(ln.d_cvm.ensure(std::max<size_t>(rows * V.sub_w32 * sizeof(u32), 16), ls));
+            hipLaunchKernelGGL(k_cv_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, ls,
+                               P.cvp[p][k][buf].as<u32>(), V.stride_w32, V.sub_w32, ln.d_cvm.as<u32>(), rows,
                                cs.moff[buf].as<u32>(), cs.mpos[buf].as<u64>(), V.d_pos_sorted.as<u64>(), V.C);
-            HIPC(hipMemsetAsync(V.d_counts.p, 0, std::max<size_t>(V.C, 1) * sizeof(u32), st));
+            HIPC(hipMemsetAsync(V.d_counts.p, 0, std::max<size_t>(V.C, 1) * sizeof(u32), ls));
             if (V.C) {
                 const unsigned gy = (unsigned)std::min<size_t>(std::max<size_t>(rows / 512, 1), 256);
-                hipLaunchKernelGGL(k_cv_count, dim3((unsigned)ceil_div(V.C, 256), gy), dim3(256), 0, st, c->d_cvm.as<u32>(), V.sub_w32, rows, V.C, V.d_counts.as<u32>());
+                hipLaunchKernelGGL(k_cv_count, dim3((unsigned)ceil_div(V.C, 256), gy), dim3(256), 0, ls, ln.d_cvm.as<u32>(), V.sub_w32, rows, V.C, V.d_counts.as<u32>());
             }
             // fast path: one root population and the block's rows fit LDS; else the general per-individual kernel
             const u32 S1 = V.sub_w32 | 1u;
             int ipb = 0;
             if (c->rp_bits == 0 && V.C) { for (int cand : {256, 128, 64}) if ((size_t)2 * cand * S1 * 4 <= 64 * 1024) { ipb = cand; break; } }
             if (ipb) {
-                GEVC(V.d_tab.ensure((size_t)V.C * 6 * sizeof(double), st));
-                hipLaunchKernelGGL(k_cv_table, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, st, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n,
+                GEVC(V.d_tab.ensure((size_t)V.C * 6 * sizeof(double), ls));
+                hipLaunchKernelGGL(k_cv_table, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, ls, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n,
                                    V.d_a.as<double>(), V.d_d.as<double>(), V.d_pos_file.as<u64>(), S.rbp.front(), S.rbp.back(), V.vd, V.d_frq.as<double>(), V.d_tab.as<double>());
                 const size_t lds = (size_t)2 * ipb * S1 * 4;
                 const unsigned nb = (unsigned)ceil_div(n, ipb);
-                if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb), dim3(256), lds, st, c->d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
-                else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb), dim3(128), lds, st, c->d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
-                else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb), dim3(64), lds, st, c->d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
+                if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb), dim3(256), lds, ls, ln.d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
+                else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb), dim3(128), lds, ls, ln.d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
+                else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb), dim3(64), lds, ls, ln.d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
             } else {
-                if (V.C) hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, st, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n, V.d_frq.as<double>());
-                hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
-                                   c->d_cvm.as<u32>(), V.sub_w32, P.cvp[p][k][buf].as<u32>(), V.stride_w32, c->rp_bits,
+                if (V.C) hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, ls, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n, V.d_frq.as<double>());
+                hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ls,
+                                   ln.d_cvm.as<u32>(), V.sub_w32, P.cvp[p][k][buf].as<u32>(), V.stride_w32, c->rp_bits,
                                    V.d_col_of_icv.as<u32>(), V.d_frq.as<double>(), V.d_aptr.as<const double*>(), V.d_dptr.as<const double*>(), pop,
                                    V.d_pos_file.as<u64>(), S.rbp.front(), S.rbp.back(), V.vd, V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
             }
             KCHECK();
         }
+    GEVC(lanes_join(c));
     hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_addchr.as<double>(), c->d_add.as<double>(), n, nchr, nphen);
     hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_domchr.as<double>(), c->d_dom.as<double>(), n, nchr, nphen);
     KCHECK();
