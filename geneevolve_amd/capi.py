@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "last_error", "version", "create", "destroy", "set_rmap", "set_mutmap", "set_snps", "set_cvs",
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
-    "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
+    "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
@@ -283,6 +283,13 @@ class GevContext:
         nb = n_snps * (4 * self.pop_size(pop) + 1)
         out = np.zeros(nb, dtype=np.uint8)
         self._call("format_vcf_gt", C.c_int(pop), C.c_int(chr), C.c_size_t(snp_begin), C.c_size_t(n_snps), _p(out), C.c_size_t(nb))
+        return out
+
+    def rank_f64(self, x):
+        """CommFunc::ras_rank (zero-based, ties by index)"""
+        x = _arr(x, np.float64)
+        out = np.zeros(len(x), dtype=np.uint64)
+        self._call("rank_f64", _p(x), C.c_size_t(len(x)), _p(out))
         return out
 
     def download_plink_matrix(self, pop, chr, ind_begin=0, n_ind=None):

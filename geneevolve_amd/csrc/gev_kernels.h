@@ -1111,6 +1111,39 @@ __global__ void __launch_bounds__(256) k_format_hap_text(const u64* __restrict__
     if (o + 16 <= total) *reinterpret_cast<uint4*>(out + o) = u.v;
     else for (int b = 0; b < 16 && o + b < total; b++) out[o + b] = u.ch[b];
 }
+// CommFunc::ras_rank (src/CommFunc.cpp:152-161): r[k] = #{j : x[j] < x[k]} + #{j < k : x[j] == x[k]}  -- what the reference's
+// O(n^2) pair loop leaves in r[k] (for j < i: x[j] <= x[i] ? r[i]++ : r[j]++).  Evaluated as the same all-pairs count, one
+// element per thread against LDS tiles of 1024 values; NaNs follow the reference's comparisons literally.
+__global__ void __launch_bounds__(256) k_rank_f64(const double* __restrict__ x, size_t n, unsigned long long* __restrict__ rank)
+{
+    __shared__ double tile[1024];
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const double xk = k < n ? x[k] : 0.0;
+    unsigned long long r = 0;
+    for (size_t base = 0; base < n; base += 1024) {
+        __syncthreads();
+        for (u32 t = threadIdx.x; t < 1024; t += 256) tile[t] = base + t < n ? x[base + t] : 0.0;
+        __syncthreads();
+        const u32 m = (u32)min((size_t)1024, n - base);
+        if (k < n) {
+            u32 cnt = 0;
+            if (base + m <= k) {                               // every j < k:  x[j] <= x[k] -> r[k]++
+#pragma unroll 8
+                for (u32 t = 0; t < m; t++) cnt += tile[t] <= xk ? 1u : 0u;
+            } else if (base > k) {                             // every j > k:  !(x[k] <= x[j]) -> r[k]++
+#pragma unroll 8
+                for (u32 t = 0; t < m; t++) cnt += !(xk <= tile[t]) ? 1u : 0u;
+            } else {
+                for (u32 t = 0; t < m; t++) {
+                    const size_t j = base + t;
+                    if (j < k) cnt += tile[t] <= xk ? 1u : 0u; else if (j > k) cnt += !(xk <= tile[t]) ? 1u : 0u;
+                }
+            }
+            r += cnt;
+        }
+    }
+    if (k < n) rank[k] = r;
+}
 // VCF genotype columns of one data line (format_vcf::write_vcf_file, src/format_vcf.cpp:55-59): per individual "\ta|b"
 // (a, b = haplotype rows 2i, 2i+1 at this SNP), then '\n'; flat-stream layout as above
 __global__ void __launch_bounds__(256) k_format_vcf_gt(const u64* __restrict__ snpmajor, size_t stride_w64, size_t n_ind, u32 n_snps, char* __restrict__ out)

@@ -1642,6 +1642,23 @@ int gev_download_plink_matrix(gev_ctx* c, int pop, int chr, size_t ind_begin, si
     }
     return GEV_OK;
 }
+// CommFunc::ras_rank on the device (the O(n^2) host loop of assort_mate, src/Simulation.cpp:2278-2279)
+int gev_rank_f64(gev_ctx* c, const double* x, size_t n, unsigned long long* rank_out)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    if (n && (!x || !rank_out)) return fail(GEV_EINVAL, "rank_f64: null buffer");
+    if (!n) return GEV_OK;
+    HIPC(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    GEVC(c->d_tmp.ensure(n * 16, st));
+    double* dx = c->d_tmp.as<double>(); unsigned long long* dr = (unsigned long long*)(dx + n);
+    HIPC(hipMemcpyAsync(dx, x, n * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rank_f64, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, dx, n, dr);
+    KCHECK();
+    HIPC(hipMemcpyAsync(rank_out, dr, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    return GEV_OK;
+}
 // GT columns of the VCF data lines: n_snps * (4*n_people + 1) bytes; the caller writes the nine fixed columns in front
 int gev_format_vcf_gt(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes)
 {

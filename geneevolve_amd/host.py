@@ -117,6 +117,182 @@ def random_mate(sex, selection_value_func, pop_size, seed):
     return couples_array(pos_male[i_f.astype(np.int64)], pos_female[i_m.astype(np.int64)])
 
 
+class GlibcRand:
+    """glibc srand(seed) / rand() (TYPE_3 additive feedback generator, stdlib/random_r.c): r[i] = 16807*r[i-1] mod (2^31-1)
+    for i < 31, then r[i] = r[i-3] + r[i-31] mod 2^32, the first 310 outputs discarded, rand() = r[i] >> 1.
+    Host-side stream for the mating code only (std::random_shuffle in assort_mate); the hot path's rand() chains
+    are evaluated on the device."""
+
+    def __init__(self, seed):
+        x = int(seed) & 0xFFFFFFFF
+        if x == 0:
+            x = 1
+        w = x - (1 << 32) if x >= (1 << 31) else x           # int32_t word = seed: Schrage's method in signed arithmetic
+        r = [w & 0xFFFFFFFF]
+        for _ in range(30):
+            hi = (abs(w) // 127773) * (1 if w >= 0 else -1)      # C division truncates toward zero
+            lo = w - hi * 127773
+            w = 16807 * lo - 2836 * hi
+            if w < 0:
+                w += 2147483647
+            r.append(w & 0xFFFFFFFF)
+        for i in range(31, 34):
+            r.append(r[i - 31])
+        for i in range(34, 344):
+            r.append((r[i - 31] + r[i - 3]) & 0xFFFFFFFF)
+        self.r = r[-31:]
+
+    def rand(self):
+        v = (self.r[-31] + self.r[-3]) & 0xFFFFFFFF
+        self.r.append(v); self.r.pop(0)
+        return v >> 1
+
+
+def random_shuffle(items, rnd):
+    """std::random_shuffle of libstdc++ (bits/stl_algo.h): for i = 1..n-1 swap(i, rnd(i+1)), skipped when equal"""
+    for i in range(1, len(items)):
+        j = rnd(i + 1)
+        if i != j:
+            items[i], items[j] = items[j], items[i]
+
+
+def normal_stream(seed, n):
+    """n draws of std::normal_distribution<double>(0,1) on default_random_engine(seed): Marsaglia polar method of
+    libstdc++ (bits/random.tcc): x, y = 2*U-1 until 0 < r2 <= 1; returns y*mult first, then the saved x*mult."""
+    import math
+    out = []
+    st = MinstdStream(seed)
+    while len(out) < n:
+        m = max(16, int((n - len(out)) * 0.7) + 16)
+        u = st.u01(2 * m)
+        x = 2.0 * u[0::2] - 1.0; y = 2.0 * u[1::2] - 1.0
+        r2 = x * x + y * y
+        for xi, yi, ri in zip(x.tolist(), y.tolist(), r2.tolist()):
+            if ri > 1.0 or ri == 0.0:
+                continue
+            mult = math.sqrt(-2.0 * math.log(ri) / ri)
+            out.append(yi * mult); out.append(xi * mult)
+    return np.array(out[:n])         # (the engine state past the n-th draw is never observed: one stream per call)
+
+
+def ras_rank(x):
+    """CommFunc::ras_rank (src/CommFunc.cpp:152-161): zero-based rank, ties by index (the O(n^2) loop counts, for element k,
+    the strictly smaller elements plus the earlier equal ones) = position in a stable ascending sort"""
+    order = np.argsort(np.asarray(x, dtype=np.float64), kind="stable")
+    r = np.empty(len(order), dtype=np.uint64)
+    r[order] = np.arange(len(order), dtype=np.uint64)
+    return r
+
+
+def ras_rpois(n, lam, seed):
+    """RasRandomNumber::ras_rpois (src/RasRandomNumber.cpp:56-66) = std::poisson_distribution<int>(lam) on
+    default_random_engine(seed); libstdc++ uses the product-of-uniforms method for mean < 12 (bits/random.tcc)."""
+    import math
+    if lam >= 12:
+        raise NotImplementedError("poisson_distribution with mean >= 12 (libstdc++ rejection branch) is not restated")
+    thr = math.exp(-lam)
+    st = MinstdStream(seed)
+    out = np.empty(n, dtype=np.int64)
+    buf = st.u01(int(n * (lam + 1) * 1.3) + 64).tolist(); k = 0
+    for i in range(n):
+        x, prod = 0, 1.0
+        while True:
+            if k == len(buf):
+                buf = st.u01(max(1024, n)).tolist(); k = 0
+            prod *= buf[k]; k += 1; x += 1
+            if not prod > thr:
+                break
+        out[i] = x - 1
+    return out
+
+
+class Pedigree:
+    """ID fields of reference `class Human` the mating code reads (src/Population.h:126-137); gen 0: everything = i (:3037-3043)"""
+    FIELDS = ("ID", "ID_Father", "ID_Mother", "ID_Fathers_Father", "ID_Fathers_Mother", "ID_Mothers_Father", "ID_Mothers_Mother")
+
+    def __init__(self, n):
+        i = np.arange(n, dtype=np.int64)
+        for f in self.FIELDS:
+            setattr(self, f, i.copy())
+
+    def offspring(self, pos_father, pos_mother):
+        """pedigree of the next generation in enumeration order (src/Simulation.cpp:2473-2479)"""
+        q = Pedigree(len(pos_father))
+        q.ID_Father = self.ID[pos_father]; q.ID_Fathers_Mother = self.ID_Mother[pos_father]; q.ID_Fathers_Father = self.ID_Father[pos_father]
+        q.ID_Mother = self.ID[pos_mother]; q.ID_Mothers_Mother = self.ID_Mother[pos_mother]; q.ID_Mothers_Father = self.ID_Father[pos_mother]
+        return q
+
+
+def assort_mate(sex, selection_value_func, mating_value, ped, pop_size, mat_cor, seeds, mm_percent=0.0,
+                avoid_inbreeding=False, offspring_dist="p", rank=None):
+    """Simulation::assort_mate (reference src/Simulation.cpp:2167-2360).  `seeds` = the ras_glob_seed() values in draw order:
+    srand seed (:2170), selection generator (:2173), ras_mvnorm (:2268), and -- Poisson offspring numbers only -- ras_rpois
+    (:2330).  Returns the couples list.  std::sort's order among EQUAL mating values is unspecified in the reference; a
+    stable sort is used here (doubled entries of one individual are identical, so only exact ties between different
+    individuals could differ)."""
+    n_h = len(sex)
+    rnd = GlibcRand(seeds[0])
+    u = MinstdStream(seeds[1]).u01(2 * n_h).tolist(); k = 0
+    males, females = [], []
+    svf = np.asarray(selection_value_func, dtype=np.float64).tolist()
+    for i in range(n_h):
+        r = u[k]; k += 1
+        if r < svf[i]:
+            lst = males if sex[i] == 1 else (females if sex[i] == 2 else None)
+            if lst is not None:
+                lst.append(i)
+                r = u[k]; k += 1
+                if r < mm_percent:                      # a second spouse (:2196-2198)
+                    lst.append(i)
+    couples = min(len(males), len(females))
+    if couples == 0:
+        raise RuntimeError(f"Error: couples=0, num_males_mate={len(males)}, num_females_mate={len(females)}")
+    if len(males) > len(females):                       # drop the surplus after a shuffle (:2232-2245)
+        random_shuffle(males, lambda m: rnd.rand() % m); males = males[len(males) - len(females):]
+    elif len(males) < len(females):
+        random_shuffle(females, lambda m: rnd.rand() % m); females = females[len(females) - len(males):]
+    mv = np.asarray(mating_value, dtype=np.float64)
+    males = np.asarray(males, dtype=np.int64); females = np.asarray(females, dtype=np.int64)
+    males = males[np.argsort(mv[males], kind="stable")]; females = females[np.argsort(mv[females], kind="stable")]
+    n2 = couples
+    # template: ras_mvnorm(n, 0, [[1,c],[c,1]]) = z * chol, chol = LLT upper factor [[1, c], [0, sqrt(1-c*c)]] (:2268, RasRandomNumber.cpp:15-51)
+    z = normal_stream(seeds[2], 2 * n2).reshape(n2, 2)
+    c = float(mat_cor)
+    x11 = 1.0 - (c / 1.0) * (c / 1.0)                  # Eigen's unblocked LLT stops at a non-positive pivot and leaves A(1,1) = 1 in place
+    u00, u01_, u11 = 1.0, c / 1.0, (float(np.sqrt(x11)) if x11 > 0 else 1.0)
+    t1 = (0.0 + z[:, 0] * u00) + z[:, 1] * 0.0
+    t2 = (0.0 + z[:, 0] * u01_) + z[:, 1] * u11
+    rank = rank or ras_rank                            # CommFunc::ras_rank: `rank=ctx.rank_f64` evaluates it on the device
+    rank_m = rank(t1).astype(np.int64); rank_f = rank(t2).astype(np.int64)
+    pos_m = males[rank_m]; pos_f = females[rank_f]
+    inbreed = np.zeros(n2, dtype=np.int32)
+    if avoid_inbreeding:                                # :2306-2322
+        P = ped
+        sib = P.ID_Father[pos_m] == P.ID_Father[pos_f]
+        cousin = ((P.ID_Fathers_Father[pos_m] == P.ID_Fathers_Father[pos_f]) | (P.ID_Fathers_Father[pos_m] == P.ID_Mothers_Father[pos_f]) |
+                  (P.ID_Mothers_Father[pos_m] == P.ID_Fathers_Father[pos_f]) | (P.ID_Mothers_Father[pos_m] == P.ID_Mothers_Father[pos_f]) |
+                  (P.ID_Fathers_Mother[pos_m] == P.ID_Fathers_Mother[pos_f]) | (P.ID_Fathers_Mother[pos_m] == P.ID_Mothers_Mother[pos_f]) |
+                  (P.ID_Mothers_Mother[pos_m] == P.ID_Fathers_Mother[pos_f]) | (P.ID_Mothers_Mother[pos_m] == P.ID_Mothers_Mother[pos_f]))
+        inbreed = (sib | cousin).astype(np.int32)
+        can_marry = []                                  # pos_couple_can_marry is only filled in the else branch (:2324-2328)
+    else:
+        can_marry = list(range(n2))
+    n_inbreed = int(inbreed.sum())
+    if offspring_dist in ("p", "P"):
+        lam = float(pop_size) / (n2 - n_inbreed)
+        num = ras_rpois(n2, lam, seeds[3])
+    elif offspring_dist in ("f", "F"):
+        nf = int(np.floor(float(pop_size) / (n2 - n_inbreed)))
+        num = np.full(n2, nf, dtype=np.int64)
+        remain = int(pop_size) - nf * (n2 - n_inbreed)
+        random_shuffle(can_marry, lambda m: rnd.rand() % m)
+        for i in range(remain):
+            num[can_marry[i]] += 1                      # (with --avoid_inbreeding the reference indexes an empty vector here)
+    else:
+        num = np.zeros(n2, dtype=np.int64)
+    return couples_array(pos_m, pos_f, num, inbreed)
+
+
 def couples_array(pos_male, pos_female, num_offspring=1, inbreed=0):
     c = np.zeros(len(pos_male), dtype=COUPLE_DTYPE)
     c["pos_male"], c["pos_female"], c["num_offspring"], c["inbreed"] = pos_male, pos_female, num_offspring, inbreed
@@ -181,17 +357,30 @@ class SyntheticConfig:
 class Simulation:
     """The seam of reference `class Simulation` (src/Simulation.h:64-144) on top of the C-ABI."""
 
-    def __init__(self, ctx, seed, nchr, has_mutation_map):
-        self.ctx, self.nchr, self.has_mut = ctx, nchr, has_mutation_map
+    def __init__(self, ctx, seed, nchr, has_mutation_map, track_pedigree=False):
+        self.ctx, self.nchr, self.has_mut, self.track_pedigree = ctx, nchr, has_mutation_map, track_pedigree
         self.glob = GlobSeedStream(seed)             # glob_generator.seed(par._seed), :75-76
         self.couples = {}                            # population[ipop]._couples_info
         self.sex = {}
+        self.ped = {}                                # pedigree ids of the current generation (host bookkeeping, :2473-2479)
 
     def ras_glob_seed(self, n=1):
         return self.glob.draw(n)
 
     def ras_initial_human_gen0(self, ipop, n_people):          # :3000
         self.sex[ipop] = self.ctx.init_gen0(ipop, n_people, int(self.ras_glob_seed()[0]))
+        self.ped[ipop] = Pedigree(n_people)
+        return True
+
+    def random_mate(self, ipop, selection_value_func, pop_size):           # :2090 (one ras_glob_seed() draw, :2092)
+        self.couples[ipop] = random_mate(self.sex[ipop], selection_value_func, pop_size, int(self.ras_glob_seed()[0]))
+        return True
+
+    def assort_mate(self, ipop, selection_value_func, mating_value, pop_size, mat_cor, mm_percent=0.0,
+                    avoid_inbreeding=False, offspring_dist="p", rank=None):   # :2167 (3 draws, +1 for Poisson offspring numbers)
+        seeds = [int(x) for x in self.ras_glob_seed(4 if offspring_dist in ("p", "P") else 3)]
+        self.couples[ipop] = assort_mate(self.sex[ipop], selection_value_func, mating_value, self.ped[ipop], pop_size, mat_cor, seeds,
+                                         mm_percent, avoid_inbreeding, offspring_dist, rank=rank or self.ctx.rank_f64)
         return True
 
     def reproduce(self, ipop, gen_num=0, seeds=None, n_people=None):   # :2394 (n_people: known offspring count, skips a host pass)
@@ -201,6 +390,10 @@ class Simulation:
         if seeds is None:                                       # 1 + n_people*nchr ras_glob_seed() draws (:2398, :2500)
             seeds = self.ras_glob_seed(1 + (n_people * self.nchr if self.has_mut else 0))
         self.sex[ipop] = self.ctx.reproduce(ipop, c, int(seeds[0]), seeds[1:] if self.has_mut else None, n_people=n_people)
+        if self.track_pedigree and ipop in self.ped:            # enumeration order of the couple loop (:2433-2443)
+            ok = c["inbreed"] == 0
+            rep = c["num_offspring"][ok].astype(np.int64)
+            self.ped[ipop] = self.ped[ipop].offspring(np.repeat(c["pos_male"][ok].astype(np.int64), rep), np.repeat(c["pos_female"][ok].astype(np.int64), rep))
         return self.sex[ipop]
 
     def ras_compute_AD(self, ipop, gen_num=0, per_chr=False):   # :2624

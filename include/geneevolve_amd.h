@@ -199,6 +199,10 @@ int gev_download_snp_major(gev_ctx*, int pop, int chr, size_t snp_begin, size_t 
 int gev_format_hap_text(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes);
 int gev_format_bed(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, uint8_t* out, size_t out_bytes);
 int gev_format_vcf_gt(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes);
+/* ---- mating support [SURVEY 8(f) row 2] ------------------------------------------------------
+ * == CommFunc::ras_rank (src/CommFunc.cpp:152-161), the O(n^2) zero-based rank assort_mate applies to its bivariate-normal
+ * template (src/Simulation.cpp:2278-2279): rank[k] = #{x[j] < x[k]} + #{j < k : x[j] == x[k]}.  Host buffers. */
+int gev_rank_f64(gev_ctx*, const double* x, size_t n, unsigned long long* rank_out);
 /* ---- PLINK siblings of the dense assembly (src/Simulation.cpp:1308-1416, src/format_plink.cpp:5-141), individual-major:
  *  gev_download_plink_matrix : matrix_plink_ped of ras_convert_interval_to_format_plink (:1335-1362): row = individual
  *                              ind_begin + i, bit 2*snp + hap; ceil(L/32) words per row

@@ -181,6 +181,14 @@ static int run_sim(int argc, char** argv)
                 std::uniform_int_distribution<unsigned> dm(1, 1000000);
                 fprintf(g_out, "MATE pop %d rm %d seed %u popsize %lu n %zu\n", ipop, (int)P._RM, dm(snapm), (unsigned long)P._pop_size[gen_num - 1], P.h.size());
                 for (size_t i = 0; i < P.h.size(); i++) fprintf(g_out, "MS %d %a\n", P.h[i].sex, P.h[i].selection_value_func);
+                if (!P._RM) {   // assort_mate (:2167-2360): its parameters, the four ras_glob_seed() values it may draw, mating values, pedigree
+                    unsigned s1 = dm(snapm), s2 = dm(snapm), s3 = dm(snapm);          // (the MATE line consumed the first one)
+                    fprintf(g_out, "MATEP pop %d matcor %a mm %a avoid %d dist %s seeds %u %u %u\n", ipop, P._mat_cor[gen_num - 1], P._MM_percent,
+                            (int)P._avoid_inbreeding, P._offspring_dist[gen_num - 1].c_str(), s1, s2, s3);
+                    for (size_t i = 0; i < P.h.size(); i++)
+                        fprintf(g_out, "MV %a %ld %ld %ld %ld %ld\n", P.h[i].mating_value, (long)P.h[i].ID_Father, (long)P.h[i].ID_Fathers_Father,
+                                (long)P.h[i].ID_Fathers_Mother, (long)P.h[i].ID_Mothers_Father, (long)P.h[i].ID_Mothers_Mother);
+                }
             }
             bool ok = P._RM ? sim.random_mate(ipop, gen_num - 1) : sim.assort_mate(ipop, gen_num - 1);   // :1907-1918
             if (!ok) return 5;
@@ -313,6 +321,19 @@ static int run_kat(const char* path)
         std::normal_distribution<double> d(0.0, sd);
         fprintf(g_out, "NORMAL %u %a", s, sd);
         for (int i = 0; i < 9; i++) fprintf(g_out, " %a", d(g));
+        fprintf(g_out, "\n");
+    }
+    // CommFunc::ras_rank (src/CommFunc.cpp:152-161) on vectors with ties, signed zeros and repeated blocks
+    for (unsigned s : {5u, 6u, 7u}) {
+        std::mt19937 g(s);
+        const int n = s == 5u ? 37 : (s == 6u ? 200 : 1);
+        std::vector<double> x(n);
+        for (int i = 0; i < n; i++) x[i] = (double)((int)(g() % 23) - 11) * 0.25;      // many exact ties
+        if (n > 10) { x[3] = 0.0; x[7] = -0.0; x[9] = 1e300; x[10] = -1e300; }
+        std::vector<unsigned long int> r = CommFunc::ras_rank(x);
+        fprintf(g_out, "RANK %d", n);
+        for (int i = 0; i < n; i++) fprintf(g_out, " %a", x[i]);
+        for (int i = 0; i < n; i++) fprintf(g_out, " %lu", r[i]);
         fprintf(g_out, "\n");
     }
     // Simulation::ras_sim_loc_rec (:2973-2995) on a synthetic uniform map, then the next two rand() outputs

@@ -166,6 +166,10 @@ def parse_dump(path):
                 out.setdefault("mate", []).append(cur)
             elif k == "MS":
                 cur["MS"].append((int(t[1]), hexf(t[2])))
+            elif k == "MATEP":
+                cur["am"] = {"matcor": hexf(t[4]), "mm": hexf(t[6]), "avoid": int(t[8]), "dist": t[10], "seeds": [int(t[12]), int(t[13]), int(t[14])], "MV": []}
+            elif k == "MV":
+                cur["am"]["MV"].append((hexf(t[1]),) + tuple(int(x) for x in t[2:7]))
             elif k == "GEF":
                 cur = {"pop": int(t[2]), "phen": int(t[4]), "seed": int(t[6]), "par": [hexf(t[i]) for i in (8, 10, 12, 14, 16, 18, 20)], "vt": int(t[22]), "GI": [], "GO": []}
                 out.setdefault("gef", []).append(cur)
@@ -424,6 +428,13 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             k = f"g{g}_pop{ma['pop']}_mate_"
             arrs[k + "rm"] = np.int64(ma["rm"]); arrs[k + "seed"] = np.uint32(ma["seed"]); arrs[k + "popsize"] = np.int64(ma["popsize"])
             arrs[k + "sex"] = np.array([m[0] for m in ma["MS"]], dtype=np.uint8); arrs[k + "svf"] = np.array([m[1] for m in ma["MS"]])
+            if "am" in ma:                # assort_mate: parameters, the 4 glob seeds in draw order, mating values, pedigree ids
+                am = ma["am"]
+                arrs[k + "am_par"] = np.array([am["matcor"], am["mm"], float(am["avoid"])])
+                arrs[k + "am_dist"] = np.frombuffer(am["dist"].encode(), dtype=np.uint8)
+                arrs[k + "am_seeds"] = np.array([ma["seed"]] + am["seeds"], dtype=np.uint32)
+                arrs[k + "am_mv"] = np.array([m[0] for m in am["MV"]])
+                arrs[k + "am_ped"] = np.array([m[1:] for m in am["MV"]], dtype=np.int64)      # ID_Father, FF, FM, MF, MM
         for ge in d.get("gef", []):       # ras_scale_AD_compute_GEF inputs / outputs
             k = f"g{g}_pop{ge['pop']}_ph{ge['phen']}_gef_"
             arrs[k + "seed"] = np.uint32(ge["seed"]); arrs[k + "par"] = np.array(ge["par"]); arrs[k + "vt"] = np.int64(ge["vt"])
@@ -570,6 +581,27 @@ def main():
             f.write("0.9 0.1 0.2 0.8\n")
     c.args_extra = ["--file_migration", os.path.join(WORK, "mig.txt")]
     run_case(c, 9001, dense_gens={1, 2, 3, 4})
+
+    # ---- am1: assortative mating variants: mat_cor != 0, two spouses (--MM), inbreeding avoidance,
+    #      Poisson and fixed offspring numbers, logit selection; small single chromosome
+    rs = np.random.RandomState(77)
+    R = 101
+    rbp = (1000 + 1000 * np.arange(R)).astype(np.uint64)
+    rcM = np.cumsum(np.r_[0.0, np.full(R - 1, 1.0)])
+    snp = np.arange(1500, 100000, 400).astype(np.uint64)
+    nf = 240
+    founders = (rs.rand(nf, len(snp)) < 0.3).astype(np.uint8)
+    cvbp = np.sort(rs.choice(np.arange(1100, 100000, 50), size=80, replace=False)).astype(np.uint64)
+    ph = {"bp": [cvbp], "a": [rs.randn(80)], "d": [np.zeros(80)], "val": [(rs.rand(nf, 80) < 0.4).astype(np.uint8)], "va": 0.6, "ve": 0.4}
+    c = Case("am1")
+    c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph],
+              popinfo=["130 0.4 p logit 1 1", "140 0.3 p logit 1 1", "120 -0.5 p logit 0.5 1", "125 0.8 p thr 1 1", "110 0.2 p logit 1 1"])
+    c.args_extra = ["--MM", "0.15", "--avoid_inbreeding"]
+    run_case(c, 31337, dense_gens={5})
+    c = Case("am2")
+    c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph],
+              popinfo=["130 0.4 f logit 1 1", "141 0.3 f logit 1 1", "120 0 f logit 0.5 1", "125 1 f thr 1 1"])
+    run_case(c, 4711, dense_gens={4})
 
     # ---- syn1k: config-1 shape, deterministic synthetic founders (tests/synth.py), hashes only
     L, N0 = 10000, 1000

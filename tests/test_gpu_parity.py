@@ -527,3 +527,23 @@ def test_whole_genome_22_chromosomes_on_the_reference_genetic_map(gpu_lib, oracl
     total_parts = sum(len(g.download_intervals(0, k)[0]) for k in range(nchr))
     assert total_parts > 2 * n * nchr * 1.5          # ~36 crossovers per gamete set per generation
     g.close(); o.close()
+
+
+def test_device_rank_matches_reference_and_oracle(gpu_lib, oracle_lib):
+    """gev_rank_f64 == CommFunc::ras_rank: the reference's vectors, then random vectors with many ties against the oracle's
+    literal O(n^2) loop, then a 200k-element vector against the stable-sort identity (the reference would need 2e10 compares)"""
+    from geneevolve_amd.host import ras_rank
+    g = gpu_lib.create(1, 1, 1); o = oracle_lib.create(1, 1, 1)
+    with gzip.open(os.path.join(helpers.GOLDEN, "kat.txt.gz"), "rt") as f:
+        rows = [l.split() for l in f if l.startswith("RANK ")]
+    for t in rows:
+        n = int(t[1]); x = np.array([float.fromhex(v) for v in t[2:2 + n]]); want = np.array([int(v) for v in t[2 + n:2 + 2 * n]], dtype=np.uint64)
+        assert np.array_equal(g.rank_f64(x), want)
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 255, 256, 257, 1023, 1024, 1025, 5000):
+        x = np.round(rng.standard_normal(n) * 4) / 4
+        assert np.array_equal(g.rank_f64(x), o.rank_f64(x)), n
+    x = rng.standard_normal(200_000); x[::7] = x[3::7][:len(x[::7])]
+    r = g.rank_f64(x)
+    assert np.array_equal(r, ras_rank(x)) and np.array_equal(np.sort(r), np.arange(len(x), dtype=np.uint64))
+    g.close(); o.close()

@@ -126,3 +126,16 @@ def test_oracle_scale_ad_compute_gef_matches_reference(oracle_lib, case):
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
     checked = helpers.replay_case(oracle_lib, fx, seeds, f"oracle-gef/{case}", check_lists=False, check_gef=True)
     assert checked >= 0
+
+
+def test_rank_matches_reference_vectors(oracle_lib):
+    """CommFunc::ras_rank vectors (ties, signed zeros, huge values): the oracle's literal loop and the host mirror's stable-sort form"""
+    from geneevolve_amd.host import ras_rank
+    rows = kat_lines("RANK")
+    assert len(rows) == 3
+    o = oracle_lib.create(1, 1, 1)
+    for t in rows:
+        n = int(t[1]); x = np.array([float.fromhex(v) for v in t[2:2 + n]]); want = np.array([int(v) for v in t[2 + n:2 + 2 * n]], dtype=np.uint64)
+        assert np.array_equal(o.rank_f64(x), want)
+        assert np.array_equal(ras_rank(x), want)
+    o.close()
