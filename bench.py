@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-presample", action="store_true", help="do not hand the next generation's seeds to the library ahead of its couples (gev_presample)")
     ap.add_argument("--n-ind", type=int, default=100_000)
     ap.add_argument("--n-loci", type=int, default=1_000_000)
     ap.add_argument("--n-cv", type=int, default=1000)
@@ -202,15 +203,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ad_ms, mate_ms, repro_ms, mig_ms = [], [], [], []
+    ad_ms, mate_ms, repro_ms, mig_ms, step_ms = [], [], [], [], []
     if migrate:
         from geneevolve_amd.distributed import migrate_all_to_all
+
+    presample = not args.no_presample
 
     def step(i):
         t0 = time.perf_counter()
         sim.couples[P] = synthetic_random_mate(sim.sex[P], args.n_ind, rng, out=sim.couples.get(P))   # host mating (outside the hot path)
         t1 = time.perf_counter()
         sim.reproduce(P, i + 1, seeds=seeds[i], n_people=args.n_ind)             # Simulation::reproduce
+        if presample and i + 1 < total:                                          # next generation's seeds are already known: sample while the host mates
+            sim.presample(P, seeds[i + 1], args.n_ind)
         t2 = time.perf_counter()
         sim.ras_compute_AD(P, i + 1)                                             # Simulation::ras_compute_AD
         t3 = time.perf_counter()
@@ -230,11 +235,11 @@ def main():
             dist.all_gather_object(recv_sex, sent_sex)
             sim.sex[P] = np.concatenate([sex[~gone]] + [recv_sex[i][rank] for i in range(world) if i != rank])
             mig_ms.append((time.perf_counter() - t3) * 1e3)
-        mate_ms.append((t1 - t0) * 1e3); repro_ms.append((t2 - t1) * 1e3); ad_ms.append((t3 - t2) * 1e3)
+        mate_ms.append((t1 - t0) * 1e3); repro_ms.append((t2 - t1) * 1e3); ad_ms.append((t3 - t2) * 1e3); step_ms.append((time.perf_counter() - t0) * 1e3)
 
     for i in range(args.warmup):
         step(i)
-    del ad_ms[:], mate_ms[:], repro_ms[:], mig_ms[:]
+    del ad_ms[:], mate_ms[:], repro_ms[:], mig_ms[:], step_ms[:]
     tot0, n0 = ctx.timing_totals()                       # (implies a sync of both library streams)
     barrier()
     t0 = time.perf_counter()
@@ -289,6 +294,7 @@ def main():
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
                          "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
                          "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None},
+               "host_step_ms": [round(x, 2) for x in step_ms[:args.steps]],
             "roofline": {"bound": "hbm", "kernel": "k_stitch_parent", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": stitch,

@@ -45,7 +45,7 @@ MOVE_DTYPE = np.dtype([("src_pop", "<i4"), ("dst_pop", "<i4"), ("src_pos", "<u8"
 ABI_SYMBOLS = [
     "last_error", "version", "create", "destroy", "set_rmap", "set_mutmap", "set_snps", "set_cvs",
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
-    "reproduce", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
+    "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
@@ -202,6 +202,11 @@ class GevContext:
         self._call("reproduce", C.c_int(pop), _p(couples), C.c_size_t(len(couples)), C.c_uint32(int(seed_reproduce)),
                    _p(ms), C.c_size_t(0 if ms is None else len(ms)), C.c_size_t(n_people), _p(sex))
         return sex
+
+    def presample(self, pop, seed_reproduce, mut_seeds, n_people):
+        """head start for the next reproduce() with the same seeds / n_people (returns without waiting)"""
+        ms = None if mut_seeds is None else _arr(mut_seeds, np.uint32)
+        self._call("presample", C.c_int(pop), C.c_uint32(int(seed_reproduce)), _p(ms), C.c_size_t(0 if ms is None else len(ms)), C.c_size_t(n_people))
 
     def compute_ad(self, pop, per_chr=True):
         n = self.pop_size(pop)

@@ -4,6 +4,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC gev_library.hip -o libgeneevolve_amd.so
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -36,6 +37,9 @@ static inline size_t round_up(size_t a, size_t b) { return ceil_div(a, b) * b; }
 // Device buffers that were outgrown while kernels may still be reading them: freeing (hipFree waits for the whole device)
 // would stall the host behind the running stitch, so they are parked here and released at the next point where the
 // device is idle anyway (gev_sync, serialised generations, gev_destroy) or when too much has piled up.
+static bool g_trace_host = getenv("GEV_TRACE_HOST") != nullptr;      // stderr: where the host spends its time inside gev_reproduce
+static double host_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double g_malloc_ms = 0; static size_t g_malloc_n = 0, g_malloc_bytes = 0;   // GEV_TRACE_HOST bookkeeping
 struct Graveyard {
     struct Item { void* p; size_t bytes; int device; };
     std::vector<Item> items; size_t bytes = 0;
@@ -47,15 +51,19 @@ struct Graveyard {
         if (!any) return;
         int cur = 0; (void)hipGetDevice(&cur);
         (void)hipSetDevice(device);
+        const double t0 = host_ms();
         if (!device_is_idle) (void)hipDeviceSynchronize();
+        const double t1 = host_ms(); const size_t n0 = items.size(), b0 = bytes;
         size_t w = 0;
         for (auto& it : items) { if (it.device == device) { (void)hipFree(it.p); bytes -= it.bytes; } else items[w++] = it; }
         items.resize(w);
+        if (g_trace_host) fprintf(stderr, "[gev] graveyard drain: sync %.2f ms, %zu frees of %.1f MiB in %.2f ms\n", t1 - t0, n0 - w, (b0 - bytes) / 1048576.0, host_ms() - t1);
         (void)hipSetDevice(cur);
     }
 };
 static Graveyard g_graveyard;                 // one host thread calls the seam
-static const size_t GRAVEYARD_LIMIT = (size_t)4 << 30;
+
+static const size_t GRAVEYARD_LIMIT = (size_t)16 << 30;
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -68,7 +76,9 @@ struct DevBuf {
         if (need <= bytes && p) return GEV_OK;
         size_t want = std::max<size_t>((size_t)(need * slack), 256);
         void* q = nullptr;
+        const double tm0 = host_ms();
         hipError_t e = hipMalloc(&q, want);
+        g_malloc_ms += host_ms() - tm0; g_malloc_n++; g_malloc_bytes += want;
         if (e != hipSuccess && g_graveyard.bytes) {                      // out of memory with parked buffers: release them and retry
             (void)hipGetLastError();
             int d = 0; (void)hipGetDevice(&d); g_graveyard.drain(d, false);
@@ -142,8 +152,10 @@ struct gev_ctx {
     // while sampling / sparse state of generation g+1 (stream) fill the other one
     struct Scratch {
         DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, ghist, goff, glist, status;
-        hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         bool timing_pending = false, stitch_pending = false;
+        // gev_presample: the sampling kernels of the next gev_reproduce were already enqueued for exactly these inputs
+        bool presampled = false; int ps_pop = -1; u32 ps_seed = 0; size_t ps_n_people = 0; bool ps_has_mut = false;
     } sc[2];
     unsigned gen_counter = 0;
     hipStream_t stream_big = nullptr;
@@ -152,6 +164,7 @@ struct gev_ctx {
     double ms_sum[4] = {0, 0, 0, 0}; unsigned long long ms_count = 0;
     size_t bk_ovf_cap = 1 << 16, nm_ovf_cap = 1 << 16;       // overflow regions of the breakpoint / new-mutation records
     void* h_stage = nullptr; size_t h_stage_bytes = 0;       // pinned host staging
+    void* h_seeds = nullptr; size_t h_seeds_bytes = 0;       // pinned copy of the mutation seeds handed to gev_presample
     void* h_ad = nullptr; size_t h_ad_bytes = 0;             // pinned A/D result cache
     int ad_cached_pop = -1;                                  // population whose current-generation A/D sits in h_ad
     bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
@@ -333,6 +346,7 @@ void gev_destroy(gev_ctx* c)
     for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
     hipStream_t s = c->stream;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_seeds) (void)hipHostFree(c->h_seeds);
     if (c->h_ad) (void)hipHostFree(c->h_ad);
     delete c;
     if (s) (void)hipStreamDestroy(s);
@@ -664,7 +678,7 @@ static int harvest_timing(gev_ctx* c, gev_ctx::Scratch& sc)
     float t; float ms[4];
     HIPC(hipEventElapsedTime(&t, sc.t[0], sc.t[1])); ms[0] = t;
     HIPC(hipEventElapsedTime(&t, sc.t[4], sc.t[3])); ms[1] = t;
-    HIPC(hipEventElapsedTime(&t, sc.t[1], sc.t[2])); ms[2] = t;
+    HIPC(hipEventElapsedTime(&t, sc.t[5], sc.t[2])); ms[2] = t;
     ms[3] = ms[0] + ms[1] + ms[2];
     for (int i = 0; i < 4; i++) { c->last_ms[i] = ms[i]; c->ms_sum[i] += ms[i]; }
     c->ms_count++;
@@ -706,12 +720,29 @@ static SampleDev make_sd(gev_ctx* c, gev_ctx::Scratch& sc, size_t T)
     sd.status = sc.status.as<u32>();
     return sd;
 }
-static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut, u32 seed_reproduce)
+// per-generation scratch every phase needs (sizes depend on n_people only)
+static int ensure_scratch(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, bool has_mut)
+{
+    hipStream_t st = c->stream;
+    const size_t T = n_people * (size_t)c->nchr;
+    const size_t n_status = ST_TOTALS + 2 * (size_t)c->nchr;
+    GEVC(sc.father.ensure(n_people * sizeof(u32), st)); GEVC(sc.mother.ensure(n_people * sizeof(u32), st));
+    GEVC(sc.seed_pat.ensure((T + 1) * sizeof(u32), st)); GEVC(sc.seed_mat.ensure(T * sizeof(u32), st));
+    GEVC(sc.k.ensure(2 * T * sizeof(u32), st)); GEVC(sc.bk_off.ensure((2 * T + 1) * sizeof(u32), st));
+    GEVC(sc.start.ensure(2 * T, st)); GEVC(sc.sex.ensure(n_people, st));
+    GEVC(sc.nmut.ensure(T * sizeof(u32), st)); GEVC(sc.nm_off.ensure((T + 1) * sizeof(u32), st));
+    GEVC(sc.nm_pos.ensure(16, st)); GEVC(sc.nm_side.ensure(16, st));
+    GEVC(sc.status.ensure(n_status * sizeof(u32), st));
+    if (has_mut) GEVC(sc.mutseeds.ensure(T * sizeof(u32), st));
+    return GEV_OK;
+}
+// K1-K3: crossover / mutation sampling and the rand() seed chain; depends on the seeds and n_people only, not on the couples
+static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut, u32 seed_reproduce)
 {
     PopState& P = c->pop[pop];
     hipStream_t st = c->stream;
     const int nchr = c->nchr;
-    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
+    const size_t T = n_people * (size_t)nchr;
     const GevRngTables* Tb = c->d_tables.as<GevRngTables>();
     const ChrDev* chrs = P.d_chrdev.as<ChrDev>();
     const size_t bk_fixed = 2 * T * GEV_BK_CAP, nm_fixed = T * GEV_NM_CAP;
@@ -735,7 +766,19 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
     hipLaunchKernelGGL(k_bk_to_idx, dim3((unsigned)ceil_div(2 * T, 256)), dim3(256), 0, st, chrs, nchr, 2 * T, sd);
     KCHECK();
     HIPC(hipEventRecord(sc.t[1], st));
+    return GEV_OK;
+}
+static const size_t LIST_HEADROOM = 48;    // spare list entries per haplotype row when a list buffer is (re)allocated
+// K4/K6 + grouping: everything of the small work that needs the couples (parents) on top of the sampling results
+static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut)
+{
+    PopState& P = c->pop[pop];
+    hipStream_t st = c->stream;
+    const int nchr = c->nchr;
+    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
+    SampleDev sd = make_sd(c, sc, T);
     if (c->sparse_after_stitch && c->planes_pending) HIPC(hipStreamWaitEvent(st, c->ev_planes, 0));
+    HIPC(hipEventRecord(sc.t[5], st));
     // ---- sparse state: mutation lists + ancestry intervals + CV planes
     const int cur = P.cur, alt = P.cur ^ 1;
     for (int l = 0; l < c->n_lanes; l++) GEVC(c->lane[l].d_cnt.ensure((rows + 1) * sizeof(u32), st));
@@ -747,8 +790,10 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
         gev_ctx::Lane& ln = c->lane[k % c->n_lanes];
         hipStream_t ls = ln.st;
         const u64 bp0 = S.rbp.front(), bpe = S.rbp.back();
-        // capacity guess: last generation's total scaled to the new size, plus room for this generation's events
-        size_t want = std::max<size_t>(cs.mut_need, (size_t)(cs.mut_total[cur] * grow * 1.5) + rows * 4 + 4096);
+        // capacity guess: last generation's total scaled to the new size, plus room for the events of many generations
+        // (lists lengthen by about one entry per row and generation; a growth step allocates GBs, which on some hosts is
+        // not lazy and costs 10-250 ms of host time -- keep such steps rare and geometric)
+        size_t want = std::max<size_t>(cs.mut_need, (size_t)(cs.mut_total[cur] * grow * 1.5) + rows * LIST_HEADROOM + 4096);
         GEVC(cs.mpos[alt].ensure(want * sizeof(u64), ls, false, 2.0));        // grow geometrically: lists lengthen every generation
         const u32 mcap = (u32)std::min<size_t>(cs.mpos[alt].bytes / sizeof(u64), 0xfffffff0u);
         hipLaunchKernelGGL((k_mutlist<false>), dim3(row_blocks), dim3(256), 0, ls, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
@@ -760,7 +805,7 @@ static int enqueue_small(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_peo
         hipLaunchKernelGGL(k_collect_total, dim3(1), dim3(64), 0, ls, cs.moff[alt].as<u32>(), rows, sd.status + ST_TOTALS + 2 * k);
         KCHECK();
         if (c->track_intervals) {
-            want = std::max<size_t>(cs.parts_need, (size_t)(cs.parts_total[cur] * grow * 1.5) + rows * 4 + 4096);
+            want = std::max<size_t>(cs.parts_need, (size_t)(cs.parts_total[cur] * grow * 1.5) + rows * LIST_HEADROOM + 4096);
             GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), ls, false, 2.0));
             const u32 pcap = (u32)std::min<size_t>(cs.parts[alt].bytes / sizeof(gev_part), 0xfffffff0u);
             hipLaunchKernelGGL((k_parts<false>), dim3(row_blocks), dim3(256), 0, ls, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
@@ -879,34 +924,39 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
         }
     }
     if (ip != n_people) return fail(GEV_EINVAL, "reproduce: n_people=%zu but the couples list yields %zu offspring", n_people, ip);
-    if (has_mut) memcpy(hseeds, mut_seeds, T * sizeof(u32));
     GEVC(finalize_static(c, pop));
     GEVC(ensure_capacity(c, pop, n_people));
     hipStream_t st = c->stream;
     gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
-    // the stitch that last read this scratch set must be over before the set is refilled
-    GEVC(harvest_timing(c, sc));
-    if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); sc.stitch_pending = false; }
-    GEVC(sc.father.ensure(n_people * sizeof(u32), st)); GEVC(sc.mother.ensure(n_people * sizeof(u32), st));
-    GEVC(sc.seed_pat.ensure((T + 1) * sizeof(u32), st)); GEVC(sc.seed_mat.ensure(T * sizeof(u32), st));
-    GEVC(sc.k.ensure(2 * T * sizeof(u32), st)); GEVC(sc.bk_off.ensure((2 * T + 1) * sizeof(u32), st));
-    GEVC(sc.start.ensure(2 * T, st)); GEVC(sc.sex.ensure(n_people, st));
-    GEVC(sc.nmut.ensure(T * sizeof(u32), st)); GEVC(sc.nm_off.ensure((T + 1) * sizeof(u32), st));
-    GEVC(sc.nm_pos.ensure(16, st)); GEVC(sc.nm_side.ensure(16, st));
-    GEVC(sc.status.ensure(n_status * sizeof(u32), st));
-    if (has_mut) GEVC(sc.mutseeds.ensure(T * sizeof(u32), st));
+    // sampling already enqueued by gev_presample for exactly these inputs?
+    const bool pre = sc.presampled && sc.ps_pop == pop && sc.ps_seed == (u32)seed_reproduce && sc.ps_n_people == n_people && sc.ps_has_mut == has_mut &&
+                     (!has_mut || (c->h_seeds && memcmp(c->h_seeds, mut_seeds, T * sizeof(u32)) == 0));
+    sc.presampled = false;
+    if (!pre) {
+        // the stitch that last read this scratch set must be over before the set is refilled
+        GEVC(harvest_timing(c, sc));
+        if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); sc.stitch_pending = false; }
+        GEVC(ensure_scratch(c, sc, n_people, has_mut));
+        if (has_mut) { memcpy(hseeds, mut_seeds, T * sizeof(u32)); HIPC(hipMemcpyAsync(sc.mutseeds.p, hseeds, T * sizeof(u32), hipMemcpyHostToDevice, st)); }
+    }
     HIPC(hipMemcpyAsync(sc.father.p, father, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
     HIPC(hipMemcpyAsync(sc.mother.p, mother, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
-    if (has_mut) HIPC(hipMemcpyAsync(sc.mutseeds.p, hseeds, T * sizeof(u32), hipMemcpyHostToDevice, st));
 
     const int alt = P.cur ^ 1;
     for (int attempt = 0;; attempt++) {
-        GEVC(enqueue_small(c, sc, pop, n_people, has_mut, (u32)seed_reproduce));
+        const double th0 = host_ms();
+        if (!(pre && attempt == 0)) GEVC(enqueue_sampling(c, sc, pop, n_people, has_mut, (u32)seed_reproduce));
+        const double th1 = host_ms();
+        GEVC(enqueue_sparse(c, sc, pop, n_people, has_mut));
+        const double th2 = host_ms();
         c->ad_cached_pop = -1;
         if (c->eager_ad && c->pop[pop].cv[0][0].d_aptr.p) GEVC(enqueue_ad(c, pop, alt, n_people));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
         HIPC(hipMemcpyAsync(hstatus, sc.status.p, n_status * sizeof(u32), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
         const u32 flags = hstatus[ST_FLAGS];
+        if (g_trace_host) fprintf(stderr, "[gev] gen %u attempt %d pre %d: enqueue sampling %.2f ms, sparse %.2f ms, A/D + wait %.2f ms, flags %u, graveyard %.1f MiB\n",
+                                  c->gen_counter, attempt, (int)pre, th1 - th0, th2 - th1, host_ms() - th2, flags, g_graveyard.bytes / 1048576.0);
+        if (g_trace_host && g_malloc_n) { fprintf(stderr, "[gev]   %zu hipMalloc calls, %.1f MiB, %.2f ms\n", g_malloc_n, g_malloc_bytes / 1048576.0, g_malloc_ms); g_malloc_ms = 0; g_malloc_n = 0; g_malloc_bytes = 0; }
         for (int k = 0; k < nchr; k++) { P.st[k].mut_total[alt] = hstatus[ST_TOTALS + 2 * k]; P.st[k].parts_total[alt] = hstatus[ST_TOTALS + 2 * k + 1]; }
         if (!flags) break;
         if (attempt == 3) return fail(GEV_EDEVICE, "reproduce: buffers still too small after %d attempts (flags %u)", attempt + 1, flags);
@@ -925,6 +975,42 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     GEVC(enqueue_stitch(c, sc, pop, n_people));          // not waited for
     P.cur = alt; P.n_people = n_people; P.n_phys = n_people; P.logical.clear();
     c->gen_counter++;
+    return GEV_OK;
+}
+// Enqueue the sampling kernels of the NEXT gev_reproduce of `pop` now (they need the seeds and the offspring count, not the
+// couples) and return at once: the host can form the couples while the GPU samples.  gev_reproduce recognises the
+// same (seed, mutation seeds, n_people) and skips its own sampling; anything else simply samples again.
+int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people)
+{
+    GEVC(check_idx(c, pop, 0));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "presample: population %d has no current generation (call gev_init_gen0)", pop);
+    HIPC(hipSetDevice(c->device));
+    const size_t T = n_people * (size_t)c->nchr;
+    if (n_people == 0) return fail(GEV_EINVAL, "presample: no offspring");
+    if (2 * T * GEV_BK_CAP >= 0xf0000000ull) return fail(GEV_EINVAL, "presample: too many gametes");
+    const bool has_mut = mut_seeds != nullptr;
+    if (has_mut && n_mut_seeds != T) return fail(GEV_EINVAL, "presample: n_mut_seeds=%zu, expected n_people*nchr=%zu", n_mut_seeds, T);
+    GEVC(finalize_static(c, pop));
+    hipStream_t st = c->stream;
+    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    sc.presampled = false;
+    GEVC(harvest_timing(c, sc));
+    if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); sc.stitch_pending = false; }
+    GEVC(ensure_scratch(c, sc, n_people, has_mut));
+    if (has_mut) {
+        if (c->h_seeds_bytes < T * sizeof(u32)) {
+            HIPC(hipStreamSynchronize(st));              // an earlier copy out of the old buffer may be in flight
+            if (c->h_seeds) (void)hipHostFree(c->h_seeds);
+            c->h_seeds = nullptr; c->h_seeds_bytes = 0;
+            HIPC(hipHostMalloc(&c->h_seeds, T * sizeof(u32) * 5 / 4 + 4096, hipHostMallocDefault));
+            c->h_seeds_bytes = T * sizeof(u32) * 5 / 4 + 4096;
+        }
+        memcpy(c->h_seeds, mut_seeds, T * sizeof(u32));
+        HIPC(hipMemcpyAsync(sc.mutseeds.p, c->h_seeds, T * sizeof(u32), hipMemcpyHostToDevice, st));
+    }
+    GEVC(enqueue_sampling(c, sc, pop, n_people, has_mut, seed_reproduce));
+    sc.presampled = true; sc.ps_pop = pop; sc.ps_seed = seed_reproduce; sc.ps_n_people = n_people; sc.ps_has_mut = has_mut;
     return GEV_OK;
 }
 // wait for all device work of the context (both streams) and collect pending kernel timings

@@ -396,6 +396,11 @@ class Simulation:
             self.ped[ipop] = self.ped[ipop].offspring(np.repeat(c["pos_male"][ok].astype(np.int64), rep), np.repeat(c["pos_female"][ok].astype(np.int64), rep))
         return self.sex[ipop]
 
+    def presample(self, ipop, seeds, n_people):
+        """the seeds the next reproduce() will be given (1 + n_people*nchr ras_glob_seed() values, drawn in the reference's
+        order) are known before the couples are: let the GPU sample while the host mates"""
+        self.ctx.presample(ipop, int(seeds[0]), seeds[1:] if self.has_mut else None, n_people)
+
     def ras_compute_AD(self, ipop, gen_num=0, per_chr=False):   # :2624
         return self.ctx.compute_ad(ipop, per_chr=per_chr)
 

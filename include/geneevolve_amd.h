@@ -135,6 +135,12 @@ int gev_reproduce(gev_ctx*, int pop, const gev_couple* couples, size_t n_couples
                   uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds,
                   size_t n_people, uint8_t* sex_out);
 
+/* Optional head start for the next gev_reproduce of `pop`: crossover / mutation sampling and the rand() seed chain depend
+ * on the ras_glob_seed() values and the offspring count only, not on the couples, so they can be enqueued as soon as those
+ * are known (random mating with one child per couple: n_people = pop_size) while the host is still forming couples.
+ * Returns without waiting.  gev_reproduce called next with the same seed_reproduce, mut_seeds and n_people uses the
+ * results; with anything else it samples again.  Same argument checks / errors as gev_reproduce. */
+int gev_presample(gev_ctx*, int pop, uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people);
 /* ---- Simulation::ras_compute_AD + ras_find_cv (src/Simulation.cpp:2624-2815) --------------
  * additive/dominance : [n_people * nphen], index ih*nphen + iphen  (Human::additive/dominance, raw)
  * add_chr/dom_chr    : [n_people * nchr * nphen], index (ih*nchr + ichr)*nphen + iphen, or NULL

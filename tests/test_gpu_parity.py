@@ -543,7 +543,62 @@ def test_device_rank_matches_reference_and_oracle(gpu_lib, oracle_lib):
     for n in (0, 1, 2, 255, 256, 257, 1023, 1024, 1025, 5000):
         x = np.round(rng.standard_normal(n) * 4) / 4
         assert np.array_equal(g.rank_f64(x), o.rank_f64(x)), n
-    x = rng.standard_normal(200_000); x[::7] = x[3::7][:len(x[::7])]
+    x = rng.standard_normal(200_000); x[0:199_990:7] = x[3:199_993:7]            # exact ties between different positions
     r = g.rank_f64(x)
     assert np.array_equal(r, ras_rank(x)) and np.array_equal(np.sort(r), np.arange(len(x), dtype=np.uint64))
     g.close(); o.close()
+
+
+def test_presample_gives_the_same_generation_and_falls_back_on_any_mismatch(gpu_lib, oracle_lib):
+    """gev_presample only moves the sampling kernels ahead of the couples: states with / without it are identical to the
+    oracle's; a presample whose seeds, offspring count or population do not match the following gev_reproduce is ignored."""
+    cfg = SyntheticConfig(90, 700, nchr=2, chrom_bp=500_000, map_step=5000, rec_per_row=0.02, mut_per_row=0.03, n_cv=30, seed=8)
+    ctxs = []
+    for lib in (gpu_lib, gpu_lib, oracle_lib):
+        g = lib.create(2, 2, 1)
+        for pop in (0, 1):
+            cfg.apply_static(g, pop)
+            for c in range(2):
+                if lib is gpu_lib:
+                    g.synth_founders(pop, c, 180, 11 + c + 7 * pop); g.synth_cv_founders(pop, 0, c, 180, 52 + c + 7 * pop)
+                else:
+                    g.upload_founders(pop, c, synth_packed(11 + c + 7 * pop, 180, 700), 700)
+                    g.upload_cv_founders(pop, 0, c, synth_packed(52 + c + 7 * pop, 180, 30), 30)
+        ctxs.append(g)
+    sims = [Simulation(g, 99, 2, True) for g in ctxs]
+    for s in sims:
+        s.ras_initial_human_gen0(0, 90); s.ras_initial_human_gen0(1, 90)
+    rng = np.random.default_rng(1)
+    a, b, o = sims
+    for gen in range(1, 7):
+        n_off = int(rng.integers(60, 120))
+        for pop in (0, 1):
+            couples = synthetic_random_mate(a.sex[pop], n_off, rng)
+            seeds = a.ras_glob_seed(1 + n_off * 2); b.ras_glob_seed(1 + n_off * 2); o.ras_glob_seed(1 + n_off * 2)
+            # a: presample with the right inputs (odd generations) or with wrong ones that must be ignored (even)
+            if gen % 2:
+                a.presample(pop, seeds, n_off)
+            elif gen == 2:
+                wrong = seeds.copy(); wrong[5] ^= 1
+                a.presample(pop, wrong, n_off)                         # one mutation seed differs
+            elif gen == 4:
+                a.presample(pop, seeds[:1 + (n_off - 1) * 2], n_off - 1)    # other offspring count
+            else:
+                a.presample(1 - pop, seeds, n_off)                     # other population
+            for s in sims:
+                s.couples[pop] = couples
+                s.reproduce(pop, gen, seeds=seeds, n_people=n_off)
+            assert np.array_equal(a.sex[pop], o.sex[pop]) and np.array_equal(b.sex[pop], o.sex[pop])
+            xa, xb, xo = a.ras_compute_AD(pop), b.ras_compute_AD(pop), o.ras_compute_AD(pop)
+            assert helpers.bits_equal(xa[0], xo[0]) and helpers.bits_equal(xb[0], xo[0]), (gen, pop)
+            for c in range(2):
+                want = ctxs[2].download_haps(pop, c)
+                assert np.array_equal(ctxs[0].download_haps(pop, c), want) and np.array_equal(ctxs[1].download_haps(pop, c), want), (gen, pop, c)
+                pa, oa = ctxs[0].download_intervals(pop, c); po, oo = ctxs[2].download_intervals(pop, c)
+                assert np.array_equal(oa, oo) and np.array_equal(pa, po)
+                ma, moa = ctxs[0].download_mutations(pop, c); mo, moo = ctxs[2].download_mutations(pop, c)
+                assert np.array_equal(moa, moo) and np.array_equal(ma, mo)
+    with pytest.raises(capi.GevError):
+        ctxs[0].presample(0, 1, np.zeros(3, dtype=np.uint32), 90)      # wrong seed count
+    for g in ctxs:
+        g.close()
