@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
-    "pop_size", "plane_ptr", "reserve", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
+    "pop_size", "plane_ptr", "reserve", "set_chr_active", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -368,6 +368,9 @@ class GevContext:
         ms = (C.c_double * 4)(); n = C.c_ulonglong()
         self._call("timing_totals", ms, C.byref(n))
         return [float(x) for x in ms], n.value
+
+    def set_chr_active(self, chr, active):
+        self._call("set_chr_active", C.c_int(chr), C.c_int(1 if active else 0))
 
     def set_overlap(self, on):
         """True (default) / False / 2 (sampling-only overlap), or None: decide from two timed serialised generations"""

@@ -34,7 +34,7 @@ struct ChrDev {
     u32 R, M;
     u32 r_amax, m_amax;   // largest a_hi of the recombination / mutation thresholds (scan prefilter)
     const u64* snp_pos;   // [L] Legend.pos of the genotype plane
-    u32 L, pad_;
+    u32 L, active;        // active == 0: this context holds no genotype / CV state of the chromosome (locus-split populations)
 };
 
 // per-generation sampling results (all chromosomes; task t = offspring*nchr + chr, gamete G = 2t+s)
@@ -334,7 +334,15 @@ __global__ void __launch_bounds__(256) k_rec_sample(const GevRngTables* __restri
         u32 seed_pat;
         if (t == 0) { g.seed(T, seed_reproduce); seed_pat = g.out(T, 0); }     // srand(seed) :2400, first rand() :2447
         else seed_pat = sd.seed_pat[t];
-        task_sample(T, chrs[t % nchr], seed_pat, t, g, sd);
+        const ChrDev& C = chrs[t % nchr];
+        if (!C.active) {                 // another context owns this chromosome: only the seed chain (k_mut_sample) is needed here
+            if ((threadIdx.x & 63) == 0) {
+                sd.k[2 * t] = 0; sd.k[2 * t + 1] = 0; sd.bk_off[2 * t] = (u32)(2 * t) * GEV_BK_CAP; sd.bk_off[2 * t + 1] = (u32)(2 * t + 1) * GEV_BK_CAP;
+                sd.start[2 * t] = 0; sd.start[2 * t + 1] = 0; sd.seed_mat[t] = 0;
+            }
+            continue;
+        }
+        task_sample(T, C, seed_pat, t, g, sd);
     }
 }
 // serial form (no mutation map): every gamete's seed depends on the previous gamete's crossover

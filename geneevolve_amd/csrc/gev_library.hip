@@ -158,6 +158,8 @@ struct gev_ctx {
         bool presampled = false; int ps_pop = -1; u32 ps_seed = 0; size_t ps_n_people = 0; bool ps_has_mut = false;
     } sc[2];
     unsigned gen_counter = 0;
+    std::vector<uint8_t> chr_active;        // 0: chromosome held by another context (gev_set_chr_active); sampling chain only
+    bool any_inactive = false;
     hipStream_t stream_big = nullptr;
     bool planes_pending = false;            // a stitch may still be writing the current planes (stream_big)
     hipEvent_t ev_planes = nullptr;         // recorded after the most recent stitch
@@ -239,6 +241,17 @@ static int check_idx(gev_ctx* c, int pop, int chr, int phen = 0)
     return GEV_OK;
 }
 
+// data of a chromosome this context does not hold / operations that move whole individuals
+static int check_active(gev_ctx* c, int chr, const char* what)
+{
+    if (!c->chr_active[chr]) return fail(GEV_ESTATE, "%s: chromosome %d is not active on this context (gev_set_chr_active)", what, chr);
+    return GEV_OK;
+}
+static int check_all_active(gev_ctx* c, const char* what)
+{
+    if (c->any_inactive) return fail(GEV_EUNSUPPORTED, "%s: not available while chromosomes are inactive on this context (locus-split population)", what);
+    return GEV_OK;
+}
 // bit-column permutation of small planes (CV grid): out column j <- in column src_col[j]
 __global__ void k_permute_cols(const u32* __restrict__ in, size_t in_w32, u32* __restrict__ out, size_t out_w32, u32 used_w32,
                                const u32* __restrict__ src_col, u32 Cn, size_t n_rows)
@@ -296,6 +309,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     for (auto& ev : c->ev) HIPC(hipEventCreate(&ev));
     HIPC(hipStreamCreateWithPriority(&c->stream_big, hipStreamNonBlocking, prio_least));
     HIPC(hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming));
+    c->chr_active.assign(nchr, 1);
     c->n_lanes = std::max(1, std::min(nchr, (int)gev_ctx::MAX_LANES));
     if (const char* e = getenv("GEV_LANES")) c->n_lanes = std::max(1, std::min(atoi(e), (int)gev_ctx::MAX_LANES));
     c->lane[0].st = c->stream;
@@ -445,6 +459,7 @@ static int ensure_capacity(gev_ctx* c, int pop, size_t people)
     if (people <= P.cap_people) return GEV_OK;
     const size_t rows = 2 * people;
     for (int k = 0; k < c->nchr; k++) {
+        if (!c->chr_active[k]) continue;
         if (!P.cs[k].stride) return fail(GEV_ESTATE, "set_snps must precede allocation (pop %d chr %d)", pop, k);
         for (int b = 0; b < 2; b++) {
             GEVC(P.st[k].plane[b].ensure(rows * P.cs[k].stride, c->stream, /*keep=*/b == P.cur));
@@ -458,6 +473,22 @@ static int ensure_capacity(gev_ctx* c, int pop, size_t people)
         }
     }
     P.cap_people = people;
+    return GEV_OK;
+}
+// Locus-split populations (BASELINE config 4: 125k individuals x 5M loci do not fit one GPU twice): a context can hold the
+// genotype / CV / list state of a subset of the chromosomes only.  The rand() seed chain of Simulation::reproduce runs over
+// ALL (offspring, chromosome) tasks in order (:2447-2501), so every context still evaluates the mutation-sampling chain of
+// every task (maps of all chromosomes are required) but samples crossovers, tracks lists, stitches planes and accumulates
+// A/D for its active chromosomes only; gev_compute_ad returns exact zeros for the others.  Needs a mutation map (without
+// one the chain also depends on every crossover count: then all sampling runs everywhere).
+int gev_set_chr_active(gev_ctx* c, int chr, int active)
+{
+    GEVC(check_idx(c, 0, chr));
+    for (auto& P : c->pop) if (P.gen0) return fail(GEV_ESTATE, "set_chr_active: must precede gev_init_gen0");
+    c->chr_active[chr] = active ? 1 : 0;
+    c->any_inactive = false;
+    for (uint8_t a : c->chr_active) c->any_inactive |= !a;
+    for (auto& P : c->pop) P.finalized = false;
     return GEV_OK;
 }
 int gev_reserve(gev_ctx* c, int pop, size_t max_people)
@@ -569,7 +600,7 @@ static int finalize_static(gev_ctx* c, int pop)
         S.idx_lo = (u32)(std::lower_bound(S.pos.begin(), S.pos.end(), bp0) - S.pos.begin());
         S.idx_hi = (u32)(std::lower_bound(S.pos.begin(), S.pos.end(), bpe) - S.pos.begin());
         cd[k] = ChrDev{S.d_rthr.as<GevThr>(), S.d_rbp.as<u64>(), S.d_mthr.as<GevThr>(), S.d_mbp.as<u64>(), S.bp_dist, bp0, bpe,
-                       (u32)S.rbp.size(), (u32)S.mbp.size(), S.r_amax, S.m_amax, S.d_pos.as<u64>(), (u32)S.L, 0u};
+                       (u32)S.rbp.size(), (u32)S.mbp.size(), S.r_amax, S.m_amax, S.d_pos.as<u64>(), (u32)S.L, (u32)c->chr_active[k]};
         for (int p = 0; p < c->nphen; p++) {
             CvStatic& V = P.cv[p][k];
             if (!V.set) continue;
@@ -588,6 +619,7 @@ static int check_multipop(gev_ctx* c)
 {
     for (int pop = 1; pop < c->n_pop; pop++)
         for (int k = 0; k < c->nchr; k++) {
+            if (!c->chr_active[k]) continue;
             const ChrStatic& A = c->pop[0].cs[k]; const ChrStatic& B = c->pop[pop].cs[k];
             if (A.pos != B.pos) return fail(GEV_EUNSUPPORTED, "populations 0 and %d have different SNP grids on chromosome %d", pop, k);
             if (A.rbp.front() != B.rbp.front() || A.rbp.back() != B.rbp.back()) return fail(GEV_EUNSUPPORTED, "populations 0 and %d have different map ranges on chromosome %d", pop, k);
@@ -618,12 +650,14 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     GEVC(finalize_static(c, pop));
     const size_t rows = 2 * n_people;
     for (int k = 0; k < c->nchr; k++) {
+        if (!c->chr_active[k]) continue;
         if (P.cs[k].founder_rows < rows) return fail(GEV_ESTATE, "init_gen0: population %d chromosome %d has %zu founder haplotypes, %zu needed", pop, k, P.cs[k].founder_rows, rows);
         for (int p = 0; p < c->nphen; p++)
             if (P.cv[p][k].founder_rows < rows) return fail(GEV_ESTATE, "init_gen0: population %d phenotype %d chromosome %d has %zu CV founder haplotypes, %zu needed", pop, p, k, P.cv[p][k].founder_rows, rows);
     }
     GEVC(ensure_capacity(c, pop, std::max(n_people, P.cap_people)));
     for (int k = 0; k < c->nchr; k++) {
+        if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& st = P.st[k];
         hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(rows * (S.stride / 4), 256)), dim3(256), 0, c->stream,
                            st.plane[P.cur].as<u32>(), S.stride / 4, rows, S.idx_lo, S.idx_hi);
@@ -647,7 +681,7 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     KCHECK();
     if (sex_out) HIPC(hipMemcpyAsync(sex_out, c->d_sex0.p, n_people, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = rows; }
+    for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = c->chr_active[k] ? rows : 0; }
     c->ad_cached_pop = -1;
     P.n_people = n_people; P.n_phys = n_people; P.logical.clear(); P.gen0 = true;
     return GEV_OK;
@@ -786,6 +820,7 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
     const double grow = (double)rows / (double)std::max<size_t>(2 * P.n_people, 1);
     for (int k = 0; k < nchr; k++) {
+        if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         gev_ctx::Lane& ln = c->lane[k % c->n_lanes];
         hipStream_t ls = ln.st;
@@ -855,6 +890,7 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     HIPC(hipStreamWaitEvent(sb, sc.ev_small_done, 0));
     HIPC(hipEventRecord(sc.t[4], sb));
     for (int k = 0; k < nchr; k++) {
+        if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         const u32 chunks = (u32)(S.stride / 16);
         // enough workgroups to fill 256 CUs even for small populations; one span >= 4 KiB
@@ -1046,9 +1082,13 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
     GEVC(c->d_add.ensure(n * nphen * sizeof(double), st)); GEVC(c->d_dom.ensure(n * nphen * sizeof(double), st));
     GEVC(c->d_flag.ensure(16, st));
     HIPC(hipMemsetAsync(c->d_flag.p, 0xff, 4, st));
+    if (c->any_inactive) {                                   // chromosomes held elsewhere contribute exact zeros here
+        HIPC(hipMemsetAsync(c->d_addchr.p, 0, n * nchr * nphen * sizeof(double), st)); HIPC(hipMemsetAsync(c->d_domchr.p, 0, n * nchr * nphen * sizeof(double), st));
+    }
     GEVC(lanes_fork(c));
     for (int p = 0; p < nphen; p++)
         for (int k = 0; k < nchr; k++) {
+            if (!c->chr_active[k]) continue;
             CvStatic& V = P.cv[p][k]; ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
             gev_ctx::Lane& ln = c->lane[k % c->n_lanes];
             hipStream_t ls = ln.st;
@@ -1169,6 +1209,7 @@ int gev_scale_ad_compute_gef(gev_ctx* c, int pop, int phen, const gev_gef_params
                              const double* common_sibling, const double* f_father, const double* f_mother,
                              double* additive, double* dominance, double* bv, double* e_noise, double* parental_effect, double* phen_out)
 {
+    if (c) GEVC(check_all_active(c, "scale_ad_compute_gef"));
     GEVC(check_idx(c, pop, 0, phen));
     if (!par) return fail(GEV_EINVAL, "scale_ad_compute_gef: null parameters");
     PopState& P = c->pop[pop];
@@ -1220,6 +1261,7 @@ int gev_scale_ad_compute_gef(gev_ctx* c, int pop, int phen, const gev_gef_params
 int gev_get_cv_freq(gev_ctx* c, int pop, int phen, int chr, double* frq, size_t C)
 {
     GEVC(check_idx(c, pop, chr, phen));
+    GEVC(check_active(c, chr, "get_cv_freq"));
     CvStatic& V = c->pop[pop].cv[phen][chr];
     if (!V.frq_valid) return fail(GEV_ESTATE, "get_cv_freq: call gev_compute_ad first");
     if (C != V.C || !frq) return fail(GEV_EINVAL, "get_cv_freq: C=%zu, expected %u", C, V.C);
@@ -1322,6 +1364,7 @@ static int materialize_order(gev_ctx* c, int pop)
 }
 int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
 {
+    if (c) GEVC(check_all_active(c, "migrate"));
     if (!c) return fail(GEV_EINVAL, "null context");
     if (n_moves && !moves) return fail(GEV_EINVAL, "migrate: null moves");
     HIPC(hipSetDevice(c->device));
@@ -1417,6 +1460,7 @@ static int export_counts(gev_ctx* c, int pop, const uint64_t* positions, size_t 
 }
 int gev_export_size(gev_ctx* c, int pop, const uint64_t* positions, size_t n, size_t* bytes)
 {
+    if (c) GEVC(check_all_active(c, "export_size"));
     GEVC(check_idx(c, pop, 0));
     if (!bytes || (n && !positions)) return fail(GEV_EINVAL, "export_size: null argument");
     PopState& P = c->pop[pop];
@@ -1429,6 +1473,7 @@ int gev_export_size(gev_ctx* c, int pop, const uint64_t* positions, size_t n, si
 }
 int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, void* device_buf, size_t bytes)
 {
+    if (c) GEVC(check_all_active(c, "export_rows"));
     GEVC(check_idx(c, pop, 0));
     if (n && (!positions || !device_buf)) return fail(GEV_EINVAL, "export_rows: null argument");
     PopState& P = c->pop[pop];
@@ -1478,6 +1523,7 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
 }
 int gev_remove_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n)
 {
+    if (c) GEVC(check_all_active(c, "remove_rows"));
     GEVC(check_idx(c, pop, 0));
     if (n && !positions) return fail(GEV_EINVAL, "remove_rows: null positions");
     PopState& P = c->pop[pop];
@@ -1496,6 +1542,7 @@ int gev_remove_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n)
 }
 int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, size_t n)
 {
+    if (c) GEVC(check_all_active(c, "import_rows"));
     GEVC(check_idx(c, pop, 0));
     PopState& P = c->pop[pop];
     if (!P.gen0) return fail(GEV_ESTATE, "import_rows: population %d has no current generation", pop);
@@ -1559,6 +1606,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
 int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, u64* bits, size_t row_stride_words)
 {
     GEVC(check_idx(c, pop, chr));
+    GEVC(check_active(c, chr, "download_haps"));
     PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_haps: population %d has no current generation", pop);
     GEVC(materialize_order(c, pop));
@@ -1621,6 +1669,7 @@ static size_t snp_chunk(size_t bytes_per_snp) { return std::max<size_t>((256u <<
 int gev_download_snp_major(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, u64* bits, size_t row_stride_words)
 {
     GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "download_snp_major"));
+    GEVC(check_active(c, chr, "download_snp_major"));
     PopState& P = c->pop[pop];
     const size_t rows = 2 * P.n_people, w = ceil_div(rows, 64);
     if (n_snps && (!bits || row_stride_words < w)) return fail(GEV_EINVAL, "download_snp_major: bad output buffer");
@@ -1638,6 +1687,7 @@ int gev_download_snp_major(gev_ctx* c, int pop, int chr, size_t snp_begin, size_
 int gev_format_hap_text(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes)
 {
     GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "format_hap_text"));
+    GEVC(check_active(c, chr, "format_hap_text"));
     PopState& P = c->pop[pop];
     const size_t rows = 2 * P.n_people, line = 2 * rows + 1;
     if (out_bytes < n_snps * line || (n_snps && !out)) return fail(GEV_EINVAL, "format_hap_text: buffer of %zu bytes, %zu needed", out_bytes, n_snps * line);
@@ -1682,6 +1732,7 @@ static int ind_range_check(gev_ctx* c, int pop, int chr, size_t ind0, size_t n, 
 int gev_format_ped_text(gev_ctx* c, int pop, int chr, size_t ind_begin, size_t n_ind, const char* al0, const char* al1, char* out, size_t out_bytes)
 {
     GEVC(ind_range_check(c, pop, chr, ind_begin, n_ind, "format_ped_text"));
+    GEVC(check_active(c, chr, "format_ped_text"));
     ChrStatic& S = c->pop[pop].cs[chr];
     const size_t line = 4 * S.L + 1;
     if ((al0 == nullptr) != (al1 == nullptr)) return fail(GEV_EINVAL, "format_ped_text: al0 and al1 must both be given or both be NULL");
@@ -1710,6 +1761,7 @@ int gev_format_ped_text(gev_ctx* c, int pop, int chr, size_t ind_begin, size_t n
 int gev_download_plink_matrix(gev_ctx* c, int pop, int chr, size_t ind_begin, size_t n_ind, u64* bits, size_t row_stride_words)
 {
     GEVC(ind_range_check(c, pop, chr, ind_begin, n_ind, "download_plink_matrix"));
+    GEVC(check_active(c, chr, "download_plink_matrix"));
     ChrStatic& S = c->pop[pop].cs[chr];
     const size_t w32 = ceil_div(S.L, 32);                  // one source word -> one 64-bit output word
     if (n_ind && (!bits || row_stride_words < w32)) return fail(GEV_EINVAL, "download_plink_matrix: bad output buffer (need %zu words per row)", w32);
@@ -1749,6 +1801,7 @@ int gev_rank_f64(gev_ctx* c, const double* x, size_t n, unsigned long long* rank
 int gev_format_vcf_gt(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes)
 {
     GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "format_vcf_gt"));
+    GEVC(check_active(c, chr, "format_vcf_gt"));
     PopState& P = c->pop[pop];
     const size_t line = 4 * P.n_people + 1;
     if (out_bytes < n_snps * line || (n_snps && !out)) return fail(GEV_EINVAL, "format_vcf_gt: buffer of %zu bytes, %zu needed", out_bytes, n_snps * line);
@@ -1768,6 +1821,7 @@ int gev_format_vcf_gt(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_s
 int gev_format_bed(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, uint8_t* out, size_t out_bytes)
 {
     GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "format_bed"));
+    GEVC(check_active(c, chr, "format_bed"));
     PopState& P = c->pop[pop];
     const size_t bpl = ceil_div(P.n_people, 4);
     if (out_bytes < n_snps * bpl || (n_snps && !out)) return fail(GEV_EINVAL, "format_bed: buffer of %zu bytes, %zu needed", out_bytes, n_snps * bpl);
@@ -1787,6 +1841,7 @@ int gev_format_bed(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps
 int gev_download_cv(gev_ctx* c, int pop, int phen, int chr, u64* bits, size_t row_stride_words)
 {
     GEVC(check_idx(c, pop, chr, phen));
+    GEVC(check_active(c, chr, "download_cv"));
     PopState& P = c->pop[pop]; CvStatic& V = P.cv[phen][chr]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_cv: population %d has no current generation", pop);
     GEVC(materialize_order(c, pop));
@@ -1811,6 +1866,7 @@ int gev_download_cv(gev_ctx* c, int pop, int phen, int chr, u64* bits, size_t ro
 int gev_download_intervals(gev_ctx* c, int pop, int chr, gev_part* out, u64* hap_offsets, size_t* n_parts)
 {
     GEVC(check_idx(c, pop, chr));
+    GEVC(check_active(c, chr, "download_intervals"));
     PopState& P = c->pop[pop]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_intervals: population %d has no current generation", pop);
     GEVC(materialize_order(c, pop));
@@ -1832,6 +1888,7 @@ int gev_download_intervals(gev_ctx* c, int pop, int chr, gev_part* out, u64* hap
 int gev_download_mutations(gev_ctx* c, int pop, int chr, u64* out, u64* hap_offsets, size_t* n_mut)
 {
     GEVC(check_idx(c, pop, chr));
+    GEVC(check_active(c, chr, "download_mutations"));
     PopState& P = c->pop[pop]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_mutations: population %d has no current generation", pop);
     GEVC(materialize_order(c, pop));
@@ -1855,6 +1912,7 @@ int gev_pop_size(gev_ctx* c, int pop, size_t* n) { GEVC(check_idx(c, pop, 0)); i
 int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows)
 {
     GEVC(check_idx(c, pop, chr));
+    GEVC(check_active(c, chr, "plane_ptr"));
     GEVC(gev_sync(c));
     if (c->pop[pop].gen0) GEVC(materialize_order(c, pop));
     PopState& P = c->pop[pop];

@@ -61,3 +61,26 @@ def migrate_all_to_all(ctx, outgoing, local_pop, device=None, group=None):
             ctx.import_rows(local_pop, recv.data_ptr() + off, recv_bytes[i], recv_n[i])
         off += recv_bytes[i]
     return recv_n
+
+
+def compute_ad_locus_split(ctx, pop, group=None, device=None):
+    """Simulation::ras_compute_AD (reference src/Simulation.cpp:2624-2749) for a population whose chromosomes are split
+    over the ranks of `group` (gev_set_chr_active): every rank holds exact zeros for the chromosomes it does not own, so
+    an all-reduce(SUM) of the per-chromosome arrays reproduces each entry bit for bit (x + 0 + ... + 0), and the totals are
+    re-summed over chromosomes in the reference's order (:2729-2746).  This is the only collective of a locus-split
+    population: N x nchr x nphen doubles per generation.
+    Returns (additive, dominance, additive_chr, dominance_chr), identical on every rank of the group."""
+    import torch
+    import torch.distributed as dist
+    _, _, addc, domc = ctx.compute_ad(pop, per_chr=True)
+    both = np.stack([addc, domc])                                   # [2][n][nchr][nphen]
+    backend = dist.get_backend(group)
+    dev = device if device is not None else ("cuda" if backend == "nccl" else "cpu")
+    t = torch.from_numpy(both).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    both = t.cpu().numpy()
+    addc, domc = both[0], both[1]
+    add = np.zeros(addc.shape[:1] + addc.shape[2:]); dom = np.zeros_like(add)
+    for k in range(addc.shape[1]):                                  # sequential FP64 sums, chromosome order
+        add = add + addc[:, k, :]; dom = dom + domc[:, k, :]
+    return add, dom, addc, domc

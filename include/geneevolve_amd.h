@@ -236,6 +236,13 @@ int gev_pop_size(gev_ctx*, int pop, size_t* n_people);
 /* device pointer + stride of the resident genotype plane of the current generation (founder
  * alleles only: mutations are kept as a sparse overlay). */
 int gev_plane_ptr(gev_ctx*, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows);
+/* Locus-split population: mark the chromosomes whose genotype / CV / list state THIS context holds (default: all).
+ * Inactive chromosomes still need gev_set_rmap / gev_set_mutmap (the rand() seed chain of Simulation::reproduce,
+ * src/Simulation.cpp:2447-2501, runs through every (offspring, chromosome) task), nothing else; their A/D entries come back
+ * as exact zeros, so the contexts sharing one population add their per-chromosome arrays (all-reduce) and sum over
+ * chromosomes in order (geneevolve_amd/distributed.py:compute_ad_locus_split).  Call before gev_init_gen0.
+ * Row movement (migration) and gev_scale_ad_compute_gef are refused on such a context. */
+int gev_set_chr_active(gev_ctx*, int chr, int active);
 /* reserve device capacity for populations of up to max_people (avoids reallocation) */
 int gev_reserve(gev_ctx*, int pop, size_t max_people);
 /* HIP stream the context launches on (hipStream_t as void*), for event timing by the caller */

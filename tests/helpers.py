@@ -37,8 +37,9 @@ def find_gen0_seeds(fx, oracle_lib):
     return seeds
 
 
-def setup_static(ctx, fx):
-    """ras_init_parameters equivalent: maps, SNP/CV grids, founder panels."""
+def setup_static(ctx, fx, only_chr=None):
+    """ras_init_parameters equivalent: maps, SNP/CV grids, founder panels.  only_chr: the chromosomes whose genotype / CV
+    inputs this context is given (locus-split populations); the others get their maps only."""
     n_pop, nchr, nphen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"])
     for ip in range(n_pop):
         pre = f"pop{ip}_"
@@ -47,6 +48,8 @@ def setup_static(ctx, fx):
             ctx.set_rmap(ip, ic, fx[f"{pre}chr{ic}_rmap_bp"], fx[f"{pre}chr{ic}_rmap_prob"], int(fx[f"{pre}chr{ic}_bp_dist"]))
             if int(fx[pre + "has_mut"]):
                 ctx.set_mutmap(ip, ic, fx[f"{pre}chr{ic}_mut_bp"], fx[f"{pre}chr{ic}_mut_rate"])
+            if only_chr is not None and ic not in only_chr:
+                continue
             pos = fx[f"{pre}chr{ic}_snp_pos"]
             ctx.set_snps(ip, ic, pos)
             if f"{pre}chr{ic}_founders" in fx:

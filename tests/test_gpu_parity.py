@@ -219,6 +219,17 @@ def test_two_rank_migration_on_gpu_matches_reference_fixture():
         assert msg == "ok", f"rank {r}: {msg}"
 
 
+def test_locus_split_population_on_gpu_matches_the_unsplit_reference_run():
+    """gev_set_chr_active: one population split along chromosomes over two processes (BASELINE config 4's layout; both share
+    the test box's GPU, gloo carries the per-chromosome A/D all-reduce).  Each context is given genotype / CV inputs of its
+    own chromosomes only; sex (the seed chain spans all chromosomes), per-chromosome and total A/D, dense genotypes and
+    interval offsets equal the reference's unsplit run (fixture ex1mut) bit for bit."""
+    from tests import dist_worker
+    res = dist_worker.launch("gpu", target=dist_worker.run_locus_split)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
 def test_baseline_config2_full_size_dense_state_equals_interval_state(gpu_lib):
     """BASELINE config 2 at FULL size (100k individuals x 1M SNPs; the oracle would need hours):
     after two generations the dense genotype rows produced by the stitch kernel must equal what the
