@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--plane-less", action="store_true", help="interval state only (gev_set_dense_state 0): the mode of populations that exceed HBM; no stitch, roofline not applicable")
     ap.add_argument("--no-presample", action="store_true", help="do not hand the next generation's seeds to the library ahead of its couples (gev_presample)")
     ap.add_argument("--n-ind", type=int, default=100_000)
     ap.add_argument("--n-loci", type=int, default=1_000_000)
@@ -184,11 +185,14 @@ def main():
     ctx = lib.create(n_pop_ctx, args.nchr, 1, local_rank)
     if args.no_intervals:
         ctx.set_track_intervals(False)
+    if args.plane_less:                                         # BASELINE config 5's mode (not the headline): no resident genotype planes
+        ctx.set_dense_state(False)
     for p in range(n_pop_ctx):
         cfg.apply_static(ctx, p)
     P = my_pop
     for c in range(args.nchr):
-        ctx.synth_founders(P, c, 2 * args.n_ind, 1000 + 100 * c + rank)
+        if not args.plane_less:
+            ctx.synth_founders(P, c, 2 * args.n_ind, 1000 + 100 * c + rank)
         ctx.synth_cv_founders(P, 0, c, 2 * args.n_ind, 2000 + 100 * c + rank)
     sim = Simulation(ctx, 12345 + rank, args.nchr, True)
     sim.ras_initial_human_gen0(P, args.n_ind)
@@ -257,7 +261,7 @@ def main():
 
     # a few extra, untimed generations with the two library streams serialised: the stitch kernel alone on the GPU
     iso = None
-    if args.isolated_steps > 0 and not migrate:
+    if args.isolated_steps > 0 and not migrate and not args.plane_less:
         ctx.set_overlap(False)
         more = [sim.ras_glob_seed(1 + args.n_ind * args.nchr) for _ in range(args.isolated_steps)]
         ta, na = ctx.timing_totals()
@@ -273,7 +277,7 @@ def main():
         gens_per_s = world * args.steps / dt
         alg_bytes = args.n_ind * args.n_loci / 2.0 * args.nchr   # per generation: one stitch launch per chromosome, N*L/2 bytes each
         stitch = float(np.mean(stitch_ms))
-        achieved = alg_bytes / (stitch * 1e-3) / 1e9
+        achieved = alg_bytes / (max(stitch, 1e-9) * 1e-3) / 1e9 if not args.plane_less else 0.0
         traffic = None                                      # HBM bytes per launch from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r01_final_config2_pmc_hbm.json")
         if os.path.exists(pmc) and (args.n_ind, args.n_loci, args.nchr) == (100_000, 1_000_000, 1):
@@ -289,7 +293,7 @@ def main():
                        if (args.n_ind, args.n_loci, args.nchr) == (100_000, 1_000_000, 1) else
                        f"config-2 family, non-default size: {args.n_ind} individuals x {args.nchr} chromosome(s) x {args.n_loci} SNPs",
                        "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_chromosomes": args.nchr, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
-                       "interval_state_tracked": not args.no_intervals},
+                       "interval_state_tracked": not args.no_intervals, "resident_genotype_planes": not args.plane_less},
             "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci * args.nchr / dt,
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
                          "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
-    "pop_size", "plane_ptr", "reserve", "set_chr_active", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
+    "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -371,6 +371,21 @@ class GevContext:
 
     def set_chr_active(self, chr, active):
         self._call("set_chr_active", C.c_int(chr), C.c_int(1 if active else 0))
+
+    def set_dense_state(self, on):
+        self._call("set_dense_state", C.c_int(1 if on else 0))
+
+    def materialize(self, pop, chr, founder_tile, row_begin=0, n_rows=None, snp_begin=0, n_snps=None):
+        """genotype tile from the interval state; founder_tile: uint64 [n_founder_haps][words] holding SNPs [snp_begin, +n_snps)"""
+        L = self._nsnp[(pop, chr)]
+        n_snps = L - snp_begin if n_snps is None else n_snps
+        n_rows = 2 * self.pop_size(pop) - row_begin if n_rows is None else n_rows
+        ft = np.ascontiguousarray(founder_tile, dtype=np.uint64)
+        w = words_for(n_snps)
+        out = np.zeros((n_rows, w), dtype=np.uint64)
+        self._call("materialize", C.c_int(pop), C.c_int(chr), C.c_size_t(row_begin), C.c_size_t(n_rows), C.c_size_t(snp_begin), C.c_size_t(n_snps),
+                   _p(ft), C.c_size_t(ft.shape[1]), C.c_size_t(ft.shape[0]), _p(out), C.c_size_t(w))
+        return out
 
     def set_overlap(self, on):
         """True (default) / False / 2 (sampling-only overlap), or None: decide from two timed serialised generations"""

@@ -937,6 +937,55 @@ __global__ void __launch_bounds__(256) k_snp_apply_mut(
         }
     }
 }
+// K8: genotype tile from the ancestry intervals == Simulation::ras_convert_interval_to_hap_matrix (src/Simulation.cpp:1186-1230)
+// restricted to haplotype rows [row0, row0+n_rows) x loci [s0, s0+ns): out[r][ii] = founder[part.hap_index][ii] for the part
+// that contains pos[ii]; loci outside every part stay 0.  One thread per 32-bit word of the tile; the parts of a row are
+// disjoint and ascending, so the first candidate is found by bisection on `en` and usually covers the whole word.
+// `founder` holds the same loci range of every founder haplotype (bit j = locus s0 + j).  Mutations: k_tile_apply_mut.
+__global__ void __launch_bounds__(256) k_materialize_tile(const u32* __restrict__ p_off, const gev_part* __restrict__ parts, size_t row0, size_t n_rows,
+                                                          const u64* __restrict__ pos, u32 s0, u32 ns, const u32* __restrict__ founder, size_t founder_w32,
+                                                          size_t n_founder_rows, u32* __restrict__ out, size_t out_w32, u32* __restrict__ status)
+{
+    const u32 words = (ns + 31) / 32;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_rows * words) return;
+    const size_t r = q / words; const u32 w = (u32)(q % words);
+    const u32 nb = min(32u, ns - 32u * w);
+    const u64* wp = pos + s0 + 32u * w;                       // positions of this word's loci
+    const u64 x0 = wp[0], x1 = wp[nb - 1];
+    u32 lo = p_off[row0 + r], hi = p_off[row0 + r + 1];
+    const u32 end = hi;
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (parts[m].en <= x0) lo = m + 1; else hi = m; }    // first part with en > x0
+    u32 acc = 0;
+    for (u32 i = lo; i < end && parts[i].st <= x1; i++) {
+        const u64 st = parts[i].st, en = parts[i].en;
+        u32 a = 0, b = 0;
+        for (u32 t = 0; t < nb; t++) { a += wp[t] < st ? 1u : 0u; b += wp[t] < en ? 1u : 0u; }        // loci [a, b) lie in [st, en)
+        if (b > a) {
+            const u32 mask = (b - a == 32u) ? 0xffffffffu : (((1u << (b - a)) - 1u) << a);
+            const u64 h = parts[i].hap_index;
+            if (h >= n_founder_rows) { atomicOr(status, 1u); continue; }                              // :1205-1209 "hap_index is not in range"
+            acc |= founder[h * founder_w32 + w] & mask;
+        }
+    }
+    out[r * out_w32 + w] = acc;
+}
+// mutation overlay of a tile: out bit = !unmutated bit at every tile locus whose position is in the row's mutation list (:1212-1216)
+__global__ void __launch_bounds__(256) k_tile_apply_mut(const u32* __restrict__ plain, u32* __restrict__ out, size_t w32, size_t row0, size_t n_rows,
+                                                        const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ pos, u32 s0, u32 ns)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const u32* in = plain + r * w32; u32* o = out + r * w32;
+    for (u32 j = m_off[row0 + r]; j < m_off[row0 + r + 1]; j++) {
+        const u64 x = m_pos[j];
+        u32 c = lower_bound_u64(pos + s0, ns, x);
+        for (; c < ns && pos[s0 + c] == x; c++) {
+            const u32 f = (in[c >> 5] >> (c & 31)) & 1u;
+            if (f) o[c >> 5] &= ~(1u << (c & 31)); else o[c >> 5] |= (1u << (c & 31));
+        }
+    }
+}
 // generic row gather (migration, capacity growth, download staging): dst row r <- src row map[r]
 __global__ void __launch_bounds__(256) k_gather_rows16(uint4* __restrict__ dst, size_t dst_stride16, const uint4* __restrict__ src, size_t src_stride16,
                                                        const u32* __restrict__ map, size_t n_rows, u32 chunks)

@@ -160,6 +160,7 @@ struct gev_ctx {
     unsigned gen_counter = 0;
     std::vector<uint8_t> chr_active;        // 0: chromosome held by another context (gev_set_chr_active); sampling chain only
     bool any_inactive = false;
+    bool dense = true;                      // false: no resident genotype planes (gev_set_dense_state); lists + CV planes only, output by gev_materialize
     hipStream_t stream_big = nullptr;
     bool planes_pending = false;            // a stitch may still be writing the current planes (stream_big)
     hipEvent_t ev_planes = nullptr;         // recorded after the most recent stitch
@@ -245,6 +246,11 @@ static int check_idx(gev_ctx* c, int pop, int chr, int phen = 0)
 static int check_active(gev_ctx* c, int chr, const char* what)
 {
     if (!c->chr_active[chr]) return fail(GEV_ESTATE, "%s: chromosome %d is not active on this context (gev_set_chr_active)", what, chr);
+    return GEV_OK;
+}
+static int check_dense(gev_ctx* c, const char* what)
+{
+    if (!c->dense) return fail(GEV_ESTATE, "%s: this context keeps no resident genotype planes (gev_set_dense_state 0); use gev_materialize", what);
     return GEV_OK;
 }
 static int check_all_active(gev_ctx* c, const char* what)
@@ -462,7 +468,7 @@ static int ensure_capacity(gev_ctx* c, int pop, size_t people)
         if (!c->chr_active[k]) continue;
         if (!P.cs[k].stride) return fail(GEV_ESTATE, "set_snps must precede allocation (pop %d chr %d)", pop, k);
         for (int b = 0; b < 2; b++) {
-            GEVC(P.st[k].plane[b].ensure(rows * P.cs[k].stride, c->stream, /*keep=*/b == P.cur));
+            if (c->dense) GEVC(P.st[k].plane[b].ensure(rows * P.cs[k].stride, c->stream, /*keep=*/b == P.cur));
             GEVC(P.st[k].moff[b].ensure((rows + 1) * sizeof(u32), c->stream, b == P.cur));
             GEVC(P.st[k].poff[b].ensure((rows + 1) * sizeof(u32), c->stream, b == P.cur));
         }
@@ -491,6 +497,17 @@ int gev_set_chr_active(gev_ctx* c, int chr, int active)
     for (auto& P : c->pop) P.finalized = false;
     return GEV_OK;
 }
+// Populations whose genotype matrix cannot be resident (BASELINE config 5: 1M individuals x 10M loci): keep the reference's
+// own state only -- ancestry intervals + mutation sets (and the small CV planes A/D needs) -- and assemble genotype tiles
+// on demand with gev_materialize.  Must precede gev_init_gen0; founder SNP panels are not uploaded in this mode.
+int gev_set_dense_state(gev_ctx* c, int on)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    for (auto& P : c->pop) if (P.gen0) return fail(GEV_ESTATE, "set_dense_state: must precede gev_init_gen0");
+    c->dense = on != 0;
+    if (!c->dense) c->track_intervals = true;
+    return GEV_OK;
+}
 int gev_reserve(gev_ctx* c, int pop, size_t max_people)
 {
     GEVC(check_idx(c, pop, 0));
@@ -500,6 +517,7 @@ int gev_reserve(gev_ctx* c, int pop, size_t max_people)
 
 int gev_upload_founders(gev_ctx* c, int pop, int chr, const u64* bits, size_t row_stride_words, size_t nhap, size_t L)
 {
+    if (c) GEVC(check_dense(c, "upload_founders"));
     GEVC(check_idx(c, pop, chr));
     PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr];
     if (!bits || nhap < 2 || (nhap & 1)) return fail(GEV_EINVAL, "upload_founders: need an even number (>=2) of haplotype rows");
@@ -521,6 +539,7 @@ int gev_upload_founders(gev_ctx* c, int pop, int chr, const u64* bits, size_t ro
 }
 int gev_synth_founders(gev_ctx* c, int pop, int chr, size_t nhap, u64 seed)
 {
+    if (c) GEVC(check_dense(c, "synth_founders"));
     GEVC(check_idx(c, pop, chr));
     PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr];
     if (nhap < 2 || (nhap & 1)) return fail(GEV_EINVAL, "synth_founders: need an even number of haplotypes");
@@ -651,7 +670,7 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     const size_t rows = 2 * n_people;
     for (int k = 0; k < c->nchr; k++) {
         if (!c->chr_active[k]) continue;
-        if (P.cs[k].founder_rows < rows) return fail(GEV_ESTATE, "init_gen0: population %d chromosome %d has %zu founder haplotypes, %zu needed", pop, k, P.cs[k].founder_rows, rows);
+        if (c->dense && P.cs[k].founder_rows < rows) return fail(GEV_ESTATE, "init_gen0: population %d chromosome %d has %zu founder haplotypes, %zu needed", pop, k, P.cs[k].founder_rows, rows);
         for (int p = 0; p < c->nphen; p++)
             if (P.cv[p][k].founder_rows < rows) return fail(GEV_ESTATE, "init_gen0: population %d phenotype %d chromosome %d has %zu CV founder haplotypes, %zu needed", pop, p, k, P.cv[p][k].founder_rows, rows);
     }
@@ -659,8 +678,9 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     for (int k = 0; k < c->nchr; k++) {
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& st = P.st[k];
-        hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(rows * (S.stride / 4), 256)), dim3(256), 0, c->stream,
-                           st.plane[P.cur].as<u32>(), S.stride / 4, rows, S.idx_lo, S.idx_hi);
+        if (c->dense)
+            hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(rows * (S.stride / 4), 256)), dim3(256), 0, c->stream,
+                               st.plane[P.cur].as<u32>(), S.stride / 4, rows, S.idx_lo, S.idx_hi);
         HIPC(hipMemsetAsync(st.moff[P.cur].p, 0, (rows + 1) * sizeof(u32), c->stream));
         GEVC(st.parts[P.cur].ensure(rows * sizeof(gev_part), c->stream));
         hipLaunchKernelGGL(k_init_parts, dim3((unsigned)ceil_div(rows + 1, 256)), dim3(256), 0, c->stream,
@@ -890,7 +910,7 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     HIPC(hipStreamWaitEvent(sb, sc.ev_small_done, 0));
     HIPC(hipEventRecord(sc.t[4], sb));
     for (int k = 0; k < nchr; k++) {
-        if (!c->chr_active[k]) continue;
+        if (!c->chr_active[k] || !c->dense) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         const u32 chunks = (u32)(S.stride / 16);
         // enough workgroups to fill 256 CUs even for small populations; one span >= 4 KiB
@@ -1364,6 +1384,7 @@ static int materialize_order(gev_ctx* c, int pop)
 }
 int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
 {
+    if (c) GEVC(check_dense(c, "migrate"));
     if (c) GEVC(check_all_active(c, "migrate"));
     if (!c) return fail(GEV_EINVAL, "null context");
     if (n_moves && !moves) return fail(GEV_EINVAL, "migrate: null moves");
@@ -1460,6 +1481,7 @@ static int export_counts(gev_ctx* c, int pop, const uint64_t* positions, size_t 
 }
 int gev_export_size(gev_ctx* c, int pop, const uint64_t* positions, size_t n, size_t* bytes)
 {
+    if (c) GEVC(check_dense(c, "export_size"));
     if (c) GEVC(check_all_active(c, "export_size"));
     GEVC(check_idx(c, pop, 0));
     if (!bytes || (n && !positions)) return fail(GEV_EINVAL, "export_size: null argument");
@@ -1473,6 +1495,7 @@ int gev_export_size(gev_ctx* c, int pop, const uint64_t* positions, size_t n, si
 }
 int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, void* device_buf, size_t bytes)
 {
+    if (c) GEVC(check_dense(c, "export_rows"));
     if (c) GEVC(check_all_active(c, "export_rows"));
     GEVC(check_idx(c, pop, 0));
     if (n && (!positions || !device_buf)) return fail(GEV_EINVAL, "export_rows: null argument");
@@ -1523,6 +1546,7 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
 }
 int gev_remove_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n)
 {
+    if (c) GEVC(check_dense(c, "remove_rows"));
     if (c) GEVC(check_all_active(c, "remove_rows"));
     GEVC(check_idx(c, pop, 0));
     if (n && !positions) return fail(GEV_EINVAL, "remove_rows: null positions");
@@ -1542,6 +1566,7 @@ int gev_remove_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n)
 }
 int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, size_t n)
 {
+    if (c) GEVC(check_dense(c, "import_rows"));
     if (c) GEVC(check_all_active(c, "import_rows"));
     GEVC(check_idx(c, pop, 0));
     PopState& P = c->pop[pop];
@@ -1605,6 +1630,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
 // ---- output materialisation ---------------------------------------------------------------
 int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, u64* bits, size_t row_stride_words)
 {
+    if (c) GEVC(check_dense(c, "download_haps"));
     GEVC(check_idx(c, pop, chr));
     GEVC(check_active(c, chr, "download_haps"));
     PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
@@ -1668,6 +1694,7 @@ static int snp_range_check(gev_ctx* c, int pop, int chr, size_t s0, size_t ns, c
 static size_t snp_chunk(size_t bytes_per_snp) { return std::max<size_t>((256u << 20) / std::max<size_t>(bytes_per_snp, 1), 64) & ~(size_t)63; }
 int gev_download_snp_major(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, u64* bits, size_t row_stride_words)
 {
+    if (c) GEVC(check_dense(c, "download_snp_major"));
     GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "download_snp_major"));
     GEVC(check_active(c, chr, "download_snp_major"));
     PopState& P = c->pop[pop];
@@ -1686,6 +1713,7 @@ int gev_download_snp_major(gev_ctx* c, int pop, int chr, size_t snp_begin, size_
 // bytes of the reference's .hap file for SNP lines [snp_begin, snp_begin+n_snps): n_snps * (4*n_people + 1)
 int gev_format_hap_text(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes)
 {
+    if (c) GEVC(check_dense(c, "format_hap_text"));
     GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "format_hap_text"));
     GEVC(check_active(c, chr, "format_hap_text"));
     PopState& P = c->pop[pop];
@@ -1731,6 +1759,7 @@ static int ind_range_check(gev_ctx* c, int pop, int chr, size_t ind0, size_t n, 
 // genotype columns of the PLINK .ped text, one line per individual (the caller writes the six id columns in front)
 int gev_format_ped_text(gev_ctx* c, int pop, int chr, size_t ind_begin, size_t n_ind, const char* al0, const char* al1, char* out, size_t out_bytes)
 {
+    if (c) GEVC(check_dense(c, "format_ped_text"));
     GEVC(ind_range_check(c, pop, chr, ind_begin, n_ind, "format_ped_text"));
     GEVC(check_active(c, chr, "format_ped_text"));
     ChrStatic& S = c->pop[pop].cs[chr];
@@ -1760,6 +1789,7 @@ int gev_format_ped_text(gev_ctx* c, int pop, int chr, size_t ind_begin, size_t n
 // matrix_plink_ped rows (bit 2*snp + hap), ceil(2L/64) words per individual
 int gev_download_plink_matrix(gev_ctx* c, int pop, int chr, size_t ind_begin, size_t n_ind, u64* bits, size_t row_stride_words)
 {
+    if (c) GEVC(check_dense(c, "download_plink_matrix"));
     GEVC(ind_range_check(c, pop, chr, ind_begin, n_ind, "download_plink_matrix"));
     GEVC(check_active(c, chr, "download_plink_matrix"));
     ChrStatic& S = c->pop[pop].cs[chr];
@@ -1797,9 +1827,57 @@ int gev_rank_f64(gev_ctx* c, const double* x, size_t n, unsigned long long* rank
     HIPC(hipStreamSynchronize(st));
     return GEV_OK;
 }
+// K8: rows [row_begin, +n_rows) x loci [snp_begin, +n_snps) of the genotype matrix from the interval state and a founder tile
+int gev_materialize(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
+                    const u64* founder_bits, size_t founder_stride_words, size_t n_founder_rows, u64* bits, size_t row_stride_words)
+{
+    GEVC(check_idx(c, pop, chr));
+    GEVC(check_active(c, chr, "materialize"));
+    PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
+    if (!P.gen0) return fail(GEV_ESTATE, "materialize: population %d has no current generation", pop);
+    if (!c->track_intervals) return fail(GEV_ESTATE, "materialize: interval tracking is disabled");
+    if (c->n_pop > 1) return fail(GEV_EUNSUPPORTED, "materialize: one founder panel per call; contexts with several populations (parts of foreign root populations) are not supported yet");
+    GEVC(materialize_order(c, pop));
+    if (row_begin + n_rows > 2 * P.n_people) return fail(GEV_EINVAL, "materialize: rows [%zu,%zu) beyond 2*n_people=%zu", row_begin, row_begin + n_rows, 2 * P.n_people);
+    if (snp_begin + n_snps > S.L) return fail(GEV_EINVAL, "materialize: SNPs [%zu,%zu) beyond L=%zu", snp_begin, snp_begin + n_snps, S.L);
+    const size_t w64 = ceil_div(n_snps, 64);
+    if (!n_rows || !n_snps) return GEV_OK;
+    if (!founder_bits || founder_stride_words < w64 || !n_founder_rows) return fail(GEV_EINVAL, "materialize: bad founder tile");
+    if (!bits || row_stride_words < w64) return fail(GEV_EINVAL, "materialize: bad output buffer");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    // founder tile -> device (compacted to w64 words per row)
+    GEVC(c->d_snpmajor.ensure(n_founder_rows * w64 * 8, st));
+    HIPC(hipMemcpy2DAsync(c->d_snpmajor.p, w64 * 8, founder_bits, founder_stride_words * 8, w64 * 8, n_founder_rows, hipMemcpyHostToDevice, st));
+    GEVC(c->d_flag.ensure(16, st));
+    HIPC(hipMemsetAsync(c->d_flag.p, 0, 4, st));
+    const size_t w32 = 2 * w64;
+    const size_t max_rows = std::max<size_t>((128u << 20) / (w64 * 8), 1);
+    for (size_t r0 = 0; r0 < n_rows; r0 += max_rows) {
+        const size_t nr = std::min(max_rows, n_rows - r0);
+        GEVC(c->d_stage.ensure(nr * w64 * 8, st)); GEVC(c->d_text.ensure(nr * w64 * 8, st));
+        HIPC(hipMemsetAsync(c->d_stage.p, 0, nr * w64 * 8, st));                          // pad bits of the last word stay 0
+        hipLaunchKernelGGL(k_materialize_tile, dim3((unsigned)ceil_div(nr * ceil_div(n_snps, 32), 256)), dim3(256), 0, st,
+                           cs.poff[P.cur].as<u32>(), cs.parts[P.cur].as<gev_part>(), row_begin + r0, nr, S.d_pos.as<u64>(), (u32)snp_begin, (u32)n_snps,
+                           c->d_snpmajor.as<u32>(), w32, n_founder_rows, c->d_stage.as<u32>(), w32, c->d_flag.as<u32>());
+        HIPC(hipMemcpyAsync(c->d_text.p, c->d_stage.p, nr * w64 * 8, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_tile_apply_mut, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st, c->d_stage.as<u32>(), c->d_text.as<u32>(), w32, row_begin + r0, nr,
+                           cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)snp_begin, (u32)n_snps);
+        KCHECK();
+        if (row_stride_words > w64)
+            for (size_t r = 0; r < nr; r++) memset(bits + (r0 + r) * row_stride_words + w64, 0, (row_stride_words - w64) * 8);
+        HIPC(hipMemcpy2DAsync(bits + r0 * row_stride_words, row_stride_words * 8, c->d_text.p, w64 * 8, w64 * 8, nr, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+    }
+    u32 flag = 0;
+    HIPC(hipMemcpy(&flag, c->d_flag.p, 4, hipMemcpyDeviceToHost));
+    if (flag) return fail(GEV_EINVAL, "materialize: Error: p.hap_index is not in range (founder tile has %zu rows)", n_founder_rows);
+    return GEV_OK;
+}
 // GT columns of the VCF data lines: n_snps * (4*n_people + 1) bytes; the caller writes the nine fixed columns in front
 int gev_format_vcf_gt(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes)
 {
+    if (c) GEVC(check_dense(c, "format_vcf_gt"));
     GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "format_vcf_gt"));
     GEVC(check_active(c, chr, "format_vcf_gt"));
     PopState& P = c->pop[pop];
@@ -1820,6 +1898,7 @@ int gev_format_vcf_gt(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_s
 // PLINK .bed body (SNP-major, without the 3 magic bytes 0x6c 0x1b 0x01): n_snps * ceil(n_people/4) bytes
 int gev_format_bed(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, uint8_t* out, size_t out_bytes)
 {
+    if (c) GEVC(check_dense(c, "format_bed"));
     GEVC(snp_range_check(c, pop, chr, snp_begin, n_snps, "format_bed"));
     GEVC(check_active(c, chr, "format_bed"));
     PopState& P = c->pop[pop];
@@ -1911,6 +1990,7 @@ int gev_download_mutations(gev_ctx* c, int pop, int chr, u64* out, u64* hap_offs
 int gev_pop_size(gev_ctx* c, int pop, size_t* n) { GEVC(check_idx(c, pop, 0)); if (!n) return fail(GEV_EINVAL, "null"); *n = c->pop[pop].n_people; return GEV_OK; }
 int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows)
 {
+    if (c) GEVC(check_dense(c, "plane_ptr"));
     GEVC(check_idx(c, pop, chr));
     GEVC(check_active(c, chr, "plane_ptr"));
     GEVC(gev_sync(c));

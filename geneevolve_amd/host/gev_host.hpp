@@ -110,6 +110,30 @@ public:
         sex[ipop].swap(s);
         return sex[ipop];
     }
+    // random mating with a head start for the GPU: the ras_glob_seed() values of random_mate (:2092) and of
+    // reproduce (:2398, :2500) are drawn in the reference's order BEFORE the couples are formed (one child per couple, so
+    // the offspring count is pop_size, :2146-2151); gev_presample starts the sampling kernels, the host mates meanwhile.
+    bool random_mate_and_reproduce(int ipop, const std::vector<double>& selection_value_func, size_t pop_size)
+    {
+        const unsigned seed_mate = ras_glob_seed();
+        const unsigned seed = ras_glob_seed();
+        std::vector<uint32_t> mut_seeds;
+        if (has_mutation_map) { mut_seeds.resize(pop_size * nchr); for (auto& s : mut_seeds) s = ras_glob_seed(); }
+        check(gev_presample(ctx, ipop, seed, has_mutation_map ? mut_seeds.data() : nullptr, mut_seeds.size(), pop_size));
+        if (!random_mate(sex[ipop], selection_value_func, pop_size, seed_mate, couples[ipop])) return false;
+        std::vector<uint8_t> s(pop_size);
+        check(gev_reproduce(ctx, ipop, couples[ipop].data(), couples[ipop].size(), seed,
+                            has_mutation_map ? mut_seeds.data() : nullptr, mut_seeds.size(), pop_size, s.data()));
+        sex[ipop].swap(s);
+        return true;
+    }
+    // CommFunc::ras_rank (src/CommFunc.cpp:152-161) on the device: the O(n^2) step of assort_mate (:2278-2279)
+    std::vector<unsigned long long> ras_rank(const std::vector<double>& x)
+    {
+        std::vector<unsigned long long> r(x.size());
+        check(gev_rank_f64(ctx, x.data(), x.size(), r.data()));
+        return r;
+    }
     bool ras_compute_AD(int ipop, std::vector<double>& additive, std::vector<double>& dominance)   // :2624
     {
         size_t n = 0; check(gev_pop_size(ctx, ipop, &n));

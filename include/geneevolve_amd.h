@@ -219,6 +219,18 @@ int gev_rank_f64(gev_ctx*, const double* x, size_t n, unsigned long long* rank_o
  *                              writes them in front of each line. */
 int gev_download_plink_matrix(gev_ctx*, int pop, int chr, size_t ind_begin, size_t n_ind, uint64_t* bits, size_t row_stride_words);
 int gev_format_ped_text(gev_ctx*, int pop, int chr, size_t ind_begin, size_t n_ind, const char* al0, const char* al1, char* out, size_t out_bytes);
+/* ---- K8: genotype tiles from the interval state ------------------------------------------------
+ * gev_set_dense_state(ctx, 0): keep no resident genotype planes (populations whose individuals x loci matrix exceeds HBM,
+ * BASELINE config 5); the per-generation work is then sampling + interval/mutation lists + CV planes + A/D.  Call before
+ * gev_init_gen0; founder SNP panels are not uploaded (gev_upload_founders is refused), CV founders are.
+ * gev_materialize == ras_convert_interval_to_hap_matrix (src/Simulation.cpp:1186-1230) for haplotype rows
+ * [row_begin, +n_rows) and SNPs [snp_begin, +n_snps): founder_bits = the same SNP range of every founder haplotype
+ * (row = founder haplotype = part::hap_index, bit j = SNP snp_begin + j); output rows as gev_download_haps, bit j = SNP
+ * snp_begin + j.  Works on dense contexts too (same result as the resident planes).  One population per context. */
+int gev_set_dense_state(gev_ctx*, int on);
+int gev_materialize(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
+                    const uint64_t* founder_bits, size_t founder_stride_words, size_t n_founder_rows,
+                    uint64_t* bits, size_t row_stride_words);
 /* CV genotype matrix of ras_find_cv (the --debug .cvval dump, :2665-2683), FILE column order. */
 int gev_download_cv(gev_ctx*, int pop, int phen, int chr, uint64_t* bits, size_t row_stride_words);
 /* ancestry interval lists (the .int output, :1596-1633): hap_offsets has 2*n_people+1 entries;

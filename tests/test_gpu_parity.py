@@ -283,6 +283,10 @@ def test_cpp_host_drives_the_c_abi_like_the_python_host(gpu_lib):
     N, L, G, R, C = 500, 5000, 4, 201, 64
     out = subprocess.run([exe, str(N), str(L), str(G)], capture_output=True, text=True, check=True).stdout
     want = dict(l.split() for l in out.strip().splitlines())
+    # same scenario with gev_presample: the host draws [mate seed][reproduce seed][mutation seeds] -- the reference's order --
+    # before it forms the couples, the GPU samples meanwhile: identical results
+    out2 = subprocess.run([exe, str(N), str(L), str(G), "1"], capture_output=True, text=True, check=True).stdout
+    assert dict(l.split() for l in out2.strip().splitlines()) == want
 
     def fnv(b):
         h = 1469598103934665603
@@ -611,5 +615,77 @@ def test_presample_gives_the_same_generation_and_falls_back_on_any_mismatch(gpu_
                 assert np.array_equal(moa, moo) and np.array_equal(ma, mo)
     with pytest.raises(capi.GevError):
         ctxs[0].presample(0, 1, np.zeros(3, dtype=np.uint32), 90)      # wrong seed count
+    for g in ctxs:
+        g.close()
+
+
+def slice_bits(packed, L, s0, ns):
+    """columns [s0, s0+ns) of a bit matrix packed in uint64 words -> packed again (bit j = column s0 + j)"""
+    u = capi.unpack_rows(packed, L)[:, s0:s0 + ns]
+    return capi.pack_rows(u)
+
+
+def test_materialize_tiles_from_intervals_and_the_plane_less_mode(gpu_lib, oracle_lib):
+    """K8 / BASELINE config 5's mode: (1) on a dense context gev_materialize (intervals + mutation sets + a founder
+    tile) reproduces the resident planes tile by tile; (2) a context WITHOUT resident planes (gev_set_dense_state 0) run through
+    the same generations gives the same sex, A/D, intervals and mutation sets, and its materialised tiles equal the dense
+    context's genotypes and the oracle's statement of ras_convert_interval_to_hap_matrix on the same tile."""
+    cfg = SyntheticConfig(150, 3001, nchr=2, chrom_bp=1_000_000, map_step=10_000, rec_per_row=0.02, mut_per_row=0.05, n_cv=40, seed=21)
+    nh, L = 300, 3001
+    ctxs = []
+    for kind in ("dense", "sparse", "oracle"):
+        lib = oracle_lib if kind == "oracle" else gpu_lib
+        g = lib.create(1, 2, 1)
+        if kind == "sparse":
+            g.set_dense_state(False)
+        cfg.apply_static(g)
+        for c in range(2):
+            if kind == "dense":
+                g.synth_founders(0, c, nh, 300 + c)
+            elif kind == "oracle":
+                g.upload_founders(0, c, synth_packed(300 + c, nh, L), L)
+            if kind == "oracle":
+                g.upload_cv_founders(0, 0, c, synth_packed(400 + c, nh, 40), 40)
+            else:
+                g.synth_cv_founders(0, 0, c, nh, 400 + c)
+        ctxs.append(g)
+    dense, sparse, orc = ctxs
+    with pytest.raises(capi.GevError):
+        sparse.synth_founders(0, 0, nh, 1)                         # no resident planes in this mode
+    sims = [Simulation(g, 5, 2, True) for g in ctxs]
+    for s in sims:
+        s.ras_initial_human_gen0(0, 150)
+    founders = [synth_packed(300 + c, nh, L) for c in range(2)]
+    rng = np.random.default_rng(9)
+    for gen in range(1, 6):
+        n_off = int(rng.integers(100, 200))
+        couples = synthetic_random_mate(sims[0].sex[0], n_off, rng)
+        seeds = sims[0].ras_glob_seed(1 + 2 * n_off)
+        for s in sims[1:]:
+            s.ras_glob_seed(1 + 2 * n_off)
+        sex = []
+        for s in sims:
+            s.couples[0] = couples
+            sex.append(s.reproduce(0, gen, seeds=seeds, n_people=n_off))
+        assert np.array_equal(sex[0], sex[2]) and np.array_equal(sex[1], sex[2])
+        ad = [s.ras_compute_AD(0, gen, per_chr=True) for s in sims]
+        for x, y, z in zip(*ad):
+            assert helpers.bits_equal(x, z) and helpers.bits_equal(y, z), f"A/D gen {gen}"
+        for c in range(2):
+            full = dense.download_haps(0, c)
+            assert np.array_equal(full, orc.download_haps(0, c))
+            ps, osx = sparse.download_intervals(0, c); po, oo = orc.download_intervals(0, c)
+            assert np.array_equal(osx, oo) and np.array_equal(ps, po)
+            ms, mos = sparse.download_mutations(0, c); mo, moo = orc.download_mutations(0, c)
+            assert np.array_equal(mos, moo) and np.array_equal(ms, mo)
+            for (s0, ns, r0, nr) in ((0, L, 0, 2 * n_off), (64, 1000, 3, 57), (2990, 11, 2 * n_off - 1, 1), (31, 33, 0, 10)):
+                tile = slice_bits(founders[c], L, s0, ns)
+                want = slice_bits(full[r0:r0 + nr], L, s0, ns)
+                for g in (dense, sparse, orc):
+                    assert np.array_equal(g.materialize(0, c, tile, r0, nr, s0, ns), want), (gen, c, s0, ns, r0, nr)
+            with pytest.raises(capi.GevError):
+                sparse.download_haps(0, c)
+            with pytest.raises(capi.GevError):
+                sparse.materialize(0, c, slice_bits(founders[c], L, 0, 64)[:10], 0, 2 * n_off, 0, 64)     # founder tile too short: hap_index not in range
     for g in ctxs:
         g.close()

@@ -19,6 +19,7 @@ int main(int argc, char** argv)
 {
     const size_t N = argc > 1 ? atol(argv[1]) : 500, L = argc > 2 ? atol(argv[2]) : 5000;
     const int G = argc > 3 ? atoi(argv[3]) : 4;
+    const bool presample = argc > 4 && atoi(argv[4]) != 0;     // draw the seeds first and let the GPU sample while the host mates
     const size_t R = 201, C = 64;
     try {
         gev::Simulation sim(-1, 1, 1, 1, 12345, true);
@@ -38,13 +39,21 @@ int main(int argc, char** argv)
         for (int g = 1; g <= G; g++) {
             // Simulation::sim_next_generation order (src/Simulation.cpp:1907-1935): random_mate, reproduce, ras_compute_AD
             const std::vector<double> svf(sim.sex[0].size(), 1.0);                    // selection_value_func: everybody may marry
-            if (!gev::random_mate(sim.sex[0], svf, N, sim.ras_glob_seed(), sim.couples[0])) return 1;
-            sim.reproduce(0);
+            if (presample) { if (!sim.random_mate_and_reproduce(0, svf, N)) return 1; }
+            else {
+                if (!gev::random_mate(sim.sex[0], svf, N, sim.ras_glob_seed(), sim.couples[0])) return 1;
+                sim.reproduce(0);
+            }
             if (!sim.ras_compute_AD(0, A, D)) return 1;
         }
         const size_t w = (L + 63) / 64;
         std::vector<uint64_t> bits(2 * N * w);
         gev::check(gev_download_haps(sim.ctx, 0, 0, 0, 2 * N, bits.data(), w));
+        {   // the device rank against the definition
+            std::vector<double> x = {0.5, -1.0, 0.5, 2.0, -1.0, 0.0};
+            const std::vector<unsigned long long> r = sim.ras_rank(x), want = {3, 0, 4, 5, 1, 2};
+            if (r != want) { printf("Error: ras_rank\n"); return 1; }
+        }
         printf("HAPS %016llx\nADD %016llx\nSEX %016llx\n", (unsigned long long)fnv(bits.data(), bits.size() * 8),
                (unsigned long long)fnv(A.data(), A.size() * 8), (unsigned long long)fnv(sim.sex[0].data(), sim.sex[0].size()));
     } catch (const std::exception& e) { printf("Error: %s\n", e.what()); return 1; }
