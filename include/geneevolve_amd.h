@@ -198,9 +198,9 @@ int gev_download_haps(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_row
  *                           reference has no .bed writer (BASELINE config 5 asks for one): checked by definition.
  *  gev_format_vcf_gt      : the sample columns format_vcf::write_vcf_file (src/format_vcf.cpp:55-59) appends to each data
  *                           line: per individual "\ta|b", then '\n' = n_snps * (4*n_people + 1) bytes; the nine fixed
- *                           columns (CHROM..FORMAT, host strings of the input VCF) are the caller's.  The reference's
- *                           VCF-panel path cannot run here (format_vcf.cpp:367-389 falls off a bool function; crashes
- *                           under g++ 11 -O3): checked by definition and against the oracle -- parity unpinned. */
+ *                           columns (CHROM..FORMAT, host strings of the input VCF) are the caller's.  Pinned on the
+ *                           reference's own .vcf output (fixture `dense`; the reference's VCF-panel path needs the one
+ *                           missing `return` of format_vcf.cpp:367-389 supplied, see oracle/ref_vcf_return.cpp). */
 int gev_download_snp_major(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, uint64_t* bits, size_t row_stride_words);
 int gev_format_hap_text(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes);
 int gev_format_bed(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps, uint8_t* out, size_t out_bytes);

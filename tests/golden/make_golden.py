@@ -357,9 +357,9 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
     # panel, so the same founders are also written as phased VCF and the stock CLI is run on them with --out_vcf; the
     # run is the same simulation (identical .info files are asserted).  Stored: hash of the GT columns of every data line
     # ("\ta|b" per individual + newline = what gev_format_vcf_gt produces), hash of the whole data section.
-    # NOT USED (vcf=False everywhere): built with its own flags (-O3) by g++ 11 the reference crashes on every VCF
-    # reference panel -- format_vcf::read_vcf_header_sample (src/format_vcf.cpp:367-389) has no return statement
-    # (undefined behaviour) -- so gev_format_vcf_gt is checked by definition and against the oracle only.
+    # Built with its own flags (-O3) by g++ 11 the reference crashes on every VCF panel: format_vcf::read_vcf_header_sample
+    # (src/format_vcf.cpp:367-389) has no return statement.  oracle/_ref/GeneEvolve_ref_vcf is the same program with that one
+    # return supplied (oracle/ref_vcf_return.cpp); it is used here and nowhere else.
     if vcf:
         wd4 = os.path.join(wd, "cli_vcf"); os.makedirs(wd4)
         args4 = [x if x != os.path.join(wd, "out") else os.path.join(wd4, "out") for x in args] + ["--out_vcf"]
@@ -374,7 +374,7 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             k = args4.index(os.path.join(wd, f"p{ip}.hapaddr.txt"))
             args4[k - 1] = "--file_ref_vcf"; args4[k] = addr
         with open(os.path.join(wd4, "log.txt"), "w") as log:
-            sh([os.path.join(ORACLE, "_ref", "GeneEvolve_ref")] + args4, stdout=log, stderr=subprocess.STDOUT)
+            sh([os.path.join(ORACLE, "_ref", "GeneEvolve_ref_vcf")] + args4, stdout=log, stderr=subprocess.STDOUT)
         for g in range(ngen + 1):
             for ip in range(len(case.pops)):
                 fa = os.path.join(wd, f"out.info.pop{ip+1}.gen{g}.txt"); fb = os.path.join(wd4, f"out.info.pop{ip+1}.gen{g}.txt")
@@ -566,7 +566,7 @@ def main():
     c = Case("dense")
     c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=phens, RM=True,
               mut_bp=[rbp], mut_rate=[np.full(R, 0.02)], popinfo=["120 0 p thr 1 1"] * 6)
-    run_case(c, 4242, dense_gens={1, 2, 3, 4, 5, 6})
+    run_case(c, 4242, dense_gens={1, 2, 3, 4, 5, 6}, vcf=True)
 
     # ---- mig2: two populations + migration
     c = Case("mig2")

@@ -182,6 +182,14 @@ def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_l
                     assert len(txt) == int(fx[k + "size"]), f"{label}: .hap size"
                     assert np.array_equal(txt[:4096], fx[k + "head"]), f"{label}: .hap head differs"
                     assert np.array_equal(sha(txt), fx[k + "sha"]), f"{label}: .hap text differs from the reference's file (pop {ip} chr {ic})"
+    # the reference's own .vcf output of the last generation (format_vcf::write_vcf_file): sample columns of every data line
+    if ngen == int(fx["n_gen"]) and lib.exports("format_vcf_gt"):
+        for ip in range(n_pop):
+            for ic in range(nchr):
+                k = f"vcffile_pop{ip}_chr{ic}_"
+                if k + "gt_sha" in fx:
+                    assert ctx.pop_size(ip) == int(fx[k + "n_samples"])
+                    assert np.array_equal(sha(ctx.format_vcf_gt(ip, ic)), fx[k + "gt_sha"]), f"{label}: VCF sample columns differ from the reference's file (pop {ip} chr {ic})"
     # the reference's own .ped files of the last generation (format_plink::write_ped_map / write_ped01_map)
     if ngen == int(fx["n_gen"]) and lib.exports("format_ped_text"):
         for ip in range(n_pop):
