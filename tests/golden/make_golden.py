@@ -274,6 +274,8 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
         a = ["--file_gen_info", os.path.join(wd, f"p{ip}.popinfo.txt"), "--file_hap_name", os.path.join(wd, f"p{ip}.hapaddr.txt"),
              "--file_recom_map", os.path.join(wd, f"p{ip}.rmap.txt")]
         write_popinfo(os.path.join(wd, f"p{ip}.popinfo.txt"), P["popinfo"])
+        arrs[f"{pre}popinfo"] = np.array(P["popinfo"])         # rows of --file_gen_info: pop_size mat_cor offspring_dist selection_func par1 par2
+        arrs[f"{pre}rm"] = np.int64(1 if P.get("RM") else 0)
         arrs[f"{pre}has_mut"] = np.int64(1 if P.get("mut_bp") is not None else 0)
         if P.get("mut_bp") is not None:
             write_map(os.path.join(wd, f"p{ip}.mmap.txt"), "chr bp mutation_rate", [(c, P["mut_bp"][ic], P["mut_rate"][ic]) for ic, c in enumerate(chrs)])
@@ -298,6 +300,7 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
                         arrs[f"{pre}ph{iph}_chr{ic}_cv_val"] = np.packbits(ph["val"][ic].astype(np.uint8), axis=1, bitorder="little")
             a += ["--file_cv_info", os.path.join(wd, f"p{ip}.ph{iph}.cvinfo.txt"), "--file_cvs", os.path.join(wd, f"p{ip}.ph{iph}.cvaddr.txt")]
             arrs[f"{pre}ph{iph}_vd"] = np.float64(ph.get("vd", -1.0))
+            arrs[f"{pre}ph{iph}_var"] = np.array([ph.get(k, dflt) for k, dflt in (("va", -1.0), ("vd", -1.0), ("ve", 1.0), ("vf", 0.0))])   # CLI defaults: parameters.cpp
         for key in ("va", "vd", "ve", "vf"):
             for ph in P["phens"]:
                 if key in ph:
@@ -306,6 +309,7 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             args.append("--next_population")
         args += a
     args += ["--seed", str(seed), "--prefix", os.path.join(wd, "out")] + case.args_extra
+    arrs["args_extra"] = np.array(case.args_extra if case.args_extra else [""])
     env = dict(os.environ, GEV_DUMP=os.path.join(wd, "d"), GEV_DUMP_DENSE="1",
                GEV_DENSE_GENS=",".join(str(g) for g in sorted(set(dense_gens) | {0})))
     with open(os.path.join(wd, "log.txt"), "w") as log:

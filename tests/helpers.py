@@ -232,3 +232,109 @@ def check_ped_files(ctx, fx, ngen, ip, ic, label):
         for i in range(n):
             h.update(" ".join(str(int(v)) for v in cols[i]).encode()); h.update(lines[i].tobytes())
         assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), fx[k + "sha"]), f"{label}: .{tag} file differs from the reference's (pop {ip} chr {ic})"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# closed loop: the whole generation loop of the reference from --seed alone (host mirror + library), single population
+# ---------------------------------------------------------------------------------------------------------------
+def comm_mean(x):
+    """CommFunc::mean (src/CommFunc.cpp:38-45): sequential sum / n"""
+    s = 0.0
+    for v in np.asarray(x, dtype=np.float64).tolist():
+        s += v
+    return s / len(x)
+
+
+def comm_var(x):
+    """CommFunc::var (src/CommFunc.cpp:57-68): two passes, sequential sums, n-1"""
+    xs = np.asarray(x, dtype=np.float64).tolist()
+    if len(xs) <= 1:
+        return 0.0
+    mu = 0.0
+    for v in xs:
+        mu += v
+    mu /= len(xs)
+    s2 = 0.0
+    for v in xs:
+        s2 += (v - mu) * (v - mu)
+    return s2 / (len(xs) - 1)
+
+
+def selection_func(kind, p1, p2, z):
+    """Simulation::ras_selection_func (src/Simulation.cpp:3386-3428) for generations >= 1; logit and thr"""
+    import math
+    if kind == "logit":
+        out = []
+        for v in np.asarray(z, dtype=np.float64).tolist():
+            y = math.exp(p1 + p2 * v)
+            out.append(y / (1 + y))
+        return np.array(out)
+    if kind == "thr":
+        return np.where(np.asarray(z) <= p2, p1, 1.0)
+    raise NotImplementedError(kind)
+
+
+def closed_loop_case(lib, fx, label, device=-1, exact=True):
+    """Simulation::run for an assortative-mating fixture, driven from the seed ALONE: ras_glob_seed() stream, gen-0 founders,
+    ras_compute_AD, ras_scale_AD_compute_GEF, mating / selection values, assort_mate (device rank), reproduce -- every
+    generation's couples, sexes, raw A/D, phenotypes and next-generation mating inputs are compared with what the reference
+    did.  exact=False (device phenotype scaling is within 1e-12, not bit-exact) relaxes the float comparisons only."""
+    from geneevolve_amd.host import Simulation
+    assert int(fx["n_pop"]) == 1 and int(fx["nphen"]) == 1 and int(fx["pop0_rm"]) == 0
+    nchr, ngen = int(fx["nchr"]), int(fx["n_gen"])
+    ctx = lib.create(1, nchr, 1, device) if lib.has_device_arg else lib.create(1, nchr, 1)
+    setup_static(ctx, fx)
+    va, vd, ve, vf = [float(v) for v in fx["pop0_ph0_var"]]
+    assert vf == 0.0
+    extra = [str(x) for x in fx["args_extra"]]
+    mm = float(extra[extra.index("--MM") + 1]) if "--MM" in extra else 0.0
+    avoid = "--avoid_inbreeding" in extra
+    sim = Simulation(ctx, int(fx["seed"]), nchr, bool(int(fx["pop0_has_mut"])), track_pedigree=True)
+
+    def close(a, b, what):
+        if exact:
+            assert bits_equal(a, b), f"{label}: {what} not bit-identical (max abs diff {np.max(np.abs(np.asarray(a) - np.asarray(b)))})"
+        else:
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12), f"{label}: {what} differs (max abs diff {np.max(np.abs(np.asarray(a) - np.asarray(b)))})"
+
+    sim.ras_initial_human_gen0(0, len(fx["g0_pop0_sex"]))                       # ras_init_generation0 (:529)
+    assert np.array_equal(sim.sex[0], fx["g0_pop0_sex"]), f"{label}: gen-0 sex"
+    add, dom, _, _ = ctx.compute_ad(0)
+    s2a, s2d = comm_var(add[:, 0]), comm_var(dom[:, 0])                         # _var_a_gen0 / _var_d_gen0 (:557-561)
+    n = len(sim.sex[0])
+    out = ctx.scale_ad_compute_gef(0, 0, 0, int(sim.ras_glob_seed()[0]), va, vd, ve, vf, 1.0, s2a, s2d,
+                                   common_sibling=np.zeros(n), f_father=np.zeros(n), f_mother=np.zeros(n))
+    phen = out["phen"]
+    mv = 0.0 + 1.0 * phen; sv = 0.0 + 1.0 * phen                                # omega = lambda = 1 (:3311-3320)
+    sv_mean, sv_var = comm_mean(sv), comm_var(sv)                               # standardised to generation 0 (:3326-3330)
+    svf = np.ones(n)                                                            # generation 0: everybody may marry (:3388)
+    for g in range(1, ngen + 1):
+        pop_size, mat_cor, dist, func, p1, p2 = str(fx["pop0_popinfo"][g - 1]).split()
+        k = f"g{g}_pop0_mate_"
+        close(mv, fx[k + "am_mv"], f"mating values entering generation {g}")
+        close(svf, fx[k + "svf"], f"selection function values entering generation {g}")
+        sim.assort_mate(0, svf, mv, int(pop_size), float(mat_cor), mm_percent=mm, avoid_inbreeding=avoid, offspring_dist=dist,
+                        rank=ctx.rank_f64 if lib.exports("rank_f64") else None)
+        c, want = sim.couples[0], fx[f"g{g}_pop0_couples"]
+        assert len(c) == len(want) and np.array_equal(c["pos_male"].astype(np.int64), want[:, 0]) and np.array_equal(c["pos_female"].astype(np.int64), want[:, 1]) \
+            and np.array_equal(c["inbreed"], want[:, 2]) and np.array_equal(c["num_offspring"], want[:, 3]), f"{label}: couples of generation {g}"
+        prev_phen = phen
+        sim.reproduce(0, g)
+        assert np.array_equal(sim.sex[0], fx[f"g{g}_pop0_sex"]), f"{label}: sex generation {g}"
+        ped = sim.ped[0]
+        assert np.array_equal(np.stack([ped.ID, ped.ID_Father, ped.ID_Mother], axis=1), fx[f"g{g}_pop0_ids"]), f"{label}: pedigree generation {g}"
+        add, dom, _, _ = ctx.compute_ad(0)
+        assert bits_equal(add, fx[f"g{g}_pop0_additive"]) and bits_equal(dom, fx[f"g{g}_pop0_dominance"]), f"{label}: raw A/D generation {g}"
+        n = len(sim.sex[0])
+        kk = f"g{g}_pop0_ph0_gef_"
+        seed = int(sim.ras_glob_seed()[0])
+        assert seed == int(fx[kk + "seed"]), f"{label}: the ras_glob_seed() stream is out of step at generation {g}"
+        out = ctx.scale_ad_compute_gef(0, 0, g, seed, va, vd, ve, vf, 1.0, s2a, s2d, common_sibling=np.zeros(n),
+                                       f_father=prev_phen[ped.ID_Father], f_mother=prev_phen[ped.ID_Mother])
+        phen = out["phen"]
+        close(phen, fx[kk + "out"][:, 5], f"phenotypes generation {g}")
+        mv = 0.0 + 1.0 * phen; sv = 0.0 + 1.0 * phen
+        z = (sv - sv_mean) / np.sqrt(sv_var) if sv_var > 0 else sv - sv_mean
+        svf = selection_func(func, float(p1), float(p2), z)
+    compare_dense(ctx, fx, ngen, 0, nchr, label)
+    ctx.close()

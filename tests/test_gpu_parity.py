@@ -689,3 +689,46 @@ def test_materialize_tiles_from_intervals_and_the_plane_less_mode(gpu_lib, oracl
                 sparse.materialize(0, c, slice_bits(founders[c], L, 0, 64)[:10], 0, 2 * n_off, 0, 64)     # founder tile too short: hap_index not in range
     for g in ctxs:
         g.close()
+
+
+def test_long_run_exercises_list_growth_and_redo_paths(gpu_lib, oracle_lib):
+    """60 generations with ~5 crossovers and ~3 mutations per gamete per generation: the interval and mutation lists outgrow
+    their buffers several times (capacity guess too small -> status flag -> grow -> the small work is enqueued again; outgrown
+    buffers parked and freed later), with gev_presample on every other generation.  State compared with the oracle every 10."""
+    cfg = SyntheticConfig(120, 1500, nchr=2, chrom_bp=1_000_000, map_step=5_000, rec_per_row=0.025, mut_per_row=0.015, n_cv=25, seed=33)
+    g = gpu_lib.create(1, 2, 1); o = oracle_lib.create(1, 2, 1)
+    cfg.apply_static(g); cfg.apply_static(o)
+    for c in range(2):
+        g.synth_founders(0, c, 240, 70 + c); o.upload_founders(0, c, synth_packed(70 + c, 240, 1500), 1500)
+        g.synth_cv_founders(0, 0, c, 240, 80 + c); o.upload_cv_founders(0, 0, c, synth_packed(80 + c, 240, 25), 25)
+    sg, so = Simulation(g, 3, 2, True), Simulation(o, 3, 2, True)
+    sg.ras_initial_human_gen0(0, 120); so.ras_initial_human_gen0(0, 120)
+    rng = np.random.default_rng(4)
+    for gen in range(1, 61):
+        n_off = 120 if gen % 7 else 150                      # population size changes now and then
+        couples = synthetic_random_mate(sg.sex[0], n_off, rng)
+        seeds = sg.ras_glob_seed(1 + 2 * n_off); so.ras_glob_seed(1 + 2 * n_off)
+        if gen % 2:
+            sg.presample(0, seeds, n_off)
+        sg.couples[0] = couples; so.couples[0] = couples
+        a = sg.reproduce(0, gen, seeds=seeds, n_people=n_off); b = so.reproduce(0, gen, seeds=seeds, n_people=n_off)
+        assert np.array_equal(a, b), f"sex gen {gen}"
+        xa, xo = sg.ras_compute_AD(0, gen), so.ras_compute_AD(0, gen)
+        assert helpers.bits_equal(xa[0], xo[0]), f"A gen {gen}"
+        if gen % 10 == 0:
+            for c in range(2):
+                assert np.array_equal(g.download_haps(0, c), o.download_haps(0, c)), f"dense gen {gen} chr {c}"
+                pg, og = g.download_intervals(0, c); po, oo = o.download_intervals(0, c)
+                assert np.array_equal(og, oo) and np.array_equal(pg, po), f"intervals gen {gen} chr {c}"
+                mg, mog = g.download_mutations(0, c); mo, moo = o.download_mutations(0, c)
+                assert np.array_equal(mog, moo) and np.array_equal(mg, mo), f"mutations gen {gen} chr {c}"
+    pg, og = g.download_intervals(0, 0)
+    assert og[-1] > 240 * 60                                   # lists really grew far beyond the initial headroom
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("case", ["am1", "am2"])
+def test_closed_loop_from_the_seed_alone_on_gpu(gpu_lib, case):
+    """the same closed loop on the HIP library (A/D, intervals, genotypes, couples, sexes bit-exact; scaled phenotypes and what
+    derives from them within 1e-9 relative: the device's parallel variance / log are not bit-identical to libm's)"""
+    helpers.closed_loop_case(gpu_lib, helpers.load_fixture(case), f"gpu/{case}", device=0, exact=False)

@@ -139,3 +139,10 @@ def test_rank_matches_reference_vectors(oracle_lib):
         assert np.array_equal(o.rank_f64(x), want)
         assert np.array_equal(ras_rank(x), want)
     o.close()
+
+
+@pytest.mark.parametrize("case", ["am1", "am2"])
+def test_closed_loop_from_the_seed_alone(oracle_lib, case):
+    """the reference's whole generation loop (assortative mating, inbreeding avoidance, Poisson / fixed families, logit
+    selection) re-driven from --seed by the host mirror on top of the C-ABI (oracle build): bit-identical at every step"""
+    helpers.closed_loop_case(oracle_lib, helpers.load_fixture(case), f"oracle/{case}")
