@@ -354,6 +354,64 @@ class SyntheticConfig:
                 ctx.set_cvs(pop, p, c, bp, a, d, self.vd)
 
 
+def comm_mean(x):
+    """CommFunc::mean (src/CommFunc.cpp:38-45): sequential sum / n"""
+    s = 0.0
+    for v in np.asarray(x, dtype=np.float64).tolist():
+        s += v
+    return s / len(x)
+
+
+def comm_var(x):
+    """CommFunc::var (src/CommFunc.cpp:57-68): two passes, sequential sums, n-1"""
+    xs = np.asarray(x, dtype=np.float64).tolist()
+    if len(xs) <= 1:
+        return 0.0
+    mu = 0.0
+    for v in xs:
+        mu += v
+    mu /= len(xs)
+    s2 = 0.0
+    for v in xs:
+        s2 += (v - mu) * (v - mu)
+    return s2 / (len(xs) - 1)
+
+
+def selection_func(kind, p1, p2, z):
+    """Simulation::ras_selection_func (reference src/Simulation.cpp:3386-3428) for generations >= 1 (generation 0: 1 for all);
+    logit and thr; z = selection value standardised to generation 0 (ras_compute_mating_value_selection_value, :3300-3342)"""
+    import math
+    if kind == "logit":
+        out = []
+        for v in np.asarray(z, dtype=np.float64).tolist():
+            y = math.exp(p1 + p2 * v)
+            out.append(y / (1 + y))
+        return np.array(out)
+    if kind == "thr":
+        return np.where(np.asarray(z) <= p2, p1, 1.0)
+    raise NotImplementedError(kind)
+
+
+def ras_save_human_info(ped, sex, per_phen, mating_value, selection_value, selection_value_func):
+    """bytes of Population::ras_save_human_info's file (reference src/Population.cpp:510-568).  per_phen: one dict per phenotype
+    with the vectors additive, dominance, bv, common_sibling, e_noise, parental_effect, phen.  Doubles go through the
+    default ostream format = printf %g with 6 significant digits; ids are printed 1-based."""
+    hdr = ["ID", "ID_Father", "ID_Mother", "ID_Fathers_Father", "ID_Fathers_Mother", "ID_Mothers_Father", "ID_Mothers_Mother", "sex"]
+    for j in range(len(per_phen)):
+        hdr += [f"ph{j+1}_{c}" for c in "ADGCEFP"]
+    hdr += ["MV", "SV", "SV_f"]
+    ids = np.stack([getattr(ped, f) for f in ("ID", "ID_Father", "ID_Mother", "ID_Fathers_Father", "ID_Fathers_Mother", "ID_Mothers_Father", "ID_Mothers_Mother")], axis=1) + 1
+    cols = []
+    for d in per_phen:
+        cols += [d["additive"], d["dominance"], d["bv"], d["common_sibling"], d["e_noise"], d["parental_effect"], d["phen"]]
+    cols += [mating_value, selection_value, selection_value_func]
+    cols = np.stack([np.asarray(c, dtype=np.float64) for c in cols], axis=1)
+    lines = [" ".join(hdr)]
+    for i in range(len(sex)):
+        lines.append(" ".join([str(int(v)) for v in ids[i]] + [str(int(sex[i]))] + ["%g" % v for v in cols[i]]))
+    return ("\n".join(lines) + "\n").encode()
+
+
 class Simulation:
     """The seam of reference `class Simulation` (src/Simulation.h:64-144) on top of the C-ABI."""
 

@@ -325,6 +325,11 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             fa = os.path.join(wd, f"out.info.pop{ip+1}.gen{g}.txt"); fb = os.path.join(wd2, f"out.info.pop{ip+1}.gen{g}.txt")
             assert open(fa, "rb").read() == open(fb, "rb").read(), f"harness != CLI at gen {g} pop {ip+1}"
     arrs["n_gen"] = np.int64(ngen)
+    # the reference's per-generation text dump (Population::ras_save_human_info, src/Population.cpp:510-568)
+    for g in range(ngen + 1):
+        for ip in range(len(case.pops)):
+            raw = open(os.path.join(wd, f"out.info.pop{ip+1}.gen{g}.txt"), "rb").read()
+            arrs[f"infofile_pop{ip}_gen{g}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
     # the reference's own .hap text of the last generation (format_hap::write_hap, src/format_hap.cpp:6-30): hash + head
     for ip in range(len(case.pops)):
         for ic, c in enumerate(case.pops[ip]["chrs"]):

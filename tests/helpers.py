@@ -237,41 +237,7 @@ def check_ped_files(ctx, fx, ngen, ip, ic, label):
 # ---------------------------------------------------------------------------------------------------------------
 # closed loop: the whole generation loop of the reference from --seed alone (host mirror + library), single population
 # ---------------------------------------------------------------------------------------------------------------
-def comm_mean(x):
-    """CommFunc::mean (src/CommFunc.cpp:38-45): sequential sum / n"""
-    s = 0.0
-    for v in np.asarray(x, dtype=np.float64).tolist():
-        s += v
-    return s / len(x)
-
-
-def comm_var(x):
-    """CommFunc::var (src/CommFunc.cpp:57-68): two passes, sequential sums, n-1"""
-    xs = np.asarray(x, dtype=np.float64).tolist()
-    if len(xs) <= 1:
-        return 0.0
-    mu = 0.0
-    for v in xs:
-        mu += v
-    mu /= len(xs)
-    s2 = 0.0
-    for v in xs:
-        s2 += (v - mu) * (v - mu)
-    return s2 / (len(xs) - 1)
-
-
-def selection_func(kind, p1, p2, z):
-    """Simulation::ras_selection_func (src/Simulation.cpp:3386-3428) for generations >= 1; logit and thr"""
-    import math
-    if kind == "logit":
-        out = []
-        for v in np.asarray(z, dtype=np.float64).tolist():
-            y = math.exp(p1 + p2 * v)
-            out.append(y / (1 + y))
-        return np.array(out)
-    if kind == "thr":
-        return np.where(np.asarray(z) <= p2, p1, 1.0)
-    raise NotImplementedError(kind)
+from geneevolve_amd.host import comm_mean, comm_var, selection_func  # noqa: E402  (host mirror of CommFunc::mean/var, ras_selection_func)
 
 
 def closed_loop_case(lib, fx, label, device=-1, exact=True):
@@ -308,6 +274,18 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
     mv = 0.0 + 1.0 * phen; sv = 0.0 + 1.0 * phen                                # omega = lambda = 1 (:3311-3320)
     sv_mean, sv_var = comm_mean(sv), comm_var(sv)                               # standardised to generation 0 (:3326-3330)
     svf = np.ones(n)                                                            # generation 0: everybody may marry (:3388)
+
+    def check_info_file(g, out, mv, z, svf):
+        """Population::ras_save_human_info: the reference's .info.popK.genG.txt, byte for byte (exact builds only)"""
+        if not exact or f"infofile_pop0_gen{g}_sha" not in fx:
+            return
+        from geneevolve_amd.host import ras_save_human_info
+        d = dict(out); d["common_sibling"] = np.zeros(len(mv))
+        txt = ras_save_human_info(sim.ped[0], sim.sex[0], [d], mv, z, svf)
+        assert np.array_equal(np.frombuffer(hashlib.sha256(txt).digest(), dtype=np.uint8), fx[f"infofile_pop0_gen{g}_sha"]), f"{label}: .info file of generation {g} differs from the reference's"
+
+    z0 = (sv - sv_mean) / np.sqrt(sv_var) if sv_var > 0 else sv - sv_mean
+    check_info_file(0, out, mv, z0, svf)
     for g in range(1, ngen + 1):
         pop_size, mat_cor, dist, func, p1, p2 = str(fx["pop0_popinfo"][g - 1]).split()
         k = f"g{g}_pop0_mate_"
@@ -336,5 +314,6 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
         mv = 0.0 + 1.0 * phen; sv = 0.0 + 1.0 * phen
         z = (sv - sv_mean) / np.sqrt(sv_var) if sv_var > 0 else sv - sv_mean
         svf = selection_func(func, float(p1), float(p2), z)
+        check_info_file(g, out, mv, z, svf)
     compare_dense(ctx, fx, ngen, 0, nchr, label)
     ctx.close()
