@@ -241,21 +241,23 @@ from geneevolve_amd.host import comm_mean, comm_var, selection_func  # noqa: E40
 
 
 def closed_loop_case(lib, fx, label, device=-1, exact=True):
-    """Simulation::run for an assortative-mating fixture, driven from the seed ALONE: ras_glob_seed() stream, gen-0 founders,
-    ras_compute_AD, ras_scale_AD_compute_GEF, mating / selection values, assort_mate (device rank), reproduce -- every
-    generation's couples, sexes, raw A/D, phenotypes and next-generation mating inputs are compared with what the reference
-    did.  exact=False (device phenotype scaling is within 1e-12, not bit-exact) relaxes the float comparisons only."""
-    from geneevolve_amd.host import Simulation
-    assert int(fx["n_pop"]) == 1 and int(fx["nphen"]) == 1 and int(fx["pop0_rm"]) == 0
-    nchr, ngen = int(fx["nchr"]), int(fx["n_gen"])
-    ctx = lib.create(1, nchr, 1, device) if lib.has_device_arg else lib.create(1, nchr, 1)
+    """Simulation::run for a single-population fixture, driven from the seed ALONE: ras_glob_seed() stream, gen-0 founders,
+    ras_compute_AD, ras_scale_AD_compute_GEF (every phenotype, parental effect with the adjusted beta), mating / selection
+    values, random_mate or assort_mate (device rank), reproduce -- every generation's couples, sexes, pedigree, raw A/D,
+    phenotypes, next-generation mating inputs and the reference's .info files are compared with what the reference did.
+    exact=False (device phenotype scaling is within 1e-12, not bit-exact) relaxes the float comparisons only."""
+    from geneevolve_amd.host import Simulation, ras_save_human_info
+    assert int(fx["n_pop"]) == 1
+    nchr, nphen, ngen, rm = int(fx["nchr"]), int(fx["nphen"]), int(fx["n_gen"]), bool(int(fx["pop0_rm"]))
+    ctx = lib.create(1, nchr, nphen, device) if lib.has_device_arg else lib.create(1, nchr, nphen)
     setup_static(ctx, fx)
-    va, vd, ve, vf = [float(v) for v in fx["pop0_ph0_var"]]
-    assert vf == 0.0
+    var = [[float(v) for v in fx[f"pop0_ph{p}_var"]] for p in range(nphen)]       # va, vd, ve, vf
+    beta = [1.0] * nphen                                                          # parameters.cpp default; adjusted after generation 0
     extra = [str(x) for x in fx["args_extra"]]
     mm = float(extra[extra.index("--MM") + 1]) if "--MM" in extra else 0.0
     avoid = "--avoid_inbreeding" in extra
-    sim = Simulation(ctx, int(fx["seed"]), nchr, bool(int(fx["pop0_has_mut"])), track_pedigree=True)
+    has_mut = bool(int(fx["pop0_has_mut"]))
+    sim = Simulation(ctx, int(fx["seed"]), nchr, has_mut, track_pedigree=True)
 
     def close(a, b, what):
         if exact:
@@ -263,57 +265,71 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
         else:
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12), f"{label}: {what} differs (max abs diff {np.max(np.abs(np.asarray(a) - np.asarray(b)))})"
 
+    def scale(g, s2, prev_phen):
+        """ras_scale_AD_compute_GEF for every phenotype (:1938-1946), one ras_glob_seed() each"""
+        n = len(sim.sex[0]); outs = []
+        for p in range(nphen):
+            va, vd, ve, vf = var[p]
+            seed = int(sim.ras_glob_seed()[0])
+            if g > 0:
+                assert seed == int(fx[f"g{g}_pop0_ph{p}_gef_seed"]), f"{label}: the ras_glob_seed() stream is out of step at generation {g}"
+            ff = prev_phen[p][sim.ped[0].ID_Father] if g > 0 else np.zeros(n)
+            fm = prev_phen[p][sim.ped[0].ID_Mother] if g > 0 else np.zeros(n)
+            o = ctx.scale_ad_compute_gef(0, p, g, seed, va, vd, ve, vf, beta[p], s2[p][0], s2[p][1], common_sibling=np.zeros(n), f_father=ff, f_mother=fm)
+            o["common_sibling"] = np.zeros(n)
+            if g > 0:
+                close(o["phen"], fx[f"g{g}_pop0_ph{p}_gef_out"][:, 5], f"phenotype {p} generation {g}")
+            outs.append(o)
+        return outs
+
+    def values(outs):
+        mv = np.zeros(len(sim.sex[0])); sv = np.zeros(len(sim.sex[0]))
+        for o in outs:                                                           # omega = lambda = 1 (:3311-3320)
+            mv = mv + 1.0 * o["phen"]; sv = sv + 1.0 * o["phen"]
+        return mv, sv
+
+    def check_info_file(g, outs, mv, z, svf):
+        """Population::ras_save_human_info: the reference's .info.popK.genG.txt, byte for byte (exact builds only)"""
+        if exact and f"infofile_pop0_gen{g}_sha" in fx:
+            txt = ras_save_human_info(sim.ped[0], sim.sex[0], outs, mv, z, svf)
+            assert np.array_equal(np.frombuffer(hashlib.sha256(txt).digest(), dtype=np.uint8), fx[f"infofile_pop0_gen{g}_sha"]), f"{label}: .info file of generation {g} differs from the reference's"
+
     sim.ras_initial_human_gen0(0, len(fx["g0_pop0_sex"]))                       # ras_init_generation0 (:529)
     assert np.array_equal(sim.sex[0], fx["g0_pop0_sex"]), f"{label}: gen-0 sex"
     add, dom, _, _ = ctx.compute_ad(0)
-    s2a, s2d = comm_var(add[:, 0]), comm_var(dom[:, 0])                         # _var_a_gen0 / _var_d_gen0 (:557-561)
-    n = len(sim.sex[0])
-    out = ctx.scale_ad_compute_gef(0, 0, 0, int(sim.ras_glob_seed()[0]), va, vd, ve, vf, 1.0, s2a, s2d,
-                                   common_sibling=np.zeros(n), f_father=np.zeros(n), f_mother=np.zeros(n))
-    phen = out["phen"]
-    mv = 0.0 + 1.0 * phen; sv = 0.0 + 1.0 * phen                                # omega = lambda = 1 (:3311-3320)
+    s2 = [(comm_var(add[:, p]), comm_var(dom[:, p])) for p in range(nphen)]      # _var_a_gen0 / _var_d_gen0 (:557-561)
+    outs = scale(0, s2, None)
+    mv, sv = values(outs)
     sv_mean, sv_var = comm_mean(sv), comm_var(sv)                               # standardised to generation 0 (:3326-3330)
-    svf = np.ones(n)                                                            # generation 0: everybody may marry (:3388)
-
-    def check_info_file(g, out, mv, z, svf):
-        """Population::ras_save_human_info: the reference's .info.popK.genG.txt, byte for byte (exact builds only)"""
-        if not exact or f"infofile_pop0_gen{g}_sha" not in fx:
-            return
-        from geneevolve_amd.host import ras_save_human_info
-        d = dict(out); d["common_sibling"] = np.zeros(len(mv))
-        txt = ras_save_human_info(sim.ped[0], sim.sex[0], [d], mv, z, svf)
-        assert np.array_equal(np.frombuffer(hashlib.sha256(txt).digest(), dtype=np.uint8), fx[f"infofile_pop0_gen{g}_sha"]), f"{label}: .info file of generation {g} differs from the reference's"
-
-    z0 = (sv - sv_mean) / np.sqrt(sv_var) if sv_var > 0 else sv - sv_mean
-    check_info_file(0, out, mv, z0, svf)
+    z = (sv - sv_mean) / np.sqrt(sv_var) if sv_var > 0 else sv - sv_mean
+    svf = np.ones(len(mv))                                                      # generation 0: everybody may marry (:3388)
+    check_info_file(0, outs, mv, z, svf)
+    for p in range(nphen):                                                      # "adjust beta", vt_type 1 (:650-653)
+        beta[p] = float(np.sqrt(var[p][3] / (2 * comm_var(outs[p]["phen"]))))
     for g in range(1, ngen + 1):
         pop_size, mat_cor, dist, func, p1, p2 = str(fx["pop0_popinfo"][g - 1]).split()
         k = f"g{g}_pop0_mate_"
-        close(mv, fx[k + "am_mv"], f"mating values entering generation {g}")
         close(svf, fx[k + "svf"], f"selection function values entering generation {g}")
-        sim.assort_mate(0, svf, mv, int(pop_size), float(mat_cor), mm_percent=mm, avoid_inbreeding=avoid, offspring_dist=dist,
-                        rank=ctx.rank_f64 if lib.exports("rank_f64") else None)
+        if rm:
+            sim.random_mate(0, svf, int(pop_size))
+        else:
+            close(mv, fx[k + "am_mv"], f"mating values entering generation {g}")
+            sim.assort_mate(0, svf, mv, int(pop_size), float(mat_cor), mm_percent=mm, avoid_inbreeding=avoid, offspring_dist=dist,
+                            rank=ctx.rank_f64 if lib.exports("rank_f64") else None)
         c, want = sim.couples[0], fx[f"g{g}_pop0_couples"]
         assert len(c) == len(want) and np.array_equal(c["pos_male"].astype(np.int64), want[:, 0]) and np.array_equal(c["pos_female"].astype(np.int64), want[:, 1]) \
             and np.array_equal(c["inbreed"], want[:, 2]) and np.array_equal(c["num_offspring"], want[:, 3]), f"{label}: couples of generation {g}"
-        prev_phen = phen
+        prev_phen = [o["phen"] for o in outs]
         sim.reproduce(0, g)
         assert np.array_equal(sim.sex[0], fx[f"g{g}_pop0_sex"]), f"{label}: sex generation {g}"
         ped = sim.ped[0]
         assert np.array_equal(np.stack([ped.ID, ped.ID_Father, ped.ID_Mother], axis=1), fx[f"g{g}_pop0_ids"]), f"{label}: pedigree generation {g}"
         add, dom, _, _ = ctx.compute_ad(0)
         assert bits_equal(add, fx[f"g{g}_pop0_additive"]) and bits_equal(dom, fx[f"g{g}_pop0_dominance"]), f"{label}: raw A/D generation {g}"
-        n = len(sim.sex[0])
-        kk = f"g{g}_pop0_ph0_gef_"
-        seed = int(sim.ras_glob_seed()[0])
-        assert seed == int(fx[kk + "seed"]), f"{label}: the ras_glob_seed() stream is out of step at generation {g}"
-        out = ctx.scale_ad_compute_gef(0, 0, g, seed, va, vd, ve, vf, 1.0, s2a, s2d, common_sibling=np.zeros(n),
-                                       f_father=prev_phen[ped.ID_Father], f_mother=prev_phen[ped.ID_Mother])
-        phen = out["phen"]
-        close(phen, fx[kk + "out"][:, 5], f"phenotypes generation {g}")
-        mv = 0.0 + 1.0 * phen; sv = 0.0 + 1.0 * phen
+        outs = scale(g, s2, prev_phen)
+        mv, sv = values(outs)
         z = (sv - sv_mean) / np.sqrt(sv_var) if sv_var > 0 else sv - sv_mean
         svf = selection_func(func, float(p1), float(p2), z)
-        check_info_file(g, out, mv, z, svf)
+        check_info_file(g, outs, mv, z, svf)
     compare_dense(ctx, fx, ngen, 0, nchr, label)
     ctx.close()
