@@ -73,9 +73,16 @@ class MinstdStream:
         k = np.arange(1, m + 1, dtype=np.uint64)
         return (GlobSeedStream._powmod(k) * np.uint64(self.x)) % np.uint64(M31)
 
+    def rewind_u01(self, n_unused):
+        """undo the last n_unused draws of the most recent u01() batch (the caller over-drew)"""
+        xs, n = self._last_u01
+        keep = n - n_unused
+        self.x = int(xs[2 * keep - 1]) if keep > 0 else self._last_u01_start
+
     def u01(self, n):
         """n draws of uniform_real_distribution<double>(0,1) = generate_canonical<double,53> (2 engine calls each)"""
         xs = self._outputs(2 * n)
+        self._last_u01 = (xs, n); self._last_u01_start = self.x
         self.x = int(xs[-1]) if n else self.x
         lo = (xs[0::2] - np.uint64(1)).astype(np.float64); hi = (xs[1::2] - np.uint64(1)).astype(np.float64)
         r = (lo + hi * 2147483646.0) / float(2147483646 ** 2)
@@ -214,6 +221,18 @@ class Pedigree:
         i = np.arange(n, dtype=np.int64)
         for f in self.FIELDS:
             setattr(self, f, i.copy())
+
+    def take(self, idx):
+        q = Pedigree(0)
+        for f in self.FIELDS:
+            setattr(q, f, getattr(self, f)[idx])
+        return q
+
+    def append(self, other):
+        q = Pedigree(0)
+        for f in self.FIELDS:
+            setattr(q, f, np.concatenate([getattr(self, f), getattr(other, f)]))
+        return q
 
     def offspring(self, pos_father, pos_mother):
         """pedigree of the next generation in enumeration order (src/Simulation.cpp:2473-2479)"""
@@ -390,6 +409,63 @@ def selection_func(kind, p1, p2, z):
     if kind == "thr":
         return np.where(np.asarray(z) <= p2, p1, 1.0)
     raise NotImplementedError(kind)
+
+
+class SampleWithoutReplacement:
+    """RasRandomNumber::ras_SampleWithoutReplacement (reference src/RasRandomNumber.cpp:90-120): Knuth's selection sampling on
+    a `static` default_random_engine -- it is seeded by the seed of the FIRST call of the process and every later call
+    continues that stream (its seed argument is ignored).  One instance = that process-wide static."""
+
+    def __init__(self):
+        self.stream = None
+
+    def __call__(self, population_size, sample_size, seed):
+        if self.stream is None:
+            self.stream = MinstdStream(seed)
+        n, N = int(sample_size), int(population_size)
+        out, t, m = [], 0, 0
+        buf, k = [], 0
+        while m < n:
+            if k == len(buf):
+                buf = self.stream.u01(max(N - t, 16)).tolist(); k = 0      # over-drawn; the unused tail is given back below
+            u = buf[k]; k += 1
+            if (N - t) * u >= n - m:
+                t += 1
+            else:
+                out.append(t); t += 1; m += 1
+        # give back the unused part of the last batch: the engine must stand exactly after the draws consumed
+        if k < len(buf):
+            unused = len(buf) - k
+            self.stream.rewind_u01(unused)
+        return np.array(out, dtype=np.int64)
+
+
+def ras_do_migration(pop_sizes, migration_row, glob_draw, sampler):
+    """WHO moves in Simulation::ras_do_migration (reference src/Simulation.cpp:877-937): counts round(m_ij * n_i) (:909), one
+    sample per origin over all its emigrants (:921, one ras_glob_seed() each), sorted descending (:922), handed to the
+    destinations in ascending j by the reference's loop `while (k < num_move[i][j])` (:930-935, k runs on across j -- kept
+    literally).  Returns the moves (src_pop, src_pos, dst_pop) in the append order of :971-981."""
+    npop = len(pop_sizes)
+    mat = np.asarray(migration_row, dtype=np.float64).reshape(npop, npop)
+    num_move = [[0 if i == j else int(np.floor(mat[i][j] * float(pop_sizes[i]) + 0.5)) for j in range(npop)] for i in range(npop)]
+    camp = [[[] for _ in range(npop)] for _ in range(npop)]
+    for i in range(npop):
+        s = sum(num_move[i])
+        sample = sorted(sampler(pop_sizes[i], s, int(glob_draw(1)[0])).tolist(), reverse=True)
+        k = 0
+        for j in range(npop):
+            if i == j:
+                continue
+            lst = [None] * num_move[i][j]; it = 0
+            while k < num_move[i][j]:
+                lst[it] = sample[k]; k += 1; it += 1
+            camp[i][j] = lst
+    moves = []
+    for i in range(npop):
+        for j in range(npop):
+            if i != j:
+                moves += [(i, int(pos), j) for pos in camp[i][j] if pos is not None]
+    return moves
 
 
 def ras_save_human_info(ped, sex, per_phen, mating_value, selection_value, selection_value_func):

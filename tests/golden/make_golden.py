@@ -310,6 +310,8 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
         args += a
     args += ["--seed", str(seed), "--prefix", os.path.join(wd, "out")] + case.args_extra
     arrs["args_extra"] = np.array(case.args_extra if case.args_extra else [""])
+    if "--file_migration" in case.args_extra:                      # one row per generation, n_pop^2 row-major entries (:839-896)
+        arrs["migration_mat_gen"] = np.loadtxt(case.args_extra[case.args_extra.index("--file_migration") + 1], ndmin=2)
     env = dict(os.environ, GEV_DUMP=os.path.join(wd, "d"), GEV_DUMP_DENSE="1",
                GEV_DENSE_GENS=",".join(str(g) for g in sorted(set(dense_gens) | {0})))
     with open(os.path.join(wd, "log.txt"), "w") as log:

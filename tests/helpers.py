@@ -333,3 +333,116 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
         check_info_file(g, outs, mv, z, svf)
     compare_dense(ctx, fx, ngen, 0, nchr, label)
     ctx.close()
+
+
+def closed_loop_migration_case(lib, fx, label, device=-1, exact=True):
+    """the same closed loop for SEVERAL populations with migration (fixture mig2, BASELINE config 3's shape): per generation
+    and population random_mate -> reproduce -> ras_compute_AD -> ras_scale_AD_compute_GEF, then mating/selection values, then
+    ras_do_migration -- WHO moves is restated on the host (selection sampling on the reference's process-wide static engine),
+    the rows move inside the library -- all from --seed alone; post-migration populations and the .info files of both
+    populations are compared with the reference's."""
+    from geneevolve_amd.host import SampleWithoutReplacement, Simulation, ras_do_migration, ras_save_human_info
+    n_pop, nchr, nphen, ngen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"]), int(fx["n_gen"])
+    assert nphen == 1 and all(int(fx[f"pop{ip}_rm"]) == 1 for ip in range(n_pop))
+    ctx = lib.create(n_pop, nchr, nphen, device) if lib.has_device_arg else lib.create(n_pop, nchr, nphen)
+    setup_static(ctx, fx)
+    sim = Simulation(ctx, int(fx["seed"]), nchr, bool(int(fx["pop0_has_mut"])), track_pedigree=True)
+    sampler = SampleWithoutReplacement()
+    var = [[float(v) for v in fx[f"pop{ip}_ph0_var"]] for ip in range(n_pop)]
+    assert all(v[3] == 0.0 for v in var)
+
+    def close(a, b, what):
+        if exact:
+            assert bits_equal(a, b), f"{label}: {what} not bit-identical"
+        else:
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12), f"{label}: {what} differs"
+
+    rec = [dict() for _ in range(n_pop)]        # per population: outs (phenotype components), mv, z, svf of the CURRENT individuals
+    s2, sv0 = [None] * n_pop, [None] * n_pop
+
+    def scale(ip, g):
+        n = len(sim.sex[ip]); va, vd, ve, vf = var[ip]
+        seed = int(sim.ras_glob_seed()[0])
+        if g > 0:
+            assert seed == int(fx[f"g{g}_pop{ip}_ph0_gef_seed"]), f"{label}: ras_glob_seed() stream out of step (gen {g} pop {ip})"
+        o = ctx.scale_ad_compute_gef(ip, 0, g, seed, va, vd, ve, vf, 1.0, s2[ip][0], s2[ip][1], common_sibling=np.zeros(n), f_father=np.zeros(n), f_mother=np.zeros(n))
+        o["common_sibling"] = np.zeros(n)
+        if g > 0:
+            close(o["phen"], fx[f"g{g}_pop{ip}_ph0_gef_out"][:, 5], f"phenotypes gen {g} pop {ip}")
+        return o
+
+    def values(ip, g, o, func=None):
+        mv = 0.0 + 1.0 * o["phen"]; sv = 0.0 + 1.0 * o["phen"]
+        if g == 0:
+            sv0[ip] = (comm_mean(sv), comm_var(sv))
+        z = (sv - sv0[ip][0]) / np.sqrt(sv0[ip][1]) if sv0[ip][1] > 0 else sv - sv0[ip][0]
+        svf = np.ones(len(mv)) if g == 0 else selection_func(func[0], func[1], func[2], z)
+        rec[ip] = {"out": o, "mv": mv, "z": z, "svf": svf}
+
+    def info_file(ip, g):
+        if exact and f"infofile_pop{ip}_gen{g}_sha" in fx:
+            r = rec[ip]
+            txt = ras_save_human_info(sim.ped[ip], sim.sex[ip], [r["out"]], r["mv"], r["z"], r["svf"])
+            assert np.array_equal(np.frombuffer(hashlib.sha256(txt).digest(), dtype=np.uint8), fx[f"infofile_pop{ip}_gen{g}_sha"]), f"{label}: .info file gen {g} pop {ip}"
+
+    for ip in range(n_pop):                                                      # ras_init_generation0
+        sim.ras_initial_human_gen0(ip, len(fx[f"g0_pop{ip}_sex"]))
+        assert np.array_equal(sim.sex[ip], fx[f"g0_pop{ip}_sex"])
+        add, dom, _, _ = ctx.compute_ad(ip)
+        s2[ip] = (comm_var(add[:, 0]), comm_var(dom[:, 0]))
+        rec[ip]["o"] = scale(ip, 0)
+    for ip in range(n_pop):
+        values(ip, 0, rec[ip]["o"])
+    for ip in range(n_pop):
+        info_file(ip, 0)
+    for g in range(1, ngen + 1):
+        funcs = []
+        for ip in range(n_pop):
+            pop_size, mat_cor, dist, func, p1, p2 = str(fx[f"pop{ip}_popinfo"][g - 1]).split()
+            funcs.append((func, float(p1), float(p2)))
+            close(rec[ip]["svf"], fx[f"g{g}_pop{ip}_mate_svf"], f"selection function values entering gen {g} pop {ip}")
+            sim.random_mate(ip, rec[ip]["svf"], int(pop_size))
+            c, want = sim.couples[ip], fx[f"g{g}_pop{ip}_couples"]
+            assert np.array_equal(c["pos_male"].astype(np.int64), want[:, 0]) and np.array_equal(c["pos_female"].astype(np.int64), want[:, 1]), f"{label}: couples gen {g} pop {ip}"
+            sim.reproduce(ip, g)
+            assert np.array_equal(sim.sex[ip], fx[f"g{g}_pop{ip}_sex"]), f"{label}: sex gen {g} pop {ip}"
+            add, dom, _, _ = ctx.compute_ad(ip)
+            assert bits_equal(add, fx[f"g{g}_pop{ip}_additive"]) and bits_equal(dom, fx[f"g{g}_pop{ip}_dominance"]), f"{label}: raw A/D gen {g} pop {ip}"
+            rec[ip]["o"] = scale(ip, g)
+        for ip in range(n_pop):
+            values(ip, g, rec[ip]["o"], funcs[ip])
+        # ---- ras_do_migration(gen_num - 1)
+        moves = ras_do_migration([len(sim.sex[ip]) for ip in range(n_pop)], fx["migration_mat_gen"][g - 1], sim.ras_glob_seed, sampler)
+        assert moves == derive_moves(fx, g), f"{label}: WHO migrates in generation {g}"
+        sim.ras_do_migration(moves)
+        # the host's Human records follow (erase at the origin, append at the destination in move order)
+        gone = [np.zeros(len(sim.sex[ip]), dtype=bool) for ip in range(n_pop)]
+        for sp, pos, dp in moves:
+            gone[sp][pos] = True
+        old = [(sim.sex[ip], sim.ped[ip], rec[ip]) for ip in range(n_pop)]
+        for ip in range(n_pop):
+            keep = np.flatnonzero(~gone[ip])
+            sx, pd, r = old[ip]
+            sex_new = [sx[keep]]; ped_new = pd.take(keep)
+            cols = {k: [r[k][keep]] for k in ("mv", "z", "svf")}
+            out_new = {k: [v[keep]] for k, v in r["out"].items()}
+            for sp, pos, dp in moves:
+                if dp != ip:
+                    continue
+                osx, opd, orr = old[sp]
+                sex_new.append(osx[pos:pos + 1]); ped_new = ped_new.append(opd.take(np.array([pos])))
+                for k in cols:
+                    cols[k].append(orr[k][pos:pos + 1])
+                for k in out_new:
+                    out_new[k].append(orr["out"][k][pos:pos + 1])
+            sim.sex[ip] = np.concatenate(sex_new); sim.ped[ip] = ped_new
+            rec[ip] = {k: np.concatenate(v) for k, v in cols.items()}
+            rec[ip]["out"] = {k: np.concatenate(v) for k, v in out_new.items()}
+            assert ctx.pop_size(ip) == len(sim.sex[ip])
+            assert np.array_equal(sim.sex[ip], fx[f"g{g}_pop{ip}_postmig_sex"]), f"{label}: post-migration sex gen {g} pop {ip}"
+            assert np.array_equal(np.stack([sim.ped[ip].ID, sim.ped[ip].ID_Father, sim.ped[ip].ID_Mother], axis=1), fx[f"g{g}_pop{ip}_postmig_ids"]), f"{label}: post-migration ids gen {g} pop {ip}"
+        for ip in range(n_pop):
+            info_file(ip, g)
+        for ip in range(n_pop):
+            compare_dense(ctx, fx, g, ip, nchr, label)
+    ctx.close()

@@ -732,3 +732,7 @@ def test_closed_loop_from_the_seed_alone_on_gpu(gpu_lib, case):
     """the same closed loop on the HIP library (A/D, intervals, genotypes, couples, sexes bit-exact; scaled phenotypes and what
     derives from them within 1e-9 relative: the device's parallel variance / log are not bit-identical to libm's)"""
     helpers.closed_loop_case(gpu_lib, helpers.load_fixture(case), f"gpu/{case}", device=0, exact=False)
+
+
+def test_closed_loop_two_populations_with_migration_on_gpu(gpu_lib):
+    helpers.closed_loop_migration_case(gpu_lib, helpers.load_fixture("mig2"), "gpu/mig2", device=0, exact=False)

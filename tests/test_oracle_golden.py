@@ -146,3 +146,9 @@ def test_closed_loop_from_the_seed_alone(oracle_lib, case):
     """the reference's whole generation loop (assortative mating, inbreeding avoidance, Poisson / fixed families, logit
     selection) re-driven from --seed by the host mirror on top of the C-ABI (oracle build): bit-identical at every step"""
     helpers.closed_loop_case(oracle_lib, helpers.load_fixture(case), f"oracle/{case}")
+
+
+def test_closed_loop_two_populations_with_migration(oracle_lib):
+    """BASELINE config 3's shape end to end from the seed alone: two populations, random mating, mutation, migration decided by
+    the host restatement of ras_do_migration (selection sampling on the process-wide static engine), rows moved by the library"""
+    helpers.closed_loop_migration_case(oracle_lib, helpers.load_fixture("mig2"), "oracle/mig2")
