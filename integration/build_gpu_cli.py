@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Build oracle/_ref/GeneEvolve_gpu: the reference's own command-line program with its reproduction hot path bound to
+libgeneevolve_amd.so (the patch of INTEGRATION.md, applied mechanically).
+
+Nothing of the reference is stored in this repository: an edited build copy of src/Simulation.{h,cpp} is generated under a
+temporary directory from the sources where they lie, compiled together with integration/gev_glue.cpp, linked with the
+reference's other (unmodified) objects that oracle/Makefile.ref already produced, and deleted.  Edits (all located by the
+function signatures / the one marker comment, not by line numbers):
+
+  Simulation.h    class Simulation gets `friend struct GevGlue;`
+  Simulation.cpp  ras_init_parameters       + hand the static inputs to the library before its final `return true`
+                  ras_initial_human_gen0    + gev_init_gen0 with the function's own `seed` before its final `return true`
+                  reproduce                 body -> gevglue_reproduce
+                  ras_compute_AD            body -> gevglue_compute_AD
+                  ras_do_migration          + gev_migrate before the "remove migrants from the origin population" block
+                  ras_convert_interval_to_hap_matrix   body -> gevglue_hap_matrix
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("GEV_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "oracle", "_ref")
+
+
+def body_span(src, signature_regex):
+    """(start of '{', index after matching '}') of the function whose definition matches the regex"""
+    m = re.search(signature_regex, src, flags=re.M)
+    if not m:
+        raise SystemExit(f"build_gpu_cli: cannot find {signature_regex!r} in the reference")
+    i = src.index("{", m.end() - 1)
+    depth, j = 0, i
+    while True:
+        c = src[j]
+        if c == "{":
+            depth += 1
+        elif c == "}":
+            depth -= 1
+            if depth == 0:
+                return i, j + 1
+        j += 1
+
+
+def replace_body(src, signature_regex, new_body):
+    i, j = body_span(src, signature_regex)
+    return src[:i] + "{\n" + new_body + "\n}" + src[j:]
+
+
+def insert_before_last_return_true(src, signature_regex, stmt):
+    i, j = body_span(src, signature_regex)
+    body = src[i:j]
+    k = body.rindex("return true;")
+    return src[:i] + body[:k] + stmt + "\n    " + body[k:] + src[j:]
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("build_gpu_cli: no reference tree, skipped"); return 0
+    need = [os.path.join(OUT, "ge", f"{n}.o") for n in ("Main", "Population", "CommFunc", "RasRandomNumber", "RasMatrix", "format_hap", "format_plink", "format_vcf", "parameters")]
+    need.append(os.path.join(OUT, "libStatGen.a"))
+    for f in need:
+        if not os.path.exists(f):
+            raise SystemExit(f"build_gpu_cli: {f} missing -- run make -C oracle -f Makefile.ref first")
+    h = open(os.path.join(REF, "src", "Simulation.h")).read()
+    cpp = open(os.path.join(REF, "src", "Simulation.cpp")).read()
+    m = re.search(r"class\s+Simulation\s*\{", h)
+    h = h[:m.end()] + "\n    friend struct GevGlue;\n" + h[m.end():]
+    decl = ("\nclass Simulation;\nbool gevglue_init_static(Simulation&);\nbool gevglue_after_gen0(Simulation&, int, unsigned);\n"
+            "std::vector<Human> gevglue_reproduce(Simulation&, int, int);\nbool gevglue_compute_AD(Simulation&, int, int);\n"
+            "bool gevglue_migrate(Simulation&, const std::vector<std::vector<unsigned long int> >&, const std::vector<std::vector<unsigned long int> >&);\n"
+            "bool gevglue_hap_matrix(Simulation&, int, std::vector<Legend>&, int, Hap_SNP&);\n")
+    inc = re.search(r'#include\s+"Simulation.h"', cpp)
+    cpp = cpp[:inc.end()] + decl + cpp[inc.end():]
+    cpp = insert_before_last_return_true(cpp, r"^bool\s+Simulation::ras_init_parameters\s*\(", "if (!gevglue_init_static(*this)) return false;")
+    cpp = insert_before_last_return_true(cpp, r"^bool\s+Simulation::ras_initial_human_gen0\s*\(\s*int\s+ipop\s*\)", "if (!gevglue_after_gen0(*this, ipop, seed)) return false;")
+    cpp = replace_body(cpp, r"^std::vector<Human>\s+Simulation::reproduce\s*\(\s*int\s+ipop\s*,\s*int\s+gen_num\s*\)", "    return gevglue_reproduce(*this, ipop, gen_num);")
+    cpp = replace_body(cpp, r"^bool\s+Simulation::ras_compute_AD\s*\(\s*int\s+ipop\s*,\s*int\s+gen_num\s*\)", "    return gevglue_compute_AD(*this, ipop, gen_num);")
+    cpp = replace_body(cpp, r"^bool\s+Simulation::ras_convert_interval_to_hap_matrix\s*\(", "    return gevglue_hap_matrix(*this, ipop, pops_legend, ichr, hap_snp);")
+    i, j = body_span(cpp, r"^bool\s+Simulation::ras_do_migration\s*\(")
+    body = cpp[i:j]
+    k = body.index("// remove migrants from the origin population")
+    cpp = cpp[:i] + body[:k] + "if (!gevglue_migrate(*this, move_sample_pop, num_move)) return false;\n    " + body[k:] + cpp[j:]
+
+    tmp = tempfile.mkdtemp(prefix="gev_gpu_cli_")
+    try:
+        open(os.path.join(tmp, "Simulation.h"), "w").write(h)
+        open(os.path.join(tmp, "Simulation.cpp"), "w").write(cpp)
+        sg = os.path.join(REF, "Library", "libStatGen")
+        dbg = ["-O1", "-g", "-fsanitize=address"] if os.environ.get("GEV_GLUE_ASAN") else ["-O3"]     # CPU-side debugging of the glue only
+        flags = dbg + ["-std=c++11", "-w", "-D__ZLIB_AVAILABLE__", "-D_FILE_OFFSET_BITS=64", "-D__STDC_LIMIT_MACROS",
+                 "-I" + tmp, "-I" + os.path.join(sg, "general"), "-I" + os.path.join(sg, "vcf"), "-I" + os.path.join(sg, "samtools"),
+                 "-I" + os.path.join(REF, "Library", "eigen3"), "-I" + os.path.join(REF, "src"), "-I" + os.path.join(ROOT, "include"),
+                 "-include", os.path.join(ROOT, "oracle", "ref_compat.h")]
+        for name, srcf in (("Simulation_gpu.o", os.path.join(tmp, "Simulation.cpp")), ("gev_glue.o", os.path.join(ROOT, "integration", "gev_glue.cpp"))):
+            subprocess.run(["g++"] + flags + ["-c", srcf, "-o", os.path.join(tmp, name)], check=True)
+        libdir = os.path.join(ROOT, "geneevolve_amd", "csrc")
+        objs = [f for f in need if f.endswith(".o")]
+        common = [os.path.join(tmp, "Simulation_gpu.o"), os.path.join(tmp, "gev_glue.o")] + objs + [os.path.join(OUT, "libStatGen.a"), "-lz"]
+        asan = ["-fsanitize=address"] if os.environ.get("GEV_GLUE_ASAN") else []
+        subprocess.run(["g++", "-o", os.path.join(OUT, "GeneEvolve_gpu")] + asan + common + ["-L" + libdir, "-lgeneevolve_amd", "-Wl,-rpath,$ORIGIN/../../geneevolve_amd/csrc"], check=True)
+        # the same program on the CPU oracle (test infrastructure: checks glue + edits where there is no GPU)
+        subprocess.run(["g++"] + flags + ["-c", os.path.join(ROOT, "integration", "gev_on_oracle.cpp"), "-o", os.path.join(tmp, "gev_on_oracle.o")], check=True)
+        subprocess.run(["g++", "-o", os.path.join(OUT, "GeneEvolve_glue_on_oracle")] + asan + common + [os.path.join(tmp, "gev_on_oracle.o"), "-L" + os.path.join(ROOT, "oracle"), "-lgev_oracle",
+                        "-Wl,-rpath,$ORIGIN/.."], check=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    print("built", os.path.join(OUT, "GeneEvolve_gpu"), "and GeneEvolve_glue_on_oracle")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,185 @@
+// integration/gev_glue.cpp -- the reference-side binding of INTEGRATION.md, for real: GeneEvolve's own host (Main.cpp,
+// parameters, every reader/writer, mating, phenotype scaling, migration decisions, summaries) with the reproduction hot
+// path running in libgeneevolve_amd.so.  integration/build_gpu_cli.py makes an edited build copy of the reference's
+// Simulation.{h,cpp} (six call sites rerouted to the functions below; nothing of the reference is stored in this repo)
+// and links it with this file, the reference's other objects and the library into oracle/_ref/GeneEvolve_gpu.
+// tests/test_gpu_parity.py runs that program on the reference's own kind of input files and compares its output files
+// with the unmodified reference's (hashes in tests/golden).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <random>
+#include <string>
+#include <vector>
+#include "Simulation.h"          // the EDITED copy: class Simulation has `friend struct GevGlue;`
+#include "CommFunc.h"
+#include "geneevolve_amd.h"
+
+struct GevGlue {
+    static gev_ctx*& ctx() { static gev_ctx* g = nullptr; return g; }
+    static bool fail(const char* where)
+    {
+        std::cout << "Error: " << where << ": " << gev_last_error() << std::endl;    // the reference's convention: message + false
+        return false;
+    }
+    static std::vector<uint64_t> pack(const std::vector<std::vector<bool> >& rows, size_t ncol, size_t& words)
+    {
+        words = (ncol + 63) / 64;
+        std::vector<uint64_t> out(rows.size() * std::max<size_t>(words, 1), 0);
+        for (size_t r = 0; r < rows.size(); r++)
+            for (size_t j = 0; j < ncol; j++)
+                if (rows[r][j]) out[r * words + (j >> 6)] |= 1ull << (j & 63);
+        return out;
+    }
+
+    // end of Simulation::ras_init_parameters (src/Simulation.cpp:164-525): hand the static inputs over
+    static bool init_static(Simulation& S)
+    {
+        const int n_pop = S._n_pop, nchr = S.population[0]._nchr, nphen = (int)S.population[0]._pheno_scheme.size();
+        if (S._ref_is_vcf) { std::cout << "Error: the GPU build reads hap/legend panels only." << std::endl; return false; }
+        if (gev_create(&ctx(), -1, n_pop, nchr, nphen)) return fail("gev_create");
+        for (int ipop = 0; ipop < n_pop; ipop++) {
+            Population& P = S.population[ipop];
+            for (int c = 0; c < nchr; c++) {
+                if (gev_set_rmap(ctx(), ipop, c, P._rmap[c].bp.data(), P._recom_prob[c].data(), P._rmap[c].bp.size(), P._rmap[c].bp_dist_in_rmap)) return fail("gev_set_rmap");
+                if (P._mutation_map.size() > 0 &&
+                    gev_set_mutmap(ctx(), ipop, c, P._mutation_map[c].bp.data(), P._mutation_map[c].mutation_rate.data(), P._mutation_map[c].bp.size())) return fail("gev_set_mutmap");
+                // the founder panel the reference itself only reads at output time (ras_read_hap_legend_sample_chr, :1105)
+                Legend legend; Hap_SNP hs;
+                const long nind = CommFunc::ras_FileLineNumber(P._hap_legend_sample_name[c][2]);
+                const long nsnp = format_hap::read_legend(legend, P._hap_legend_sample_name[c][1]);
+                if (!format_hap::read_hap(hs, P._hap_legend_sample_name[c][0], nind, nsnp, false)) return false;
+                if (gev_set_snps(ctx(), ipop, c, legend.pos.data(), legend.pos.size())) return fail("gev_set_snps");
+                size_t w; std::vector<uint64_t> bits = pack(hs.hap, legend.pos.size(), w);
+                if (gev_upload_founders(ctx(), ipop, c, bits.data(), w, hs.hap.size(), legend.pos.size())) return fail("gev_upload_founders");
+                for (int p = 0; p < nphen; p++) {
+                    CV_INFO& I = P._pheno_scheme[p]._cv_info[c];
+                    if (gev_set_cvs(ctx(), ipop, p, c, I.bp.data(), I.genetic_value_a.data(), I.genetic_value_d.data(), I.bp.size(), P._pheno_scheme[p]._vd)) return fail("gev_set_cvs");
+                    bits = pack(P._pheno_scheme[p]._cvs[c].val, I.bp.size(), w);
+                    if (gev_upload_cv_founders(ctx(), ipop, p, c, bits.data(), w, P._pheno_scheme[p]._cvs[c].val.size(), I.bp.size())) return fail("gev_upload_cv_founders");
+                }
+            }
+        }
+        return true;
+    }
+
+    // end of Simulation::ras_initial_human_gen0 (:3000-3072): the reference has just built its gen-0 humans from `seed`
+    static bool after_gen0(Simulation& S, int ipop, unsigned seed)
+    {
+        std::vector<Human>& h = S.population[ipop].h;
+        std::vector<uint8_t> sex(h.size());
+        if (gev_init_gen0(ctx(), ipop, h.size(), seed, sex.data())) return fail("gev_init_gen0");
+        for (size_t i = 0; i < h.size(); i++)
+            if (h[i].sex != (int)sex[i]) { std::cout << "Error: gev_init_gen0: sex of founder " << i << " differs from the host's." << std::endl; return false; }
+        return true;
+    }
+
+    // Simulation::reproduce (:2394-2493): same ras_glob_seed() draws, same host bookkeeping, genotype work in the library
+    static std::vector<Human> reproduce(Simulation& S, int ipop, int gen_num)
+    {
+        Population& P = S.population[ipop];
+        const unsigned seed = S.ras_glob_seed();                                   // :2398
+        std::srand(seed);                                                          // :2400 (process rand() state as the reference leaves it)
+        const unsigned long n_couples = P._couples_info.size();
+        unsigned long n_people = 0;
+        for (unsigned long i = 0; i < n_couples; i++) if (!P._couples_info[i].inbreed) n_people += P._couples_info[i].num_offspring;
+        const int nchr = (int)P.h[0].chr.size(), nphen = (int)P._pheno_scheme.size();
+        std::vector<Human> h_ret;
+        S.ras_allocate_memory_for_humans(h_ret, n_people, nchr, nphen);
+        std::default_random_engine generator(seed + 1);                            // common effect, :2417-2429
+        std::vector<std::vector<double> > val_common(nphen, std::vector<double>(n_couples, 0));
+        for (int iphen = 0; iphen < nphen; iphen++)
+            if (P._pheno_scheme[iphen]._vc > 0) {
+                std::normal_distribution<double> distribution(0.0, sqrt(P._pheno_scheme[iphen]._vc));
+                for (unsigned long it = 0; it < n_couples; it++) val_common[iphen][it] = distribution(generator);
+            }
+        std::vector<gev_couple> cpl(n_couples);
+        for (unsigned long it = 0; it < n_couples; it++)
+            cpl[it] = gev_couple{P._couples_info[it].pos_male, P._couples_info[it].pos_female, P._couples_info[it].inbreed ? 1 : 0, P._couples_info[it].num_offspring};
+        std::vector<uint32_t> mut_seeds;
+        if (P._mutation_map.size() > 0) {                                          // the draws ras_add_mutation would make (:2500), same order
+            mut_seeds.resize(n_people * (size_t)nchr);
+            for (size_t t = 0; t < mut_seeds.size(); t++) mut_seeds[t] = S.ras_glob_seed();
+        }
+        std::vector<uint8_t> sex(n_people);
+        if (gev_reproduce(ctx(), ipop, cpl.data(), n_couples, seed, mut_seeds.empty() ? NULL : mut_seeds.data(), mut_seeds.size(), n_people, sex.data())) {
+            fail("gev_reproduce"); return std::vector<Human>();
+        }
+        unsigned long i_people = 0;
+        for (unsigned long it = 0; it < n_couples; it++) {
+            if (P._couples_info[it].inbreed) continue;
+            const Human& h_pat = P.h[P._couples_info[it].pos_male]; const Human& h_mat = P.h[P._couples_info[it].pos_female];
+            for (int ns = 0; ns < P._couples_info[it].num_offspring; ns++) {
+                Human& o = h_ret[i_people];
+                o.gen_num = gen_num; o.sex = sex[i_people]; o.ID = i_people;                       // :2471-2479
+                o.ID_Father = h_pat.ID; o.ID_Fathers_Mother = h_pat.ID_Mother; o.ID_Fathers_Father = h_pat.ID_Father;
+                o.ID_Mother = h_mat.ID; o.ID_Mothers_Mother = h_mat.ID_Mother; o.ID_Mothers_Father = h_mat.ID_Father;
+                for (int iphen = 0; iphen < nphen; iphen++) o.common_sibling[iphen] = val_common[iphen][it];   // :2481-2484
+                i_people++;
+            }
+        }
+        return h_ret;
+    }
+
+    // Simulation::ras_compute_AD (:2624-2749)
+    static bool compute_AD(Simulation& S, int ipop, int /*gen_num*/)
+    {
+        std::vector<Human>& h = S.population[ipop].h;
+        const size_t n = h.size(), nchr = h[0].chr.size(), nphen = S.population[ipop]._pheno_scheme.size();
+        std::vector<double> A(n * nphen), D(n * nphen), Ac(n * nchr * nphen), Dc(n * nchr * nphen);
+        if (gev_compute_ad(ctx(), ipop, A.data(), D.data(), Ac.data(), Dc.data())) return fail("gev_compute_ad");
+        for (size_t ih = 0; ih < n; ih++)
+            for (size_t p = 0; p < nphen; p++) {
+                double bv = 0;
+                for (size_t k = 0; k < nchr; k++) {
+                    const double a = Ac[(ih * nchr + k) * nphen + p], d = Dc[(ih * nchr + k) * nphen + p];
+                    h[ih].chr[k].additive_chr[p] = a; h[ih].chr[k].dominance_chr[p] = d; h[ih].chr[k].bv_chr[p] = a + d;
+                    bv += a + d;                                                                   // :2738
+                }
+                h[ih].additive[p] = A[ih * nphen + p]; h[ih].dominance[p] = D[ih * nphen + p]; h[ih].bv[p] = bv;
+            }
+        return true;
+    }
+
+    // row movement of Simulation::ras_do_migration (:959-981); WHO moves was decided by the reference's own code just above
+    static bool migrate(Simulation& S, const std::vector<std::vector<unsigned long int> >& move_sample_pop, const std::vector<std::vector<unsigned long int> >& num_move)
+    {
+        std::vector<gev_move> moves;                   // append order of :971-981: for i, for j != i, for k (with the reference's running k, :925-936)
+        for (int i = 0; i < S._n_pop; i++) {
+            unsigned long k = 0;
+            for (int j = 0; j < S._n_pop; j++) {
+                if (i == j) continue;
+                while (k < num_move[i][j]) { moves.push_back(gev_move{i, j, move_sample_pop[i][k]}); k++; }
+            }
+            if (k != move_sample_pop[i].size()) {      // with more than two populations the reference's running k (:930) leaves sampled people in no camp: they vanish
+                std::cout << "Error: the GPU build does not reproduce the loss of unassigned emigrants (more than two populations)." << std::endl;
+                return false;
+            }
+        }
+        if (gev_migrate(ctx(), moves.data(), moves.size())) return fail("gev_migrate");
+        return true;
+    }
+
+    // Simulation::ras_convert_interval_to_hap_matrix (:1186-1230)
+    static bool hap_matrix(Simulation& S, int ipop, std::vector<Legend>& pops_legend, int ichr, Hap_SNP& hap_snp)
+    {
+        const size_t n_human = S.population[ipop].h.size(), nsnp = pops_legend[ipop].id.size(), w = (nsnp + 63) / 64;
+        std::vector<uint64_t> bits(2 * n_human * std::max<size_t>(w, 1));
+        if (gev_download_haps(ctx(), ipop, ichr, 0, 2 * n_human, bits.data(), w)) return fail("gev_download_haps");
+        hap_snp.hap.assign(2 * n_human, std::vector<bool>(nsnp, false));
+        for (size_t r = 0; r < 2 * n_human; r++)
+            for (size_t ii = 0; ii < nsnp; ii++) hap_snp.hap[r][ii] = (bits[r * w + (ii >> 6)] >> (ii & 63)) & 1;
+        return true;
+    }
+};
+
+// free functions the edited Simulation.cpp calls
+bool gevglue_init_static(Simulation& S) { return GevGlue::init_static(S); }
+bool gevglue_after_gen0(Simulation& S, int ipop, unsigned seed) { return GevGlue::after_gen0(S, ipop, seed); }
+std::vector<Human> gevglue_reproduce(Simulation& S, int ipop, int gen_num) { return GevGlue::reproduce(S, ipop, gen_num); }
+bool gevglue_compute_AD(Simulation& S, int ipop, int gen_num) { return GevGlue::compute_AD(S, ipop, gen_num); }
+bool gevglue_migrate(Simulation& S, const std::vector<std::vector<unsigned long int> >& a, const std::vector<std::vector<unsigned long int> >& b) { return GevGlue::migrate(S, a, b); }
+bool gevglue_hap_matrix(Simulation& S, int ipop, std::vector<Legend>& pops_legend, int ichr, Hap_SNP& hap_snp) { return GevGlue::hap_matrix(S, ipop, pops_legend, ichr, hap_snp); }

@@ -269,7 +269,8 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
         for ic in range(nchr):
             bp = np.asarray(P["rmap_bp"][ic], dtype=np.uint64); cM = np.asarray(P["rmap_cM"][ic], dtype=np.float64)
             prob = np.zeros(len(cM)); prob[1:] = (cM[1:] - cM[:-1]) * .01      # Population.cpp:471-480
-            arrs[f"{pre}chr{ic}_rmap_bp"] = bp; arrs[f"{pre}chr{ic}_rmap_prob"] = prob
+            arrs[f"{pre}chr{ic}_rmap_bp"] = bp; arrs[f"{pre}chr{ic}_rmap_prob"] = prob; arrs[f"{pre}chr{ic}_rmap_cM"] = cM   # cM: the file's own column (tests/cli_inputs.py rewrites the file)
+            arrs[f"{pre}chr{ic}_label"] = np.int64(chrs[ic])
             arrs[f"{pre}chr{ic}_bp_dist"] = np.uint64(bp[1] - bp[0])           # Population.cpp:396-397
         a = ["--file_gen_info", os.path.join(wd, f"p{ip}.popinfo.txt"), "--file_hap_name", os.path.join(wd, f"p{ip}.hapaddr.txt"),
              "--file_recom_map", os.path.join(wd, f"p{ip}.rmap.txt")]

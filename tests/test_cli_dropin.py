@@ -1,0 +1,58 @@
+"""The drop-in for real: the reference's OWN command-line program (Main.cpp, parameters, all file readers and writers, mating,
+phenotype scaling, migration decisions, summaries -- compiled from the reference tree, unmodified) with the six call sites of
+INTEGRATION.md rerouted through the C-ABI (integration/gev_glue.cpp, integration/build_gpu_cli.py), run on the same input
+files the unmodified reference was given when the golden fixtures were made.  Every per-generation .info file and the .hap
+genotype files of the last generation must equal the unmodified reference's byte for byte (sha256 in the fixtures).
+
+  GeneEvolve_glue_on_oracle : linked to the CPU oracle  -> checks the glue and the edit script without a GPU
+  GeneEvolve_gpu            : linked to libgeneevolve_amd.so (the product)  -> the GPU test
+Both binaries are built in the container (where the reference tree is) and travel with oracle/_ref/."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from tests.cli_inputs import write_inputs_from_fixture
+
+REFDIR = os.path.join(os.path.dirname(helpers.GOLDEN), "..", "oracle", "_ref")
+CASES = ["dense", "am1", "am2", "mig2", "ex1mut", "ex1sub"]
+
+
+def run_cli(exe, case, tmp_path):
+    fx = helpers.load_fixture(case)
+    wd = str(tmp_path / case)
+    args = write_inputs_from_fixture(fx, wd)
+    r = subprocess.run([exe] + args + ["--out_hap"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"{case}: exit {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
+    ngen = int(fx["n_gen"])
+    for g in range(ngen + 1):
+        for ip in range(int(fx["n_pop"])):
+            raw = open(os.path.join(wd, f"out.info.pop{ip+1}.gen{g}.txt"), "rb").read()
+            assert np.array_equal(np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8), fx[f"infofile_pop{ip}_gen{g}_sha"]), \
+                f"{case}: .info file of generation {g} population {ip+1} differs from the unmodified reference's"
+    for ip in range(int(fx["n_pop"])):
+        for ic in range(int(fx["nchr"])):
+            lab = int(fx[f"pop{ip}_chr{ic}_label"])
+            raw = open(os.path.join(wd, f"out.pop{ip+1}.gen{ngen}.chr{lab}.hap"), "rb").read()
+            assert np.array_equal(np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8), fx[f"hapfile_pop{ip}_chr{ic}_sha"]), \
+                f"{case}: .hap file of population {ip+1} chromosome {lab} differs from the unmodified reference's"
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_reference_cli_on_the_c_abi_oracle_backend(case, tmp_path):
+    exe = os.path.join(REFDIR, "GeneEvolve_glue_on_oracle")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/GeneEvolve_glue_on_oracle not built (needs the reference tree: python -c 'import __graft_entry__ as g; g.build()')")
+    run_cli(exe, case, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_reference_cli_on_the_hip_library(case, tmp_path):
+    exe = os.path.join(REFDIR, "GeneEvolve_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/GeneEvolve_gpu not built (needs the reference tree at build time)")
+    run_cli(exe, case, tmp_path)
