@@ -13,7 +13,9 @@ function signatures / the one marker comment, not by line numbers):
                   reproduce                 body -> gevglue_reproduce
                   ras_compute_AD            body -> gevglue_compute_AD
                   ras_do_migration          + gev_migrate before the "remove migrants from the origin population" block
-                  ras_convert_interval_to_hap_matrix   body -> gevglue_hap_matrix
+                  ras_convert_interval_to_hap_matrix     body -> gevglue_hap_matrix      (--out_hap)
+                  ras_convert_interval_to_format_plink   body -> gevglue_plink_matrix    (--out_plink, --out_plink01)
+                  ras_write_hap_to_interval_format       body -> gevglue_write_interval  (--out_interval)
 """
 import os
 import re
@@ -72,7 +74,9 @@ def main():
     decl = ("\nclass Simulation;\nbool gevglue_init_static(Simulation&);\nbool gevglue_after_gen0(Simulation&, int, unsigned);\n"
             "std::vector<Human> gevglue_reproduce(Simulation&, int, int);\nbool gevglue_compute_AD(Simulation&, int, int);\n"
             "bool gevglue_migrate(Simulation&, const std::vector<std::vector<unsigned long int> >&, const std::vector<std::vector<unsigned long int> >&);\n"
-            "bool gevglue_hap_matrix(Simulation&, int, std::vector<Legend>&, int, Hap_SNP&);\n")
+            "bool gevglue_hap_matrix(Simulation&, int, std::vector<Legend>&, int, Hap_SNP&);\n"
+            "bool gevglue_plink_matrix(Simulation&, int, std::vector<Legend>&, int, std::vector<std::vector<bool> >&, plink_PED_ids&, plink_MAP&);\n"
+            "bool gevglue_write_interval(Simulation&, int);\n")
     inc = re.search(r'#include\s+"Simulation.h"', cpp)
     cpp = cpp[:inc.end()] + decl + cpp[inc.end():]
     cpp = insert_before_last_return_true(cpp, r"^bool\s+Simulation::ras_init_parameters\s*\(", "if (!gevglue_init_static(*this)) return false;")
@@ -80,6 +84,8 @@ def main():
     cpp = replace_body(cpp, r"^std::vector<Human>\s+Simulation::reproduce\s*\(\s*int\s+ipop\s*,\s*int\s+gen_num\s*\)", "    return gevglue_reproduce(*this, ipop, gen_num);")
     cpp = replace_body(cpp, r"^bool\s+Simulation::ras_compute_AD\s*\(\s*int\s+ipop\s*,\s*int\s+gen_num\s*\)", "    return gevglue_compute_AD(*this, ipop, gen_num);")
     cpp = replace_body(cpp, r"^bool\s+Simulation::ras_convert_interval_to_hap_matrix\s*\(", "    return gevglue_hap_matrix(*this, ipop, pops_legend, ichr, hap_snp);")
+    cpp = replace_body(cpp, r"^bool\s+Simulation::ras_convert_interval_to_format_plink\s*\(", "    return gevglue_plink_matrix(*this, ipop, pops_legend, ichr, matrix_plink_ped, plink_ped_ids, plink_map);")
+    cpp = replace_body(cpp, r"^bool\s+Simulation::ras_write_hap_to_interval_format\s*\(\s*int\s+gen_num\s*\)", "    return gevglue_write_interval(*this, gen_num);")
     i, j = body_span(cpp, r"^bool\s+Simulation::ras_do_migration\s*\(")
     body = cpp[i:j]
     k = body.index("// remove migrants from the origin population")

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <random>
 #include <string>
@@ -174,9 +175,63 @@ struct GevGlue {
             for (size_t ii = 0; ii < nsnp; ii++) hap_snp.hap[r][ii] = (bits[r * w + (ii >> 6)] >> (ii & 63)) & 1;
         return true;
     }
+
+    // Simulation::ras_convert_interval_to_format_plink (:1308-1416): matrix from the device, ids and map exactly as :1391-1413
+    static bool plink_matrix(Simulation& S, int ipop, std::vector<Legend>& pops_legend, int ichr, std::vector<std::vector<bool> >& matrix_plink_ped,
+                             plink_PED_ids& plink_ped_ids, plink_MAP& plink_map)
+    {
+        Population& P = S.population[ipop];
+        const size_t n_human = P.h.size(), nsnp = pops_legend[ipop].id.size(), w = (2 * nsnp + 63) / 64;
+        std::vector<uint64_t> bits(n_human * std::max<size_t>(w, 1));
+        if (gev_download_plink_matrix(ctx(), ipop, ichr, 0, n_human, bits.data(), w)) return fail("gev_download_plink_matrix");
+        matrix_plink_ped.assign(n_human, std::vector<bool>(nsnp * 2, false));
+        plink_ped_ids.alloc(n_human); plink_map.alloc(nsnp);
+        for (size_t ih = 0; ih < n_human; ih++) {
+            for (size_t b = 0; b < 2 * nsnp; b++) matrix_plink_ped[ih][b] = (bits[ih * w + (b >> 6)] >> (b & 63)) & 1;
+            plink_ped_ids.FID[ih] = std::to_string(P.h[ih].ID_Father + 1); plink_ped_ids.IID[ih] = std::to_string(P.h[ih].ID + 1);
+            plink_ped_ids.PID[ih] = std::to_string(P.h[ih].ID_Father + 1); plink_ped_ids.MID[ih] = std::to_string(P.h[ih].ID_Mother + 1);
+            plink_ped_ids.sex[ih] = P.h[ih].sex; plink_ped_ids.phen[ih] = -9;
+        }
+        for (size_t i = 0; i < nsnp; i++) {
+            plink_map.chr[i] = std::to_string(S._all_active_chrs[ichr]); plink_map.rs[i] = pops_legend[ipop].id[i]; plink_map.cM[i] = 0;
+            plink_map.pos[i] = pops_legend[ipop].pos[i]; plink_map.al0[i] = pops_legend[ipop].al0[i]; plink_map.al1[i] = pops_legend[ipop].al1[i];
+        }
+        return true;
+    }
+
+    // Simulation::ras_write_hap_to_interval_format (:1582-1633): the interval state lives in the library
+    static bool write_interval(Simulation& S, int gen_num)
+    {
+        const std::string sep = " ";
+        const int n_chr = (int)S.population[0].h[0].chr.size();
+        for (int ipop = 0; ipop < S._n_pop; ipop++) {
+            Population& P = S.population[ipop];
+            const size_t nind = P.h.size();
+            for (int ichr = 0; ichr < n_chr; ichr++) {
+                size_t n_parts = 0;
+                std::vector<uint64_t> off(2 * nind + 1);
+                if (gev_download_intervals(ctx(), ipop, ichr, NULL, off.data(), &n_parts)) return fail("gev_download_intervals");
+                std::vector<gev_part> parts(std::max<size_t>(n_parts, 1));
+                if (gev_download_intervals(ctx(), ipop, ichr, parts.data(), off.data(), &n_parts)) return fail("gev_download_intervals");
+                std::ofstream file_out((S._out_prefix + ".pop" + std::to_string(ipop + 1) + ".gen" + std::to_string(gen_num) + ".chr" + std::to_string(S._all_active_chrs[ichr]) + ".int").c_str());
+                file_out << "h_ID" << sep << "chr" << sep << "hap" << sep << "st" << sep << "en" << sep << "hap_index" << sep << "gen0_indv" << sep << "root_pop" << std::endl;
+                for (size_t ih = 0; ih < nind; ih++)
+                    for (int ihap = 0; ihap < 2; ihap++)
+                        for (uint64_t ip = off[2 * ih + ihap]; ip < off[2 * ih + ihap + 1]; ip++) {
+                            const gev_part& p = parts[ip];
+                            const std::string gen0_indv = S.population[p.root_population]._indv_id[p.hap_index / 2] + ((p.hap_index & 1) ? ".2" : ".1");   // :3031-3033
+                            file_out << P.h[ih].ID + 1 << sep << S._all_active_chrs[ichr] << sep << ihap << sep << p.st << sep << p.en << sep << p.hap_index + 1 << sep
+                                     << gen0_indv << sep << p.root_population + 1 << std::endl;
+                        }
+            }
+        }
+        return true;
+    }
 };
 
 // free functions the edited Simulation.cpp calls
+bool gevglue_plink_matrix(Simulation& S, int ipop, std::vector<Legend>& pops_legend, int ichr, std::vector<std::vector<bool> >& m, plink_PED_ids& ids, plink_MAP& map) { return GevGlue::plink_matrix(S, ipop, pops_legend, ichr, m, ids, map); }
+bool gevglue_write_interval(Simulation& S, int gen_num) { return GevGlue::write_interval(S, gen_num); }
 bool gevglue_init_static(Simulation& S) { return GevGlue::init_static(S); }
 bool gevglue_after_gen0(Simulation& S, int ipop, unsigned seed) { return GevGlue::after_gen0(S, ipop, seed); }
 std::vector<Human> gevglue_reproduce(Simulation& S, int ipop, int gen_num) { return GevGlue::reproduce(S, ipop, gen_num); }

@@ -19,6 +19,8 @@ int gevo_reproduce(Ctx*, int, const gev_couple*, size_t, uint32_t, const uint32_
 int gevo_compute_ad(Ctx*, int, double*, double*, double*, double*);
 int gevo_migrate(Ctx*, const gev_move*, size_t);
 int gevo_download_haps(Ctx*, int, int, size_t, size_t, uint64_t*, size_t);
+int gevo_download_plink_matrix(Ctx*, int, int, size_t, size_t, uint64_t*, size_t);
+int gevo_download_intervals(Ctx*, int, int, gev_part*, uint64_t*, size_t*);
 
 const char* gev_last_error(void) { return gevo_last_error(); }
 int gev_create(gev_ctx** out, int, int n_pop, int nchr, int nphen) { return gevo_create((Ctx**)out, n_pop, nchr, nphen); }
@@ -33,4 +35,6 @@ int gev_reproduce(gev_ctx* c, int p, const gev_couple* cp, size_t nc, uint32_t s
 int gev_compute_ad(gev_ctx* c, int p, double* a, double* d, double* ac, double* dc) { return gevo_compute_ad((Ctx*)c, p, a, d, ac, dc); }
 int gev_migrate(gev_ctx* c, const gev_move* m, size_t n) { return gevo_migrate((Ctx*)c, m, n); }
 int gev_download_haps(gev_ctx* c, int p, int k, size_t r0, size_t nr, uint64_t* bits, size_t w) { return gevo_download_haps((Ctx*)c, p, k, r0, nr, bits, w); }
+int gev_download_plink_matrix(gev_ctx* c, int p, int k, size_t i0, size_t n, uint64_t* bits, size_t w) { return gevo_download_plink_matrix((Ctx*)c, p, k, i0, n, bits, w); }
+int gev_download_intervals(gev_ctx* c, int p, int k, gev_part* out, uint64_t* off, size_t* n) { return gevo_download_intervals((Ctx*)c, p, k, out, off, n); }
 }

@@ -319,7 +319,7 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
         sh([HARNESS] + args, env=env, stdout=log, stderr=subprocess.STDOUT)
     # validate the harness driver against the stock CLI on this very input
     wd2 = os.path.join(wd, "cli"); os.makedirs(wd2)
-    args2 = [x if x != os.path.join(wd, "out") else os.path.join(wd2, "out") for x in args] + ["--out_hap"]
+    args2 = [x if x != os.path.join(wd, "out") else os.path.join(wd2, "out") for x in args] + ["--out_hap", "--out_interval"]
     with open(os.path.join(wd2, "log.txt"), "w") as log:
         sh([os.path.join(ORACLE, "_ref", "GeneEvolve_ref")] + args2, stdout=log, stderr=subprocess.STDOUT)
     ngen = len(case.pops[0]["popinfo"])
@@ -340,6 +340,8 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             arrs[f"hapfile_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
             arrs[f"hapfile_pop{ip}_chr{ic}_size"] = np.int64(len(raw))
             arrs[f"hapfile_pop{ip}_chr{ic}_head"] = np.frombuffer(raw[:4096], dtype=np.uint8)
+            raw = open(os.path.join(wd2, f"out.pop{ip+1}.gen{ngen}.chr{c}.int"), "rb").read()      # --out_interval (:1582-1633)
+            arrs[f"intfile_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
     # the reference's PLINK text of the last generation (format_plink::write_ped_map / write_ped01_map, src/format_plink.cpp):
     # both flags write the same <prefix>.ped, so one CLI run each.  Stored: hash of the whole file, hash of the genotype
     # columns alone (each line after its six id columns = what gev_format_ped_text produces) and the id columns.

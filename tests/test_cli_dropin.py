@@ -1,8 +1,8 @@
 """The drop-in for real: the reference's OWN command-line program (Main.cpp, parameters, all file readers and writers, mating,
 phenotype scaling, migration decisions, summaries -- compiled from the reference tree, unmodified) with the six call sites of
 INTEGRATION.md rerouted through the C-ABI (integration/gev_glue.cpp, integration/build_gpu_cli.py), run on the same input
-files the unmodified reference was given when the golden fixtures were made.  Every per-generation .info file and the .hap
-genotype files of the last generation must equal the unmodified reference's byte for byte (sha256 in the fixtures).
+files the unmodified reference was given when the golden fixtures were made.  Every per-generation .info file and the .hap, .ped (both
+variants) and .int files of the last generation must equal the unmodified reference's byte for byte (sha256 in the fixtures).
 
   GeneEvolve_glue_on_oracle : linked to the CPU oracle  -> checks the glue and the edit script without a GPU
   GeneEvolve_gpu            : linked to libgeneevolve_amd.so (the product)  -> the GPU test
@@ -25,9 +25,26 @@ def run_cli(exe, case, tmp_path):
     fx = helpers.load_fixture(case)
     wd = str(tmp_path / case)
     args = write_inputs_from_fixture(fx, wd)
-    r = subprocess.run([exe] + args + ["--out_hap"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe] + args + ["--out_hap", "--out_interval", "--out_plink"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, f"{case}: exit {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
     ngen = int(fx["n_gen"])
+
+    def same(path, key):
+        raw = open(path, "rb").read()
+        return np.array_equal(np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8), fx[key])
+    for ip in range(int(fx["n_pop"])):
+        for ic in range(int(fx["nchr"])):
+            base = os.path.join(wd, f"out.pop{ip+1}.gen{ngen}.chr{int(fx[f'pop{ip}_chr{ic}_label'])}")
+            assert same(base + ".int", f"intfile_pop{ip}_chr{ic}_sha"), f"{case}: .int (--out_interval) file differs (pop {ip+1} chr index {ic})"
+            assert same(base + ".ped", f"pedfile_pop{ip}_chr{ic}_sha"), f"{case}: .ped (--out_plink) file differs (pop {ip+1} chr index {ic})"
+    if case in ("dense", "mig2"):               # both PLINK flags write <prefix>.ped: the 0/1 variant needs its own run
+        wd01 = str(tmp_path / (case + "_01"))
+        r = subprocess.run([exe] + write_inputs_from_fixture(fx, wd01) + ["--out_plink01"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0
+        for ip in range(int(fx["n_pop"])):
+            for ic in range(int(fx["nchr"])):
+                raw = open(os.path.join(wd01, f"out.pop{ip+1}.gen{ngen}.chr{int(fx[f'pop{ip}_chr{ic}_label'])}.ped"), "rb").read()
+                assert np.array_equal(np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8), fx[f"ped01file_pop{ip}_chr{ic}_sha"]), f"{case}: .ped (--out_plink01) differs"
     for g in range(ngen + 1):
         for ip in range(int(fx["n_pop"])):
             raw = open(os.path.join(wd, f"out.info.pop{ip+1}.gen{g}.txt"), "rb").read()
