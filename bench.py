@@ -13,16 +13,20 @@ returned sexes (mating is outside the hot path), then Simulation::reproduce and
 Simulation::ras_compute_AD run on the GPU through the C-ABI.  gev_reproduce returns once the
 small per-generation work is done; the HBM-bound dense stitch continues on the library's second
 stream and overlaps A/D, host mating and the next generation's sampling (every generation's
-stitch is complete before the timed region ends: the closing barrier synchronises the device).  The founder panel is generated on
-the device before the timed region, so genotype state is resident in HBM throughout.
+stitch is complete before the timed region ends: the closing barrier synchronises the device).
+The ras_glob_seed() values of the next generation are pure draws of the host's stream, known before its couples
+are: they are handed over early (gev_presample) so the GPU samples while the host mates (--no-presample: hand
+seeds and couples over together).  The founder panel is generated on the device before the timed region, so
+genotype state is resident in HBM throughout.  --plane-less times BASELINE config 5's mode (interval state only,
+no per-generation genotype assembly) and is NOT the headline configuration.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_parent):
 algorithmic bytes per launch = 2N rows x (L/8 read + L/8 written) = N*L/2, divided
 by its duration measured with HIP events on the library's own stream.  The kernel reads LESS than
 the algorithmic bytes (a parent's chunk is loaded once for all of its gametes), so `achieved` can
 exceed what a plain device copy of N*L/2 bytes reaches; `traffic` holds the measured HBM bytes.  `cpu_baseline` times the
-bit-exact CPU oracle (a port of the reference algorithm, oracle/gev_oracle.cpp) on a bounded
-sample of the same workload on this box's host cores (1 thread: the reference is single threaded).
+unmodified reference (oracle/_ref/ref_harness, kind "reference"; when it is absent the bit-exact CPU oracle, kind
+"port") on a bounded sample of the same workload on this box's host cores (1 thread: the reference is single threaded).
 """
 import argparse
 import json
