@@ -311,6 +311,9 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     // stitch workgroups are short-lived, so freed CU slots go to the small kernels first
     int prio_least = 0, prio_greatest = 0;
     HIPC(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    if (const char* e = getenv("GEV_STITCH_PRIORITY")) {      // experiment knob: 1 = stitch stream high / small streams low, 2 = all equal (default: small high, stitch low)
+        if (atoi(e) == 1) std::swap(prio_least, prio_greatest); else if (atoi(e) == 2) prio_least = prio_greatest = (prio_least + prio_greatest) / 2;
+    }
     HIPC(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
     for (auto& ev : c->ev) HIPC(hipEventCreate(&ev));
     HIPC(hipStreamCreateWithPriority(&c->stream_big, hipStreamNonBlocking, prio_least));
