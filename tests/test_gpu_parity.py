@@ -736,3 +736,20 @@ def test_closed_loop_from_the_seed_alone_on_gpu(gpu_lib, case):
 
 def test_closed_loop_two_populations_with_migration_on_gpu(gpu_lib):
     helpers.closed_loop_migration_case(gpu_lib, helpers.load_fixture("mig2"), "gpu/mig2", device=0, exact=False)
+
+
+def test_nan_effect_sizes_are_reported_like_the_reference(gpu_lib):
+    """Simulation::ras_compute_AD returns false with "Error: A or D is nan for human ..." (src/Simulation.cpp:2716-2720);
+    gev_compute_ad returns GEV_ENAN with the same line instead of handing NaNs back"""
+    cfg = SyntheticConfig(64, 500, chrom_bp=200_000, map_step=10_000, n_cv=12, seed=2)
+    g = gpu_lib.create(1, 1, 1)
+    cfg.apply_static(g)
+    bp, a, d = cfg.cv[0][0]
+    a = a.copy(); a[5] = np.nan
+    g.set_cvs(0, 0, 0, bp, a, d, 0.0)
+    g.synth_founders(0, 0, 128, 5); g.synth_cv_founders(0, 0, 0, 128, 6)
+    g.init_gen0(0, 64, 11)
+    with pytest.raises(capi.GevError) as e:
+        g.compute_ad(0)
+    assert "A or D is nan for human" in str(e.value)
+    g.close()
