@@ -408,6 +408,11 @@ def selection_func(kind, p1, p2, z):
         return np.array(out)
     if kind == "thr":
         return np.where(np.asarray(z) <= p2, p1, 1.0)
+    if kind == "probit":                      # CommFunc::NormalCDF (src/CommFunc.cpp:257-262): .5*(1+erf((x-mu)/(sqrt(2)*sigma)))
+        return np.array([.5 * (1 + math.erf((v - p1) / (math.sqrt(2) * p2))) for v in np.asarray(z, dtype=np.float64).tolist()])
+    if kind == "stab":                        # CommFunc::NormalPDF (:266-270): 1/(sqrt(2*pi)*sigma) * exp(-0.5*pow((x-mu)/sigma,2))
+        pi = 3.1415926                         # the reference's own constant (src/CommFunc.cpp:4)
+        return np.array([1 / (math.sqrt(2.0 * pi) * p2) * math.exp(-0.5 * math.pow((v - p1) / p2, 2)) for v in np.asarray(z, dtype=np.float64).tolist()])
     raise NotImplementedError(kind)
 
 

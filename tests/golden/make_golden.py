@@ -18,6 +18,7 @@ Cases
   dense        tiny synthetic chromosome with SNPs every 7 bp and a hot mutation map so that
                mutations land on SNPs and CVs; 2 phenotypes, unsorted CV file order, vd>0
   mig2         two populations with different founder panels / CV effects and migration
+  sel1         probit / stabilising selection functions, random mating
   syn1k        BASELINE config-1 shape: 1000 ind x 10000 SNPs, 1 chr of 100 Mb, 10 gen, mutation
 """
 import gzip
@@ -616,6 +617,12 @@ def main():
     c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph],
               popinfo=["130 0.4 f logit 1 1", "141 0.3 f logit 1 1", "120 0 f logit 0.5 1", "125 1 f thr 1 1"])
     run_case(c, 4711, dense_gens={4})
+
+    # ---- sel1: probit and stabilising selection (CommFunc::NormalCDF / NormalPDF), random mating, small
+    c = Case("sel1")
+    c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph], RM=True,
+              popinfo=["130 0 p probit 0 1", "125 0 p stab 0 1", "120 0 p probit -0.5 0.8", "128 0 p stab 0.3 1.5"])
+    run_case(c, 2718, dense_gens={4})
 
     # ---- syn1k: config-1 shape, deterministic synthetic founders (tests/synth.py), hashes only
     L, N0 = 10000, 1000
