@@ -172,7 +172,9 @@ struct gev_ctx {
     int ad_cached_pop = -1;                                  // population whose current-generation A/D sits in h_ad
     bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
     int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
-    unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels (GEV_SAMPLE_GRID)
+    unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels when they have the GPU to themselves (GEV_SAMPLE_GRID)
+    unsigned sample_grid_shared = 384;        // ... and next to a running stitch: 6 waves per CU take fewer of the stitch's slots for longer, which costs
+                                              // it less than many slots briefly (config 2: +2 %, 11-chromosome shard: +5 % generations/s over 1024)
     bool serialize = false;        // wait for every stitch (no overlap between the two streams)
     int overlap_mode = 1;          // 1 everything (default), 0 never, 2 sampling only, -1 decide after two serialised generations
     bool sparse_after_stitch = false;   // mode 2: the memory-bound sparse/CV/A-D kernels wait for the running stitch, only the ALU-bound sampling shares the GPU with it
@@ -344,7 +346,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     if (const char* e = getenv("GEV_OVERLAP")) { const int v = atoi(e); c->overlap_mode = v < 0 ? -1 : std::min(v, 2); }
     c->serialize = c->overlap_mode <= 0;                             // auto starts serialised
     c->sparse_after_stitch = c->overlap_mode == 2;
-    if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = (unsigned)g; }
+    if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = c->sample_grid_shared = (unsigned)g; }
     if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // tuning knob: stitch workgroups per CU (default: unlimited = 8)
         const int occ = atoi(e);
         if (occ >= 1 && occ < 8) c->stitch_lds_pad = (unsigned)std::min(160 * 1024 / occ - 3 * 1024, 64 * 1024 - 2048);
@@ -813,7 +815,7 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
 
     HIPC(hipEventRecord(sc.t[0], st));
     // ---- sampling: one map scan per gamete / per mutation task
-    const unsigned task_blocks = (unsigned)std::min<size_t>(ceil_div(T, 4), c->sample_grid);
+    const unsigned task_blocks = (unsigned)std::min<size_t>(ceil_div(T, 4), (c->dense && !c->serialize) ? c->sample_grid_shared : c->sample_grid);
     if (has_mut) {
         hipLaunchKernelGGL(k_mut_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, sc.mutseeds.as<u32>(), T, sd);
         hipLaunchKernelGGL(k_rec_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd);
