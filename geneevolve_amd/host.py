@@ -182,6 +182,39 @@ def normal_stream(seed, n):
     return np.array(out[:n])         # (the engine state past the n-th draw is never observed: one stream per call)
 
 
+class NormalEngine:
+    """one std::default_random_engine shared by successive std::normal_distribution objects (a fresh distribution per call, as
+    in reproduce's common-effect loop, reference src/Simulation.cpp:2417-2429): draw(n) leaves the engine exactly where the
+    reference's would stand -- after the candidate pair that produced the last value (a saved second value is dropped)"""
+
+    def __init__(self, seed):
+        self.stream = MinstdStream(seed)
+
+    def draw(self, n, stddev=1.0):
+        import math
+        out = []
+        while len(out) < n:
+            need_pairs = (n - len(out) + 1) // 2
+            m = max(8, int(need_pairs * 1.4) + 8)
+            u = self.stream.u01(2 * m)
+            x = (2.0 * u[0::2] - 1.0).tolist(); y = (2.0 * u[1::2] - 1.0).tolist()
+            used = m
+            for j in range(m):
+                r2 = x[j] * x[j] + y[j] * y[j]
+                if r2 > 1.0 or r2 == 0.0:
+                    continue
+                mult = math.sqrt(-2.0 * math.log(r2) / r2)
+                out.append(y[j] * mult)
+                if len(out) < n:
+                    out.append(x[j] * mult)
+                if len(out) >= n:
+                    used = j + 1
+                    break
+            if used < m:
+                self.stream.rewind_u01(2 * (m - used))
+        return np.array(out[:n]) * stddev + 0.0
+
+
 def ras_rank(x):
     """CommFunc::ras_rank (src/CommFunc.cpp:152-161): zero-based rank, ties by index (the O(n^2) loop counts, for element k,
     the strictly smaller elements plus the earlier equal ones) = position in a stable ascending sort"""
@@ -528,6 +561,7 @@ class Simulation:
             n_people = int(c["num_offspring"][c["inbreed"] == 0].sum())
         if seeds is None:                                       # 1 + n_people*nchr ras_glob_seed() draws (:2398, :2500)
             seeds = self.ras_glob_seed(1 + (n_people * self.nchr if self.has_mut else 0))
+        self.last_seed_reproduce = int(seeds[0])
         self.sex[ipop] = self.ctx.reproduce(ipop, c, int(seeds[0]), seeds[1:] if self.has_mut else None, n_people=n_people)
         if self.track_pedigree and ipop in self.ped:            # enumeration order of the couple loop (:2433-2443)
             ok = c["inbreed"] == 0
@@ -539,6 +573,19 @@ class Simulation:
         """the seeds the next reproduce() will be given (1 + n_people*nchr ras_glob_seed() values, drawn in the reference's
         order) are known before the couples are: let the GPU sample while the host mates"""
         self.ctx.presample(ipop, int(seeds[0]), seeds[1:] if self.has_mut else None, n_people)
+
+    def common_sibling(self, ipop, vc):
+        """val_common of the reproduce() call just made (:2417-2429, :2481-2484): per phenotype with vc > 0 one N(0, sqrt(vc)) per
+        COUPLE (inbred ones included) from default_random_engine(seed + 1), handed to every child of the couple"""
+        c = self.couples[ipop]
+        eng = NormalEngine(self.last_seed_reproduce + 1)
+        ok = c["inbreed"] == 0
+        rep = np.where(ok, c["num_offspring"], 0).astype(np.int64)
+        out = []
+        for v in vc:
+            val = eng.draw(len(c), float(np.sqrt(v))) if v > 0 else np.zeros(len(c))
+            out.append(np.repeat(val, rep))
+        return out
 
     def ras_compute_AD(self, ipop, gen_num=0, per_chr=False):   # :2624
         return self.ctx.compute_ad(ipop, per_chr=per_chr)

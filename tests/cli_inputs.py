@@ -90,6 +90,8 @@ def write_inputs_from_fixture(fx, wd, prefix="out"):
         for j, key in enumerate(("va", "vd", "ve", "vf")):
             for iph in range(nphen):
                 a += [f"--{key}", repr(float(fx[f"{pre}ph{iph}_var"][j]))]
+        for iph in range(nphen):
+            a += ["--vc", repr(float(fx[f"{pre}ph{iph}_vc"]))]
         if ip > 0:
             args.append("--next_population")
         args += a

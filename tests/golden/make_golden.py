@@ -18,6 +18,7 @@ Cases
   dense        tiny synthetic chromosome with SNPs every 7 bp and a hot mutation map so that
                mutations land on SNPs and CVs; 2 phenotypes, unsorted CV file order, vd>0
   mig2         two populations with different founder panels / CV effects and migration
+  vc1          common sibling environment (--vc), two phenotypes
   sel1         probit / stabilising selection functions, random mating
   syn1k        BASELINE config-1 shape: 1000 ind x 10000 SNPs, 1 chr of 100 Mb, 10 gen, mutation
 """
@@ -303,7 +304,8 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             a += ["--file_cv_info", os.path.join(wd, f"p{ip}.ph{iph}.cvinfo.txt"), "--file_cvs", os.path.join(wd, f"p{ip}.ph{iph}.cvaddr.txt")]
             arrs[f"{pre}ph{iph}_vd"] = np.float64(ph.get("vd", -1.0))
             arrs[f"{pre}ph{iph}_var"] = np.array([ph.get(k, dflt) for k, dflt in (("va", -1.0), ("vd", -1.0), ("ve", 1.0), ("vf", 0.0))])   # CLI defaults: parameters.cpp
-        for key in ("va", "vd", "ve", "vf"):
+            arrs[f"{pre}ph{iph}_vc"] = np.float64(ph.get("vc", 0.0))
+        for key in ("va", "vd", "ve", "vf", "vc"):
             for ph in P["phens"]:
                 if key in ph:
                     a += [f"--{key}", repr(float(ph[key]))]
@@ -617,6 +619,14 @@ def main():
     c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph],
               popinfo=["130 0.4 f logit 1 1", "141 0.3 f logit 1 1", "120 0 f logit 0.5 1", "125 1 f thr 1 1"])
     run_case(c, 4711, dense_gens={4})
+
+    # ---- vc1: common (sibling) environment, two phenotypes sharing one normal stream, families of several children
+    ph_a = dict(ph); ph_a.update(vc=0.15)
+    ph_b = {"bp": [cvbp], "a": [rs.randn(80)], "d": [np.zeros(80)], "val": [(rs.rand(nf, 80) < 0.4).astype(np.uint8)], "va": 0.5, "ve": 0.3, "vc": 0.2}
+    c = Case("vc1")
+    c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph_a, ph_b],
+              popinfo=["131 0.3 p logit 1 1", "120 0.2 f logit 1 1", "125 0.4 p thr 1 1"])
+    run_case(c, 1618, dense_gens={3})
 
     # ---- sel1: probit and stabilising selection (CommFunc::NormalCDF / NormalPDF), random mating, small
     c = Case("sel1")

@@ -252,6 +252,7 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
     ctx = lib.create(1, nchr, nphen, device) if lib.has_device_arg else lib.create(1, nchr, nphen)
     setup_static(ctx, fx)
     var = [[float(v) for v in fx[f"pop0_ph{p}_var"]] for p in range(nphen)]       # va, vd, ve, vf
+    vc = [float(fx[f"pop0_ph{p}_vc"]) if f"pop0_ph{p}_vc" in fx else 0.0 for p in range(nphen)]
     beta = [1.0] * nphen                                                          # parameters.cpp default; adjusted after generation 0
     extra = [str(x) for x in fx["args_extra"]]
     mm = float(extra[extra.index("--MM") + 1]) if "--MM" in extra else 0.0
@@ -268,6 +269,7 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
     def scale(g, s2, prev_phen):
         """ras_scale_AD_compute_GEF for every phenotype (:1938-1946), one ras_glob_seed() each"""
         n = len(sim.sex[0]); outs = []
+        common = sim.common_sibling(0, vc) if (g > 0 and any(v > 0 for v in vc)) else common_gen0
         for p in range(nphen):
             va, vd, ve, vf = var[p]
             seed = int(sim.ras_glob_seed()[0])
@@ -275,8 +277,10 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
                 assert seed == int(fx[f"g{g}_pop0_ph{p}_gef_seed"]), f"{label}: the ras_glob_seed() stream is out of step at generation {g}"
             ff = prev_phen[p][sim.ped[0].ID_Father] if g > 0 else np.zeros(n)
             fm = prev_phen[p][sim.ped[0].ID_Mother] if g > 0 else np.zeros(n)
-            o = ctx.scale_ad_compute_gef(0, p, g, seed, va, vd, ve, vf, beta[p], s2[p][0], s2[p][1], common_sibling=np.zeros(n), f_father=ff, f_mother=fm)
-            o["common_sibling"] = np.zeros(n)
+            if g > 0:
+                assert bits_equal(common[p], fx[f"g{g}_pop0_ph{p}_gef_in"][:, 0]), f"{label}: common sibling effect, phenotype {p} generation {g}"
+            o = ctx.scale_ad_compute_gef(0, p, g, seed, va, vd, ve, vf, beta[p], s2[p][0], s2[p][1], common_sibling=common[p], f_father=ff, f_mother=fm)
+            o["common_sibling"] = common[p]
             if g > 0:
                 close(o["phen"], fx[f"g{g}_pop0_ph{p}_gef_out"][:, 5], f"phenotype {p} generation {g}")
             outs.append(o)
@@ -296,6 +300,11 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
 
     sim.ras_initial_human_gen0(0, len(fx["g0_pop0_sex"]))                       # ras_init_generation0 (:529)
     assert np.array_equal(sim.sex[0], fx["g0_pop0_sex"]), f"{label}: gen-0 sex"
+    from geneevolve_amd.host import NormalEngine
+    common_gen0 = []                                                             # common effect of generation 0 (:3053-3066): one ras_glob_seed() per phenotype with vc > 0
+    for p in range(nphen):
+        n0 = len(sim.sex[0])
+        common_gen0.append(NormalEngine(int(sim.ras_glob_seed()[0])).draw(n0, float(np.sqrt(vc[p]))) if vc[p] > 0 else np.zeros(n0))
     add, dom, _, _ = ctx.compute_ad(0)
     s2 = [(comm_var(add[:, p]), comm_var(dom[:, p])) for p in range(nphen)]      # _var_a_gen0 / _var_d_gen0 (:557-561)
     outs = scale(0, s2, None)

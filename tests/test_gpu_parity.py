@@ -727,7 +727,7 @@ def test_long_run_exercises_list_growth_and_redo_paths(gpu_lib, oracle_lib):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1"])
+@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1"])
 def test_closed_loop_from_the_seed_alone_on_gpu(gpu_lib, case):
     """the same closed loop on the HIP library (A/D, intervals, genotypes, couples, sexes bit-exact; scaled phenotypes and what
     derives from them within 1e-9 relative: the device's parallel variance / log are not bit-identical to libm's)"""

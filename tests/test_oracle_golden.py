@@ -141,7 +141,7 @@ def test_rank_matches_reference_vectors(oracle_lib):
     o.close()
 
 
-@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1"])
+@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1"])
 def test_closed_loop_from_the_seed_alone(oracle_lib, case):
     """the reference's whole generation loop (assortative mating, inbreeding avoidance, Poisson / fixed families, logit
     selection) re-driven from --seed by the host mirror on top of the C-ABI (oracle build): bit-identical at every step"""
