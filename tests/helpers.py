@@ -269,7 +269,7 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
     def scale(g, s2, prev_phen):
         """ras_scale_AD_compute_GEF for every phenotype (:1938-1946), one ras_glob_seed() each"""
         n = len(sim.sex[0]); outs = []
-        common = sim.common_sibling(0, vc) if (g > 0 and any(v > 0 for v in vc)) else common_gen0
+        common = common_gen0 if g == 0 else (sim.common_sibling(0, vc) if any(v > 0 for v in vc) else [np.zeros(n)] * nphen)
         for p in range(nphen):
             va, vd, ve, vf = var[p]
             seed = int(sim.ras_glob_seed()[0])
