@@ -944,7 +944,8 @@ __global__ void __launch_bounds__(256) k_snp_apply_mut(
 // `founder` holds the same loci range of every founder haplotype (bit j = locus s0 + j).  Mutations: k_tile_apply_mut.
 __global__ void __launch_bounds__(256) k_materialize_tile(const u32* __restrict__ p_off, const gev_part* __restrict__ parts, size_t row0, size_t n_rows,
                                                           const u64* __restrict__ pos, u32 s0, u32 ns, const u32* __restrict__ founder, size_t founder_w32,
-                                                          size_t n_founder_rows, u32* __restrict__ out, size_t out_w32, u32* __restrict__ status)
+                                                          const u64* __restrict__ founder_row0 /* [n_pop+1]: rows of root population p are [row0[p], row0[p+1]) of `founder` */,
+                                                          int n_pop, u32* __restrict__ out, size_t out_w32, u32* __restrict__ status)
 {
     const u32 words = (ns + 31) / 32;
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -964,8 +965,9 @@ __global__ void __launch_bounds__(256) k_materialize_tile(const u32* __restrict_
         if (b > a) {
             const u32 mask = (b - a == 32u) ? 0xffffffffu : (((1u << (b - a)) - 1u) << a);
             const u64 h = parts[i].hap_index;
-            if (h >= n_founder_rows) { atomicOr(status, 1u); continue; }                              // :1205-1209 "hap_index is not in range"
-            acc |= founder[h * founder_w32 + w] & mask;
+            const int rp = parts[i].root_population;                                                  // founder panel of the part's ROOT population (:1204)
+            if (rp < 0 || rp >= n_pop || h >= founder_row0[rp + 1] - founder_row0[rp]) { atomicOr(status, 1u); continue; }   // :1205-1209 "hap_index is not in range"
+            acc |= founder[(founder_row0[rp] + h) * founder_w32 + w] & mask;
         }
     }
     out[r * out_w32 + w] = acc;

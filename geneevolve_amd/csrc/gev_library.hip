@@ -1832,28 +1832,39 @@ int gev_rank_f64(gev_ctx* c, const double* x, size_t n, unsigned long long* rank
     HIPC(hipStreamSynchronize(st));
     return GEV_OK;
 }
-// K8: rows [row_begin, +n_rows) x loci [snp_begin, +n_snps) of the genotype matrix from the interval state and a founder tile
-int gev_materialize(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
-                    const u64* founder_bits, size_t founder_stride_words, size_t n_founder_rows, u64* bits, size_t row_stride_words)
+// K8: rows [row_begin, +n_rows) x loci [snp_begin, +n_snps) of the genotype matrix from the interval state and founder tiles
+// (one per root population: after migration a part may descend from another population's founders, :1204)
+int gev_materialize_pops(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
+                         const u64* const* founder_bits, const size_t* founder_stride_words, const size_t* n_founder_rows, u64* bits, size_t row_stride_words)
 {
     GEVC(check_idx(c, pop, chr));
     GEVC(check_active(c, chr, "materialize"));
     PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "materialize: population %d has no current generation", pop);
     if (!c->track_intervals) return fail(GEV_ESTATE, "materialize: interval tracking is disabled");
-    if (c->n_pop > 1) return fail(GEV_EUNSUPPORTED, "materialize: one founder panel per call; contexts with several populations (parts of foreign root populations) are not supported yet");
     GEVC(materialize_order(c, pop));
     if (row_begin + n_rows > 2 * P.n_people) return fail(GEV_EINVAL, "materialize: rows [%zu,%zu) beyond 2*n_people=%zu", row_begin, row_begin + n_rows, 2 * P.n_people);
     if (snp_begin + n_snps > S.L) return fail(GEV_EINVAL, "materialize: SNPs [%zu,%zu) beyond L=%zu", snp_begin, snp_begin + n_snps, S.L);
     const size_t w64 = ceil_div(n_snps, 64);
     if (!n_rows || !n_snps) return GEV_OK;
-    if (!founder_bits || founder_stride_words < w64 || !n_founder_rows) return fail(GEV_EINVAL, "materialize: bad founder tile");
+    if (!founder_bits || !founder_stride_words || !n_founder_rows) return fail(GEV_EINVAL, "materialize: bad founder tile");
+    std::vector<u64> row0(c->n_pop + 1, 0);
+    for (int p = 0; p < c->n_pop; p++) {
+        if (n_founder_rows[p] && (!founder_bits[p] || founder_stride_words[p] < w64)) return fail(GEV_EINVAL, "materialize: bad founder tile of population %d", p);
+        row0[p + 1] = row0[p] + n_founder_rows[p];
+    }
+    if (!row0[c->n_pop]) return fail(GEV_EINVAL, "materialize: bad founder tile");
     if (!bits || row_stride_words < w64) return fail(GEV_EINVAL, "materialize: bad output buffer");
     HIPC(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    // founder tile -> device (compacted to w64 words per row)
-    GEVC(c->d_snpmajor.ensure(n_founder_rows * w64 * 8, st));
-    HIPC(hipMemcpy2DAsync(c->d_snpmajor.p, w64 * 8, founder_bits, founder_stride_words * 8, w64 * 8, n_founder_rows, hipMemcpyHostToDevice, st));
+    // founder tiles -> device, stacked population after population (compacted to w64 words per row)
+    GEVC(c->d_snpmajor.ensure(row0[c->n_pop] * w64 * 8, st));
+    for (int p = 0; p < c->n_pop; p++)
+        if (n_founder_rows[p])
+            HIPC(hipMemcpy2DAsync(c->d_snpmajor.as<u64>() + row0[p] * w64, w64 * 8, founder_bits[p], founder_stride_words[p] * 8, w64 * 8, n_founder_rows[p], hipMemcpyHostToDevice, st));
+    GEVC(c->d_map.ensure((c->n_pop + 1) * sizeof(u64) + 16, st));
+    HIPC(hipMemcpyAsync(c->d_map.p, row0.data(), (c->n_pop + 1) * sizeof(u64), hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));                      // row0 is a local
     GEVC(c->d_flag.ensure(16, st));
     HIPC(hipMemsetAsync(c->d_flag.p, 0, 4, st));
     const size_t w32 = 2 * w64;
@@ -1864,7 +1875,7 @@ int gev_materialize(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_row
         HIPC(hipMemsetAsync(c->d_stage.p, 0, nr * w64 * 8, st));                          // pad bits of the last word stay 0
         hipLaunchKernelGGL(k_materialize_tile, dim3((unsigned)ceil_div(nr * ceil_div(n_snps, 32), 256)), dim3(256), 0, st,
                            cs.poff[P.cur].as<u32>(), cs.parts[P.cur].as<gev_part>(), row_begin + r0, nr, S.d_pos.as<u64>(), (u32)snp_begin, (u32)n_snps,
-                           c->d_snpmajor.as<u32>(), w32, n_founder_rows, c->d_stage.as<u32>(), w32, c->d_flag.as<u32>());
+                           c->d_snpmajor.as<u32>(), w32, c->d_map.as<u64>(), c->n_pop, c->d_stage.as<u32>(), w32, c->d_flag.as<u32>());
         HIPC(hipMemcpyAsync(c->d_text.p, c->d_stage.p, nr * w64 * 8, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_tile_apply_mut, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st, c->d_stage.as<u32>(), c->d_text.as<u32>(), w32, row_begin + r0, nr,
                            cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)snp_begin, (u32)n_snps);
@@ -1876,8 +1887,16 @@ int gev_materialize(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_row
     }
     u32 flag = 0;
     HIPC(hipMemcpy(&flag, c->d_flag.p, 4, hipMemcpyDeviceToHost));
-    if (flag) return fail(GEV_EINVAL, "materialize: Error: p.hap_index is not in range (founder tile has %zu rows)", n_founder_rows);
+    if (flag) return fail(GEV_EINVAL, "materialize: Error: p.hap_index is not in range");
     return GEV_OK;
+}
+// one population per context: a single founder tile
+int gev_materialize(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
+                    const u64* founder_bits, size_t founder_stride_words, size_t n_founder_rows, u64* bits, size_t row_stride_words)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    if (c->n_pop > 1) return fail(GEV_EINVAL, "materialize: this context has %d populations: use gev_materialize_pops (one founder tile per root population)", c->n_pop);
+    return gev_materialize_pops(c, pop, chr, row_begin, n_rows, snp_begin, n_snps, &founder_bits, &founder_stride_words, &n_founder_rows, bits, row_stride_words);
 }
 // GT columns of the VCF data lines: n_snps * (4*n_people + 1) bytes; the caller writes the nine fixed columns in front
 int gev_format_vcf_gt(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps, char* out, size_t out_bytes)

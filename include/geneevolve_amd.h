@@ -188,6 +188,9 @@ int gev_import_rows(gev_ctx*, int pop, const void* device_buf, size_t bytes, siz
  * rows [row_begin, row_begin+n_rows) of the 2*n_people x L matrix, mutations applied. */
 int gev_download_haps(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_rows,
                       uint64_t* bits, size_t row_stride_words);
+int gev_materialize_pops(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
+                         const uint64_t* const* founder_bits, const size_t* founder_stride_words, const size_t* n_founder_rows,
+                         uint64_t* bits, size_t row_stride_words);
 /* ---- K9 output packing [SURVEY 8(f) row 3]: SNP-major forms of the same matrix, built on the device
  * (64x64 bit-tile transposes + mutation overlay).
  *  gev_download_snp_major : row = SNP (snp_begin + j), bit h = haplotype row h; ceil(2*n_people/64) words per row
@@ -226,7 +229,9 @@ int gev_format_ped_text(gev_ctx*, int pop, int chr, size_t ind_begin, size_t n_i
  * gev_materialize == ras_convert_interval_to_hap_matrix (src/Simulation.cpp:1186-1230) for haplotype rows
  * [row_begin, +n_rows) and SNPs [snp_begin, +n_snps): founder_bits = the same SNP range of every founder haplotype
  * (row = founder haplotype = part::hap_index, bit j = SNP snp_begin + j); output rows as gev_download_haps, bit j = SNP
- * snp_begin + j.  Works on dense contexts too (same result as the resident planes).  One population per context. */
+ * snp_begin + j.  Works on dense contexts too (same result as the resident planes).  gev_materialize_pops takes one
+ * founder tile per ROOT population (arrays of n_pop entries; after migration a part may descend from another population's
+ * founders, :1204); gev_materialize is the single-population form. */
 int gev_set_dense_state(gev_ctx*, int on);
 int gev_materialize(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
                     const uint64_t* founder_bits, size_t founder_stride_words, size_t n_founder_rows,

@@ -172,6 +172,16 @@ def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_l
                     compare_lists(ctx, fx, f"g{g}_pop{ip}_postmig_", ip, nchr, f"{label} gen {g} post-migration pop {ip}")
         for ip in range(n_pop):
             n_dense += compare_dense(ctx, fx, g, ip, nchr, label)
+    # K8: genotype tiles rebuilt from the interval state + founder tiles of every root population == the dense matrix
+    if lib.exports("materialize_pops") and all(f"pop{ip}_chr0_founders" in fx for ip in range(n_pop)):
+        from geneevolve_amd.capi import pack_rows, unpack_rows
+        for ic in range(nchr):
+            L = len(fx[f"pop0_chr{ic}_snp_pos"])
+            for (s0, ns) in ((0, L), (L // 3, min(L - L // 3, 77))):
+                tiles = [pack_rows(unpack_rows(bytes_to_words(fx[f"pop{ip}_chr{ic}_founders"], L), L)[:, s0:s0 + ns]) for ip in range(n_pop)]
+                for ip in range(n_pop):
+                    want = pack_rows(unpack_rows(ctx.download_haps(ip, ic), L)[:, s0:s0 + ns])
+                    assert np.array_equal(ctx.materialize_pops(ip, ic, tiles, 0, None, s0, ns), want), f"{label}: materialised tile differs (pop {ip} chr {ic} SNPs {s0}+{ns})"
     # the reference's own .hap output file of the last generation (format_hap::write_hap)
     if ngen == int(fx["n_gen"]) and lib.exports("format_hap_text"):
         for ip in range(n_pop):
