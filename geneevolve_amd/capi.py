@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
-    "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
+    "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -400,6 +400,19 @@ class GevContext:
         out = np.zeros((n_rows, w), dtype=np.uint64)
         self._call("materialize_pops", C.c_int(pop), C.c_int(chr), C.c_size_t(row_begin), C.c_size_t(n_rows), C.c_size_t(snp_begin), C.c_size_t(n_snps),
                    ptrs, strides, rows, _p(out), C.c_size_t(w))
+        return out
+
+    def materialize_bed(self, pop, chr, founder_tiles, snp_begin=0, n_snps=None):
+        """PLINK .bed body of a SNP range from the interval state + one founder tile per root population"""
+        L = self._nsnp[(pop, chr)]
+        n_snps = L - snp_begin if n_snps is None else n_snps
+        tiles = [np.ascontiguousarray(t, dtype=np.uint64) for t in founder_tiles]
+        ptrs = (C.c_void_p * len(tiles))(*[t.ctypes.data for t in tiles])
+        strides = (C.c_size_t * len(tiles))(*[t.shape[1] for t in tiles])
+        rows = (C.c_size_t * len(tiles))(*[t.shape[0] for t in tiles])
+        nb = n_snps * ((self.pop_size(pop) + 3) // 4)
+        out = np.zeros(nb, dtype=np.uint8)
+        self._call("materialize_bed", C.c_int(pop), C.c_int(chr), C.c_size_t(snp_begin), C.c_size_t(n_snps), ptrs, strides, rows, _p(out), C.c_size_t(nb))
         return out
 
     def set_overlap(self, on):

@@ -1834,12 +1834,13 @@ int gev_rank_f64(gev_ctx* c, const double* x, size_t n, unsigned long long* rank
 }
 // K8: rows [row_begin, +n_rows) x loci [snp_begin, +n_snps) of the genotype matrix from the interval state and founder tiles
 // (one per root population: after migration a part may descend from another population's founders, :1204)
-int gev_materialize_pops(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
-                         const u64* const* founder_bits, const size_t* founder_stride_words, const size_t* n_founder_rows, u64* bits, size_t row_stride_words)
+// checks + founder tiles to the device (c->d_snpmajor, stacked population after population; row offsets in c->d_map)
+static int materialize_prepare(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
+                               const u64* const* founder_bits, const size_t* founder_stride_words, const size_t* n_founder_rows)
 {
     GEVC(check_idx(c, pop, chr));
     GEVC(check_active(c, chr, "materialize"));
-    PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
+    PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "materialize: population %d has no current generation", pop);
     if (!c->track_intervals) return fail(GEV_ESTATE, "materialize: interval tracking is disabled");
     GEVC(materialize_order(c, pop));
@@ -1854,10 +1855,8 @@ int gev_materialize_pops(gev_ctx* c, int pop, int chr, size_t row_begin, size_t 
         row0[p + 1] = row0[p] + n_founder_rows[p];
     }
     if (!row0[c->n_pop]) return fail(GEV_EINVAL, "materialize: bad founder tile");
-    if (!bits || row_stride_words < w64) return fail(GEV_EINVAL, "materialize: bad output buffer");
     HIPC(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    // founder tiles -> device, stacked population after population (compacted to w64 words per row)
     GEVC(c->d_snpmajor.ensure(row0[c->n_pop] * w64 * 8, st));
     for (int p = 0; p < c->n_pop; p++)
         if (n_founder_rows[p])
@@ -1867,28 +1866,78 @@ int gev_materialize_pops(gev_ctx* c, int pop, int chr, size_t row_begin, size_t 
     HIPC(hipStreamSynchronize(st));                      // row0 is a local
     GEVC(c->d_flag.ensure(16, st));
     HIPC(hipMemsetAsync(c->d_flag.p, 0, 4, st));
-    const size_t w32 = 2 * w64;
+    return GEV_OK;
+}
+// rows [row0, row0+nr) of the tile into `out` (nr x w64 words, mutations applied); `plain` = scratch of the same size
+static int materialize_rows(gev_ctx* c, int pop, int chr, size_t row0, size_t nr, size_t snp_begin, size_t n_snps, u64* plain, u64* out)
+{
+    PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
+    hipStream_t st = c->stream;
+    const size_t w64 = ceil_div(n_snps, 64), w32 = 2 * w64;
+    HIPC(hipMemsetAsync(plain, 0, nr * w64 * 8, st));                                     // pad bits of the last word stay 0
+    hipLaunchKernelGGL(k_materialize_tile, dim3((unsigned)ceil_div(nr * ceil_div(n_snps, 32), 256)), dim3(256), 0, st,
+                       cs.poff[P.cur].as<u32>(), cs.parts[P.cur].as<gev_part>(), row0, nr, S.d_pos.as<u64>(), (u32)snp_begin, (u32)n_snps,
+                       c->d_snpmajor.as<u32>(), w32, c->d_map.as<u64>(), c->n_pop, (u32*)plain, w32, c->d_flag.as<u32>());
+    HIPC(hipMemcpyAsync(out, plain, nr * w64 * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_tile_apply_mut, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st, (const u32*)plain, (u32*)out, w32, row0, nr,
+                       cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)snp_begin, (u32)n_snps);
+    KCHECK();
+    return GEV_OK;
+}
+static int materialize_status(gev_ctx* c)
+{
+    u32 flag = 0;
+    HIPC(hipMemcpy(&flag, c->d_flag.p, 4, hipMemcpyDeviceToHost));
+    if (flag) return fail(GEV_EINVAL, "materialize: Error: p.hap_index is not in range");
+    return GEV_OK;
+}
+int gev_materialize_pops(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
+                         const u64* const* founder_bits, const size_t* founder_stride_words, const size_t* n_founder_rows, u64* bits, size_t row_stride_words)
+{
+    GEVC(materialize_prepare(c, pop, chr, row_begin, n_rows, snp_begin, n_snps, founder_bits, founder_stride_words, n_founder_rows));
+    const size_t w64 = ceil_div(n_snps, 64);
+    if (!n_rows || !n_snps) return GEV_OK;
+    if (!bits || row_stride_words < w64) return fail(GEV_EINVAL, "materialize: bad output buffer");
+    hipStream_t st = c->stream;
     const size_t max_rows = std::max<size_t>((128u << 20) / (w64 * 8), 1);
     for (size_t r0 = 0; r0 < n_rows; r0 += max_rows) {
         const size_t nr = std::min(max_rows, n_rows - r0);
         GEVC(c->d_stage.ensure(nr * w64 * 8, st)); GEVC(c->d_text.ensure(nr * w64 * 8, st));
-        HIPC(hipMemsetAsync(c->d_stage.p, 0, nr * w64 * 8, st));                          // pad bits of the last word stay 0
-        hipLaunchKernelGGL(k_materialize_tile, dim3((unsigned)ceil_div(nr * ceil_div(n_snps, 32), 256)), dim3(256), 0, st,
-                           cs.poff[P.cur].as<u32>(), cs.parts[P.cur].as<gev_part>(), row_begin + r0, nr, S.d_pos.as<u64>(), (u32)snp_begin, (u32)n_snps,
-                           c->d_snpmajor.as<u32>(), w32, c->d_map.as<u64>(), c->n_pop, c->d_stage.as<u32>(), w32, c->d_flag.as<u32>());
-        HIPC(hipMemcpyAsync(c->d_text.p, c->d_stage.p, nr * w64 * 8, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_tile_apply_mut, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st, c->d_stage.as<u32>(), c->d_text.as<u32>(), w32, row_begin + r0, nr,
-                           cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)snp_begin, (u32)n_snps);
-        KCHECK();
+        GEVC(materialize_rows(c, pop, chr, row_begin + r0, nr, snp_begin, n_snps, c->d_stage.as<u64>(), c->d_text.as<u64>()));
         if (row_stride_words > w64)
             for (size_t r = 0; r < nr; r++) memset(bits + (r0 + r) * row_stride_words + w64, 0, (row_stride_words - w64) * 8);
         HIPC(hipMemcpy2DAsync(bits + r0 * row_stride_words, row_stride_words * 8, c->d_text.p, w64 * 8, w64 * 8, nr, hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
     }
-    u32 flag = 0;
-    HIPC(hipMemcpy(&flag, c->d_flag.p, 4, hipMemcpyDeviceToHost));
-    if (flag) return fail(GEV_EINVAL, "materialize: Error: p.hap_index is not in range");
-    return GEV_OK;
+    return materialize_status(c);
+}
+// PLINK .bed body of SNPs [snp_begin, +n_snps) straight from the interval state (BASELINE config 5: "PLINK bit-packed output" of a
+// population whose genotype matrix is never resident): tile of ALL haplotype rows -> 64x64 bit-tile transpose -> 2-bit packing
+int gev_materialize_bed(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n_snps,
+                        const u64* const* founder_bits, const size_t* founder_stride_words, const size_t* n_founder_rows, uint8_t* out, size_t out_bytes)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    GEVC(check_idx(c, pop, chr));
+    PopState& P = c->pop[pop];
+    const size_t rows = 2 * P.n_people, bpl = ceil_div(P.n_people, 4), w64 = ceil_div(n_snps, 64);
+    GEVC(materialize_prepare(c, pop, chr, 0, rows, snp_begin, n_snps, founder_bits, founder_stride_words, n_founder_rows));
+    if (!n_snps || !rows) return GEV_OK;
+    if (!out || out_bytes < n_snps * bpl) return fail(GEV_EINVAL, "materialize_bed: buffer of %zu bytes, %zu needed", out_bytes, n_snps * bpl);
+    hipStream_t st = c->stream;
+    GEVC(c->d_stage.ensure(rows * w64 * 8, st)); GEVC(c->d_tmp.ensure(rows * w64 * 8, st));
+    GEVC(materialize_rows(c, pop, chr, 0, rows, snp_begin, n_snps, c->d_stage.as<u64>(), c->d_tmp.as<u64>()));
+    const size_t stride_sm = ceil_div(rows, 64);
+    GEVC(c->d_text.ensure(std::max<size_t>(n_snps * stride_sm * 8 + n_snps * bpl, 16), st));
+    u64* snpmajor = c->d_text.as<u64>(); uint8_t* bed = c->d_text.as<uint8_t>() + n_snps * stride_sm * 8;
+    HIPC(hipMemsetAsync(snpmajor, 0, n_snps * stride_sm * 8, st));
+    const u32 wpw = 16;
+    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)stride_sm, (unsigned)ceil_div(ceil_div(w64, wpw), 4)), dim3(256), 0, st, c->d_tmp.as<u64>(), w64, rows, (u32)n_snps,
+                       0u, (u32)n_snps, snpmajor, stride_sm, wpw);
+    hipLaunchKernelGGL(k_format_bed, dim3((unsigned)ceil_div(n_snps * bpl, 256)), dim3(256), 0, st, snpmajor, stride_sm, P.n_people, (u32)n_snps, bed);
+    KCHECK();
+    HIPC(hipMemcpyAsync(out, bed, n_snps * bpl, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    return materialize_status(c);
 }
 // one population per context: a single founder tile
 int gev_materialize(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,

@@ -191,6 +191,11 @@ int gev_download_haps(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_row
 int gev_materialize_pops(gev_ctx*, int pop, int chr, size_t row_begin, size_t n_rows, size_t snp_begin, size_t n_snps,
                          const uint64_t* const* founder_bits, const size_t* founder_stride_words, const size_t* n_founder_rows,
                          uint64_t* bits, size_t row_stride_words);
+/* PLINK .bed body (as gev_format_bed) of SNPs [snp_begin, +n_snps) assembled from the interval state + founder tiles: the output
+ * path of plane-less contexts (BASELINE config 5: "PLINK bit-packed output"); n_snps * ceil(n_people/4) bytes. */
+int gev_materialize_bed(gev_ctx*, int pop, int chr, size_t snp_begin, size_t n_snps,
+                        const uint64_t* const* founder_bits, const size_t* founder_stride_words, const size_t* n_founder_rows,
+                        uint8_t* out, size_t out_bytes);
 /* ---- K9 output packing [SURVEY 8(f) row 3]: SNP-major forms of the same matrix, built on the device
  * (64x64 bit-tile transposes + mutation overlay).
  *  gev_download_snp_major : row = SNP (snp_begin + j), bit h = haplotype row h; ceil(2*n_people/64) words per row

@@ -683,6 +683,10 @@ def test_materialize_tiles_from_intervals_and_the_plane_less_mode(gpu_lib, oracl
                 want = slice_bits(full[r0:r0 + nr], L, s0, ns)
                 for g in (dense, sparse, orc):
                     assert np.array_equal(g.materialize(0, c, tile, r0, nr, s0, ns), want), (gen, c, s0, ns, r0, nr)
+            for (s0, ns) in ((0, L), (100, 640), (2999, 2)):                      # .bed straight from the interval state == the dense context's
+                tiles = [slice_bits(founders[c], L, s0, ns)]
+                want = dense.format_bed(0, c, s0, ns)
+                assert np.array_equal(sparse.materialize_bed(0, c, tiles, s0, ns), want) and np.array_equal(dense.materialize_bed(0, c, tiles, s0, ns), want), (gen, c, s0, ns)
             with pytest.raises(capi.GevError):
                 sparse.download_haps(0, c)
             with pytest.raises(capi.GevError):
