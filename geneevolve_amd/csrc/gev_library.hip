@@ -616,6 +616,7 @@ static int finalize_static(gev_ctx* c, int pop)
 {
     PopState& P = c->pop[pop];
     if (P.finalized) return GEV_OK;
+    for (auto& sc : c->sc) sc.presampled = false;          // maps / grids changed: a head start sampled with the old ones is void
     std::vector<ChrDev> cd(c->nchr);
     for (int k = 0; k < c->nchr; k++) {
         ChrStatic& S = P.cs[k];
