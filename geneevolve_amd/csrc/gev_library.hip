@@ -3,6 +3,15 @@
 // No CPU fallback of any kernel exists: without a GPU every compute entry point fails loudly.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC gev_library.hip -o libgeneevolve_amd.so
+//
+// Tuning / diagnosis knobs (environment, read at gev_create; defaults are what the measurements of DESIGN.md chose):
+//   GEV_OVERLAP=0|1|2|-1      stream overlap: never | everything (default) | sampling only | decide from two timed generations
+//   GEV_SERIALIZE=1           same as GEV_OVERLAP=0
+//   GEV_LANES=1..4            chromosome lanes of the sparse / A-D phases (default min(nchr, 4))
+//   GEV_SAMPLE_GRID=n         persistent workgroups of the sampling kernels (default 384 next to a stitch, 1024 alone)
+//   GEV_STITCH_WG_PER_CU=1..7 limit stitch workgroups per CU (default: wave-slot bound, 8)
+//   GEV_STITCH_PRIORITY=1|2   stitch stream high / all streams equal (default: small streams high, stitch low)
+//   GEV_TRACE_HOST=1          stderr: host time per phase of gev_reproduce, allocations, deferred frees
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <algorithm>
