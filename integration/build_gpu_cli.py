@@ -4,7 +4,8 @@ libgeneevolve_amd.so (the patch of INTEGRATION.md, applied mechanically).
 
 Nothing of the reference is stored in this repository: an edited build copy of src/Simulation.{h,cpp} is generated under a
 temporary directory from the sources where they lie, compiled together with integration/gev_glue.cpp, linked with the
-reference's other (unmodified) objects that oracle/Makefile.ref already produced, and deleted.  Edits (all located by the
+reference's other (unmodified) objects that oracle/Makefile.ref already produced, and deleted.  (tests/build_glue_on_oracle.py
+reuses build() to link the same objects against the CPU oracle: a checker for machines without a GPU, not a product.)  Edits (all located by the
 function signatures / the one marker comment, not by line numbers):
 
   Simulation.h    class Simulation gets `friend struct GevGlue;`
@@ -59,9 +60,10 @@ def insert_before_last_return_true(src, signature_regex, stmt):
     return src[:i] + body[:k] + stmt + "\n    " + body[k:] + src[j:]
 
 
-def main():
+def build(out_name, backend_link, extra_sources=()):
+    """edit + compile + link; backend_link = linker arguments of the C-ABI implementation; extra_sources = more C++ files"""
     if not os.path.isdir(REF):
-        print("build_gpu_cli: no reference tree, skipped"); return 0
+        print("build_gpu_cli: no reference tree, skipped"); return None
     need = [os.path.join(OUT, "ge", f"{n}.o") for n in ("Main", "Population", "CommFunc", "RasRandomNumber", "RasMatrix", "format_hap", "format_plink", "format_vcf", "parameters")]
     need.append(os.path.join(OUT, "libStatGen.a"))
     for f in need:
@@ -96,25 +98,27 @@ def main():
         open(os.path.join(tmp, "Simulation.h"), "w").write(h)
         open(os.path.join(tmp, "Simulation.cpp"), "w").write(cpp)
         sg = os.path.join(REF, "Library", "libStatGen")
-        dbg = ["-O1", "-g", "-fsanitize=address"] if os.environ.get("GEV_GLUE_ASAN") else ["-O3"]     # CPU-side debugging of the glue only
-        flags = dbg + ["-std=c++11", "-w", "-D__ZLIB_AVAILABLE__", "-D_FILE_OFFSET_BITS=64", "-D__STDC_LIMIT_MACROS",
+        asan = ["-fsanitize=address"] if os.environ.get("GEV_GLUE_ASAN") else []      # CPU-side debugging of the glue only
+        flags = (["-O1", "-g"] + asan if asan else ["-O3"]) + ["-std=c++11", "-w", "-D__ZLIB_AVAILABLE__", "-D_FILE_OFFSET_BITS=64", "-D__STDC_LIMIT_MACROS",
                  "-I" + tmp, "-I" + os.path.join(sg, "general"), "-I" + os.path.join(sg, "vcf"), "-I" + os.path.join(sg, "samtools"),
                  "-I" + os.path.join(REF, "Library", "eigen3"), "-I" + os.path.join(REF, "src"), "-I" + os.path.join(ROOT, "include"),
                  "-include", os.path.join(ROOT, "oracle", "ref_compat.h")]
-        for name, srcf in (("Simulation_gpu.o", os.path.join(tmp, "Simulation.cpp")), ("gev_glue.o", os.path.join(ROOT, "integration", "gev_glue.cpp"))):
-            subprocess.run(["g++"] + flags + ["-c", srcf, "-o", os.path.join(tmp, name)], check=True)
-        libdir = os.path.join(ROOT, "geneevolve_amd", "csrc")
-        objs = [f for f in need if f.endswith(".o")]
-        common = [os.path.join(tmp, "Simulation_gpu.o"), os.path.join(tmp, "gev_glue.o")] + objs + [os.path.join(OUT, "libStatGen.a"), "-lz"]
-        asan = ["-fsanitize=address"] if os.environ.get("GEV_GLUE_ASAN") else []
-        subprocess.run(["g++", "-o", os.path.join(OUT, "GeneEvolve_gpu")] + asan + common + ["-L" + libdir, "-lgeneevolve_amd", "-Wl,-rpath,$ORIGIN/../../geneevolve_amd/csrc"], check=True)
-        # the same program on the CPU oracle (test infrastructure: checks glue + edits where there is no GPU)
-        subprocess.run(["g++"] + flags + ["-c", os.path.join(ROOT, "integration", "gev_on_oracle.cpp"), "-o", os.path.join(tmp, "gev_on_oracle.o")], check=True)
-        subprocess.run(["g++", "-o", os.path.join(OUT, "GeneEvolve_glue_on_oracle")] + asan + common + [os.path.join(tmp, "gev_on_oracle.o"), "-L" + os.path.join(ROOT, "oracle"), "-lgev_oracle",
-                        "-Wl,-rpath,$ORIGIN/.."], check=True)
+        objs = []
+        for n, srcf in enumerate([os.path.join(tmp, "Simulation.cpp"), os.path.join(ROOT, "integration", "gev_glue.cpp")] + list(extra_sources)):
+            o = os.path.join(tmp, f"o{n}.o")
+            subprocess.run(["g++"] + flags + ["-c", srcf, "-o", o], check=True)
+            objs.append(o)
+        exe = os.path.join(OUT, out_name)
+        subprocess.run(["g++", "-o", exe] + asan + objs + [f for f in need if f.endswith(".o")] + [os.path.join(OUT, "libStatGen.a"), "-lz"] + list(backend_link), check=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    print("built", os.path.join(OUT, "GeneEvolve_gpu"), "and GeneEvolve_glue_on_oracle")
+    print("built", exe)
+    return exe
+
+
+def main():
+    libdir = os.path.join(ROOT, "geneevolve_amd", "csrc")
+    build("GeneEvolve_gpu", ["-L" + libdir, "-lgeneevolve_amd", "-Wl,-rpath,$ORIGIN/../../geneevolve_amd/csrc"])
     return 0
 
 

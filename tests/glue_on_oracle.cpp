@@ -1,4 +1,4 @@
-// Test infrastructure: the few gev_* entry points integration/gev_glue.cpp uses, forwarded to the CPU oracle (gevo_*), so that
+// Test infrastructure (tests/build_glue_on_oracle.py): the few gev_* entry points integration/gev_glue.cpp uses, forwarded to the CPU oracle (gevo_*), so that
 // the glue and the edit script of build_gpu_cli.py can be checked in a container without a GPU
 // (oracle/_ref/GeneEvolve_glue_on_oracle).  Never part of the product: the product program links libgeneevolve_amd.so.
 #include <cstddef>
