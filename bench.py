@@ -297,7 +297,8 @@ def main():
                        if (args.n_ind, args.n_loci, args.nchr) == (100_000, 1_000_000, 1) else
                        f"config-2 family, non-default size: {args.n_ind} individuals x {args.nchr} chromosome(s) x {args.n_loci} SNPs",
                        "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_chromosomes": args.nchr, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
-                       "interval_state_tracked": not args.no_intervals, "resident_genotype_planes": not args.plane_less},
+                       "interval_state_tracked": not args.no_intervals, "resident_genotype_planes": not args.plane_less,
+                       "seeds_handed_over_before_couples": presample},
             "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci * args.nchr / dt,
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
                          "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
