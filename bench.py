@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--n-ind", type=int, default=100_000)
     ap.add_argument("--n-loci", type=int, default=1_000_000)
     ap.add_argument("--n-cv", type=int, default=1000)
+    ap.add_argument("--map-step", type=int, default=50_000, help="bp between recombination / mutation map rows (config 2: 50 kb = 2001 rows; 100 = one row per locus, the sampling stress case)")
     ap.add_argument("--nchr", type=int, default=1, help="chromosomes (each of --n-loci SNPs and 100 Mb; config 2 has 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ind", type=int, default=20000)
@@ -183,7 +184,9 @@ def main():
     from geneevolve_amd.capi import GevLibrary
     from geneevolve_amd.host import Simulation, SyntheticConfig, synthetic_random_mate
     lib = GevLibrary()                                   # the HIP library or nothing
-    cfg = SyntheticConfig(args.n_ind, args.n_loci, nchr=args.nchr, n_cv=args.n_cv, seed=12345)   # same grids / maps / CV effects on every rank
+    scale = args.map_step / 50_000.0                     # --map-step: same expected crossovers / mutations per gamete on a finer map (SURVEY.md 8(d) "C2-stress")
+    cfg = SyntheticConfig(args.n_ind, args.n_loci, nchr=args.nchr, n_cv=args.n_cv, seed=12345, map_step=args.map_step,
+                          rec_per_row=5e-4 * scale, mut_per_row=5e-4 * scale)   # same grids / maps / CV effects on every rank
     migrate = world > 1 and args.migration_rate > 0
     n_pop_ctx, my_pop = (world, rank) if migrate else (1, 0)   # with migration every rank knows all populations' static tables
     ctx = lib.create(n_pop_ctx, args.nchr, 1, local_rank)
@@ -284,7 +287,7 @@ def main():
         achieved = alg_bytes / (max(stitch, 1e-9) * 1e-3) / 1e9 if not args.plane_less else 0.0
         traffic = None                                      # HBM bytes per launch from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r01_final_config2_pmc_hbm.json")
-        if os.path.exists(pmc) and (args.n_ind, args.n_loci, args.nchr) == (100_000, 1_000_000, 1):
+        if os.path.exists(pmc) and (args.n_ind, args.n_loci, args.nchr, args.map_step) == (100_000, 1_000_000, 1, 50_000):
             traffic = json.load(open(pmc))["k_stitch_parent_summary"]["hbm_traffic_bytes_per_launch"]
         out = {
             "metric": "generations/sec", "value": gens_per_s,
@@ -294,8 +297,8 @@ def main():
             "data": "synthetic (device-generated founder panel, uniform maps, SURVEY.md 8(d) config C2)",
             "config": {"workload": ("BASELINE config 2: 100k individuals x 1M SNPs, 1 population per GPU, 1 chromosome (100 Mb), "
                                     "uniform recombination map 2001 rows @ 5e-4, mutation 1e-8/bp, 1000 CVs, random mating")
-                       if (args.n_ind, args.n_loci, args.nchr) == (100_000, 1_000_000, 1) else
-                       f"config-2 family, non-default size: {args.n_ind} individuals x {args.nchr} chromosome(s) x {args.n_loci} SNPs",
+                       if (args.n_ind, args.n_loci, args.nchr, args.map_step) == (100_000, 1_000_000, 1, 50_000) else
+                       f"config-2 family, non-default size: {args.n_ind} individuals x {args.nchr} chromosome(s) x {args.n_loci} SNPs, map rows every {args.map_step} bp",
                        "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_chromosomes": args.nchr, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
                        "interval_state_tracked": not args.no_intervals, "resident_genotype_planes": not args.plane_less,
                        "seeds_handed_over_before_couples": presample},
