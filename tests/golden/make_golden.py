@@ -322,7 +322,7 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
         sh([HARNESS] + args, env=env, stdout=log, stderr=subprocess.STDOUT)
     # validate the harness driver against the stock CLI on this very input
     wd2 = os.path.join(wd, "cli"); os.makedirs(wd2)
-    args2 = [x if x != os.path.join(wd, "out") else os.path.join(wd2, "out") for x in args] + ["--out_hap", "--out_interval"]
+    args2 = [x if x != os.path.join(wd, "out") else os.path.join(wd2, "out") for x in args] + ["--out_hap", "--out_interval", "--debug"]
     with open(os.path.join(wd2, "log.txt"), "w") as log:
         sh([os.path.join(ORACLE, "_ref", "GeneEvolve_ref")] + args2, stdout=log, stderr=subprocess.STDOUT)
     ngen = len(case.pops[0]["popinfo"])
@@ -343,6 +343,8 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             arrs[f"hapfile_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
             arrs[f"hapfile_pop{ip}_chr{ic}_size"] = np.int64(len(raw))
             arrs[f"hapfile_pop{ip}_chr{ic}_head"] = np.frombuffer(raw[:4096], dtype=np.uint8)
+            raw = open(os.path.join(wd2, f"out.pop{ip+1}.gen{ngen}.chr{c}.cvval"), "rb").read()    # --debug dump of ras_find_cv's CV genotypes at the last generation
+            arrs[f"cvvalfile_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)   # (:2665-2683; every phenotype writes the same file name: the last one stays)
             raw = open(os.path.join(wd2, f"out.pop{ip+1}.gen{ngen}.chr{c}.int"), "rb").read()      # --out_interval (:1582-1633)
             arrs[f"intfile_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
     # the reference's PLINK text of the last generation (format_plink::write_ped_map / write_ped01_map, src/format_plink.cpp):

@@ -113,6 +113,22 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
 
 
+def check_cvval_dump(ctx, fx, ip, nchr, nphen, label):
+    """the reference's --debug dump of the CV genotypes ras_find_cv resolved (src/Simulation.cpp:2665-2683), written inside the
+    LAST generation's ras_compute_AD (before migration): per individual "c0 c1 " per CV in FILE order; every phenotype writes the
+    same file, so it holds the last phenotype"""
+    from geneevolve_amd.capi import unpack_rows
+    for ic in range(nchr):
+        k = f"cvvalfile_pop{ip}_chr{ic}_sha"
+        if k in fx:
+            ncv = len(fx[f"pop{ip}_ph{nphen-1}_chr{ic}_cv_bp"])
+            bits = unpack_rows(ctx.download_cv(ip, nphen - 1, ic), ncv)          # [2n][ncv]
+            n = bits.shape[0] // 2
+            inter = np.empty((n, 2 * ncv), dtype=np.uint8); inter[:, 0::2] = bits[0::2]; inter[:, 1::2] = bits[1::2]
+            txt = "".join(" ".join(str(int(v)) for v in row) + " \n" for row in inter).encode() if ncv else b"\n" * n
+            assert np.array_equal(np.frombuffer(hashlib.sha256(txt).digest(), dtype=np.uint8), fx[k]), f"{label}: CV genotypes differ from the reference's .cvval dump (pop {ip} chr {ic})"
+
+
 def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_lists=True, max_gen=None, check_gef=False, gef_rtol=0.0):
     """Run the whole fixture through `lib` and compare every dumped quantity."""
     n_pop, nchr, nphen, ngen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"]), int(fx["n_gen"])
@@ -152,6 +168,8 @@ def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_l
             cmp_float(dom, fx[pre + "dominance"], f"dominance gen {g}")
             if check_lists:
                 compare_lists(ctx, fx, pre, ip, nchr, f"{label} gen {g} pop {ip}")
+            if g == int(fx["n_gen"]):
+                check_cvval_dump(ctx, fx, ip, nchr, nphen, label)
             if check_gef:                      # ras_scale_AD_compute_GEF follows ras_compute_AD (src/Simulation.cpp:1943-1946)
                 for iph in range(nphen):
                     k = f"g{g}_pop{ip}_ph{iph}_gef_"
