@@ -14,6 +14,7 @@ Cases
   kat.txt.gz   RNG known-answer vectors + direct ras_sim_loc_rec / recombine calls
   ex1sub       Examples.zip:Example1 inputs (first 300 founders), 3 chr, assortative mating,
                Poisson family sizes, NO mutation map  -> serial rand() chain mode
+  ex1full      Example1.sh at full size (2000 founders, pop 3000, 10 generations), hashes
   ex1mut       same inputs, --RM, mutation map at 2e-3/row -> task-parallel mode
   dense        tiny synthetic chromosome with SNPs every 7 bp and a hot mutation map so that
                mutations land on SNPs and CVs; 2 phenotypes, unsorted CV file order, vd>0
@@ -560,6 +561,13 @@ def main():
     c = Case("ex1sub")
     c.add_pop(popinfo=["300 0 p thr 1 1"] * 4, **base)
     run_case(c, 12345, dense_gens={1, 4})
+
+    # ---- ex1full: Example1.sh at its own size -- all 2000 founders, 3 chromosomes x 1000 SNPs, 3000 individuals x 10 generations,
+    #      assortative mating with mat_cor 0, no mutation map (serial rand() chain).  Hashes of the big lists only.
+    full = example1_inputs(2000)
+    c = Case("ex1full")
+    c.add_pop(popinfo=["3000 0 p thr 1 1"] * 10, **full)
+    run_case(c, 12345, dense_gens={1, 10}, hash_only_dense=True, keep_parts_gens={1})
 
     # ---- ex1mut: same inputs, random mating + hot mutation map
     c = Case("ex1mut")
