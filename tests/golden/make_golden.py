@@ -332,6 +332,9 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             fa = os.path.join(wd, f"out.info.pop{ip+1}.gen{g}.txt"); fb = os.path.join(wd2, f"out.info.pop{ip+1}.gen{g}.txt")
             assert open(fa, "rb").read() == open(fb, "rb").read(), f"harness != CLI at gen {g} pop {ip+1}"
     arrs["n_gen"] = np.int64(ngen)
+    for ip in range(len(case.pops)):                # the run's .summary table (Simulation::ras_save_summary, src/Simulation.cpp:782-834), stock CLI
+        raw = open(os.path.join(wd2, f"out.pop{ip+1}.summary"), "rb").read()
+        arrs[f"summaryfile_pop{ip}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
     # the reference's per-generation text dump (Population::ras_save_human_info, src/Population.cpp:510-568)
     for g in range(ngen + 1):
         for ip in range(len(case.pops)):

@@ -33,6 +33,7 @@ def run_cli(exe, case, tmp_path):
         raw = open(path, "rb").read()
         return np.array_equal(np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8), fx[key])
     for ip in range(int(fx["n_pop"])):
+        assert same(os.path.join(wd, f"out.pop{ip+1}.summary"), f"summaryfile_pop{ip}_sha"), f"{case}: .summary file of population {ip+1} differs"
         for ic in range(int(fx["nchr"])):
             base = os.path.join(wd, f"out.pop{ip+1}.gen{ngen}.chr{int(fx[f'pop{ip}_chr{ic}_label'])}")
             assert same(base + ".int", f"intfile_pop{ip}_chr{ic}_sha"), f"{case}: .int (--out_interval) file differs (pop {ip+1} chr index {ic})"
