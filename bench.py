@@ -136,6 +136,35 @@ def cpu_baseline_reference(args):
                       f"of the SNP count); host has {os.cpu_count()} cores, 1 used (the reference is single threaded)"}
 
 
+def launch_ranks(n):
+    """One worker process per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in its environment, the same contract as
+    torch.distributed.run), started from a parent that has not touched the GPU.  Rank 0's stdout is this process's stdout.
+    A failing rank ends the others (by PID) and its exit code is returned."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:                        # a rank died: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,15 +186,18 @@ def main():
     ap.add_argument("--migration-rate", type=float, default=0.0,
                     help="N>1 only: fraction of each population that moves to EACH other population every generation "
                          "(BASELINE config 3 uses 0.01); rows travel by all_to_all over RCCL")
+    ap.add_argument("--spawn", action="store_true", help="go through the worker launcher even for --gpus 1 (checks that the launcher costs nothing)")
     ap.add_argument("--isolated-steps", type=int, default=3, help="extra untimed generations without stream overlap for roofline.isolated")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` as typed: no rendezvous environment yet -> this process becomes the launcher.  It starts one
+    # fresh worker process per GPU BEFORE any GPU call is made here (it never imports torch) and relays rank 0's JSON line.
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if world != args.gpus:                               # under torch.distributed.run the launcher's world size wins
         args.gpus = world
     # rehearsal knob for a ONE-GPU box: all ranks share device 0 and talk over gloo (RCCL refuses two ranks on one GPU)
     one_gpu = os.environ.get("GEV_BENCH_ONE_GPU") == "1"
@@ -205,16 +237,18 @@ def main():
     sim.ras_initial_human_gen0(P, args.n_ind)
     rng = np.random.default_rng(rank)
     total = args.warmup + args.steps
-    # the ras_glob_seed() stream is a pure function of --seed and of counts known in advance
-    # (1 + N*nchr draws per generation): draw it before the timed region
-    seeds = [sim.ras_glob_seed(1 + args.n_ind * args.nchr) for _ in range(total)]
+    # Simulation::ras_glob_seed(): 1 + N*nchr draws per generation (src/Simulation.cpp:2398, :2500), made by the host INSIDE every
+    # step, as the reference's reproduce does: step i draws the values of generation i+1 right after handing generation i over
+    # (they are pure draws of the host's stream, so they can be made -- and given to gev_presample -- before the couples exist).
+    n_seeds = 1 + args.n_ind * args.nchr
+    seeds = {0: sim.ras_glob_seed(n_seeds)}              # generation 0 of the warm-up only; every later one is drawn inside a step
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ad_ms, mate_ms, repro_ms, mig_ms, step_ms = [], [], [], [], []
+    ad_ms, mate_ms, repro_ms, mig_ms, step_ms, seed_ms = [], [], [], [], [], []
     if migrate:
         from geneevolve_amd.distributed import migrate_all_to_all
 
@@ -224,8 +258,11 @@ def main():
         t0 = time.perf_counter()
         sim.couples[P] = synthetic_random_mate(sim.sex[P], args.n_ind, rng, out=sim.couples.get(P))   # host mating (outside the hot path)
         t1 = time.perf_counter()
-        sim.reproduce(P, i + 1, seeds=seeds[i], n_people=args.n_ind)             # Simulation::reproduce
-        if presample and i + 1 < total:                                          # next generation's seeds are already known: sample while the host mates
+        sim.reproduce(P, i + 1, seeds=seeds.pop(i), n_people=args.n_ind)          # Simulation::reproduce
+        ts = time.perf_counter()
+        seeds[i + 1] = sim.ras_glob_seed(n_seeds)                                # the next generation's ras_glob_seed() draws, inside the clock
+        seed_ms.append((time.perf_counter() - ts) * 1e3)
+        if presample:                                                            # ... handed over at once: the GPU samples while the host mates
             sim.presample(P, seeds[i + 1], args.n_ind)
         t2 = time.perf_counter()
         sim.ras_compute_AD(P, i + 1)                                             # Simulation::ras_compute_AD
@@ -250,7 +287,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    del ad_ms[:], mate_ms[:], repro_ms[:], mig_ms[:], step_ms[:]
+    del ad_ms[:], mate_ms[:], repro_ms[:], mig_ms[:], step_ms[:], seed_ms[:]
     tot0, n0 = ctx.timing_totals()                       # (implies a sync of both library streams)
     barrier()
     t0 = time.perf_counter()
@@ -270,11 +307,10 @@ def main():
     iso = None
     if args.isolated_steps > 0 and not migrate and not args.plane_less:
         ctx.set_overlap(False)
-        more = [sim.ras_glob_seed(1 + args.n_ind * args.nchr) for _ in range(args.isolated_steps)]
         ta, na = ctx.timing_totals()
         for j in range(args.isolated_steps):
             sim.couples[P] = synthetic_random_mate(sim.sex[P], args.n_ind, rng, out=sim.couples.get(P))
-            sim.reproduce(P, total + j + 1, seeds=more[j], n_people=args.n_ind)
+            sim.reproduce(P, total + j + 1, seeds=seeds.pop(total) if j == 0 else sim.ras_glob_seed(n_seeds), n_people=args.n_ind)
         tb, nb = ctx.timing_totals()
         iso = (tb[1] - ta[1]) / max(nb - na, 1)
         ctx.set_overlap(True)
@@ -285,10 +321,15 @@ def main():
         alg_bytes = args.n_ind * args.n_loci / 2.0 * args.nchr   # per generation: one stitch launch per chromosome, N*L/2 bytes each
         stitch = float(np.mean(stitch_ms))
         achieved = alg_bytes / (max(stitch, 1e-9) * 1e-3) / 1e9 if not args.plane_less else 0.0
-        traffic = None                                      # HBM bytes per launch from the committed PMC passes (same workload only)
-        pmc = os.path.join(ROOT, "profiles", "r01_final_config2_pmc_hbm.json")
-        if os.path.exists(pmc) and (args.n_ind, args.n_loci, args.nchr, args.map_step) == (100_000, 1_000_000, 1, 50_000):
-            traffic = json.load(open(pmc))["k_stitch_parent_summary"]["hbm_traffic_bytes_per_launch"]
+        traffic, traffic_src = None, None                   # HBM bytes per launch from the committed PMC passes (same workload only)
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_config2_pmc_hbm.json")))       # newest round last
+        if pmcs and (args.n_ind, args.n_loci, args.nchr, args.map_step) == (100_000, 1_000_000, 1, 50_000) and not args.plane_less:
+            traffic = json.load(open(pmcs[-1]))["k_stitch_parent_summary"]["hbm_traffic_bytes_per_launch"]
+            traffic_src = os.path.relpath(pmcs[-1], ROOT)
+        # what the memory system really moved per second while the kernel ran: measured bytes / measured time.  The kernel reads a
+        # parent chunk once for all of its gametes, so this is BELOW `achieved` (which prices the algorithmic N*L/2 bytes).
+        hbm_actual = traffic / (max(stitch, 1e-9) * 1e-3) / 1e9 if traffic else None
         out = {
             "metric": "generations/sec", "value": gens_per_s,
             "unit": f"generations/s of {args.n_ind} individuals x {args.n_loci} loci populations (summed over GPUs)",
@@ -301,20 +342,23 @@ def main():
                        f"config-2 family, non-default size: {args.n_ind} individuals x {args.nchr} chromosome(s) x {args.n_loci} SNPs, map rows every {args.map_step} bp",
                        "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_chromosomes": args.nchr, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
                        "interval_state_tracked": not args.no_intervals, "resident_genotype_planes": not args.plane_less,
-                       "seeds_handed_over_before_couples": presample},
+                       "seeds_handed_over_before_couples": presample,
+                       "ras_glob_seed_draws": "inside the timed loop, one generation's worth per step (host, phase_ms.host_seed_draws)"},
             "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci * args.nchr / dt,
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
-                         "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
+                         "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "host_seed_draws": float(np.mean(seed_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
                          "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None},
                "host_step_ms": [round(x, 2) for x in step_ms[:args.steps]],
             "roofline": {"bound": "hbm", "kernel": "k_stitch_parent", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "hbm_actual_GBps": hbm_actual, "hbm_actual_frac": hbm_actual / HBM_PEAK_GBPS if hbm_actual else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": stitch,
                          "note": "kernel time measured live with HIP events on the library's stitch stream inside the timed region, where the "
                                  "kernel shares the GPU with the next generation's sampling/A-D kernels; isolated_* = same kernel with the two "
                                  "streams serialised (extra untimed generations); traffic = rocprofv3 PMC measurement committed under profiles/",
                          "isolated_kernel_ms": iso, "isolated_achieved": (alg_bytes / (iso * 1e-3) / 1e9) if iso else None,
-                         "isolated_frac": (alg_bytes / (iso * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso else None},
+                         "isolated_frac": (alg_bytes / (iso * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso else None,
+                         "isolated_hbm_actual_GBps": (traffic / (iso * 1e-3) / 1e9) if (iso and traffic) else None},
         }
         if not args.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N=1 only
             port = cpu_baseline(args, args.n_loci)

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
-    "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
+    "dbg_verify_planes", "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
 
@@ -414,6 +414,12 @@ class GevContext:
         out = np.zeros(nb, dtype=np.uint8)
         self._call("materialize_bed", C.c_int(pop), C.c_int(chr), C.c_size_t(snp_begin), C.c_size_t(n_snps), ptrs, strides, rows, _p(out), C.c_size_t(nb))
         return out
+
+    def dbg_verify_planes(self, pop, chr, founder_seed):
+        """(mismatching plane words, bad parts) of the device-side full comparison plane == materialise(intervals, synthetic founders)"""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._call("dbg_verify_planes", self.h, C.c_int(pop), C.c_int(chr), C.c_uint64(int(founder_seed)), C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def set_overlap(self, on):
         """True (default) / False / 2 (sampling-only overlap), or None: decide from two timed serialised generations"""

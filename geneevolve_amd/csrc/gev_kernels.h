@@ -972,6 +972,42 @@ __global__ void __launch_bounds__(256) k_materialize_tile(const u32* __restrict_
     }
     out[r * out_w32 + w] = acc;
 }
+// Diagnostic (gev_dbg_verify_planes): EVERY 32-bit word of the resident genotype plane (written by the dense stitch K5 from
+// breakpoints) against the reference's materialisation rule applied to the ancestry intervals (written by K4, k_parts) --
+// two independent paths.  The founder panel is the synthetic one (k_synth_rows), recomputed on the fly, so no founder copy
+// has to be resident.  Mutations are not in the plane (sparse overlay), so none are applied here.
+__global__ void __launch_bounds__(256) k_verify_plane(const u32* __restrict__ p_off, const gev_part* __restrict__ parts, size_t n_rows,
+                                                      const u64* __restrict__ pos, u32 L, const u32* __restrict__ plane, size_t stride_w32,
+                                                      const u32* __restrict__ thr, u64 seed, int own_pop, size_t n_founder_rows,
+                                                      unsigned long long* __restrict__ n_bad /* [0] mismatching words, [1] parts with a foreign / out-of-range founder */)
+{
+    const u32 words = (L + 31) / 32;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_rows * words) return;
+    const size_t r = q / words; const u32 w = (u32)(q % words);
+    const u32 nb = min(32u, L - 32u * w);
+    const u64* wp = pos + 32u * w;
+    const u64 x0 = wp[0], x1 = wp[nb - 1];
+    u32 lo = p_off[r], hi = p_off[r + 1];
+    const u32 end = hi;
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (parts[m].en <= x0) lo = m + 1; else hi = m; }
+    const u64 off = seed * 0xD1342543DE82EF95ull;
+    u32 acc = 0;
+    for (u32 i = lo; i < end && parts[i].st <= x1; i++) {
+        const u64 st = parts[i].st, en = parts[i].en;
+        u32 a = 0, b = 0;
+        for (u32 t = 0; t < nb; t++) { a += wp[t] < st ? 1u : 0u; b += wp[t] < en ? 1u : 0u; }
+        if (b <= a) continue;
+        const u64 h = parts[i].hap_index;
+        if (parts[i].root_population != own_pop || h >= n_founder_rows) { atomicAdd(&n_bad[1], 1ull); continue; }
+        for (u32 t = a; t < b; t++) {
+            const size_t ii = (size_t)32 * w + t;
+            const u64 ctr = (((u64)h << 32) | (u64)ii) + off;
+            if ((u32)(mix64(ctr) >> 32) < thr[ii]) acc |= 1u << t;
+        }
+    }
+    if (acc != plane[r * stride_w32 + w]) atomicAdd(&n_bad[0], 1ull);
+}
 // mutation overlay of a tile: out bit = !unmutated bit at every tile locus whose position is in the row's mutation list (:1212-1216)
 __global__ void __launch_bounds__(256) k_tile_apply_mut(const u32* __restrict__ plain, u32* __restrict__ out, size_t w32, size_t row0, size_t n_rows,
                                                         const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ pos, u32 s0, u32 ns)

@@ -473,11 +473,16 @@ int gev_set_cvs(gev_ctx* c, int pop, int phen, int chr, const u64* bp, const dou
     return GEV_OK;
 }
 
+static int wait_planes(gev_ctx* c);
 static int ensure_capacity(gev_ctx* c, int pop, size_t people)
 {
     PopState& P = c->pop[pop];
     if (people <= P.cap_people) return GEV_OK;
     const size_t rows = 2 * people;
+    // Growth copies the CURRENT buffers (keep = true) on `stream`; the stitch that produces the current planes may still be
+    // running on stream_big (gev_reproduce does not wait for it), so order the copies behind it -- otherwise the new buffer
+    // would receive a half-written generation.
+    GEVC(wait_planes(c));
     for (int k = 0; k < c->nchr; k++) {
         if (!c->chr_active[k]) continue;
         if (!P.cs[k].stride) return fail(GEV_ESTATE, "set_snps must precede allocation (pop %d chr %d)", pop, k);
@@ -2118,6 +2123,37 @@ __global__ void __launch_bounds__(64) k_dbg_sim_loc_rec(const GevRngTables* __re
     });
     const u32 a = g.out(T, h), b = g.out(T, h + 1);
     if (threadIdx.x == 0) { *n_out = h; next2[0] = (int)a; next2[1] = (int)b; }
+}
+// every word of the resident plane (dense stitch) against the interval state (k_parts) + the synthetic founder panel
+int gev_dbg_verify_planes(gev_ctx* c, int pop, int chr, uint64_t founder_seed, unsigned long long* n_bad_words, unsigned long long* n_bad_parts)
+{
+    if (c) GEVC(check_dense(c, "dbg_verify_planes"));
+    GEVC(check_idx(c, pop, chr));
+    GEVC(check_active(c, chr, "dbg_verify_planes"));
+    PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
+    if (!P.gen0) return fail(GEV_ESTATE, "dbg_verify_planes: population %d has no current generation", pop);
+    if (!c->track_intervals) return fail(GEV_ESTATE, "dbg_verify_planes: interval tracking is disabled");
+    if (!n_bad_words || !n_bad_parts) return fail(GEV_EINVAL, "dbg_verify_planes: null output");
+    HIPC(hipSetDevice(c->device));
+    GEVC(materialize_order(c, pop));
+    GEVC(gev_sync(c));
+    hipStream_t st = c->stream;
+    const size_t rows = 2 * P.n_people, words = ceil_div(S.L, 32);
+    if (!rows || !words) { *n_bad_words = 0; *n_bad_parts = 0; return GEV_OK; }
+    if (ceil_div(rows * words, 256) > 0x7fffffffull) return fail(GEV_EINVAL, "dbg_verify_planes: grid too large");
+    GEVC(c->d_thr32.ensure(S.L * sizeof(u32), st));
+    GEVC(c->d_flag.ensure(16, st));
+    HIPC(hipMemsetAsync(c->d_flag.p, 0, 16, st));
+    hipLaunchKernelGGL(k_synth_thresholds, dim3((unsigned)ceil_div(S.L, 256)), dim3(256), 0, st, c->d_thr32.as<u32>(), S.L, founder_seed);
+    hipLaunchKernelGGL(k_verify_plane, dim3((unsigned)ceil_div(rows * words, 256)), dim3(256), 0, st, cs.poff[P.cur].as<u32>(), cs.parts[P.cur].as<gev_part>(), rows,
+                       S.d_pos.as<u64>(), (u32)S.L, cs.plane[P.cur].as<u32>(), S.stride / 4, c->d_thr32.as<u32>(), founder_seed, pop, S.founder_rows,
+                       (unsigned long long*)c->d_flag.p);
+    KCHECK();
+    unsigned long long h[2] = {0, 0};
+    HIPC(hipMemcpyAsync(h, c->d_flag.p, 16, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    *n_bad_words = h[0]; *n_bad_parts = h[1];
+    return GEV_OK;
 }
 int gev_dbg_tables(void* out, size_t bytes)
 {

@@ -13,12 +13,27 @@ import torch
 import torch.distributed as dist
 
 
-def migrate_all_to_all(ctx, outgoing, local_pop, device=None, group=None):
+def _fence(on_gpu, trace):
+    """Order the HIP library behind torch's stream.  The library launches on its own hipStreamNonBlocking streams, which take
+    no implicit order from torch's current stream; an NCCL/RCCL collective only ENQUEUES on torch's stream and returns to the
+    host.  So before the library reads a buffer a collective (or any torch op) wrote, and before a collective sends a
+    buffer the library wrote (its export entry points already wait for their own stream), the host waits for torch's
+    current stream.  One host wait per exchange; the payload of a migration step is a few hundred MB, the wait is its
+    transfer time, which the step needs anyway."""
+    if trace is not None:
+        trace.append("fence")
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()
+
+
+def migrate_all_to_all(ctx, outgoing, local_pop, device=None, group=None, trace=None):
     """ctx: GevContext whose population `local_pop` lives on this rank.  outgoing: list (len = world)
-    of uint64 position arrays (entry [rank] must be empty).  Collective: every rank must call it."""
+    of uint64 position arrays (entry [rank] must be empty).  Collective: every rank must call it.
+    trace: optional list that receives the order of the steps (tests check the fences around the collectives)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     backend = dist.get_backend(group)
     on_gpu = device is not None and torch.device(device).type == "cuda"
+    ev = trace.append if trace is not None else (lambda e: None)
     outgoing = [np.ascontiguousarray(o, dtype=np.uint64) for o in outgoing]
     assert len(outgoing) == world and len(outgoing[rank]) == 0
     # 1. sizes and counts, exchanged first (variable-length records)
@@ -27,16 +42,19 @@ def migrate_all_to_all(ctx, outgoing, local_pop, device=None, group=None):
     meta_out = torch.tensor([[send_bytes[j], len(outgoing[j])] for j in range(world)], dtype=torch.int64, device=meta_dev)
     meta_in = torch.empty_like(meta_out)
     dist.all_to_all_single(meta_in, meta_out, group=group)
-    meta_in = meta_in.cpu().numpy()
+    ev("a2a_meta")
+    meta_in = meta_in.cpu().numpy()                      # (.cpu() waits for the collective on torch's stream)
     recv_bytes = [int(x) for x in meta_in[:, 0]]; recv_n = [int(x) for x in meta_in[:, 1]]
     # 2. pack every destination's records into one send buffer (device memory for the HIP library)
     buf_dev = torch.device(device) if on_gpu else torch.device("cpu")
     send = torch.empty(max(sum(send_bytes), 16), dtype=torch.uint8, device=buf_dev)
     recv = torch.empty(max(sum(recv_bytes), 16), dtype=torch.uint8, device=buf_dev)
+    _fence(on_gpu, trace)                                # the caching allocator may hand out memory with work pending on torch's stream
     off = 0
     for j in range(world):
         if send_bytes[j]:
-            ctx.export_rows(local_pop, outgoing[j], send.data_ptr() + off, send_bytes[j])
+            ctx.export_rows(local_pop, outgoing[j], send.data_ptr() + off, send_bytes[j])   # returns after its own stream has finished
+            ev("export")
         off += send_bytes[j]
     # 3. the exchange; gloo cannot move device memory, so a CPU rehearsal of the GPU path stages through the host
     if on_gpu and backend != "nccl":
@@ -47,19 +65,24 @@ def migrate_all_to_all(ctx, outgoing, local_pop, device=None, group=None):
         dist.all_to_all_single(recv_x[:sum(recv_bytes)] if sum(recv_bytes) else recv_x[:0],
                                send_x[:sum(send_bytes)] if sum(send_bytes) else send_x[:0],
                                output_split_sizes=recv_bytes, input_split_sizes=send_bytes, group=group)
+        ev("a2a_payload")
     if recv_x is not recv:
         recv.copy_(recv_x)
-        if on_gpu:
-            torch.cuda.synchronize()
+    # RCCL has only enqueued the exchange on torch's stream: the library must not read `recv` (nor may `send` be released)
+    # before it has completed
+    _fence(on_gpu, trace)
     # 4. erase the emigrants, then append immigrants origin by origin (ascending)
     gone = np.concatenate([o for o in outgoing]) if sum(len(o) for o in outgoing) else np.empty(0, dtype=np.uint64)
     if len(gone):
         ctx.remove_rows(local_pop, gone)
+        ev("remove")
     off = 0
     for i in range(world):
         if recv_n[i]:
             ctx.import_rows(local_pop, recv.data_ptr() + off, recv_bytes[i], recv_n[i])
+            ev("import")
         off += recv_bytes[i]
+    del send, recv                                       # import_rows returned after its copies finished: safe to release
     return recv_n
 
 

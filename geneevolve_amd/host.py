@@ -30,8 +30,7 @@ class GlobSeedStream:
         out = np.empty(0, dtype=np.uint32)
         while len(out) < n:
             m = int((n - len(out)) * 1.001) + 16
-            k = np.arange(1, m + 1, dtype=np.uint64)
-            xs = (self._powmod(k) * np.uint64(self.x)) % np.uint64(M31)
+            xs = (self._powers(m) * np.uint64(self.x)) % np.uint64(M31)
             ret = xs - np.uint64(1)
             ok = ret < np.uint64(self.PAST)
             vals = (ret[ok] // np.uint64(self.SCALING) + np.uint64(1)).astype(np.uint32)
@@ -45,6 +44,17 @@ class GlobSeedStream:
                 self.x = int(xs[-1])
                 out = np.concatenate([out, vals])
         return out
+
+    _POW = np.array([16807], dtype=np.uint64)          # 16807^k mod (2^31-1), k = 1.. (a constant of the engine, grown on demand)
+
+    @classmethod
+    def _powers(cls, m):
+        """16807^k mod (2^31-1) for k = 1..m: table doubled by p[j + len] = p[j] * 16807^len (products < 2^62)"""
+        p = cls._POW
+        while len(p) < m:
+            p = np.concatenate([p, (p * p[-1]) % np.uint64(M31)])
+        cls._POW = p
+        return p[:m]
 
     @staticmethod
     def _powmod(k):
@@ -70,8 +80,7 @@ class MinstdStream:
         self.x = x if x else 1
 
     def _outputs(self, m):
-        k = np.arange(1, m + 1, dtype=np.uint64)
-        return (GlobSeedStream._powmod(k) * np.uint64(self.x)) % np.uint64(M31)
+        return (GlobSeedStream._powers(m) * np.uint64(self.x)) % np.uint64(M31)
 
     def rewind_u01(self, n_unused):
         """undo the last n_unused draws of the most recent u01() batch (the caller over-drew)"""

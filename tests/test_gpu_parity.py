@@ -232,10 +232,11 @@ def test_locus_split_population_on_gpu_matches_the_unsplit_reference_run():
 
 def test_baseline_config2_full_size_dense_state_equals_interval_state(gpu_lib):
     """BASELINE config 2 at FULL size (100k individuals x 1M SNPs; the oracle would need hours):
-    after two generations the dense genotype rows produced by the stitch kernel must equal what the
+    after three generations the dense genotype rows produced by the stitch kernel must equal what the
     reference's materialisation rule (ras_convert_interval_to_hap_matrix, src/Simulation.cpp:1186-1230)
     gives from the device's own ancestry intervals + mutation sets + the founder panel -- checked
-    on sampled rows, founder rows regenerated independently by tests/synth.py."""
+    for EVERY row on the device (gev_dbg_verify_planes) and, including the mutation overlay, on sampled rows whose
+    founder rows are regenerated independently by tests/synth.py."""
     from tests.synth import synth_bits
     n, L = 100_000, 1_000_000
     cfg = SyntheticConfig(n, L, seed=12345)
@@ -245,11 +246,15 @@ def test_baseline_config2_full_size_dense_state_equals_interval_state(gpu_lib):
     sim = Simulation(g, 2024, 1, True)
     sim.ras_initial_human_gen0(0, n)
     rng = np.random.default_rng(5)
-    for gen in (1, 2):
+    for gen in (1, 2, 3):
         sim.couples[0] = synthetic_random_mate(sim.sex[0], n, rng)
         sim.reproduce(0, gen)
         add, dom, _, _ = sim.ras_compute_AD(0, gen)
         assert np.isfinite(add).all() and add.std() > 0
+    # FULL coverage on the device: every one of the 200 000 x 31 250 plane words (dense stitch, from breakpoints) against the
+    # materialisation rule applied to the interval state (interval kernel) and the regenerated founder panel
+    assert g.dbg_verify_planes(0, 0, 4711) == (0, 0)
+    assert g.dbg_verify_planes(0, 0, 4712)[0] > 10 ** 9          # negative control: a different founder panel does not match
     parts, off = g.download_intervals(0, 0)
     muts, moff = g.download_mutations(0, 0)
     assert off[-1] > 2 * n * 1.5                                  # recombination happened
@@ -273,6 +278,35 @@ def test_baseline_config2_full_size_dense_state_equals_interval_state(gpu_lib):
                 want[j] = 1 - want[j]; flipped.add(j)
         assert np.array_equal(got, want), f"row {r}: dense state != interval state"
     g.close()
+
+
+def test_population_growth_without_intermediate_sync(gpu_lib, oracle_lib):
+    """The population grows every generation (capacity growth reallocates and copies the CURRENT planes) while the previous
+    generation's dense stitch may still be running on the library's second stream: nothing between the generations waits
+    for it (no genotype download), rows are 500 KB so a stitch takes milliseconds.  Sex, A/D, interval and mutation lists
+    must equal the oracle's, and every word of the final planes must equal the materialised interval state."""
+    L = 4_000_000
+    sizes = [3000, 4200, 5900, 8200]
+    cfg = SyntheticConfig(sizes[0], L, n_cv=64, seed=21)
+    g = gpu_lib.create(1, 1, 1); o = oracle_lib.create(1, 1, 1)
+    cfg.apply_static(g); cfg.apply_static(o)
+    g.synth_founders(0, 0, 2 * sizes[0], 77)                     # the oracle never materialises genotypes here: no SNP panel
+    g.synth_cv_founders(0, 0, 0, 2 * sizes[0], 78); o.upload_cv_founders(0, 0, 0, synth_packed(78, 2 * sizes[0], 64), 64)
+    sg = Simulation(g, 909, 1, True); so = Simulation(o, 909, 1, True)
+    sg.ras_initial_human_gen0(0, sizes[0]); so.ras_initial_human_gen0(0, sizes[0])
+    rng = np.random.default_rng(4)
+    for gen, n in enumerate(sizes[1:], 1):
+        c = synthetic_random_mate(sg.sex[0], n, rng)
+        sg.couples[0] = c; so.couples[0] = c
+        assert np.array_equal(sg.reproduce(0, gen), so.reproduce(0, gen)), f"sex differs at generation {gen}"
+        ag = sg.ras_compute_AD(0, gen); ao = so.ras_compute_AD(0, gen)
+        assert helpers.bits_equal(ag[0], ao[0]), f"additive values differ at generation {gen}"
+    pg, og = g.download_intervals(0, 0); po, oo = o.download_intervals(0, 0)
+    assert np.array_equal(og, oo) and np.array_equal(pg, po)
+    mg, mog = g.download_mutations(0, 0); mo, moo = o.download_mutations(0, 0)
+    assert np.array_equal(mog, moo) and np.array_equal(mg, mo)
+    assert g.dbg_verify_planes(0, 0, 77) == (0, 0)
+    g.close(); o.close()
 
 
 def test_cpp_host_drives_the_c_abi_like_the_python_host(gpu_lib):
