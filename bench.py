@@ -249,6 +249,7 @@ def main():
         torch.cuda.synchronize()
 
     ad_ms, mate_ms, repro_ms, mig_ms, step_ms, seed_ms = [], [], [], [], [], []
+    mig_parts = {}
     if migrate:
         from geneevolve_amd.distributed import migrate_all_to_all
 
@@ -277,7 +278,10 @@ def main():
             sex = sim.sex[P]
             gone = np.zeros(args.n_ind, dtype=bool); gone[sample.astype(np.int64)] = True
             sent_sex = [sex[outgoing[j].astype(np.int64)] for j in range(world)]
-            migrate_all_to_all(ctx, outgoing, P, device=f"cuda:{local_rank}")
+            tr = []
+            migrate_all_to_all(ctx, outgoing, P, device=f"cuda:{local_rank}", trace=tr)
+            for name, sec in zip(tr[0::2], tr[1::2]) if all(isinstance(x, float) for x in tr[1::2]) else []:
+                mig_parts[name] = mig_parts.get(name, 0.0) + sec * 1e3
             # host bookkeeping the reference does on its Human records: sexes follow the rows
             recv_sex = [None] * world
             dist.all_gather_object(recv_sex, sent_sex)
@@ -288,6 +292,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     del ad_ms[:], mate_ms[:], repro_ms[:], mig_ms[:], step_ms[:], seed_ms[:]
+    mig_parts.clear()
     tot0, n0 = ctx.timing_totals()                       # (implies a sync of both library streams)
     barrier()
     t0 = time.perf_counter()
@@ -347,7 +352,8 @@ def main():
             "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci * args.nchr / dt,
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
                          "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "host_seed_draws": float(np.mean(seed_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
-                         "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None},
+                         "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None,
+                         "migration_steps": {k: v / args.steps for k, v in mig_parts.items()} if mig_parts else None},
                "host_step_ms": [round(x, 2) for x in step_ms[:args.steps]],
             "roofline": {"bound": "hbm", "kernel": "k_stitch_parent", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,

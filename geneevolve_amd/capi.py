@@ -418,7 +418,7 @@ class GevContext:
     def dbg_verify_planes(self, pop, chr, founder_seed):
         """(mismatching plane words, bad parts) of the device-side full comparison plane == materialise(intervals, synthetic founders)"""
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)
-        self._call("dbg_verify_planes", self.h, C.c_int(pop), C.c_int(chr), C.c_uint64(int(founder_seed)), C.byref(a), C.byref(b))
+        self._call("dbg_verify_planes", C.c_int(pop), C.c_int(chr), C.c_uint64(int(founder_seed)), C.byref(a), C.byref(b))
         return int(a.value), int(b.value)
 
     def set_overlap(self, on):

@@ -62,7 +62,8 @@ struct SampleDev {
 #define GEV_BK_CAP 8
 #define GEV_NM_CAP 8
 // status words written by the kernels of one generation, read back once at its end
-enum { ST_BK_OVF_USED = 0, ST_NM_OVF_USED = 1, ST_FLAGS = 2, ST_TOTALS = 4 /* then per chr: mut_total, parts_total */ };
+enum { ST_BK_OVF_USED = 0, ST_NM_OVF_USED = 1, ST_FLAGS = 2, ST_SLOW_MUT = 3, ST_SLOW_REC = 4 /* tasks handed to the one-task-per-wave kernels */,
+       ST_TOTALS = 8 /* then per chr: mut_total, parts_total */ };
 enum { FLAG_BK_OVF = 1, FLAG_NM_OVF = 2, FLAG_MUT_CAP = 4, FLAG_PARTS_CAP = 8 };
 
 // The RNG tables (16 KB) are read 31 words at a time for every srand(); under a concurrently
@@ -229,13 +230,18 @@ __device__ __forceinline__ u32 mut_scan_write(const GevRngTables* __restrict__ T
         });
     return h;
 }
+// `list` != NULL: only the tasks list[0 .. *n_list) (the ones the batched kernel k_mut_sample8 handed over); NULL: every task
 __global__ void __launch_bounds__(256) k_mut_sample(const GevRngTables* __restrict__ Tg, const ChrDev* __restrict__ chrs, int nchr,
-                                                    const u32* __restrict__ mut_seeds, size_t n_tasks, SampleDev sd)
+                                                    const u32* __restrict__ mut_seeds, size_t n_tasks, SampleDev sd,
+                                                    const u32* __restrict__ list, const u32* __restrict__ n_list)
 {
     __shared__ __attribute__((aligned(16))) GevRngTables s_T;
+    const size_t n_iter = list ? (size_t)*n_list : n_tasks;
+    if (n_iter == 0) return;
     const GevRngTables* T = stage_tables(Tg, &s_T);
     const u32 lane = threadIdx.x & 63;
-    for (size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < n_tasks; t += (size_t)gridDim.x * 4) {
+    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_iter; it += (size_t)gridDim.x * 4) {
+    const size_t t = list ? (size_t)list[it] : it;
     asm volatile("" : "+v"(T));          // keep the 62 table words of this lane out of registers across tasks (occupancy)
     const int c = (int)(t % nchr);
     const ChrDev& C = chrs[c];
@@ -324,11 +330,15 @@ __device__ __forceinline__ u32 task_sample(const GevRngTables* __restrict__ T, c
 // task-parallel form (a mutation map is loaded: every task's chain restarts at srand(S), see
 // SURVEY.md section 7.2-1).  seed_pat[t] for t>0 was written by k_mut_sample.
 __global__ void __launch_bounds__(256) k_rec_sample(const GevRngTables* __restrict__ Tg, const ChrDev* __restrict__ chrs, int nchr,
-                                                    u32 seed_reproduce, size_t n_tasks, SampleDev sd)
+                                                    u32 seed_reproduce, size_t n_tasks, SampleDev sd,
+                                                    const u32* __restrict__ list, const u32* __restrict__ n_list)
 {
     __shared__ __attribute__((aligned(16))) GevRngTables s_T;
+    const size_t n_iter = list ? (size_t)*n_list : n_tasks;
+    if (n_iter == 0) return;
     const GevRngTables* T = stage_tables(Tg, &s_T);
-    for (size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < n_tasks; t += (size_t)gridDim.x * 4) {
+    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_iter; it += (size_t)gridDim.x * 4) {
+        const size_t t = list ? (size_t)list[it] : it;
         asm volatile("" : "+v"(T));      // keep the 62 table words of this lane out of registers across tasks (occupancy)
         GlibcWave g;
         u32 seed_pat;
@@ -367,6 +377,8 @@ __global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict
         seed = g.out(T, n);
     }
 }
+
+#include "gev_sample8.h"
 
 // ------------------------------------------------------------------------------------------
 // K5: dense stitch -- the HBM-roofline kernel.

@@ -8,6 +8,7 @@
 //   GEV_OVERLAP=0|1|2|-1      stream overlap: never | everything (default) | sampling only | decide from two timed generations
 //   GEV_SERIALIZE=1           same as GEV_OVERLAP=0
 //   GEV_LANES=1..4            chromosome lanes of the sparse / A-D phases (default min(nchr, 4))
+//   GEV_SAMPLE_BATCHED=0|1    sampling kernels: one task per wave | eight tasks per wave (default)
 //   GEV_SAMPLE_GRID=n         persistent workgroups of the sampling kernels (default 384 next to a stitch, 1024 alone)
 //   GEV_STITCH_WG_PER_CU=1..7 limit stitch workgroups per CU (default: wave-slot bound, 8)
 //   GEV_STITCH_PRIORITY=1|2   stitch stream high / all streams equal (default: small streams high, stitch low)
@@ -160,7 +161,7 @@ struct gev_ctx {
     // per-generation scratch: two sets, because the dense stitch of generation g (stream_big) still reads set g%2
     // while sampling / sparse state of generation g+1 (stream) fill the other one
     struct Scratch {
-        DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, ghist, goff, glist, status;
+        DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, ghist, goff, glist, status, slow_mut, slow_rec;
         hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         bool timing_pending = false, stitch_pending = false;
         // gev_presample: the sampling kernels of the next gev_reproduce were already enqueued for exactly these inputs
@@ -181,6 +182,7 @@ struct gev_ctx {
     int ad_cached_pop = -1;                                  // population whose current-generation A/D sits in h_ad
     bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
     int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
+    bool sample_batched = true;               // K1-K3 as eight tasks per wave (gev_sample8.h); GEV_SAMPLE_BATCHED=0: one task per wave
     unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels when they have the GPU to themselves (GEV_SAMPLE_GRID)
     unsigned sample_grid_shared = 384;        // ... and next to a running stitch: 6 waves per CU take fewer of the stitch's slots for longer, which costs
                                               // it less than many slots briefly (config 2: +2 %, 11-chromosome shard: +5 % generations/s over 1024)
@@ -355,6 +357,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     if (const char* e = getenv("GEV_OVERLAP")) { const int v = atoi(e); c->overlap_mode = v < 0 ? -1 : std::min(v, 2); }
     c->serialize = c->overlap_mode <= 0;                             // auto starts serialised
     c->sparse_after_stitch = c->overlap_mode == 2;
+    if (const char* e = getenv("GEV_SAMPLE_BATCHED")) c->sample_batched = atoi(e) != 0;
     if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = c->sample_grid_shared = (unsigned)g; }
     if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // tuning knob: stitch workgroups per CU (default: unlimited = 8)
         const int occ = atoi(e);
@@ -807,7 +810,7 @@ static int ensure_scratch(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, boo
     GEVC(sc.nmut.ensure(T * sizeof(u32), st)); GEVC(sc.nm_off.ensure((T + 1) * sizeof(u32), st));
     GEVC(sc.nm_pos.ensure(16, st)); GEVC(sc.nm_side.ensure(16, st));
     GEVC(sc.status.ensure(n_status * sizeof(u32), st));
-    if (has_mut) GEVC(sc.mutseeds.ensure(T * sizeof(u32), st));
+    if (has_mut) { GEVC(sc.mutseeds.ensure(T * sizeof(u32), st)); GEVC(sc.slow_mut.ensure(T * sizeof(u32), st)); GEVC(sc.slow_rec.ensure(T * sizeof(u32), st)); }
     return GEV_OK;
 }
 // K1-K3: crossover / mutation sampling and the rand() seed chain; depends on the seeds and n_people only, not on the couples
@@ -831,9 +834,17 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
     HIPC(hipEventRecord(sc.t[0], st));
     // ---- sampling: one map scan per gamete / per mutation task
     const unsigned task_blocks = (unsigned)std::min<size_t>(ceil_div(T, 4), (c->dense && !c->serialize) ? c->sample_grid_shared : c->sample_grid);
-    if (has_mut) {
-        hipLaunchKernelGGL(k_mut_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, sc.mutseeds.as<u32>(), T, sd);
-        hipLaunchKernelGGL(k_rec_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd);
+    if (has_mut && c->sample_batched) {
+        // eight tasks per wave; the rare tasks that need more than 8 rand() outputs go to the one-task-per-wave kernels
+        const unsigned batch_blocks = (unsigned)std::min<size_t>(ceil_div(ceil_div(T, SB_TASKS), 4), task_blocks);
+        const unsigned slow_blocks = (unsigned)std::min<size_t>(ceil_div(T, 4), 64);
+        hipLaunchKernelGGL(k_mut_sample8, dim3(batch_blocks), dim3(256), 0, st, Tb, chrs, nchr, sc.mutseeds.as<u32>(), seed_reproduce, T, sd, sc.slow_mut.as<u32>());
+        hipLaunchKernelGGL(k_mut_sample, dim3(slow_blocks), dim3(256), 0, st, Tb, chrs, nchr, sc.mutseeds.as<u32>(), T, sd, sc.slow_mut.as<u32>(), sd.status + ST_SLOW_MUT);
+        hipLaunchKernelGGL(k_rec_sample8, dim3(batch_blocks), dim3(256), 0, st, Tb, chrs, nchr, T, sd, sc.slow_rec.as<u32>());
+        hipLaunchKernelGGL(k_rec_sample, dim3(slow_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd, sc.slow_rec.as<u32>(), sd.status + ST_SLOW_REC);
+    } else if (has_mut) {
+        hipLaunchKernelGGL(k_mut_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, sc.mutseeds.as<u32>(), T, sd, (const u32*)nullptr, (const u32*)nullptr);
+        hipLaunchKernelGGL(k_rec_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd, (const u32*)nullptr, (const u32*)nullptr);
     } else {
         hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd);
     }

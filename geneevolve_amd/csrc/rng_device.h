@@ -49,6 +49,15 @@ __device__ __forceinline__ uint32_t mulmod31(uint32_t a, uint32_t b)
     return r >= GEV_M31 ? r - GEV_M31 : r;
 }
 
+// Same product for a chain that is multiplied again: a <= 2^31, b < 2^31; the result is in [1, 2^31] and congruent to a*b, i.e.
+// canonical except that 2^31 may stand for 1 (the final conditional subtraction is left out; states are never 0 mod M).
+__device__ __forceinline__ uint32_t mulmod31_lazy(uint32_t a, uint32_t b)
+{
+    const uint32_t lo = a * b, hi = __umulhi(a, b);                  // hi <= 2^30
+    const uint32_t r = (hi << 1) + (lo >> 31) + (lo & GEV_M31);      // <= 2^32 - 2
+    return (r & GEV_M31) + (r >> 31);
+}
+
 // std::minstd_rand0::seed(s): state = s mod (2^31-1), 0 -> 1.  `s` is the unsigned expression the
 // reference constructs the engine from (seed+1 / seed+2, wrapped mod 2^32).
 __device__ __forceinline__ uint32_t minstd_seed(uint32_t s)

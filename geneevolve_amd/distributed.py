@@ -20,10 +20,10 @@ def _fence(on_gpu, trace):
     buffer the library wrote (its export entry points already wait for their own stream), the host waits for torch's
     current stream.  One host wait per exchange; the payload of a migration step is a few hundred MB, the wait is its
     transfer time, which the step needs anyway."""
-    if trace is not None:
-        trace.append("fence")
     if on_gpu:
         torch.cuda.current_stream().synchronize()
+    if trace is not None:
+        trace.append("fence"); trace.append(0.0)
 
 
 def migrate_all_to_all(ctx, outgoing, local_pop, device=None, group=None, trace=None):
@@ -33,7 +33,13 @@ def migrate_all_to_all(ctx, outgoing, local_pop, device=None, group=None, trace=
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     backend = dist.get_backend(group)
     on_gpu = device is not None and torch.device(device).type == "cuda"
-    ev = trace.append if trace is not None else (lambda e: None)
+    import time
+    t_last = [time.perf_counter()]
+
+    def ev(name):                                        # step name (+ host seconds since the previous step, for the bench's breakdown)
+        if trace is not None:
+            now = time.perf_counter()
+            trace.append(name); trace.append(now - t_last[0]); t_last[0] = now
     outgoing = [np.ascontiguousarray(o, dtype=np.uint64) for o in outgoing]
     assert len(outgoing) == world and len(outgoing[rank]) == 0
     # 1. sizes and counts, exchanged first (variable-length records)
