@@ -45,7 +45,7 @@ MOVE_DTYPE = np.dtype([("src_pop", "<i4"), ("dst_pop", "<i4"), ("src_pos", "<u8"
 ABI_SYMBOLS = [
     "last_error", "version", "create", "destroy", "set_rmap", "set_mutmap", "set_snps", "set_cvs",
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
-    "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
+    "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "set_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
     "dbg_verify_planes", "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
@@ -227,6 +227,11 @@ class GevContext:
         self._call("scale_ad_compute_gef", C.c_int(pop), C.c_int(phen), C.byref(par), C.c_uint32(int(seed)), _p(cs), _p(ff), _p(fm),
                    _p(out["additive"]), _p(out["dominance"]), _p(out["bv"]), _p(out["e_noise"]), _p(out["parental_effect"]), _p(out["phen"]))
         return out
+
+    def set_ad(self, pop, additive, dominance):
+        """raw A/D totals of the current generation from the host (locus-split populations: the all-reduced sums)"""
+        a = _arr(additive, np.float64); d = _arr(dominance, np.float64)
+        self._call("set_ad", C.c_int(pop), _p(a), _p(d))
 
     def get_cv_freq(self, pop, phen, chr):
         ncv = self._ncv[(pop, phen, chr)]

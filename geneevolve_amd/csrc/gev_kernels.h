@@ -59,6 +59,32 @@ struct SampleDev {
     u32 bk_ovf_base, bk_ovf_cap, nm_ovf_base, nm_ovf_cap;
     u32* status;     // GenStatus words (below)
 };
+// Per-generation work tables: one entry per ACTIVE chromosome (ChrWork) / per (phenotype, active chromosome) (CvWork, AdWork).
+// Every per-chromosome kernel of a generation is ONE launch whose blockIdx.y (or .z) selects the entry, instead of one launch
+// per chromosome (a 22-chromosome genome used to cost ~300 launches per generation).
+struct ChrWork {
+    const u32* moff_cur; const u64* mpos_cur; u32* moff_alt; u64* mpos_alt;                 // mutation lists (CSR), parents / offspring
+    const u32* poff_cur; const gev_part* parts_cur; u32* poff_alt; gev_part* parts_alt;     // ancestry intervals
+    uint8_t* plane_alt; const uint8_t* plane_cur; const u64* snp_pos;                       // genotype planes
+    size_t stride;
+    u64 bp0, bp_end;
+    u32 mcap, pcap, chunks, bpr, L;
+    int chr;
+};
+struct CvWork {
+    u32* cvp_alt; const u32* cvp_cur; const u64* pos_sorted;
+    u32 stride_w32, sub_w32, C;
+    int chr;
+};
+struct AdWork {
+    const u32* cvp; const u32* moff; const u64* mpos; const u64* pos_sorted; const u64* pos_file; const u32* col_of_icv;
+    const double* a; const double* d; const double* const* aptr; const double* const* dptr;
+    u32* cvm; u32* counts; double* frq; double* tab; double* add_out; double* dom_out;
+    u64 bp0, bp_end;
+    double vd;
+    u32 stride_w32, sub_w32, C;
+    int own_pop;
+};
 #define GEV_BK_CAP 8
 #define GEV_NM_CAP 8
 // status words written by the kernels of one generation, read back once at its end
@@ -97,9 +123,11 @@ __device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* lds /*>=8*/,
     block_total = tot;
     return wave_off + inc - v;
 }
-__global__ void __launch_bounds__(256) k_scan_partial(const u32* __restrict__ in, size_t n, u32* __restrict__ sums)
+// blockIdx.y = segment: `in` advances by in_stride, `sums` by sums_stride per segment (single scan: gridDim.y = 1)
+__global__ void __launch_bounds__(256) k_scan_partial(const u32* __restrict__ in, size_t n, u32* __restrict__ sums, size_t in_stride = 0, size_t sums_stride = 0)
 {
     __shared__ u32 lds[8];
+    in += blockIdx.y * in_stride; sums += blockIdx.y * sums_stride;
     const size_t base = (size_t)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
     u32 s = 0;
 #pragma unroll
@@ -107,9 +135,10 @@ __global__ void __launch_bounds__(256) k_scan_partial(const u32* __restrict__ in
     u32 tot; block_exclusive_scan_256(s, lds, tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(256) k_scan_sums(u32* __restrict__ sums, size_t nb)
+__global__ void __launch_bounds__(256) k_scan_sums(u32* __restrict__ sums, size_t nb, size_t sums_stride = 0)
 {
     __shared__ u32 lds[8];
+    sums += blockIdx.y * sums_stride;
     u32 carry = 0;
     for (size_t base = 0; base < nb; base += 256) {
         const size_t i = base + threadIdx.x;
@@ -130,6 +159,30 @@ __global__ void __launch_bounds__(256) k_scan_final(const u32* __restrict__ in, 
     u32 tot; u32 ex = block_exclusive_scan_256(s, lds, tot) + sums[blockIdx.x];
 #pragma unroll
     for (int j = 0; j < 4; j++) { if (base + j <= n) out[base + j] = ex; ex += v[j]; }
+}
+
+// segmented form for the per-chromosome list offsets of one generation: segment y < n_work scans the mutation counts of work
+// entry y into its moff_alt, segment n_work + y the interval counts into poff_alt; the totals go to the status block
+__global__ void __launch_bounds__(256) k_scan_final_tab(const u32* __restrict__ in, size_t n, size_t in_stride, const u32* __restrict__ sums, size_t sums_stride,
+                                                        const ChrWork* __restrict__ W, u32 n_work, u32* __restrict__ status)
+{
+    __shared__ u32 lds[8];
+    const u32 y = blockIdx.y;
+    const bool is_parts = y >= n_work;
+    const ChrWork& w = W[is_parts ? y - n_work : y];
+    u32* __restrict__ out = is_parts ? w.poff_alt : w.moff_alt;
+    in += (size_t)y * in_stride; sums += (size_t)y * sums_stride;
+    const size_t base = (size_t)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    u32 v[4], sv = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { v[j] = base + j < n ? in[base + j] : 0; sv += v[j]; }
+    u32 tot; u32 ex = block_exclusive_scan_256(sv, lds, tot) + sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (base + j <= n) out[base + j] = ex;
+        if (base + j == n) status[ST_TOTALS + 2 * w.chr + (is_parts ? 1 : 0)] = ex;
+        ex += v[j];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -399,13 +452,16 @@ __device__ __forceinline__ u32 lower_bound_u64(const u64* __restrict__ a, u32 n,
 #define STITCH_KMAX 256          // boundaries staged in LDS per row; more spill to a global-memory walk
 #define STITCH_UNROLL 4
 // one workgroup = one output row x one span of chunks; 16 B per lane per access
-__global__ void __launch_bounds__(STITCH_THREADS) k_stitch_rows(
-    uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t stride, u32 chunks_per_row, u32 blocks_per_row,
-    const u64* __restrict__ pos, u32 L, int chr, int nchr, SampleDev sd)
+__global__ void __launch_bounds__(STITCH_THREADS) k_stitch_rows(const ChrWork* __restrict__ Wt, u32 bpr_max, int nchr, SampleDev sd)
 {
     __shared__ u32 s_idx[STITCH_KMAX];
-    const u32 row = blockIdx.x / blocks_per_row;          // output row = 2*offspring + s
-    const u32 span = blockIdx.x % blocks_per_row;
+    const ChrWork& w = Wt[blockIdx.y];
+    uint8_t* __restrict__ dst = w.plane_alt; const uint8_t* __restrict__ src = w.plane_cur;
+    const size_t stride = w.stride; const u32 chunks_per_row = w.chunks, blocks_per_row = w.bpr, L = w.L;
+    const u64* __restrict__ pos = w.snp_pos; const int chr = w.chr;
+    const u32 row = blockIdx.x / bpr_max;                 // output row = 2*offspring + s
+    const u32 span = blockIdx.x % bpr_max;
+    if (span >= blocks_per_row) return;
     const u32 i = row >> 1, s = row & 1;
     const size_t G = 2 * ((size_t)i * nchr + chr) + s;
     const u32 parent = s ? sd.mother[i] : sd.father[i];
@@ -528,14 +584,19 @@ __device__ __forceinline__ void pm_locate(const PmIdx& I, u32 k, u32 bit0, u32& 
     nxt = cnt < k ? I.at(cnt) : 0xffffffffu;
 }
 template <int UNROLL, bool NT>
-__global__ void __launch_bounds__(256) k_stitch_parent(
-    uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t stride, u32 chunks_per_row, u32 blocks_per_parent,
-    const u64* __restrict__ pos, u32 L, int chr, int nchr, const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd)
+__global__ void __launch_bounds__(256) k_stitch_parent(const ChrWork* __restrict__ Wt, u32 bpr_max, int nchr,
+                                                       const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd)
 {
     __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big;
     // Launched with a block of unused dynamic LDS: it caps the workgroups per CU so that wave slots stay free
     // for the small kernels of the next generation running concurrently on the other stream.
-    const u32 parent = blockIdx.x / blocks_per_parent, span = blockIdx.x % blocks_per_parent;
+    // blockIdx.y = active chromosome (all chromosomes of a generation are one launch)
+    const ChrWork& w = Wt[blockIdx.y];
+    uint8_t* __restrict__ dst = w.plane_alt; const uint8_t* __restrict__ src = w.plane_cur;
+    const size_t stride = w.stride; const u32 chunks_per_row = w.chunks, blocks_per_parent = w.bpr;
+    const int chr = w.chr;
+    const u32 parent = blockIdx.x / bpr_max, span = blockIdx.x % bpr_max;
+    if (span >= blocks_per_parent) return;
     const u32 g0 = goff[parent], g1 = goff[parent + 1];
     if (g0 == g1) return;
     const v4u* __restrict__ R0 = (const v4u*)(src + (size_t)(2 * parent) * stride);
@@ -618,11 +679,163 @@ __global__ void __launch_bounds__(256) k_stitch_parent(
     }
 }
 
-// small planes (CV grid: ~125 B rows): one thread = one 32-bit word of one sub-row
-__global__ void __launch_bounds__(256) k_stitch_small(
-    u32* __restrict__ dst, const u32* __restrict__ src, u32 stride_w32, u32 sub_w32, u32 nsub, size_t n_rows_out,
-    const u64* __restrict__ pos, u32 Cn, int chr, int nchr, SampleDev sd)
+// K5, parent-major, REGION form (the production kernel).  Same workgroup = parent mapping and the same read sharing as
+// k_stitch_parent, but the per-chunk bookkeeping is hoisted out of the streaming loop: the boundaries of all staged gametes are
+// merged into the ascending list of distinct boundary CHUNKS of the span; between two consecutive boundary chunks every gamete
+// copies from ONE fixed parental row, so a region is described by one bit mask (bit j = gamete j takes row 1).  A pure chunk
+// then costs a monotone pointer advance, one LDS read and the copies; only the (few) boundary chunks run the masked blend.
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(256) k_stitch_regions(const ChrWork* __restrict__ Wt, u32 bpr_max, int nchr,
+                                                        const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd)
 {
+    __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big, s_nd;
+    __shared__ u32 s_bc[PM_KTOT + 1];        // distinct boundary chunks inside [q0, q1), ascending, then the sentinel 0xffffffff
+    __shared__ u32 s_sel[PM_KTOT + 1];       // region r = pure chunks in front of boundary chunk r (r = nd: behind the last one)
+    const ChrWork& w = Wt[blockIdx.y];
+    uint8_t* __restrict__ dst = w.plane_alt; const uint8_t* __restrict__ src = w.plane_cur;
+    const size_t stride = w.stride; const u32 chunks_per_row = w.chunks, blocks_per_parent = w.bpr;
+    const int chr = w.chr;
+    const u32 parent = blockIdx.x / bpr_max, span = blockIdx.x % bpr_max;
+    if (span >= blocks_per_parent) return;
+    const u32 g0 = goff[parent], g1 = goff[parent + 1];
+    if (g0 == g1) return;
+    const v4u* __restrict__ R0 = (const v4u*)(src + (size_t)(2 * parent) * stride);
+    const v4u* __restrict__ R1 = (const v4u*)(src + (size_t)(2 * parent + 1) * stride);
+    const u32 per_block = (chunks_per_row + blocks_per_parent - 1) / blocks_per_parent;
+    const u32 q0 = span * per_block, q1 = min(q0 + per_block, chunks_per_row);
+    u32 gb = g0;
+    while (gb < g1) {
+        __syncthreads();                                   // previous batch consumed
+        const u32 cand = min(g1 - gb, (u32)PM_GMAX);
+        if (threadIdx.x < cand) {
+            const u32 row = glist[gb + threadIdx.x];
+            const size_t G = 2 * ((size_t)(row >> 1) * nchr + chr) + (row & 1);
+            s_row[threadIdx.x] = row; s_start[threadIdx.x] = sd.start[G]; s_k[threadIdx.x] = sd.k[G]; s_bkoff[threadIdx.x] = sd.bk_off[G];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 n = 0, kt = 0, big = 0;
+            while (n < cand) {
+                const u32 k = s_k[n];
+                if (kt + k > PM_KTOT) { if (n == 0) big = 1; else break; }
+                s_kb[n] = kt; kt += k; n++;
+                if (big) break;
+            }
+            s_n = n; s_big = big;
+        }
+        __syncthreads();
+        const u32 n = s_n; const bool big = s_big != 0;
+        if (!big)
+            for (u32 j = 0; j < n; j++)
+                for (u32 m = threadIdx.x; m < s_k[j]; m += 256) s_idx[s_kb[j] + m] = sd.bk_idx[s_bkoff[j] + m];
+        __syncthreads();
+        if (big) {
+            // one gamete with more boundaries than LDS holds (> PM_KTOT crossovers): per-chunk bisection on the global index list
+            const PmIdx I{s_idx, sd.bk_idx + s_bkoff[0], true};
+            const u32 k = s_k[0];
+            v4u* D = (v4u*)(dst + (size_t)s_row[0] * stride);
+            for (u32 q = q0 + threadIdx.x; q < q1; q += 256) {
+                const u32 bit0 = q * 128u, bit1 = bit0 + 128u;
+                u32 cnt, nxt; pm_locate(I, k, bit0, cnt, nxt);
+                const u32 sel = s_start[0] ^ (cnt & 1u);
+                v4u o;
+                if (nxt >= bit1) o = sel ? R1[q] : R0[q];
+                else {
+                    v4u mask = sel ? (v4u)(0xffffffffu) : (v4u)(0u);
+                    for (u32 m = cnt; m < k; m++) { const u32 id = I.at(m); if (id >= bit1) break; mask ^= mask_from(id - bit0); }
+                    o = (R0[q] & ~mask) | (R1[q] & mask);
+                }
+                D[q] = o;
+            }
+            gb += n;
+            continue;
+        }
+        // ---- merged boundary chunks of the span (thread 0: the lists are a handful of entries long)
+        if (threadIdx.x == 0) {
+            u32 nd = 0;
+            const u32 kt = s_kb[n - 1] + s_k[n - 1];
+            for (u32 m = 0; m < kt; m++) {
+                const u32 c = s_idx[m] >> 7;
+                if (c < q0 || c >= q1) continue;
+                u32 p = nd;                                   // insertion into the ascending distinct list
+                while (p > 0 && s_bc[p - 1] > c) p--;
+                if (p > 0 && s_bc[p - 1] == c) continue;
+                for (u32 t = nd; t > p; t--) s_bc[t] = s_bc[t - 1];
+                s_bc[p] = c; nd++;
+            }
+            s_bc[nd] = 0xffffffffu;
+            s_nd = nd;
+        }
+        __syncthreads();
+        const u32 nd = s_nd;
+        for (u32 r = threadIdx.x; r <= nd; r += 256) {        // selection mask of every region
+            const u32 bit = (r == 0 ? q0 : s_bc[r - 1] + 1u) * 128u;
+            u32 mask = 0;
+            for (u32 j = 0; j < n; j++) {
+                const u32* id = s_idx + s_kb[j]; const u32 k = s_k[j];
+                u32 cnt = 0;
+                for (u32 m = 0; m < k; m++) cnt += (id[m] <= bit);
+                mask |= ((s_start[j] ^ cnt) & 1u) << j;
+            }
+            s_sel[r] = mask;
+        }
+        __syncthreads();
+        const u32 full = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+        u32 reg[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) reg[u] = 0;
+        for (u32 q = q0 + threadIdx.x; q < q1; q += 256 * UNROLL) {
+            v4u a[UNROLL], b[UNROLL];
+            u32 sel[UNROLL]; bool isb[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const u32 qq = q + u * 256;
+                sel[u] = 0; isb[u] = false;
+                if (qq >= q1) continue;
+                u32 r = reg[u];
+                while (s_bc[r] < qq) r++;                    // sentinel-terminated
+                reg[u] = r;
+                isb[u] = s_bc[r] == qq;
+                sel[u] = s_sel[r];
+                if (isb[u] || sel[u] != full) a[u] = NT ? __builtin_nontemporal_load(&R0[qq]) : R0[qq];
+                if (isb[u] || sel[u] != 0u) b[u] = NT ? __builtin_nontemporal_load(&R1[qq]) : R1[qq];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const u32 qq = q + u * 256;
+                if (qq >= q1) continue;
+                if (!isb[u]) {
+                    for (u32 j = 0; j < n; j++) {
+                        const v4u o = ((sel[u] >> j) & 1u) ? b[u] : a[u];
+                        v4u* D = (v4u*)(dst + (size_t)s_row[j] * stride);
+                        if (NT) __builtin_nontemporal_store(o, &D[qq]); else D[qq] = o;
+                    }
+                } else {
+                    const u32 bit0 = qq * 128u, bit1 = bit0 + 128u;
+                    for (u32 j = 0; j < n; j++) {
+                        const u32* id = s_idx + s_kb[j]; const u32 k = s_k[j];
+                        u32 cnt = 0;
+                        for (u32 m = 0; m < k; m++) cnt += (id[m] <= bit0);
+                        v4u mask = ((s_start[j] ^ cnt) & 1u) ? (v4u)(0xffffffffu) : (v4u)(0u);       // 1 = take row1
+                        for (u32 m = cnt; m < k; m++) { if (id[m] >= bit1) break; mask ^= mask_from(id[m] - bit0); }
+                        const v4u o = (a[u] & ~mask) | (b[u] & mask);
+                        v4u* D = (v4u*)(dst + (size_t)s_row[j] * stride);
+                        if (NT) __builtin_nontemporal_store(o, &D[qq]); else D[qq] = o;
+                    }
+                }
+            }
+        }
+        gb += n;
+    }
+}
+
+// small planes (CV grid: ~125 B rows): one thread = one 32-bit word of one sub-row
+__global__ void __launch_bounds__(256) k_stitch_small(const CvWork* __restrict__ Vt, u32 nsub, size_t n_rows_out, int nchr, SampleDev sd)
+{
+    const CvWork& v = Vt[blockIdx.y];
+    u32* __restrict__ dst = v.cvp_alt; const u32* __restrict__ src = v.cvp_cur;
+    const u32 stride_w32 = v.stride_w32, sub_w32 = v.sub_w32, Cn = v.C;
+    const u64* __restrict__ pos = v.pos_sorted; const int chr = v.chr;
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 used = sub_w32 * nsub;
     if (q >= n_rows_out * used) return;
@@ -659,11 +872,14 @@ __device__ __forceinline__ u32 parity_at(const u64* __restrict__ bk, u32 k, u64 
     return n & 1u;
 }
 template <bool FILL>
-__global__ void __launch_bounds__(256) k_mutlist(
-    const u32* __restrict__ p_off, const u64* __restrict__ p_pos,    // parent generation CSR
-    u32* __restrict__ o_cnt, const u32* __restrict__ o_off, u64* __restrict__ o_pos,
-    size_t n_rows_out, int chr, int nchr, u64 bp0, u64 bp_end, int has_mut, u32 cap, SampleDev sd)
+__global__ void __launch_bounds__(256) k_mutlist(const ChrWork* __restrict__ Wt, u32* __restrict__ cnt, size_t cnt_stride,
+                                                 size_t n_rows_out, int nchr, int has_mut, SampleDev sd)
 {
+    const ChrWork& w = Wt[blockIdx.y];
+    const u32* __restrict__ p_off = w.moff_cur; const u64* __restrict__ p_pos = w.mpos_cur;    // parent generation CSR
+    u32* __restrict__ o_cnt = cnt + (size_t)blockIdx.y * cnt_stride;
+    const u32* __restrict__ o_off = w.moff_alt; u64* __restrict__ o_pos = w.mpos_alt;
+    const int chr = w.chr; const u64 bp0 = w.bp0, bp_end = w.bp_end; const u32 cap = w.mcap;
     const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows_out) return;
     if (FILL && o_off[row + 1] > cap) { if (o_off[row] <= cap) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_MUT_CAP); return; }   // host grows and redoes
@@ -698,11 +914,14 @@ __global__ void __launch_bounds__(256) k_mutlist(
 // K4: ancestry interval lists == Simulation::recombine (:2903-2958), statement by statement on CSR
 // ------------------------------------------------------------------------------------------
 template <bool FILL>
-__global__ void __launch_bounds__(256) k_parts(
-    const u32* __restrict__ p_off, const gev_part* __restrict__ p_parts,
-    u32* __restrict__ o_cnt, const u32* __restrict__ o_off, gev_part* __restrict__ o_parts,
-    size_t n_rows_out, int chr, int nchr, u64 bp0, u64 bp_end, u32 cap, SampleDev sd)
+__global__ void __launch_bounds__(256) k_parts(const ChrWork* __restrict__ Wt, u32* __restrict__ cnt, size_t cnt_stride,
+                                               size_t n_rows_out, int nchr, SampleDev sd)
 {
+    const ChrWork& w = Wt[blockIdx.y];
+    const u32* __restrict__ p_off = w.poff_cur; const gev_part* __restrict__ p_parts = w.parts_cur;
+    u32* __restrict__ o_cnt = cnt + (size_t)blockIdx.y * cnt_stride;
+    const u32* __restrict__ o_off = w.poff_alt; gev_part* __restrict__ o_parts = w.parts_alt;
+    const int chr = w.chr; const u64 bp0 = w.bp0, bp_end = w.bp_end; const u32 cap = w.pcap;
     const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows_out) return;
     if (FILL && o_off[row + 1] > cap) { if (o_off[row] <= cap) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_PARTS_CAP); return; }
@@ -743,19 +962,16 @@ __global__ void __launch_bounds__(256) k_parts(
     if (!FILL) o_cnt[row] = n;
 }
 
-__global__ void k_collect_total(const u32* __restrict__ off, size_t n_rows, u32* __restrict__ dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = off[n_rows]; }
 
 // ------------------------------------------------------------------------------------------
 // K6/K7: ras_find_cv + ras_compute_AD (src/Simulation.cpp:2624-2815)
 // ------------------------------------------------------------------------------------------
 // resolve CV alleles: founder allele from the stitched CV plane, flipped where the CV position is
 // in the row's mutation set (:2770-2775).  One thread per haplotype row.
-__global__ void __launch_bounds__(256) k_cv_apply_mut(
-    const u32* __restrict__ plane, u32 stride_w32, u32 sub_w32, u32* __restrict__ out /*[rows][sub_w32]*/, size_t n_rows,
+__device__ __forceinline__ void cv_apply_mut_row(
+    const u32* __restrict__ plane, u32 stride_w32, u32 sub_w32, u32* __restrict__ out /*[rows][sub_w32]*/, size_t row,
     const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ cvpos_sorted, u32 Cn)
 {
-    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
     const u32* in = plane + row * stride_w32;
     u32* o = out + row * sub_w32;
     for (u32 w = 0; w < sub_w32; w++) o[w] = in[w];
@@ -768,9 +984,26 @@ __global__ void __launch_bounds__(256) k_cv_apply_mut(
         }
     }
 }
-// allele counts per CV column (sorted order): f = sum_ih cv0+cv1 (:2647-2655), exact integers
-__global__ void __launch_bounds__(256) k_cv_count(const u32* __restrict__ cvm, u32 sub_w32, size_t n_rows, u32 Cn, u32* __restrict__ counts)
+__global__ void __launch_bounds__(256) k_cv_apply_mut(
+    const u32* __restrict__ plane, u32 stride_w32, u32 sub_w32, u32* __restrict__ out, size_t n_rows,
+    const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ cvpos_sorted, u32 Cn)
 {
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < n_rows) cv_apply_mut_row(plane, stride_w32, sub_w32, out, row, m_off, m_pos, cvpos_sorted, Cn);
+}
+// all (phenotype, chromosome) pairs of a population in one launch (blockIdx.y); also clears the column counters of the pair
+__global__ void __launch_bounds__(256) k_cv_apply_mut_tab(const AdWork* __restrict__ At, size_t n_rows)
+{
+    const AdWork& a = At[blockIdx.y];
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) for (u32 c = threadIdx.x; c < a.C; c += blockDim.x) a.counts[c] = 0;     // k_cv_count (next launch) accumulates into them
+    if (row < n_rows) cv_apply_mut_row(a.cvp, a.stride_w32, a.sub_w32, a.cvm, row, a.moff, a.mpos, a.pos_sorted, a.C);
+}
+// allele counts per CV column (sorted order): f = sum_ih cv0+cv1 (:2647-2655), exact integers
+__global__ void __launch_bounds__(256) k_cv_count(const AdWork* __restrict__ At, size_t n_rows)
+{
+    const AdWork& a = At[blockIdx.z];
+    const u32* __restrict__ cvm = a.cvm; const u32 sub_w32 = a.sub_w32, Cn = a.C; u32* __restrict__ counts = a.counts;
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t rows_per = (n_rows + gridDim.y - 1) / gridDim.y;
     const size_t r0 = (size_t)blockIdx.y * rows_per, r1 = min(r0 + rows_per, n_rows);
@@ -790,23 +1023,25 @@ __global__ void __launch_bounds__(256) k_cv_count(const u32* __restrict__ cvm, u
     if (n) atomicAdd(&counts[c], n);
 }
 // frq[icv] = f / (2*n_human) in FILE order (:2655)
-__global__ void k_cv_freq(const u32* __restrict__ counts, const u32* __restrict__ col_of_icv, u32 Cn, size_t n_human, double* __restrict__ frq)
+__global__ void k_cv_freq(const AdWork* __restrict__ At, size_t n_human)
 {
+    const AdWork& a = At[blockIdx.y];
     const u32 icv = blockIdx.x * blockDim.x + threadIdx.x;
-    if (icv >= Cn) return;
-    const double f = (double)counts[col_of_icv[icv]];
-    frq[icv] = f / (double)(2 * n_human);
+    if (icv >= a.C) return;
+    const double f = (double)a.counts[a.col_of_icv[icv]];
+    a.frq[icv] = f / (double)(2 * n_human);
 }
 // per individual, CVs in FILE order, sequential FP64 (no contraction: built with -ffp-contract=off):
 //   A += (t - 2p)(a + d(q-p));  D += {-2pp, 2pq, -2qq}[t] * d      (:2686-2712)
 // a, d are the mean of the two haplotypes' root-population values (:2695-2696)
-__global__ void __launch_bounds__(256) k_ad_accumulate(
-    const u32* __restrict__ cvm, u32 sub_w32, const u32* __restrict__ plane, u32 stride_w32, u32 rp_bits,
-    const u32* __restrict__ col_of_icv, const double* __restrict__ frq,
-    const double* const* __restrict__ a_of_pop, const double* const* __restrict__ d_of_pop, int own_pop,
-    const u64* __restrict__ cvpos_file, u64 bp0, u64 bp_end, double vd, u32 Cn, size_t n_human,
-    double* __restrict__ add_out, double* __restrict__ dom_out, size_t out_stride, u32* __restrict__ nan_flag)
+__global__ void __launch_bounds__(256) k_ad_accumulate(const AdWork* __restrict__ At, u32 rp_bits, size_t n_human, size_t out_stride, u32* __restrict__ nan_flag)
 {
+    const AdWork& aw = At[blockIdx.y];
+    const u32* __restrict__ cvm = aw.cvm; const u32 sub_w32 = aw.sub_w32; const u32* __restrict__ plane = aw.cvp; const u32 stride_w32 = aw.stride_w32;
+    const u32* __restrict__ col_of_icv = aw.col_of_icv; const double* __restrict__ frq = aw.frq;
+    const double* const* __restrict__ a_of_pop = aw.aptr; const double* const* __restrict__ d_of_pop = aw.dptr; const int own_pop = aw.own_pop;
+    const u64* __restrict__ cvpos_file = aw.pos_file; const u64 bp0 = aw.bp0, bp_end = aw.bp_end; const double vd = aw.vd; const u32 Cn = aw.C;
+    double* __restrict__ add_out = aw.add_out; double* __restrict__ dom_out = aw.dom_out;
     const size_t ih = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ih >= n_human) return;
     const u32* r0 = cvm + (2 * ih) * sub_w32; const u32* r1 = cvm + (2 * ih + 1) * sub_w32;
@@ -845,10 +1080,12 @@ __global__ void __launch_bounds__(256) k_ad_accumulate(
 // Single-root-population fast path.  Per CV the three possible contributions are computed once
 // with EXACTLY the expressions of the per-individual loop (same operations, same order, so the
 // sums stay bit-identical):  tab[icv] = { (0-2p)alpha, (1-2p)alpha, (2-2p)alpha, -2pp*d, 2pq*d, -2qq*d }.
-__global__ void k_cv_table(const u32* __restrict__ counts, const u32* __restrict__ col_of_icv, u32 Cn, size_t n_human,
-                           const double* __restrict__ a_file, const double* __restrict__ d_file, const u64* __restrict__ cvpos_file,
-                           u64 bp0, u64 bp_end, double vd, double* __restrict__ frq, double* __restrict__ tab)
+__global__ void k_cv_table(const AdWork* __restrict__ At, size_t n_human)
 {
+    const AdWork& aw = At[blockIdx.y];
+    const u32* __restrict__ counts = aw.counts; const u32* __restrict__ col_of_icv = aw.col_of_icv; const u32 Cn = aw.C;
+    const double* __restrict__ a_file = aw.a; const double* __restrict__ d_file = aw.d; const u64* __restrict__ cvpos_file = aw.pos_file;
+    const u64 bp0 = aw.bp0, bp_end = aw.bp_end; const double vd = aw.vd; double* __restrict__ frq = aw.frq; double* __restrict__ tab = aw.tab;
     const u32 icv = blockIdx.x * blockDim.x + threadIdx.x;
     if (icv >= Cn) return;
     const double f = (double)counts[col_of_icv[icv]];
@@ -873,11 +1110,12 @@ __global__ void k_cv_table(const u32* __restrict__ counts, const u32* __restrict
 // coalesced read ([hap][individual][S+1] layout: row stride S+1 words is odd -> conflict-free
 // column reads).  col_of_icv / tab are wave-uniform (scalar loads); t selects per lane.
 template <int IPB>
-__global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(
-    const u32* __restrict__ cvm, u32 sub_w32, const u32* __restrict__ col_of_icv, const double* __restrict__ tab, u32 Cn, size_t n_human,
-    double* __restrict__ add_out, double* __restrict__ dom_out, size_t out_stride, u32* __restrict__ nan_flag)
+__global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restrict__ At, size_t n_human, size_t out_stride, u32* __restrict__ nan_flag)
 {
     extern __shared__ u32 s_rows[];
+    const AdWork& aw = At[blockIdx.y];
+    const u32* __restrict__ cvm = aw.cvm; const u32 sub_w32 = aw.sub_w32; const u32* __restrict__ col_of_icv = aw.col_of_icv;
+    const double* __restrict__ tab = aw.tab; const u32 Cn = aw.C; double* __restrict__ add_out = aw.add_out; double* __restrict__ dom_out = aw.dom_out;
     const u32 S1 = sub_w32 | 1u;                                 // odd row stride
     const size_t ih0 = (size_t)blockIdx.x * IPB;
     const size_t n_here = min((size_t)IPB, n_human - ih0);

@@ -7,8 +7,8 @@
 // Tuning / diagnosis knobs (environment, read at gev_create; defaults are what the measurements of DESIGN.md chose):
 //   GEV_OVERLAP=0|1|2|-1      stream overlap: never | everything (default) | sampling only | decide from two timed generations
 //   GEV_SERIALIZE=1           same as GEV_OVERLAP=0
-//   GEV_LANES=1..4            chromosome lanes of the sparse / A-D phases (default min(nchr, 4))
 //   GEV_SAMPLE_BATCHED=0|1    sampling kernels: one task per wave | eight tasks per wave (default)
+//   GEV_STITCH_MODE=0|1|2     dense stitch kernel: k_stitch_regions (default) | k_stitch_rows | k_stitch_parent (same results)
 //   GEV_SAMPLE_GRID=n         persistent workgroups of the sampling kernels (default 384 next to a stitch, 1024 alone)
 //   GEV_STITCH_WG_PER_CU=1..7 limit stitch workgroups per CU (default: wave-slot bound, 8)
 //   GEV_STITCH_PRIORITY=1|2   stitch stream high / all streams equal (default: small streams high, stitch low)
@@ -161,7 +161,8 @@ struct gev_ctx {
     // per-generation scratch: two sets, because the dense stitch of generation g (stream_big) still reads set g%2
     // while sampling / sparse state of generation g+1 (stream) fill the other one
     struct Scratch {
-        DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, ghist, goff, glist, status, slow_mut, slow_rec;
+        DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, ghist, goff, glist, status, slow_mut, slow_rec, chrwork, cvwork;
+        unsigned n_chrwork = 0, bpr_max = 1;
         hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         bool timing_pending = false, stitch_pending = false;
         // gev_presample: the sampling kernels of the next gev_reproduce were already enqueued for exactly these inputs
@@ -180,8 +181,9 @@ struct gev_ctx {
     void* h_seeds = nullptr; size_t h_seeds_bytes = 0;       // pinned copy of the mutation seeds handed to gev_presample
     void* h_ad = nullptr; size_t h_ad_bytes = 0;             // pinned A/D result cache
     int ad_cached_pop = -1;                                  // population whose current-generation A/D sits in h_ad
+    int ad_host_set_pop = -1;                                // population whose raw A/D totals on the device were supplied by gev_set_ad (locus-split: all-reduced)
     bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
-    int stitch_mode = 0;           // 0 = parent-major (production), 1 = gamete-major (k_stitch_rows)
+    int stitch_mode = 0;           // 0 = parent-major region form (production, k_stitch_regions), 1 = gamete-major (k_stitch_rows), 2 = parent-major per-chunk form (k_stitch_parent)
     bool sample_batched = true;               // K1-K3 as eight tasks per wave (gev_sample8.h); GEV_SAMPLE_BATCHED=0: one task per wave
     unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels when they have the GPU to themselves (GEV_SAMPLE_GRID)
     unsigned sample_grid_shared = 384;        // ... and next to a running stitch: 6 waves per CU take fewer of the stitch's slots for longer, which costs
@@ -194,13 +196,10 @@ struct gev_ctx {
     DevBuf d_snpmajor, d_text;
     DevBuf d_sex0, d_gef_flag, d_gef_first, d_gef_red, d_gef_io;
     DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
-    // chromosome lanes: the per-chromosome chains of the sparse / A-D phases (row-parallel, latency-bound kernels) are
-    // independent, so chromosome k runs on lane k % n_lanes; lane 0 is `stream`, the others fork from / join into it
-    static const int MAX_LANES = 4;
-    struct Lane { hipStream_t st = nullptr; hipEvent_t done = nullptr; DevBuf d_cnt, d_sums, d_cvm; };
-    Lane lane[MAX_LANES];
-    int n_lanes = 1;
-    hipEvent_t ev_fork = nullptr;
+    // per-generation work tables (gev_kernels.h: ChrWork / CvWork / AdWork) are written into a ring of pinned host memory and
+    // copied to the device on the stream that uses them
+    uint8_t* h_ring = nullptr; size_t h_ring_bytes = 0, h_ring_off = 0;
+    DevBuf d_adwork;
     std::map<double, GevThr> thr_cache;
 };
 
@@ -266,11 +265,6 @@ static int check_dense(gev_ctx* c, const char* what)
     if (!c->dense) return fail(GEV_ESTATE, "%s: this context keeps no resident genotype planes (gev_set_dense_state 0); use gev_materialize", what);
     return GEV_OK;
 }
-static int check_all_active(gev_ctx* c, const char* what)
-{
-    if (c->any_inactive) return fail(GEV_EUNSUPPORTED, "%s: not available while chromosomes are inactive on this context (locus-split population)", what);
-    return GEV_OK;
-}
 // bit-column permutation of small planes (CV grid): out column j <- in column src_col[j]
 __global__ void k_permute_cols(const u32* __restrict__ in, size_t in_w32, u32* __restrict__ out, size_t out_w32, u32 used_w32,
                                const u32* __restrict__ src_col, u32 Cn, size_t n_rows)
@@ -332,14 +326,6 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     HIPC(hipStreamCreateWithPriority(&c->stream_big, hipStreamNonBlocking, prio_least));
     HIPC(hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming));
     c->chr_active.assign(nchr, 1);
-    c->n_lanes = std::max(1, std::min(nchr, (int)gev_ctx::MAX_LANES));
-    if (const char* e = getenv("GEV_LANES")) c->n_lanes = std::max(1, std::min(atoi(e), (int)gev_ctx::MAX_LANES));
-    c->lane[0].st = c->stream;
-    for (int l = 1; l < c->n_lanes; l++) {
-        HIPC(hipStreamCreateWithPriority(&c->lane[l].st, hipStreamNonBlocking, prio_greatest));
-        HIPC(hipEventCreateWithFlags(&c->lane[l].done, hipEventDisableTiming));
-    }
-    HIPC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (auto& sc : c->sc) {
         HIPC(hipEventCreateWithFlags(&sc.ev_small_done, hipEventDisableTiming));
         HIPC(hipEventCreateWithFlags(&sc.ev_stitch_done, hipEventDisableTiming));
@@ -358,6 +344,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     c->serialize = c->overlap_mode <= 0;                             // auto starts serialised
     c->sparse_after_stitch = c->overlap_mode == 2;
     if (const char* e = getenv("GEV_SAMPLE_BATCHED")) c->sample_batched = atoi(e) != 0;
+    if (const char* e = getenv("GEV_STITCH_MODE")) c->stitch_mode = std::max(0, std::min(atoi(e), 2));
     if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = c->sample_grid_shared = (unsigned)g; }
     if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // tuning knob: stitch workgroups per CU (default: unlimited = 8)
         const int occ = atoi(e);
@@ -375,16 +362,12 @@ void gev_destroy(gev_ctx* c)
     if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (int l = 1; l < gev_ctx::MAX_LANES; l++) {
-        if (c->lane[l].st) { (void)hipStreamSynchronize(c->lane[l].st); (void)hipStreamDestroy(c->lane[l].st); }
-        if (c->lane[l].done) (void)hipEventDestroy(c->lane[l].done);
-    }
     for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
     hipStream_t s = c->stream;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_seeds) (void)hipHostFree(c->h_seeds);
     if (c->h_ad) (void)hipHostFree(c->h_ad);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
     delete c;
     if (s) (void)hipStreamDestroy(s);
 }
@@ -471,7 +454,7 @@ int gev_set_cvs(gev_ctx* c, int pop, int phen, int chr, const u64* bp, const dou
     GEVC(V.d_frq.ensure(std::max<size_t>(C, 1) * sizeof(double), c->stream));
     GEVC(V.d_counts.ensure(std::max<size_t>(C, 1) * sizeof(u32), c->stream));
     V.frq_valid = false;
-    c->ad_cached_pop = -1;
+    c->ad_cached_pop = c->ad_host_set_pop = -1;
     c->pop[pop].finalized = false;
     return GEV_OK;
 }
@@ -593,7 +576,7 @@ static int cv_founders_from_tmp(gev_ctx* c, int pop, int phen, int chr, size_t n
         KCHECK();
     }
     HIPC(hipStreamSynchronize(c->stream));
-    c->ad_cached_pop = -1;
+    c->ad_cached_pop = c->ad_host_set_pop = -1;
     V.founder_rows = nhap; P.gen0 = false;
     return GEV_OK;
 }
@@ -725,7 +708,7 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     if (sex_out) HIPC(hipMemcpyAsync(sex_out, c->d_sex0.p, n_people, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = c->chr_active[k] ? rows : 0; }
-    c->ad_cached_pop = -1;
+    c->ad_cached_pop = c->ad_host_set_pop = -1;
     P.n_people = n_people; P.n_phys = n_people; P.logical.clear(); P.gen0 = true;
     return GEV_OK;
 }
@@ -768,20 +751,25 @@ static int harvest_timing(gev_ctx* c, gev_ctx::Scratch& sc)
     sc.timing_pending = false;
     return GEV_OK;
 }
-// side lanes start after everything enqueued on `stream` so far / `stream` continues after every lane has finished
-static int lanes_fork(gev_ctx* c)
+// host table -> device buffer `dst` on stream `st`, staged through the pinned ring (the host copy must stay valid until the
+// asynchronous copy has run: a slot is reused only after a wrap, which waits for the stream)
+static int upload_table(gev_ctx* c, DevBuf& dst, const void* src, size_t bytes, hipStream_t st)
 {
-    if (c->n_lanes < 2) return GEV_OK;
-    HIPC(hipEventRecord(c->ev_fork, c->stream));
-    for (int l = 1; l < c->n_lanes; l++) HIPC(hipStreamWaitEvent(c->lane[l].st, c->ev_fork, 0));
-    return GEV_OK;
-}
-static int lanes_join(gev_ctx* c)
-{
-    for (int l = 1; l < c->n_lanes; l++) {
-        HIPC(hipEventRecord(c->lane[l].done, c->lane[l].st));
-        HIPC(hipStreamWaitEvent(c->stream, c->lane[l].done, 0));
+    GEVC(dst.ensure(std::max<size_t>(bytes, 16), st));
+    if (!bytes) return GEV_OK;
+    const size_t need = round_up(bytes, 64);
+    if (c->h_ring_bytes < 4 * need) {
+        HIPC(hipStreamSynchronize(st));
+        if (c->h_ring) (void)hipHostFree(c->h_ring);
+        c->h_ring = nullptr; c->h_ring_bytes = 0; c->h_ring_off = 0;
+        const size_t want = std::max<size_t>(8 * need, 256 << 10);
+        HIPC(hipHostMalloc((void**)&c->h_ring, want, hipHostMallocDefault));
+        c->h_ring_bytes = want;
     }
+    if (c->h_ring_off + need > c->h_ring_bytes) { HIPC(hipStreamSynchronize(c->stream)); HIPC(hipStreamSynchronize(st)); c->h_ring_off = 0; }
+    memcpy(c->h_ring + c->h_ring_off, src, bytes);
+    HIPC(hipMemcpyAsync(dst.p, c->h_ring + c->h_ring_off, bytes, hipMemcpyHostToDevice, st));
+    c->h_ring_off += need;
     return GEV_OK;
 }
 static SampleDev make_sd(gev_ctx* c, gev_ctx::Scratch& sc, size_t T)
@@ -854,7 +842,8 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
     return GEV_OK;
 }
 static const size_t LIST_HEADROOM = 48;    // spare list entries per haplotype row when a list buffer is (re)allocated
-// K4/K6 + grouping: everything of the small work that needs the couples (parents) on top of the sampling results
+// K4/K6 + grouping: everything of the small work that needs the couples (parents) on top of the sampling results.
+// Every kernel covers ALL active chromosomes in one launch (blockIdx.y = entry of the generation's ChrWork / CvWork table).
 static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut)
 {
     PopState& P = c->pop[pop];
@@ -864,58 +853,73 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     SampleDev sd = make_sd(c, sc, T);
     if (c->sparse_after_stitch && c->planes_pending) HIPC(hipStreamWaitEvent(st, c->ev_planes, 0));
     HIPC(hipEventRecord(sc.t[5], st));
-    // ---- sparse state: mutation lists + ancestry intervals + CV planes
+    // ---- work tables of this generation
     const int cur = P.cur, alt = P.cur ^ 1;
-    for (int l = 0; l < c->n_lanes; l++) GEVC(c->lane[l].d_cnt.ensure((rows + 1) * sizeof(u32), st));
-    GEVC(lanes_fork(c));
-    const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
     const double grow = (double)rows / (double)std::max<size_t>(2 * P.n_people, 1);
+    const size_t n_parent = P.n_phys;
+    std::vector<ChrWork> cw; std::vector<CvWork> vw;
+    unsigned bpr_max = 1;
     for (int k = 0; k < nchr; k++) {
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
-        gev_ctx::Lane& ln = c->lane[k % c->n_lanes];
-        hipStream_t ls = ln.st;
-        const u64 bp0 = S.rbp.front(), bpe = S.rbp.back();
         // capacity guess: last generation's total scaled to the new size, plus room for the events of many generations
         // (lists lengthen by about one entry per row and generation; a growth step allocates GBs, which on some hosts is
         // not lazy and costs 10-250 ms of host time -- keep such steps rare and geometric)
         size_t want = std::max<size_t>(cs.mut_need, (size_t)(cs.mut_total[cur] * grow * 1.5) + rows * LIST_HEADROOM + 4096);
-        GEVC(cs.mpos[alt].ensure(want * sizeof(u64), ls, false, 2.0));        // grow geometrically: lists lengthen every generation
-        const u32 mcap = (u32)std::min<size_t>(cs.mpos[alt].bytes / sizeof(u64), 0xfffffff0u);
-        hipLaunchKernelGGL((k_mutlist<false>), dim3(row_blocks), dim3(256), 0, ls, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
-                           ln.d_cnt.as<u32>(), (const u32*)nullptr, (u64*)nullptr, rows, k, nchr, bp0, bpe, (int)has_mut, 0u, sd);
-        KCHECK();
-        GEVC(scan_u32_on(ls, ln.d_sums, ln.d_cnt.as<u32>(), rows, cs.moff[alt].as<u32>()));
-        hipLaunchKernelGGL((k_mutlist<true>), dim3(row_blocks), dim3(256), 0, ls, cs.moff[cur].as<u32>(), cs.mpos[cur].as<u64>(),
-                           (u32*)nullptr, cs.moff[alt].as<u32>(), cs.mpos[alt].as<u64>(), rows, k, nchr, bp0, bpe, (int)has_mut, mcap, sd);
-        hipLaunchKernelGGL(k_collect_total, dim3(1), dim3(64), 0, ls, cs.moff[alt].as<u32>(), rows, sd.status + ST_TOTALS + 2 * k);
-        KCHECK();
+        GEVC(cs.mpos[alt].ensure(want * sizeof(u64), st, false, 2.0));        // grow geometrically: lists lengthen every generation
+        ChrWork w{};
+        w.moff_cur = cs.moff[cur].as<u32>(); w.mpos_cur = cs.mpos[cur].as<u64>(); w.moff_alt = cs.moff[alt].as<u32>(); w.mpos_alt = cs.mpos[alt].as<u64>();
+        w.mcap = (u32)std::min<size_t>(cs.mpos[alt].bytes / sizeof(u64), 0xfffffff0u);
         if (c->track_intervals) {
             want = std::max<size_t>(cs.parts_need, (size_t)(cs.parts_total[cur] * grow * 1.5) + rows * LIST_HEADROOM + 4096);
-            GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), ls, false, 2.0));
-            const u32 pcap = (u32)std::min<size_t>(cs.parts[alt].bytes / sizeof(gev_part), 0xfffffff0u);
-            hipLaunchKernelGGL((k_parts<false>), dim3(row_blocks), dim3(256), 0, ls, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
-                               ln.d_cnt.as<u32>(), (const u32*)nullptr, (gev_part*)nullptr, rows, k, nchr, bp0, bpe, 0u, sd);
-            KCHECK();
-            GEVC(scan_u32_on(ls, ln.d_sums, ln.d_cnt.as<u32>(), rows, cs.poff[alt].as<u32>()));
-            hipLaunchKernelGGL((k_parts<true>), dim3(row_blocks), dim3(256), 0, ls, cs.poff[cur].as<u32>(), cs.parts[cur].as<gev_part>(),
-                               (u32*)nullptr, cs.poff[alt].as<u32>(), cs.parts[alt].as<gev_part>(), rows, k, nchr, bp0, bpe, pcap, sd);
-            hipLaunchKernelGGL(k_collect_total, dim3(1), dim3(64), 0, ls, cs.poff[alt].as<u32>(), rows, sd.status + ST_TOTALS + 2 * k + 1);
-            KCHECK();
+            GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), st, false, 2.0));
+            w.poff_cur = cs.poff[cur].as<u32>(); w.parts_cur = cs.parts[cur].as<gev_part>(); w.poff_alt = cs.poff[alt].as<u32>(); w.parts_alt = cs.parts[alt].as<gev_part>();
+            w.pcap = (u32)std::min<size_t>(cs.parts[alt].bytes / sizeof(gev_part), 0xfffffff0u);
         }
+        w.bp0 = S.rbp.front(); w.bp_end = S.rbp.back(); w.chr = k;
+        if (c->dense) {
+            w.plane_alt = cs.plane[alt].as<uint8_t>(); w.plane_cur = cs.plane[cur].as<uint8_t>(); w.snp_pos = S.d_pos.as<u64>();
+            w.stride = S.stride; w.chunks = (u32)(S.stride / 16); w.L = (u32)S.L;
+            // enough workgroups to fill 256 CUs even for small populations; one span >= 4 KiB
+            const size_t units = c->stitch_mode != 1 ? n_parent : rows;
+            u32 bpr = 1;
+            while (units * bpr < 4096 && w.chunks / (bpr * 2) >= 256) bpr *= 2;
+            w.bpr = bpr; bpr_max = std::max(bpr_max, bpr);
+        }
+        cw.push_back(w);
         for (int p = 0; p < c->nphen; p++) {
             CvStatic& V = P.cv[p][k];
-            const u32 nsub = 1 + c->rp_bits;
-            hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows * V.sub_w32 * nsub, 256)), dim3(256), 0, ls,
-                               P.cvp[p][k][alt].as<u32>(), P.cvp[p][k][cur].as<u32>(), V.stride_w32, V.sub_w32, nsub, rows,
-                               V.d_pos_sorted.as<u64>(), V.C, k, nchr, sd);
-            KCHECK();
+            vw.push_back(CvWork{P.cvp[p][k][alt].as<u32>(), P.cvp[p][k][cur].as<u32>(), V.d_pos_sorted.as<u64>(), V.stride_w32, V.sub_w32, V.C, k});
         }
     }
-    GEVC(lanes_join(c));
+    const unsigned na = (unsigned)cw.size();
+    sc.n_chrwork = na; sc.bpr_max = bpr_max;
+    if (na) {
+        GEVC(upload_table(c, sc.chrwork, cw.data(), cw.size() * sizeof(ChrWork), st));
+        GEVC(upload_table(c, sc.cvwork, vw.data(), vw.size() * sizeof(CvWork), st));
+        const ChrWork* Wt = sc.chrwork.as<ChrWork>(); const CvWork* Vt = sc.cvwork.as<CvWork>();
+        // ---- sparse state: mutation lists + ancestry intervals (count -> segmented scan -> fill), CV planes
+        const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
+        const unsigned nseg = c->track_intervals ? 2 * na : na;            // segments [0, na): mutation lists, [na, 2 na): interval lists
+        const size_t seg = rows + 1, nb = ceil_div(rows + 1, SCAN_ITEMS);
+        GEVC(c->d_cnt.ensure((size_t)nseg * seg * sizeof(u32), st)); GEVC(c->d_sums.ensure((size_t)nseg * nb * sizeof(u32), st));
+        u32* cnt = c->d_cnt.as<u32>(); u32* sums = c->d_sums.as<u32>();
+        hipLaunchKernelGGL((k_mutlist<false>), dim3(row_blocks, na), dim3(256), 0, st, Wt, cnt, seg, rows, nchr, (int)has_mut, sd);
+        if (c->track_intervals) hipLaunchKernelGGL((k_parts<false>), dim3(row_blocks, na), dim3(256), 0, st, Wt, cnt + (size_t)na * seg, seg, rows, nchr, sd);
+        hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb, nseg), dim3(256), 0, st, cnt, rows, sums, seg, nb);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1, nseg), dim3(256), 0, st, sums, nb, nb);
+        hipLaunchKernelGGL(k_scan_final_tab, dim3((unsigned)nb, nseg), dim3(256), 0, st, cnt, rows, seg, sums, nb, Wt, na, sd.status);
+        hipLaunchKernelGGL((k_mutlist<true>), dim3(row_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, (int)has_mut, sd);
+        if (c->track_intervals) hipLaunchKernelGGL((k_parts<true>), dim3(row_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, sd);
+        const u32 nsub = 1 + c->rp_bits;
+        size_t max_used = 0;
+        for (const CvWork& v : vw) max_used = std::max<size_t>(max_used, (size_t)v.sub_w32 * nsub);
+        if (max_used) hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows * max_used, 256), (unsigned)vw.size()), dim3(256), 0, st, Vt, nsub, rows, nchr, sd);
+        KCHECK();
+    }
     // ---- gamete grouping by source individual for the parent-major stitch (same for every chromosome)
-    if (c->stitch_mode == 0) {
-        const size_t n_parent = P.n_phys;
+    if (c->stitch_mode != 1) {
+        const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
         GEVC(sc.ghist.ensure((n_parent + 1) * sizeof(u32), st)); GEVC(sc.goff.ensure((n_parent + 1) * sizeof(u32), st));
         GEVC(sc.glist.ensure(rows * sizeof(u32), st));
         HIPC(hipMemsetAsync(sc.ghist.p, 0, (n_parent + 1) * sizeof(u32), st));
@@ -929,35 +933,29 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     HIPC(hipEventRecord(sc.t[2], st));
     return GEV_OK;
 }
-// the HBM-bound part, on stream_big, after the small work of the same generation
+// the HBM-bound part, on stream_big, after the small work of the same generation: ONE launch over (parent, chromosome)
 static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people)
 {
     PopState& P = c->pop[pop];
-    const int nchr = c->nchr, cur = P.cur, alt = P.cur ^ 1;
+    const int nchr = c->nchr;
     const size_t T = n_people * (size_t)nchr, rows = 2 * n_people, n_parent = P.n_phys;
     hipStream_t sb = c->stream_big;
     SampleDev sd = make_sd(c, sc, T);
     HIPC(hipEventRecord(sc.ev_small_done, c->stream));
     HIPC(hipStreamWaitEvent(sb, sc.ev_small_done, 0));
     HIPC(hipEventRecord(sc.t[4], sb));
-    for (int k = 0; k < nchr; k++) {
-        if (!c->chr_active[k] || !c->dense) continue;
-        ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
-        const u32 chunks = (u32)(S.stride / 16);
-        // enough workgroups to fill 256 CUs even for small populations; one span >= 4 KiB
-        const size_t units = c->stitch_mode == 0 ? n_parent : rows;
-        u32 bpr = 1;
-        while (units * bpr < 4096 && chunks / (bpr * 2) >= 256) bpr *= 2;
-        const size_t nblk = units * bpr;
+    if (c->dense && sc.n_chrwork) {
+        const size_t units = c->stitch_mode != 1 ? n_parent : rows;
+        const size_t nblk = units * sc.bpr_max;
         if (nblk > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
         if (c->stitch_mode == 0)
-            hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)nblk), dim3(256), c->stitch_lds_pad, sb,
-                               cs.plane[alt].as<uint8_t>(), cs.plane[cur].as<uint8_t>(), S.stride, chunks, bpr,
-                               S.d_pos.as<u64>(), (u32)S.L, k, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd);
+            hipLaunchKernelGGL((k_stitch_regions<4, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
+                               sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd);
+        else if (c->stitch_mode == 2)
+            hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
+                               sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd);
         else
-            hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)nblk), dim3(STITCH_THREADS), 0, sb,
-                               cs.plane[alt].as<uint8_t>(), cs.plane[cur].as<uint8_t>(), S.stride, chunks, bpr,
-                               S.d_pos.as<u64>(), (u32)S.L, k, nchr, sd);
+            hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)nblk, sc.n_chrwork), dim3(STITCH_THREADS), 0, sb, sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sd);
         KCHECK();
     }
     HIPC(hipEventRecord(sc.t[3], sb));
@@ -1036,7 +1034,7 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
         const double th1 = host_ms();
         GEVC(enqueue_sparse(c, sc, pop, n_people, has_mut));
         const double th2 = host_ms();
-        c->ad_cached_pop = -1;
+        c->ad_cached_pop = c->ad_host_set_pop = -1;
         if (c->eager_ad && c->pop[pop].cv[0][0].d_aptr.p) GEVC(enqueue_ad(c, pop, alt, n_people));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
         HIPC(hipMemcpyAsync(hstatus, sc.status.p, n_status * sizeof(u32), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
@@ -1136,47 +1134,60 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
     if (c->any_inactive) {                                   // chromosomes held elsewhere contribute exact zeros here
         HIPC(hipMemsetAsync(c->d_addchr.p, 0, n * nchr * nphen * sizeof(double), st)); HIPC(hipMemsetAsync(c->d_domchr.p, 0, n * nchr * nphen * sizeof(double), st));
     }
-    GEVC(lanes_fork(c));
+    // one table entry per (phenotype, active chromosome); every kernel below covers all of them in one launch
+    std::vector<AdWork> aw;
+    size_t cvm_words = 0; u32 c_max = 0, sub_max = 0; bool all_have_cv = true;
+    for (int p = 0; p < nphen; p++)
+        for (int k = 0; k < nchr; k++) {
+            if (!c->chr_active[k]) continue;
+            CvStatic& V = P.cv[p][k];
+            cvm_words += rows * V.sub_w32; c_max = std::max(c_max, V.C); sub_max = std::max(sub_max, V.sub_w32); all_have_cv &= V.C > 0;
+        }
+    GEVC(c->d_cvm.ensure(std::max<size_t>(cvm_words * sizeof(u32), 16), st));
+    // fast path: one root population and the block's rows fit LDS; else the general per-individual kernel
+    const u32 S1 = sub_max | 1u;
+    int ipb = 0;
+    if (c->rp_bits == 0 && all_have_cv) { for (int cand : {256, 128, 64}) if ((size_t)2 * cand * S1 * 4 <= 64 * 1024) { ipb = cand; break; } }
+    size_t cvm_off = 0;
     for (int p = 0; p < nphen; p++)
         for (int k = 0; k < nchr; k++) {
             if (!c->chr_active[k]) continue;
             CvStatic& V = P.cv[p][k]; ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
-            gev_ctx::Lane& ln = c->lane[k % c->n_lanes];
-            hipStream_t ls = ln.st;
-            double* ao = c->d_addchr.as<double>() + (size_t)k * nphen + p;
-            double* dout = c->d_domchr.as<double>() + (size_t)k * nphen + p;
-            GEVC(ln.d_cvm.ensure(std::max<size_t>(rows * V.sub_w32 * sizeof(u32), 16), ls));
-            hipLaunchKernelGGL(k_cv_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, ls,
-                               P.cvp[p][k][buf].as<u32>(), V.stride_w32, V.sub_w32, ln.d_cvm.as<u32>(), rows,
-                               cs.moff[buf].as<u32>(), cs.mpos[buf].as<u64>(), V.d_pos_sorted.as<u64>(), V.C);
-            HIPC(hipMemsetAsync(V.d_counts.p, 0, std::max<size_t>(V.C, 1) * sizeof(u32), ls));
-            if (V.C) {
-                const unsigned gy = (unsigned)std::min<size_t>(std::max<size_t>(rows / 512, 1), 256);
-                hipLaunchKernelGGL(k_cv_count, dim3((unsigned)ceil_div(V.C, 256), gy), dim3(256), 0, ls, ln.d_cvm.as<u32>(), V.sub_w32, rows, V.C, V.d_counts.as<u32>());
-            }
-            // fast path: one root population and the block's rows fit LDS; else the general per-individual kernel
-            const u32 S1 = V.sub_w32 | 1u;
-            int ipb = 0;
-            if (c->rp_bits == 0 && V.C) { for (int cand : {256, 128, 64}) if ((size_t)2 * cand * S1 * 4 <= 64 * 1024) { ipb = cand; break; } }
-            if (ipb) {
-                GEVC(V.d_tab.ensure((size_t)V.C * 6 * sizeof(double), ls));
-                hipLaunchKernelGGL(k_cv_table, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, ls, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n,
-                                   V.d_a.as<double>(), V.d_d.as<double>(), V.d_pos_file.as<u64>(), S.rbp.front(), S.rbp.back(), V.vd, V.d_frq.as<double>(), V.d_tab.as<double>());
-                const size_t lds = (size_t)2 * ipb * S1 * 4;
-                const unsigned nb = (unsigned)ceil_div(n, ipb);
-                if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb), dim3(256), lds, ls, ln.d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
-                else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb), dim3(128), lds, ls, ln.d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
-                else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb), dim3(64), lds, ls, ln.d_cvm.as<u32>(), V.sub_w32, V.d_col_of_icv.as<u32>(), V.d_tab.as<double>(), V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
-            } else {
-                if (V.C) hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(V.C, 256)), dim3(256), 0, ls, V.d_counts.as<u32>(), V.d_col_of_icv.as<u32>(), V.C, n, V.d_frq.as<double>());
-                hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ls,
-                                   ln.d_cvm.as<u32>(), V.sub_w32, P.cvp[p][k][buf].as<u32>(), V.stride_w32, c->rp_bits,
-                                   V.d_col_of_icv.as<u32>(), V.d_frq.as<double>(), V.d_aptr.as<const double*>(), V.d_dptr.as<const double*>(), pop,
-                                   V.d_pos_file.as<u64>(), S.rbp.front(), S.rbp.back(), V.vd, V.C, n, ao, dout, (size_t)nchr * nphen, c->d_flag.as<u32>());
-            }
-            KCHECK();
+            if (ipb) GEVC(V.d_tab.ensure((size_t)V.C * 6 * sizeof(double), st));
+            AdWork a{};
+            a.cvp = P.cvp[p][k][buf].as<u32>(); a.moff = cs.moff[buf].as<u32>(); a.mpos = cs.mpos[buf].as<u64>();
+            a.pos_sorted = V.d_pos_sorted.as<u64>(); a.pos_file = V.d_pos_file.as<u64>(); a.col_of_icv = V.d_col_of_icv.as<u32>();
+            a.a = V.d_a.as<double>(); a.d = V.d_d.as<double>(); a.aptr = V.d_aptr.as<const double*>(); a.dptr = V.d_dptr.as<const double*>();
+            a.cvm = c->d_cvm.as<u32>() + cvm_off; cvm_off += rows * V.sub_w32;
+            a.counts = V.d_counts.as<u32>(); a.frq = V.d_frq.as<double>(); a.tab = V.d_tab.as<double>();
+            a.add_out = c->d_addchr.as<double>() + (size_t)k * nphen + p; a.dom_out = c->d_domchr.as<double>() + (size_t)k * nphen + p;
+            a.bp0 = S.rbp.front(); a.bp_end = S.rbp.back(); a.vd = V.vd;
+            a.stride_w32 = V.stride_w32; a.sub_w32 = V.sub_w32; a.C = V.C; a.own_pop = pop;
+            aw.push_back(a);
         }
-    GEVC(lanes_join(c));
+    const unsigned nw = (unsigned)aw.size();
+    if (nw) {
+        GEVC(upload_table(c, c->d_adwork, aw.data(), aw.size() * sizeof(AdWork), st));
+        const AdWork* At = c->d_adwork.as<AdWork>();
+        const size_t out_stride = (size_t)nchr * nphen;
+        hipLaunchKernelGGL(k_cv_apply_mut_tab, dim3((unsigned)ceil_div(rows, 256), nw), dim3(256), 0, st, At, rows);
+        if (c_max) {
+            const unsigned gy = (unsigned)std::min<size_t>(std::max<size_t>(rows / 512, 1), 256);
+            hipLaunchKernelGGL(k_cv_count, dim3((unsigned)ceil_div(c_max, 256), gy, nw), dim3(256), 0, st, At, rows);
+        }
+        if (ipb) {
+            hipLaunchKernelGGL(k_cv_table, dim3((unsigned)ceil_div(c_max, 256), nw), dim3(256), 0, st, At, n);
+            const size_t lds = (size_t)2 * ipb * S1 * 4;
+            const unsigned nb = (unsigned)ceil_div(n, ipb);
+            if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), lds, st, At, n, out_stride, c->d_flag.as<u32>());
+            else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb, nw), dim3(128), lds, st, At, n, out_stride, c->d_flag.as<u32>());
+            else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb, nw), dim3(64), lds, st, At, n, out_stride, c->d_flag.as<u32>());
+        } else {
+            if (c_max) hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(c_max, 256), nw), dim3(256), 0, st, At, n);
+            hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256), nw), dim3(256), 0, st, At, c->rp_bits, n, out_stride, c->d_flag.as<u32>());
+        }
+        KCHECK();
+    }
     hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_addchr.as<double>(), c->d_add.as<double>(), n, nchr, nphen);
     hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_domchr.as<double>(), c->d_dom.as<double>(), n, nchr, nphen);
     KCHECK();
@@ -1260,13 +1271,14 @@ int gev_scale_ad_compute_gef(gev_ctx* c, int pop, int phen, const gev_gef_params
                              const double* common_sibling, const double* f_father, const double* f_mother,
                              double* additive, double* dominance, double* bv, double* e_noise, double* parental_effect, double* phen_out)
 {
-    if (c) GEVC(check_all_active(c, "scale_ad_compute_gef"));
     GEVC(check_idx(c, pop, 0, phen));
+    if (c->any_inactive && c->ad_host_set_pop != pop)
+        return fail(GEV_ESTATE, "scale_ad_compute_gef: this context holds a subset of the chromosomes: give it the all-reduced raw A/D first (gev_set_ad)");
     if (!par) return fail(GEV_EINVAL, "scale_ad_compute_gef: null parameters");
     PopState& P = c->pop[pop];
     if (!P.gen0) return fail(GEV_ESTATE, "scale_ad_compute_gef: population %d has no current generation", pop);
     HIPC(hipSetDevice(c->device));
-    if (c->ad_cached_pop != pop) GEVC(gev_compute_ad(c, pop, nullptr, nullptr, nullptr, nullptr));      // raw A/D of this generation on the device
+    if (c->ad_cached_pop != pop && c->ad_host_set_pop != pop) GEVC(gev_compute_ad(c, pop, nullptr, nullptr, nullptr, nullptr));      // raw A/D of this generation on the device
     hipStream_t st = c->stream;
     const size_t n = P.n_people;
     GEVC(c->d_gef_io.ensure(10 * n * sizeof(double), st));
@@ -1309,6 +1321,25 @@ int gev_scale_ad_compute_gef(gev_ctx* c, int pop, int phen, const gev_gef_params
     return GEV_OK;
 }
 
+// Raw A/D totals of the current generation from the host: a locus-split population's contexts each hold partial sums; after the
+// all-reduce (geneevolve_amd/distributed.py:compute_ad_locus_split) every context is given the totals, and
+// gev_scale_ad_compute_gef then works as on an unsplit context.
+int gev_set_ad(gev_ctx* c, int pop, const double* additive, const double* dominance)
+{
+    GEVC(check_idx(c, pop, 0));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "set_ad: population %d has no current generation", pop);
+    if (!additive || !dominance) return fail(GEV_EINVAL, "set_ad: null array");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t nd = P.n_people * (size_t)c->nphen;
+    GEVC(c->d_add.ensure(nd * sizeof(double), st)); GEVC(c->d_dom.ensure(nd * sizeof(double), st));
+    HIPC(hipMemcpyAsync(c->d_add.p, additive, nd * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(c->d_dom.p, dominance, nd * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));
+    c->ad_host_set_pop = pop;
+    return GEV_OK;
+}
 int gev_get_cv_freq(gev_ctx* c, int pop, int phen, int chr, double* frq, size_t C)
 {
     GEVC(check_idx(c, pop, chr, phen));
@@ -1335,6 +1366,7 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
     if (n_new > D.cap_people) GEVC(ensure_capacity(c, dst, n_new));
     GEVC(c->d_cnt.ensure((rows_new + 1) * sizeof(u32), st));
     for (int k = 0; k < c->nchr; k++) {
+        if (!c->chr_active[k]) continue;                // held by another context of a locus-split population
         ChrStatic& S = D.cs[k]; ChrState& ds = D.st[k];
         for (int pass = 0; pass < 2; pass++) {          // 0: mutation lists, 1: interval lists
             if (pass == 1 && !c->track_intervals) continue;
@@ -1383,9 +1415,10 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
             for (size_t j = 0; j < sg.people.size(); j++) { map[2 * j] = 2 * sg.people[j]; map[2 * j + 1] = 2 * sg.people[j] + 1; }
             GEVC(h2d(c, c->d_map, map.data(), map.size() * sizeof(u32)));
             const u32 chunks = (u32)(S.stride / 16);
-            hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(map.size() * chunks, 256)), dim3(256), 0, st,
-                               (uint4*)(ds.plane[alt].as<uint8_t>() + row0 * S.stride), S.stride / 16,
-                               (const uint4*)Sp.st[k].plane[Sp.cur].p, Sp.cs[k].stride / 16, c->d_map.as<u32>(), map.size(), chunks);
+            if (c->dense)
+                hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(map.size() * chunks, 256)), dim3(256), 0, st,
+                                   (uint4*)(ds.plane[alt].as<uint8_t>() + row0 * S.stride), S.stride / 16,
+                                   (const uint4*)Sp.st[k].plane[Sp.cur].p, Sp.cs[k].stride / 16, c->d_map.as<u32>(), map.size(), chunks);
             for (int p = 0; p < c->nphen; p++) {
                 CvStatic& V = D.cv[p][k];
                 const u32 cch = V.stride_w32 / 4;
@@ -1410,13 +1443,11 @@ static int materialize_order(gev_ctx* c, int pop)
     Seg all; all.src_pop = pop; all.people = P.logical;
     std::vector<Seg> segs; segs.push_back(std::move(all));
     GEVC(gather_population(c, pop, segs, P.n_people));
-    P.cur ^= 1; P.n_phys = P.n_people; P.logical.clear(); c->ad_cached_pop = -1;
+    P.cur ^= 1; P.n_phys = P.n_people; P.logical.clear(); c->ad_cached_pop = c->ad_host_set_pop = -1;
     return GEV_OK;
 }
 int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
 {
-    if (c) GEVC(check_dense(c, "migrate"));
-    if (c) GEVC(check_all_active(c, "migrate"));
     if (!c) return fail(GEV_EINVAL, "null context");
     if (n_moves && !moves) return fail(GEV_EINVAL, "migrate: null moves");
     HIPC(hipSetDevice(c->device));
@@ -1456,7 +1487,7 @@ int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
     for (int p = 0; p < c->n_pop; p++) if (n_new[p] > c->pop[p].cap_people) GEVC(ensure_capacity(c, p, n_new[p]));
     for (int p = 0; p < c->n_pop; p++) GEVC(gather_population(c, p, plan[p], n_new[p]));
     for (int p = 0; p < c->n_pop; p++) { c->pop[p].cur ^= 1; c->pop[p].n_people = n_new[p]; c->pop[p].n_phys = n_new[p]; }
-    c->ad_cached_pop = -1;
+    c->ad_cached_pop = c->ad_host_set_pop = -1;
     return GEV_OK;
 }
 // ---- cross-GPU form of the migration step ---------------------------------------------------
@@ -1470,9 +1501,10 @@ static PackLayout pack_layout(gev_ctx* c, PopState& P, size_t n, const std::vect
 {
     PackLayout L; const int nchr = c->nchr;
     size_t off = 0;
+    // chromosomes this context does not hold (locus-split population) take no space: both ends of an exchange hold the same set
     L.counts = off; off = al16(off + n * nchr * 4 * sizeof(u32));
-    L.planes = off; for (int k = 0; k < nchr; k++) off = al16(off + 2 * n * P.cs[k].stride);
-    L.cv = off; for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) off = al16(off + 2 * n * P.cv[p][k].stride_w32 * sizeof(u32));
+    L.planes = off; for (int k = 0; k < nchr; k++) if (c->chr_active[k] && c->dense) off = al16(off + 2 * n * P.cs[k].stride);
+    L.cv = off; for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) off = al16(off + 2 * n * P.cv[p][k].stride_w32 * sizeof(u32));
     L.mut_chr.assign(nchr, 0); L.parts_chr.assign(nchr, 0);
     for (size_t i = 0; i < n; i++) for (int k = 0; k < nchr; k++) for (int h = 0; h < 2; h++) {
         L.mut_chr[k] += counts[((i * nchr + k) * 2 + h) * 2]; L.parts_chr[k] += counts[((i * nchr + k) * 2 + h) * 2 + 1];
@@ -1500,7 +1532,7 @@ static int export_counts(gev_ctx* c, int pop, const uint64_t* positions, size_t 
     std::vector<u32> tmp(2 * n);
     for (int k = 0; k < nchr; k++)
         for (int pass = 0; pass < 2; pass++) {
-            if (pass == 1 && !c->track_intervals) continue;
+            if (!c->chr_active[k] || (pass == 1 && !c->track_intervals)) continue;
             const u32* soff = pass == 0 ? P.st[k].moff[P.cur].as<u32>() : P.st[k].poff[P.cur].as<u32>();
             hipLaunchKernelGGL(k_csr_gather_count, dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, c->stream, soff, c->d_map.as<u32>(), 2 * n, c->d_cnt.as<u32>());
             KCHECK();
@@ -1512,8 +1544,6 @@ static int export_counts(gev_ctx* c, int pop, const uint64_t* positions, size_t 
 }
 int gev_export_size(gev_ctx* c, int pop, const uint64_t* positions, size_t n, size_t* bytes)
 {
-    if (c) GEVC(check_dense(c, "export_size"));
-    if (c) GEVC(check_all_active(c, "export_size"));
     GEVC(check_idx(c, pop, 0));
     if (!bytes || (n && !positions)) return fail(GEV_EINVAL, "export_size: null argument");
     PopState& P = c->pop[pop];
@@ -1526,8 +1556,6 @@ int gev_export_size(gev_ctx* c, int pop, const uint64_t* positions, size_t n, si
 }
 int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, void* device_buf, size_t bytes)
 {
-    if (c) GEVC(check_dense(c, "export_rows"));
-    if (c) GEVC(check_all_active(c, "export_rows"));
     GEVC(check_idx(c, pop, 0));
     if (n && (!positions || !device_buf)) return fail(GEV_EINVAL, "export_rows: null argument");
     PopState& P = c->pop[pop];
@@ -1547,11 +1575,14 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
     GEVC(c->d_cnt.ensure((2 * n + 1) * sizeof(u32) * 2, st));
     u32* d_off = c->d_cnt.as<u32>() + 2 * n + 1;
     for (int k = 0; k < nchr; k++) {
+        if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         const u32 chunks = (u32)(S.stride / 16);
-        hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, (uint4*)(out + po), S.stride / 16,
-                           (const uint4*)cs.plane[P.cur].p, S.stride / 16, c->d_map.as<u32>(), 2 * n, chunks);
-        po = al16(po + 2 * n * S.stride);
+        if (c->dense) {
+            hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, (uint4*)(out + po), S.stride / 16,
+                               (const uint4*)cs.plane[P.cur].p, S.stride / 16, c->d_map.as<u32>(), 2 * n, chunks);
+            po = al16(po + 2 * n * S.stride);
+        }
         for (int pass = 0; pass < 2; pass++) {
             if (pass == 1 && !c->track_intervals) continue;
             const u32* soff = pass == 0 ? cs.moff[P.cur].as<u32>() : cs.poff[P.cur].as<u32>();
@@ -1565,6 +1596,7 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
         mo = al16(mo + L.mut_chr[k] * sizeof(u64)); pa = al16(pa + L.parts_chr[k] * sizeof(gev_part));
     }
     for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) {
+        if (!c->chr_active[k]) continue;
         CvStatic& V = P.cv[p][k];
         const u32 cch = V.stride_w32 / 4;
         hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(2 * n * cch, 256)), dim3(256), 0, st, (uint4*)(out + co), (size_t)cch,
@@ -1577,8 +1609,6 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
 }
 int gev_remove_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n)
 {
-    if (c) GEVC(check_dense(c, "remove_rows"));
-    if (c) GEVC(check_all_active(c, "remove_rows"));
     GEVC(check_idx(c, pop, 0));
     if (n && !positions) return fail(GEV_EINVAL, "remove_rows: null positions");
     PopState& P = c->pop[pop];
@@ -1592,13 +1622,11 @@ int gev_remove_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n)
     // no row moves: only the logical order changes; stayers keep their order (src/Simulation.cpp:960-966)
     std::vector<u32> keep; keep.reserve(P.n_people - n);
     for (size_t i = 0; i < P.n_people; i++) if (!gone[i]) keep.push_back(P.logical.empty() ? (u32)i : P.logical[i]);
-    P.logical.swap(keep); P.n_people = P.logical.size(); c->ad_cached_pop = -1;
+    P.logical.swap(keep); P.n_people = P.logical.size(); c->ad_cached_pop = c->ad_host_set_pop = -1;
     return GEV_OK;
 }
 int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, size_t n)
 {
-    if (c) GEVC(check_dense(c, "import_rows"));
-    if (c) GEVC(check_all_active(c, "import_rows"));
     GEVC(check_idx(c, pop, 0));
     PopState& P = c->pop[pop];
     if (!P.gen0) return fail(GEV_ESTATE, "import_rows: population %d has no current generation", pop);
@@ -1620,9 +1648,12 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
     GEVC(ensure_capacity(c, pop, n_new));                              // keeps the current buffers' content
     size_t po = L.planes, co = L.cv, mo = L.muts, pa = L.parts;
     for (int k = 0; k < nchr; k++) {
+        if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
-        HIPC(hipMemcpyAsync(cs.plane[P.cur].as<uint8_t>() + r_old * S.stride, in + po, 2 * n * S.stride, hipMemcpyDeviceToDevice, st));
-        po = al16(po + 2 * n * S.stride);
+        if (c->dense) {
+            HIPC(hipMemcpyAsync(cs.plane[P.cur].as<uint8_t>() + r_old * S.stride, in + po, 2 * n * S.stride, hipMemcpyDeviceToDevice, st));
+            po = al16(po + 2 * n * S.stride);
+        }
         for (int pass = 0; pass < 2; pass++) {
             if (pass == 1 && !c->track_intervals) continue;
             size_t& total = pass == 0 ? cs.mut_total[P.cur] : cs.parts_total[P.cur];
@@ -1646,6 +1677,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
         mo = al16(mo + L.mut_chr[k] * sizeof(u64)); pa = al16(pa + L.parts_chr[k] * sizeof(gev_part));
     }
     for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) {
+        if (!c->chr_active[k]) continue;
         CvStatic& V = P.cv[p][k];
         HIPC(hipMemcpyAsync(P.cvp[p][k][P.cur].as<u32>() + r_old * V.stride_w32, in + co, 2 * n * V.stride_w32 * sizeof(u32), hipMemcpyDeviceToDevice, st));
         co = al16(co + 2 * n * V.stride_w32 * sizeof(u32));
@@ -1654,7 +1686,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
     HIPC(hipStreamSynchronize(st));
     if (P.logical.empty()) { P.logical.resize(P.n_people); for (size_t i = 0; i < P.n_people; i++) P.logical[i] = (u32)i; }
     for (size_t i = 0; i < n; i++) P.logical.push_back((u32)(n_old + i));
-    P.n_phys = n_new; P.n_people = P.logical.size(); c->ad_cached_pop = -1;
+    P.n_phys = n_new; P.n_people = P.logical.size(); c->ad_cached_pop = c->ad_host_set_pop = -1;
     return GEV_OK;
 }
 
@@ -1841,19 +1873,31 @@ int gev_download_plink_matrix(gev_ctx* c, int pop, int chr, size_t ind_begin, si
     }
     return GEV_OK;
 }
-// CommFunc::ras_rank on the device (the O(n^2) host loop of assort_mate, src/Simulation.cpp:2278-2279)
+// CommFunc::ras_rank on the device (the O(n^2) host loop of assort_mate, src/Simulation.cpp:2278-2279): stable radix sort of
+// order-preserving keys with the reference's tie / NaN rule (gev_sort.hip); the all-pairs form (k_rank_f64) stays selectable with
+// GEV_RANK_ALLPAIRS=1 as an independent cross-check
+extern "C" size_t gev_rank_scratch_bytes(size_t n);
+extern "C" int gev_rank_device(const double* d_x, size_t n, unsigned long long* d_rank, void* d_tmp, hipStream_t st);
 int gev_rank_f64(gev_ctx* c, const double* x, size_t n, unsigned long long* rank_out)
 {
     if (!c) return fail(GEV_EINVAL, "null context");
     if (n && (!x || !rank_out)) return fail(GEV_EINVAL, "rank_f64: null buffer");
     if (!n) return GEV_OK;
+    if (n >= 0xffffffffull) return fail(GEV_EINVAL, "rank_f64: too many values");
     HIPC(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     GEVC(c->d_tmp.ensure(n * 16, st));
     double* dx = c->d_tmp.as<double>(); unsigned long long* dr = (unsigned long long*)(dx + n);
     HIPC(hipMemcpyAsync(dx, x, n * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_rank_f64, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, dx, n, dr);
-    KCHECK();
+    static const bool allpairs = getenv("GEV_RANK_ALLPAIRS") != nullptr;
+    if (allpairs) {
+        hipLaunchKernelGGL(k_rank_f64, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, dx, n, dr);
+        KCHECK();
+    } else {
+        GEVC(c->d_text.ensure(gev_rank_scratch_bytes(n), st));
+        const int e = gev_rank_device(dx, n, dr, c->d_text.p, st);
+        if (e) return fail(GEV_EDEVICE, "rank_f64: HIP error %s in the sort", hipGetErrorString((hipError_t)e));
+    }
     HIPC(hipMemcpyAsync(rank_out, dr, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
     return GEV_OK;
@@ -2112,7 +2156,7 @@ int gev_set_overlap(gev_ctx* c, int on)
     if (c->overlap_mode >= 0) c->serialize = c->overlap_mode == 0; else { c->serialize = true; c->auto_gens = 0; c->auto_small_ms = c->auto_stitch_ms = 0; }
     return GEV_OK;
 }
-int gev_set_stitch_mode(gev_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return fail(GEV_EINVAL, "stitch mode must be 0 (parent-major) or 1 (gamete-major)"); c->stitch_mode = mode; return GEV_OK; }
+int gev_set_stitch_mode(gev_ctx* c, int mode) { if (!c || mode < 0 || mode > 2) return fail(GEV_EINVAL, "stitch mode must be 0 (parent-major, region form), 1 (gamete-major) or 2 (parent-major, per-chunk form)"); c->stitch_mode = mode; return GEV_OK; }
 
 // ---- diagnostics (tests only; no simulation state involved) --------------------------------
 __global__ void __launch_bounds__(64) k_dbg_rand(const GevRngTables* __restrict__ T, u32 seed, u32 n, int* __restrict__ out)

@@ -166,6 +166,11 @@ int gev_scale_ad_compute_gef(gev_ctx*, int pop, int phen, const gev_gef_params* 
                              double* additive, double* dominance, double* bv, double* e_noise,
                              double* parental_effect, double* phen_out);
 
+/* Locus-split populations (gev_set_chr_active): every context of the population computes the A/D of its own chromosomes; after
+ * the all-reduce + chromosome-ordered sum (geneevolve_amd/distributed.py:compute_ad_locus_split) each context is handed the raw
+ * totals [n_people * nphen] of the current generation, which is what gev_scale_ad_compute_gef scales (:3104-3105). */
+int gev_set_ad(gev_ctx*, int pop, const double* additive, const double* dominance);
+
 /* population allele frequency frq[icv] of the last gev_compute_ad (:2647-2655), FILE order. */
 int gev_get_cv_freq(gev_ctx*, int pop, int phen, int chr, double* frq, size_t C);
 
@@ -263,7 +268,8 @@ int gev_plane_ptr(gev_ctx*, int pop, int chr, void** dptr, size_t* row_stride_by
  * src/Simulation.cpp:2447-2501, runs through every (offspring, chromosome) task), nothing else; their A/D entries come back
  * as exact zeros, so the contexts sharing one population add their per-chromosome arrays (all-reduce) and sum over
  * chromosomes in order (geneevolve_amd/distributed.py:compute_ad_locus_split).  Call before gev_init_gen0.
- * Row movement (migration) and gev_scale_ad_compute_gef are refused on such a context. */
+ * Row movement works on such a context (gev_export_rows / gev_import_rows / gev_migrate carry the active chromosomes only: both
+ * ends of an exchange must hold the same chromosomes); gev_scale_ad_compute_gef needs the all-reduced totals first (gev_set_ad). */
 int gev_set_chr_active(gev_ctx*, int chr, int active);
 /* reserve device capacity for populations of up to max_people (avoids reallocation) */
 int gev_reserve(gev_ctx*, int pop, size_t max_people);
@@ -287,8 +293,8 @@ int gev_last_reproduce_ms(gev_ctx*, float ms[4]);
 int gev_timing_totals(gev_ctx*, double ms_sum[4], unsigned long long* n_generations);
 /* enable/disable keeping the ancestry interval state on the device (default on) */
 int gev_set_track_intervals(gev_ctx*, int on);
-/* dense-stitch kernel: 0 = parent-major k_stitch_parent (default), 1 = gamete-major k_stitch_rows.
- * Same results; kept selectable for A/B measurement and parity cross-checks. */
+/* dense-stitch kernel: 0 = parent-major, region form k_stitch_regions (default), 1 = gamete-major k_stitch_rows, 2 = parent-major,
+ * per-chunk form k_stitch_parent.  Same results; kept selectable for A/B measurement and parity cross-checks. */
 int gev_set_stitch_mode(gev_ctx*, int mode);
 
 /* ---- diagnostics: RNG building blocks exposed for the parity tests (no simulation state) ----

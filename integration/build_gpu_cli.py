@@ -17,6 +17,9 @@ function signatures / the one marker comment, not by line numbers):
                   ras_convert_interval_to_hap_matrix     body -> gevglue_hap_matrix      (--out_hap)
                   ras_convert_interval_to_format_plink   body -> gevglue_plink_matrix    (--out_plink, --out_plink01)
                   ras_write_hap_to_interval_format       body -> gevglue_write_interval  (--out_interval)
+                  assort_mate               the two CommFunc::ras_rank calls -> gevglue_rank (gev_rank_f64: stable sort on the device)
+                  sim_next_generation       + gevglue_presample before the mating of each population (gev_presample; random mating)
+                  ras_scale_AD_compute_GEF  + first statement: with GEV_GEF_DEVICE=1 return gevglue_scale_gef (gev_scale_ad_compute_gef)
 """
 import os
 import re
@@ -78,7 +81,9 @@ def build(out_name, backend_link, extra_sources=()):
             "bool gevglue_migrate(Simulation&, const std::vector<std::vector<unsigned long int> >&, const std::vector<std::vector<unsigned long int> >&);\n"
             "bool gevglue_hap_matrix(Simulation&, int, std::vector<Legend>&, int, Hap_SNP&);\n"
             "bool gevglue_plink_matrix(Simulation&, int, std::vector<Legend>&, int, std::vector<std::vector<bool> >&, plink_PED_ids&, plink_MAP&);\n"
-            "bool gevglue_write_interval(Simulation&, int);\n")
+            "bool gevglue_write_interval(Simulation&, int);\n"
+            "bool gevglue_presample(Simulation&, int, int);\nstd::vector<unsigned long int> gevglue_rank(std::vector<double>&);\n"
+            "bool gevglue_use_device_gef();\nbool gevglue_scale_gef(Simulation&, int, int, int, double, double);\n")
     inc = re.search(r'#include\s+"Simulation.h"', cpp)
     cpp = cpp[:inc.end()] + decl + cpp[inc.end():]
     cpp = insert_before_last_return_true(cpp, r"^bool\s+Simulation::ras_init_parameters\s*\(", "if (!gevglue_init_static(*this)) return false;")
@@ -88,6 +93,20 @@ def build(out_name, backend_link, extra_sources=()):
     cpp = replace_body(cpp, r"^bool\s+Simulation::ras_convert_interval_to_hap_matrix\s*\(", "    return gevglue_hap_matrix(*this, ipop, pops_legend, ichr, hap_snp);")
     cpp = replace_body(cpp, r"^bool\s+Simulation::ras_convert_interval_to_format_plink\s*\(", "    return gevglue_plink_matrix(*this, ipop, pops_legend, ichr, matrix_plink_ped, plink_ped_ids, plink_map);")
     cpp = replace_body(cpp, r"^bool\s+Simulation::ras_write_hap_to_interval_format\s*\(\s*int\s+gen_num\s*\)", "    return gevglue_write_interval(*this, gen_num);")
+    # assort_mate (:2278-2279): the two O(n^2) CommFunc::ras_rank calls on the bivariate-normal template -> device sort
+    i, j = body_span(cpp, r"^bool\s+Simulation::assort_mate\s*\(")
+    body = cpp[i:j]
+    if body.count("CommFunc::ras_rank(") != 2:
+        raise SystemExit("build_gpu_cli: expected two CommFunc::ras_rank calls in assort_mate")
+    cpp = cpp[:i] + body.replace("CommFunc::ras_rank(", "gevglue_rank(") + cpp[j:]
+    # sim_next_generation (:1907): head start for the sampling kernels before the host mates (random mating only)
+    i, j = body_span(cpp, r"^bool\s+Simulation::sim_next_generation\s*\(")
+    body = cpp[i:j]
+    k = body.index("if (population[ipop]._RM)")
+    cpp = cpp[:i] + body[:k] + "if (!gevglue_presample(*this, ipop, gen_num)) return false;\n        " + body[k:] + cpp[j:]
+    # ras_scale_AD_compute_GEF (:3075): optional device version (GEV_GEF_DEVICE=1), else the function's own body
+    i, j = body_span(cpp, r"^bool\s+Simulation::ras_scale_AD_compute_GEF\s*\(")
+    cpp = cpp[:i + 1] + "\n    if (gevglue_use_device_gef()) return gevglue_scale_gef(*this, gen_num, ipop, iphen, s2_a_gen0, s2_d_gen0);\n" + cpp[i + 1:]
     i, j = body_span(cpp, r"^bool\s+Simulation::ras_do_migration\s*\(")
     body = cpp[i:j]
     k = body.index("// remove migrants from the origin population")

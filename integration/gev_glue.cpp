@@ -125,6 +125,61 @@ struct GevGlue {
         return h_ret;
     }
 
+    // Simulation::sim_next_generation, just before the mating of population ipop (:1907): under random mating (one child per
+    // couple, :2146-2151) the offspring count is _pop_size[gen_num-1] and the seeds reproduce() is going to draw are the next
+    // values of glob_generator whatever couples random_mate forms.  Draw them from a COPY of the engine (the real stream is
+    // not advanced: random_mate and reproduce will draw the very same values) and let the GPU sample while the host mates.
+    static bool presample(Simulation& S, int ipop, int gen_num)
+    {
+        Population& P = S.population[ipop];
+        if (!P._RM || P._mutation_map.size() == 0) return true;        // offspring count unknown before mating / serial seed chain
+        std::default_random_engine peek = S.glob_generator;
+        auto draw = [&peek]() { std::uniform_int_distribution<unsigned> d(1, 1000000); return d(peek); };   // == ras_glob_seed (:17-21)
+        draw();                                                        // the draw random_mate makes (:2092)
+        const unsigned seed_rep = draw();                              // :2398
+        const size_t n_people = P._pop_size[gen_num - 1], nchr = P.h[0].chr.size();
+        std::vector<uint32_t> mut_seeds(n_people * nchr);
+        for (size_t t = 0; t < mut_seeds.size(); t++) mut_seeds[t] = draw();      // :2500
+        if (gev_presample(ctx(), ipop, seed_rep, mut_seeds.data(), mut_seeds.size(), n_people)) return fail("gev_presample");
+        return true;
+    }
+
+    // CommFunc::ras_rank (src/CommFunc.cpp:152-161) for assort_mate (:2278-2279): O(n^2) on the host, a stable sort on the device
+    static std::vector<unsigned long int> rank(std::vector<double>& x)
+    {
+        std::vector<unsigned long long> r(x.size());
+        if (gev_rank_f64(ctx(), x.data(), x.size(), r.data())) { fail("gev_rank_f64"); return CommFunc::ras_rank(x); }
+        return std::vector<unsigned long int>(r.begin(), r.end());
+    }
+
+    // Simulation::ras_scale_AD_compute_GEF (:3075-3206) on the device.  Its floats agree with the host's to ~1e-12 relative (device
+    // log(), parallel variance), not bit for bit, so the bound program keeps the host version unless GEV_GEF_DEVICE=1.
+    static bool use_device_gef() { static const bool on = getenv("GEV_GEF_DEVICE") && atoi(getenv("GEV_GEF_DEVICE")) != 0; return on; }
+    static bool scale_gef(Simulation& S, int gen_num, int ipop, int iphen, double s2_a_gen0, double s2_d_gen0)
+    {
+        Population& P = S.population[ipop];
+        const unsigned seed = S.ras_glob_seed();                                        // :3078
+        const size_t n = P.h.size();
+        const Phenotype_scheme& ps = P._pheno_scheme[iphen];
+        gev_gef_params par = {ps._va, ps._vd, ps._ve, ps._vf, ps._beta, s2_a_gen0, s2_d_gen0, gen_num, 0};
+        std::vector<double> cs(n), ff(n, 0.0), fm(n, 0.0), add(n), dom(n), bv(n), e(n), pe(n), phen(n);
+        for (size_t i = 0; i < n; i++) {
+            cs[i] = P.h[i].common_sibling[iphen];
+            if (gen_num > 0) {                                                          // :3118-3131
+                const unsigned long ind_f = P.h[i].ID_Father, ind_m = P.h[i].ID_Mother;
+                if (S._vt_type == 1) { ff[i] = S._Pop_info_prev_gen[ipop].phen[iphen][ind_f]; fm[i] = S._Pop_info_prev_gen[ipop].phen[iphen][ind_m]; }
+                else if (S._vt_type == 2) { ff[i] = S._Pop_info_prev_gen[ipop].parental_effect[iphen][ind_f]; fm[i] = S._Pop_info_prev_gen[ipop].parental_effect[iphen][ind_m]; }
+            }
+        }
+        if (gev_scale_ad_compute_gef(ctx(), ipop, iphen, &par, seed, cs.data(), ff.data(), fm.data(), add.data(), dom.data(), bv.data(), e.data(), pe.data(), phen.data()))
+            return fail("gev_scale_ad_compute_gef");
+        for (size_t i = 0; i < n; i++) {
+            Human& h = P.h[i];
+            h.additive[iphen] = add[i]; h.dominance[iphen] = dom[i]; h.bv[iphen] = bv[i]; h.e_noise[iphen] = e[i]; h.parental_effect[iphen] = pe[i]; h.phen[iphen] = phen[i];
+        }
+        return true;
+    }
+
     // Simulation::ras_compute_AD (:2624-2749)
     static bool compute_AD(Simulation& S, int ipop, int /*gen_num*/)
     {
@@ -238,3 +293,7 @@ std::vector<Human> gevglue_reproduce(Simulation& S, int ipop, int gen_num) { ret
 bool gevglue_compute_AD(Simulation& S, int ipop, int gen_num) { return GevGlue::compute_AD(S, ipop, gen_num); }
 bool gevglue_migrate(Simulation& S, const std::vector<std::vector<unsigned long int> >& a, const std::vector<std::vector<unsigned long int> >& b) { return GevGlue::migrate(S, a, b); }
 bool gevglue_hap_matrix(Simulation& S, int ipop, std::vector<Legend>& pops_legend, int ichr, Hap_SNP& hap_snp) { return GevGlue::hap_matrix(S, ipop, pops_legend, ichr, hap_snp); }
+bool gevglue_presample(Simulation& S, int ipop, int gen_num) { return GevGlue::presample(S, ipop, gen_num); }
+std::vector<unsigned long int> gevglue_rank(std::vector<double>& x) { return GevGlue::rank(x); }
+bool gevglue_use_device_gef() { return GevGlue::use_device_gef(); }
+bool gevglue_scale_gef(Simulation& S, int gen_num, int ipop, int iphen, double s2_a_gen0, double s2_d_gen0) { return GevGlue::scale_gef(S, gen_num, ipop, iphen, s2_a_gen0, s2_d_gen0); }

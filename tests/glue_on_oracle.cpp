@@ -22,7 +22,15 @@ int gevo_download_haps(Ctx*, int, int, size_t, size_t, uint64_t*, size_t);
 int gevo_download_plink_matrix(Ctx*, int, int, size_t, size_t, uint64_t*, size_t);
 int gevo_download_intervals(Ctx*, int, int, gev_part*, uint64_t*, size_t*);
 
+int gevo_rank_f64(Ctx*, const double*, size_t, unsigned long long*);
+int gevo_scale_ad_compute_gef(Ctx*, int, int, const gev_gef_params*, uint32_t, const double*, const double*, const double*, double*, double*, double*, double*, double*, double*);
+
 const char* gev_last_error(void) { return gevo_last_error(); }
+int gev_presample(gev_ctx*, int, uint32_t, const uint32_t*, size_t, size_t) { return 0; }      // a head start only: the oracle samples inside reproduce
+int gev_rank_f64(gev_ctx* c, const double* x, size_t n, unsigned long long* r) { return gevo_rank_f64((Ctx*)c, x, n, r); }
+int gev_scale_ad_compute_gef(gev_ctx* c, int p, int ph, const gev_gef_params* par, uint32_t seed, const double* cs, const double* ff, const double* fm,
+                             double* a, double* d, double* bv, double* e, double* pe, double* phen)
+{ return gevo_scale_ad_compute_gef((Ctx*)c, p, ph, par, seed, cs, ff, fm, a, d, bv, e, pe, phen); }
 int gev_create(gev_ctx** out, int, int n_pop, int nchr, int nphen) { return gevo_create((Ctx**)out, n_pop, nchr, nphen); }
 int gev_set_rmap(gev_ctx* c, int p, int k, const uint64_t* bp, const double* pr, size_t R, uint64_t d) { return gevo_set_rmap((Ctx*)c, p, k, bp, pr, R, d); }
 int gev_set_mutmap(gev_ctx* c, int p, int k, const uint64_t* bp, const double* r, size_t M) { return gevo_set_mutmap((Ctx*)c, p, k, bp, r, M); }

@@ -548,8 +548,67 @@ def genetic_map_fixture():
     print(f"wrote {out}: {os.path.getsize(out)/1e6:.2f} MB")
 
 
+def extra_cases(which):
+    """Cases added after round 1; each has its own RandomState so that it can be regenerated alone:
+        python tests/golden/make_golden.py mig3c c4mini
+      mig3c   two populations x THREE chromosomes, mutation map, migration every generation, parental effect (vf > 0): the
+              fixture of the locus-split + migration test (2 populations x 2 chromosome shards = 4 ranks)
+      c4mini  BASELINE config 4 in miniature: two populations x the 22 autosomes of Recom.Map.b37.50KbDiff (the reference's
+              own map file), assortative mating (mat_cor 0.4, Poisson family sizes), mutation map, migration"""
+    if "mig3c" in which:
+        rs = np.random.RandomState(555)
+        R = 151
+        rbp = (1000 + 100 * np.arange(R)).astype(np.uint64)
+        rcM = np.cumsum(np.r_[0.0, np.full(R - 1, 0.8)])
+        snp = [np.arange(900 + 3 * k, 16200, 11).astype(np.uint64) for k in range(3)]
+        cvbp = [np.sort(rs.choice(np.arange(1000, 16000), size=40, replace=False)).astype(np.uint64) for _ in range(3)]
+        c = Case("mig3c")
+        for ip, n0 in enumerate((100, 90)):
+            nf = 2 * max(n0, 100)
+            founders = [(rs.rand(nf, len(snp[k])) < rs.uniform(0.05, 0.5, len(snp[k]))).astype(np.uint8) for k in range(3)]
+            ph = {"bp": cvbp, "a": [rs.randn(40) for _ in range(3)], "d": [rs.randn(40) * 0.2 for _ in range(3)],
+                  "val": [(rs.rand(nf, 40) < 0.4).astype(np.uint8) for _ in range(3)], "va": 0.5, "vd": 0.1, "ve": 0.3, "vf": 0.1}
+            c.add_pop(chrs=[1, 2, 3], founders=founders, snp_pos=snp, rmap_bp=[rbp] * 3, rmap_cM=[rcM] * 3, phens=[ph], RM=True,
+                      mut_bp=[rbp] * 3, mut_rate=[np.full(R, 0.01)] * 3, popinfo=[f"{n0} 0 p thr 1 1"] * 4)
+        with open(os.path.join(WORK, "mig3c.txt"), "w") as f:
+            for g in range(4):
+                f.write("0.9 0.1 0.15 0.85\n")
+        c.args_extra = ["--file_migration", os.path.join(WORK, "mig3c.txt")]
+        run_case(c, 60606, dense_gens={2, 4})
+    if "c4mini" in which:
+        rs = np.random.RandomState(444)
+        d = os.path.join(WORK, "rmap")
+        with zipfile.ZipFile(os.path.join(REF, "Recom_Map.zip")) as z:
+            z.extract("Recom.Map.b37.50KbDiff", d)
+        m = np.loadtxt(os.path.join(d, "Recom.Map.b37.50KbDiff"), skiprows=1)
+        chrs = list(range(1, 23))
+        rbp = [m[m[:, 0] == k, 1].astype(np.uint64) for k in chrs]
+        rcM = [m[m[:, 0] == k, 2] for k in chrs]
+        L, C = 300, 15
+        snp = [np.sort(rs.randint(int(b[0]), int(b[-1]), L)).astype(np.uint64) for b in rbp]
+        cvbp = [np.sort(rs.randint(int(b[0]), int(b[-1]), C)).astype(np.uint64) for b in rbp]
+        c = Case("c4mini")
+        for ip, n0 in enumerate((70, 60)):
+            nf = 2 * 70
+            founders = [(rs.rand(nf, L) < rs.uniform(0.05, 0.5, L)).astype(np.uint8) for _ in chrs]
+            ph = {"bp": cvbp, "a": [rs.randn(C) for _ in chrs], "d": [np.zeros(C) for _ in chrs],
+                  "val": [(rs.rand(nf, C) < 0.4).astype(np.uint8) for _ in chrs], "va": 0.6, "ve": 0.4}
+            c.add_pop(chrs=chrs, founders=founders, snp_pos=snp, rmap_bp=rbp, rmap_cM=rcM, phens=[ph],
+                      mut_bp=rbp, mut_rate=[np.r_[0.0, np.full(len(b) - 1, 2e-4)] for b in rbp],
+                      popinfo=[f"{n0} 0.4 p logit 1 1"] * 3)
+        with open(os.path.join(WORK, "c4mini.txt"), "w") as f:
+            for g in range(3):
+                f.write("0.9 0.1 0.1 0.9\n")
+        c.args_extra = ["--file_migration", os.path.join(WORK, "c4mini.txt")]
+        run_case(c, 40404, dense_gens={3})
+
+
 def main():
     os.makedirs(WORK, exist_ok=True)
+    if len(sys.argv) > 1:                      # only the named later cases (the round-1 cases below share one RandomState and are made together)
+        sh(["make", "-f", "Makefile.ref", "-j8"], cwd=ORACLE, stdout=subprocess.DEVNULL)
+        extra_cases(set(sys.argv[1:]))
+        return
     genetic_map_fixture()
     sh(["make", "-f", "Makefile.ref", "-j8"], cwd=ORACLE, stdout=subprocess.DEVNULL)
     # ---- KAT
@@ -661,6 +720,7 @@ def main():
     c.add_pop(chrs=[1], founders=[founders], founders_synth_seed=12345, snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph], RM=True,
               mut_bp=[rbp], mut_rate=[np.r_[0.0, np.full(R - 1, 5e-4)]], popinfo=["1000 0 p logit 0 1"] * 10)
     run_case(c, 12345, dense_gens={1, 5, 10}, hash_only_dense=True, keep_parts_gens={1, 10})
+    extra_cases({"mig3c", "c4mini"})
 
 
 if __name__ == "__main__":

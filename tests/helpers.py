@@ -13,6 +13,14 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def load_fixture(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        fx = {k: z[k] for k in z.files}
+    fx["fixture_name"] = np.array(name)
+    return fx
+
+
+def bed_golden():
+    """PLINK .bed bodies packed from the unmodified reference's own .ped01 output files (tests/golden/make_bed_golden.py)"""
+    with np.load(os.path.join(GOLDEN, "bed_from_ref_ped01.npz")) as z:
         return {k: z[k] for k in z.files}
 
 
@@ -218,6 +226,24 @@ def replay_case(lib, fx, gen0_seeds, label, device=-1, float_exact=True, check_l
                 if k + "gt_sha" in fx:
                     assert ctx.pop_size(ip) == int(fx[k + "n_samples"])
                     assert np.array_equal(sha(ctx.format_vcf_gt(ip, ic)), fx[k + "gt_sha"]), f"{label}: VCF sample columns differ from the reference's file (pop {ip} chr {ic})"
+    # PLINK .bed: the reference has no writer, but its own .ped01 file holds the same genotypes as text; the golden bytes are that
+    # file packed per the PLINK specification.  Both device paths must reproduce them: the resident planes (gev_format_bed) and
+    # the interval state + founder tiles (gev_materialize_bed, the output path of plane-less contexts, BASELINE config 5).
+    if ngen == int(fx["n_gen"]) and lib.exports("format_bed"):
+        bed = bed_golden()
+        name = str(fx["fixture_name"])
+        from geneevolve_amd.capi import unpack_rows
+        for ip in range(n_pop):
+            for ic in range(nchr):
+                k = f"{name}_pop{ip}_chr{ic}_bed"
+                if k not in bed:
+                    continue
+                L = len(fx[f"pop{ip}_chr{ic}_snp_pos"])
+                assert tuple(bed[k[:-3] + "shape"]) == (ctx.pop_size(ip), L)
+                assert np.array_equal(ctx.format_bed(ip, ic), bed[k].ravel()), f"{label}: .bed differs from the reference's .ped01 genotypes (pop {ip} chr {ic})"
+                if lib.exports("materialize_bed") and all(f"pop{jp}_chr{ic}_founders" in fx for jp in range(n_pop)):
+                    tiles = [bytes_to_words(fx[f"pop{jp}_chr{ic}_founders"], L) for jp in range(n_pop)]
+                    assert np.array_equal(ctx.materialize_bed(ip, ic, tiles), bed[k].ravel()), f"{label}: .bed from the interval state differs from the reference's .ped01 genotypes (pop {ip} chr {ic})"
     # the reference's own .ped files of the last generation (format_plink::write_ped_map / write_ped01_map)
     if ngen == int(fx["n_gen"]) and lib.exports("format_ped_text"):
         for ip in range(n_pop):

@@ -72,7 +72,7 @@ def test_synth_founders_match_specification(gpu_lib):
     ctx.close()
 
 
-@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full"])
+@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini"])
 def test_gpu_replays_reference_generations_bit_exact(gpu_lib, oracle_lib, case):
     fx = helpers.load_fixture(case)
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
@@ -131,9 +131,15 @@ def test_gpu_vs_oracle_task_parallel_mode(gpu_lib, oracle_lib):
     run_pair(gpu_lib, oracle_lib, cfg, n_gen=5, seed=2024)
 
 
-def test_gamete_major_stitch_kernel_gives_the_same_state(gpu_lib, oracle_lib):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_alternative_stitch_kernels_give_the_same_state(gpu_lib, oracle_lib, mode):
+    """the production stitch is k_stitch_regions (mode 0, every other test); the gamete-major (1) and per-chunk parent-major (2)
+    kernels are independent formulations of the same rule"""
     cfg = SyntheticConfig(300, 5000, nchr=2, chrom_bp=2_000_000, map_step=1000, rec_per_row=5e-3, mut_per_row=5e-3, n_cv=100, seed=12)
-    run_pair(gpu_lib, oracle_lib, cfg, n_gen=3, seed=31, stitch_mode=1)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=3, seed=31, stitch_mode=mode)
+    # many boundaries per row and > 256 boundaries for single gametes (the LDS list of the parent-major kernels overflows)
+    cfg = SyntheticConfig(40, 40000, nchr=1, chrom_bp=4_000_000, map_step=1000, rec_per_row=0.1, mut_per_row=0.05, n_cv=200, seed=3, vd=0.1)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=2, seed=7, stitch_mode=mode)
 
 
 def test_large_families_many_gametes_per_parent(gpu_lib, oracle_lib):
@@ -595,6 +601,18 @@ def test_device_rank_matches_reference_and_oracle(gpu_lib, oracle_lib):
     x = rng.standard_normal(200_000); x[0:199_990:7] = x[3:199_993:7]            # exact ties between different positions
     r = g.rank_f64(x)
     assert np.array_equal(r, ras_rank(x)) and np.array_equal(np.sort(r), np.arange(len(x), dtype=np.uint64))
+    # the reference's comparisons, literally: NaNs, both zeros, infinities, denormals, ties -- against the oracle's O(n^2) pair loop
+    special = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 5e-324, -5e-324, 1.0, -1.0, np.nan, 0.0, -0.0, 1.7976931348623157e308, 2.0, 2.0])
+    for n in (15, 400, 3000):
+        x = special[rng.integers(0, len(special), n)]
+        assert np.array_equal(g.rank_f64(x), o.rank_f64(x)), f"special values, n={n}"
+    # config-4 size and beyond: 10^6 values (the reference's loop would need 5e11 compares); timed for profiles/
+    import time
+    x = rng.standard_normal(1_000_000); x[::5] = x[1::5]
+    g.rank_f64(x[:1000])
+    t0 = time.perf_counter(); r = g.rank_f64(x); dt = time.perf_counter() - t0
+    assert np.array_equal(r, ras_rank(x))
+    print(f"gev_rank_f64: 10^6 doubles in {dt * 1e3:.2f} ms (host to host)")
     g.close(); o.close()
 
 

@@ -111,7 +111,7 @@ def test_recombine_direct_calls(oracle_lib):
         assert list(om) == wm, f"trial {k}: mutation_pos"
 
 
-@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full"])
+@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini"])
 def test_oracle_replays_reference_generations(oracle_lib, case):
     fx = helpers.load_fixture(case)
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
@@ -119,7 +119,7 @@ def test_oracle_replays_reference_generations(oracle_lib, case):
     assert n_dense >= 1
 
 
-@pytest.mark.parametrize("case", ["dense", "ex1sub", "mig2"])
+@pytest.mark.parametrize("case", ["dense", "ex1sub", "mig2", "mig3c", "c4mini"])
 def test_oracle_scale_ad_compute_gef_matches_reference(oracle_lib, case):
     """ras_scale_AD_compute_GEF (src/Simulation.cpp:3075-3206) incl. libstdc++ normal_distribution."""
     fx = helpers.load_fixture(case)

@@ -123,20 +123,20 @@ int main(int argc, char** argv)
     struct Var { const char* name; std::function<void()> run; std::vector<float> ms; };
     std::vector<Var> vars;
 #define ADD(name, ...) vars.push_back({name, [&]() { __VA_ARGS__; }, {}})
-    ADD("prod k_stitch_rows", hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)rows), dim3(256), 0, 0, dst, src, stride, chunks, 1u, dpos, (u32)L, 0, 1, sd));
-    ADD("v U4", hipLaunchKernelGGL((stitch_v<4, false, false, false, 256>), dim3((unsigned)rows), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
-    ADD("v U4 ntLS", hipLaunchKernelGGL((stitch_v<4, true, true, false, 256>), dim3((unsigned)rows), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
-    ADD("v U4 ntLS persist2048", hipLaunchKernelGGL((stitch_v<4, true, true, true, 256>), dim3(2048), dim3(256), 0, 0, dst, src, stride, chunks, (u32)rows, dpos, (u32)L, sd));
-#define PM(name, U, NT, occ) ADD(name, hipLaunchKernelGGL((k_stitch_parent<U, NT>), dim3((unsigned)N), dim3(256), (occ) >= 8 ? 0 : std::min(160 * 1024 / (occ) - 3 * 1024, 64 * 1024 - 2048), 0, dst, src, stride, chunks, 1u, dpos, (u32)L, 0, 1, dgoff, dglist, sd))
-    PM("pm U2 nt occ8", 2, true, 8);
-    PM("pm U2 nt occ6", 2, true, 6);
-    PM("pm U4 nt occ8", 4, true, 8);
-    PM("pm U4 nt occ6", 4, true, 6);
-    PM("pm U4 nt occ5", 4, true, 5);
-    PM("pm U4 nt occ4", 4, true, 4);
-    PM("pm U8 nt occ8", 8, true, 8);
-    PM("pm U8 nt occ4", 8, true, 4);
-    PM("pm U8 nt occ3", 8, true, 3);
+    // one-entry work table (the library builds one entry per active chromosome)
+    ChrWork hw = {}; hw.plane_alt = dst; hw.plane_cur = src; hw.snp_pos = dpos; hw.stride = stride; hw.chunks = chunks; hw.bpr = 1; hw.L = (u32)L; hw.chr = 0;
+    ChrWork* dw; CK(hipMalloc(&dw, sizeof hw)); CK(hipMemcpy(dw, &hw, sizeof hw, hipMemcpyHostToDevice));
+    ADD("rows (gamete-major)", hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)rows), dim3(256), 0, 0, dw, 1u, 1, sd));
+#define PM(name, U, NT, occ) ADD(name, hipLaunchKernelGGL((k_stitch_parent<U, NT>), dim3((unsigned)N), dim3(256), (occ) >= 8 ? 0 : std::min(160 * 1024 / (occ) - 3 * 1024, 64 * 1024 - 2048), 0, dw, 1u, 1, dgoff, dglist, sd))
+#define RG(name, U, NT, occ) ADD(name, hipLaunchKernelGGL((k_stitch_regions<U, NT>), dim3((unsigned)N), dim3(256), (occ) >= 8 ? 0 : std::min(160 * 1024 / (occ) - 6 * 1024, 64 * 1024 - 4096), 0, dw, 1u, 1, dgoff, dglist, sd))
+    PM("parent per-chunk U2 nt", 2, true, 8);
+    RG("regions U2 nt", 2, true, 8);
+    RG("regions U4 nt", 4, true, 8);
+    RG("regions U4 nt occ6", 4, true, 6);
+    RG("regions U4 nt occ4", 4, true, 4);
+    RG("regions U8 nt", 8, true, 8);
+    RG("regions U8 nt occ4", 8, true, 4);
+    RG("regions U4 plain", 4, false, 8);
     ADD("copy U4 nt g2048", hipLaunchKernelGGL((copy_rows<4, true>), dim3(2048), dim3(256), 0, 0, (v4u*)dst, (const v4u*)src, rows * stride / 16));
     ADD("copy U8 g8192", hipLaunchKernelGGL((copy_rows<8, false>), dim3(8192), dim3(256), 0, 0, (v4u*)dst, (const v4u*)src, rows * stride / 16));
     for (int round = 0; round < 6; round++)
