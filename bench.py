@@ -20,7 +20,7 @@ seeds and couples over together).  The founder panel is generated on the device 
 genotype state is resident in HBM throughout.  --plane-less times BASELINE config 5's mode (interval state only,
 no per-generation genotype assembly) and is NOT the headline configuration.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_parent):
+Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_regions):
 algorithmic bytes per launch = 2N rows x (L/8 read + L/8 written) = N*L/2, divided
 by its duration measured with HIP events on the library's own stream.  The kernel reads LESS than
 the algorithmic bytes (a parent's chunk is loaded once for all of its gametes), so `achieved` can
@@ -254,15 +254,24 @@ def main():
         from geneevolve_amd.distributed import migrate_all_to_all
 
     presample = not args.no_presample
+    from concurrent.futures import ThreadPoolExecutor
+    seed_pool = ThreadPoolExecutor(1)                    # the host's second thread: draws seeds while the first waits for the GPU
+
+    def timed_draw():
+        ts = time.perf_counter()
+        v = sim.ras_glob_seed(n_seeds)
+        return v, (time.perf_counter() - ts) * 1e3
 
     def step(i):
         t0 = time.perf_counter()
         sim.couples[P] = synthetic_random_mate(sim.sex[P], args.n_ind, rng, out=sim.couples.get(P))   # host mating (outside the hot path)
         t1 = time.perf_counter()
+        # the next generation's ras_glob_seed() draws (inside the clock): made by a second host thread while this one waits inside
+        # gev_reproduce for the GPU's small kernels, so the values are ready the moment the call returns
+        fut = seed_pool.submit(timed_draw)
         sim.reproduce(P, i + 1, seeds=seeds.pop(i), n_people=args.n_ind)          # Simulation::reproduce
-        ts = time.perf_counter()
-        seeds[i + 1] = sim.ras_glob_seed(n_seeds)                                # the next generation's ras_glob_seed() draws, inside the clock
-        seed_ms.append((time.perf_counter() - ts) * 1e3)
+        seeds[i + 1], dms = fut.result()
+        seed_ms.append(dms)
         if presample:                                                            # ... handed over at once: the GPU samples while the host mates
             sim.presample(P, seeds[i + 1], args.n_ind)
         t2 = time.perf_counter()
@@ -330,7 +339,8 @@ def main():
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_config2_pmc_hbm.json")))       # newest round last
         if pmcs and (args.n_ind, args.n_loci, args.nchr, args.map_step) == (100_000, 1_000_000, 1, 50_000) and not args.plane_less:
-            traffic = json.load(open(pmcs[-1]))["k_stitch_parent_summary"]["hbm_traffic_bytes_per_launch"]
+            pm = json.load(open(pmcs[-1]))
+            traffic = (pm.get("stitch_summary") or pm["k_stitch_parent_summary"])["hbm_traffic_bytes_per_launch"]
             traffic_src = os.path.relpath(pmcs[-1], ROOT)
         # what the memory system really moved per second while the kernel ran: measured bytes / measured time.  The kernel reads a
         # parent chunk once for all of its gametes, so this is BELOW `achieved` (which prices the algorithmic N*L/2 bytes).
@@ -348,14 +358,14 @@ def main():
                        "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_chromosomes": args.nchr, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
                        "interval_state_tracked": not args.no_intervals, "resident_genotype_planes": not args.plane_less,
                        "seeds_handed_over_before_couples": presample,
-                       "ras_glob_seed_draws": "inside the timed loop, one generation's worth per step (host, phase_ms.host_seed_draws)"},
+                       "ras_glob_seed_draws": "inside the timed loop, one generation's worth per step, by a second host thread while the first waits in gev_reproduce (phase_ms.host_seed_draws)"},
             "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci * args.nchr / dt,
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
                          "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "host_seed_draws": float(np.mean(seed_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
                          "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None,
                          "migration_steps": {k: v / args.steps for k, v in mig_parts.items()} if mig_parts else None},
                "host_step_ms": [round(x, 2) for x in step_ms[:args.steps]],
-            "roofline": {"bound": "hbm", "kernel": "k_stitch_parent", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_stitch_regions", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "hbm_actual_GBps": hbm_actual, "hbm_actual_frac": hbm_actual / HBM_PEAK_GBPS if hbm_actual else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": stitch,

@@ -829,35 +829,59 @@ __global__ void __launch_bounds__(256) k_stitch_regions(const ChrWork* __restric
     }
 }
 
-// small planes (CV grid: ~125 B rows): one thread = one 32-bit word of one sub-row
+// small planes (CV grid: ~125 B rows): one HALF-WAVE (32 lanes) per output row.  The lanes first turn the row's breakpoints into
+// CV-column indices in parallel (one binary search per lane, 32 breakpoints per round) and share them with shuffles, then
+// every lane blends its own 32-bit words of the two parental rows; loads and stores are 128-byte coalesced per half-wave.
+#define SMALL_ROWS_PER_BLOCK 256         // 8 half-waves x 32 rounds: the block stages the CV position grid in LDS once
+#define SMALL_POS_LDS 4096               // CV positions held in LDS (32 KiB); longer grids are searched in global memory
 __global__ void __launch_bounds__(256) k_stitch_small(const CvWork* __restrict__ Vt, u32 nsub, size_t n_rows_out, int nchr, SampleDev sd)
 {
+    __shared__ u64 s_pos[SMALL_POS_LDS];
     const CvWork& v = Vt[blockIdx.y];
     u32* __restrict__ dst = v.cvp_alt; const u32* __restrict__ src = v.cvp_cur;
     const u32 stride_w32 = v.stride_w32, sub_w32 = v.sub_w32, Cn = v.C;
-    const u64* __restrict__ pos = v.pos_sorted; const int chr = v.chr;
-    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 used = sub_w32 * nsub;
-    if (q >= n_rows_out * used) return;
-    const u32 row = (u32)(q / used), wq = (u32)(q % used);
-    const u32 w = wq % sub_w32;
-    const u32 i = row >> 1, s = row & 1;
+    const int chr = v.chr;
+    const bool in_lds = Cn <= SMALL_POS_LDS;
+    if (in_lds) for (u32 e = threadIdx.x; e < Cn; e += 256) s_pos[e] = v.pos_sorted[e];
+    __syncthreads();
+    const u64* __restrict__ pos = in_lds ? s_pos : v.pos_sorted;
+    const u32 hl = threadIdx.x & 31u, half0 = threadIdx.x & 32u;          // lane inside the half-wave / first wave lane of the half
+    for (u32 round = 0; round < SMALL_ROWS_PER_BLOCK / 8; round++) {
+    const size_t row = (size_t)blockIdx.x * SMALL_ROWS_PER_BLOCK + round * 8 + (threadIdx.x >> 5);
+    if ((size_t)blockIdx.x * SMALL_ROWS_PER_BLOCK + round * 8 >= n_rows_out) break;      // block-uniform
+    const bool live = row < n_rows_out;                                   // dead halves keep running: their lanes take part in the shuffles
+    const u32 i = live ? (u32)(row >> 1) : 0u, s = (u32)(row & 1);
     const size_t G = 2 * ((size_t)i * nchr + chr) + s;
     const u32 parent = s ? sd.mother[i] : sd.father[i];
     const u32 start = sd.start[G];
-    const u32 k = sd.k[G];
+    const u32 k = live ? sd.k[G] : 0u;
     const u64* bk = sd.bk + sd.bk_off[G];
-    const u32 a = src[(size_t)(2 * parent + start) * stride_w32 + wq];
-    const u32 b = src[(size_t)(2 * parent + (start ^ 1)) * stride_w32 + wq];
-    const u32 bit0 = w * 32u;
-    u32 mask = 0;
-    for (u32 m = 0; m < k; m++) {
-        const u32 id = lower_bound_u64(pos, Cn, bk[m]);
-        u32 t = 0;
-        if (id <= bit0) t = 0xffffffffu; else if (id < bit0 + 32u) t = 0xffffffffu << (id - bit0);
-        mask ^= t;
+    const u32 k_other = (u32)__shfl((int)k, (int)(half0 ^ 32u));
+    const u32 kmax = k > k_other ? k : k_other;                           // wave-uniform trip count
+    const u32* __restrict__ A = src + (size_t)(2 * parent + start) * stride_w32;
+    const u32* __restrict__ B = src + (size_t)(2 * parent + (start ^ 1u)) * stride_w32;
+    u32* __restrict__ D = dst + row * stride_w32;
+    for (u32 w0 = 0; w0 < sub_w32; w0 += 32) {
+        const u32 w = w0 + hl, bit0 = w * 32u;
+        u32 mask = 0;
+        for (u32 m0 = 0; m0 < kmax; m0 += 32) {
+            u32 id = 0xffffffffu;                                         // "never": contributes nothing below
+            if (m0 + hl < k) id = lower_bound_u64(pos, Cn, bk[m0 + hl]);
+            const u32 nm = min(32u, kmax - m0);
+            for (u32 m = 0; m < nm; m++) {
+                const u32 x = (u32)__shfl((int)id, (int)(half0 + m));
+                u32 t = 0;
+                if (x <= bit0) t = 0xffffffffu; else if (x < bit0 + 32u) t = 0xffffffffu << (x - bit0);
+                mask ^= t;
+            }
+        }
+        if (live && w < sub_w32)
+            for (u32 sub = 0; sub < nsub; sub++) {
+                const u32 wq = sub * sub_w32 + w;
+                D[wq] = (A[wq] & ~mask) | (B[wq] & mask);
+            }
     }
-    dst[(size_t)row * stride_w32 + wq] = (a & ~mask) | (b & mask);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -992,12 +1016,32 @@ __global__ void __launch_bounds__(256) k_cv_apply_mut(
     if (row < n_rows) cv_apply_mut_row(plane, stride_w32, sub_w32, out, row, m_off, m_pos, cvpos_sorted, Cn);
 }
 // all (phenotype, chromosome) pairs of a population in one launch (blockIdx.y); also clears the column counters of the pair
+// Step 1 (coalesced): the allele sub-rows of the block's 256 haplotype rows are copied word by word (consecutive lanes =
+// consecutive words); step 2: one thread per row flips the CVs that are in the row's mutation set (few rows have any).
 __global__ void __launch_bounds__(256) k_cv_apply_mut_tab(const AdWork* __restrict__ At, size_t n_rows)
 {
     const AdWork& a = At[blockIdx.y];
-    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0) for (u32 c = threadIdx.x; c < a.C; c += blockDim.x) a.counts[c] = 0;     // k_cv_count (next launch) accumulates into them
-    if (row < n_rows) cv_apply_mut_row(a.cvp, a.stride_w32, a.sub_w32, a.cvm, row, a.moff, a.mpos, a.pos_sorted, a.C);
+    const size_t row0 = (size_t)blockIdx.x * 256;
+    if (blockIdx.x == 0) for (u32 c = threadIdx.x; c < a.C; c += 256) a.counts[c] = 0;     // k_cv_count (next launch) accumulates into them
+    const u32 sw = a.sub_w32;
+    const size_t n_here = min((size_t)256, n_rows - row0);
+    for (size_t e = threadIdx.x; e < n_here * sw; e += 256) {
+        const size_t r = e / sw; const u32 w = (u32)(e - r * sw);
+        a.cvm[(row0 + r) * sw + w] = a.cvp[(row0 + r) * a.stride_w32 + w];
+    }
+    __syncthreads();                                     // the flips below go to the rows this block has just written
+    const size_t row = row0 + threadIdx.x;
+    if (row >= n_rows) return;
+    const u32* in = a.cvp + row * a.stride_w32;
+    u32* o = a.cvm + row * sw;
+    for (u32 j = a.moff[row]; j < a.moff[row + 1]; j++) {
+        const u64 x = a.mpos[j];
+        u32 c = lower_bound_u64(a.pos_sorted, a.C, x);
+        for (; c < a.C && a.pos_sorted[c] == x; c++) {              // set semantics: flipped = !founder, idempotent
+            const u32 f = (in[c >> 5] >> (c & 31)) & 1u;
+            if (f) o[c >> 5] &= ~(1u << (c & 31)); else o[c >> 5] |= (1u << (c & 31));
+        }
+    }
 }
 // allele counts per CV column (sorted order): f = sum_ih cv0+cv1 (:2647-2655), exact integers
 __global__ void __launch_bounds__(256) k_cv_count(const AdWork* __restrict__ At, size_t n_rows)
@@ -1109,13 +1153,16 @@ __global__ void k_cv_table(const AdWork* __restrict__ At, size_t n_human)
 // One thread per individual; the block's 2*IPB haplotype rows are staged through LDS with a
 // coalesced read ([hap][individual][S+1] layout: row stride S+1 words is odd -> conflict-free
 // column reads).  col_of_icv / tab are wave-uniform (scalar loads); t selects per lane.
+#define AD_CHUNK 128          // CVs whose table entries sit in LDS at a time
 template <int IPB>
-__global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restrict__ At, size_t n_human, size_t out_stride, u32* __restrict__ nan_flag)
+__global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restrict__ At, u32 s1_max, size_t n_human, size_t out_stride, u32* __restrict__ nan_flag)
 {
-    extern __shared__ u32 s_rows[];
+    extern __shared__ u32 s_rows[];                              // [2 * IPB * s1_max] rows | [AD_CHUNK] columns | [AD_CHUNK * 6] table (8-byte aligned)
     const AdWork& aw = At[blockIdx.y];
     const u32* __restrict__ cvm = aw.cvm; const u32 sub_w32 = aw.sub_w32; const u32* __restrict__ col_of_icv = aw.col_of_icv;
     const double* __restrict__ tab = aw.tab; const u32 Cn = aw.C; double* __restrict__ add_out = aw.add_out; double* __restrict__ dom_out = aw.dom_out;
+    u32* s_col = s_rows + (((size_t)2 * IPB * s1_max + 1) & ~(size_t)1);
+    double* s_tab = (double*)(s_col + AD_CHUNK);
     const u32 S1 = sub_w32 | 1u;                                 // odd row stride
     const size_t ih0 = (size_t)blockIdx.x * IPB;
     const size_t n_here = min((size_t)IPB, n_human - ih0);
@@ -1125,28 +1172,34 @@ __global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restr
         const u32 row = e / sub_w32, w = e - row * sub_w32;     // row = 2*local_individual + hap
         s_rows[((row & 1u) * IPB + (row >> 1)) * S1 + w] = src[e];
     }
-    __syncthreads();
-    const bool live = threadIdx.x < n_here;                      // idle lanes still take part in the broadcasts
+    const bool live = threadIdx.x < n_here;
     const u32* r0 = s_rows + (size_t)threadIdx.x * S1;
     const u32* r1 = s_rows + ((size_t)IPB + threadIdx.x) * S1;
+    // vd == 0: the reference zeroes d (:2698-2699), every D-term is (+-0) * ... = +-0 and the running sum stays +0.0
+    const bool skip_d = aw.vd == 0;
     double A_chr = 0, D_chr = 0;
-    // col_of_icv / tab are the same for every lane: lane j of the wave fetches CV (base+j)'s entries with one
-    // coalesced load and the inner loop broadcasts them (no dependent scalar load per CV)
-    const u32 lane = threadIdx.x & 63;
-    for (u32 base = 0; base < Cn; base += 64) {
-        const u32 mine = min(base + lane, Cn - 1);
-        const u32 c_l = col_of_icv[mine];
-        double tb[6];
-#pragma unroll
-        for (int e = 0; e < 6; e++) tb[e] = tab[6 * (size_t)mine + e];
-        const u32 nj = min(64u, Cn - base);
-        for (u32 j = 0; j < nj; j++) {
-            const u32 c = rl_u32(c_l, j);
-            const u32 t = ((r0[c >> 5] >> (c & 31)) & 1u) + ((r1[c >> 5] >> (c & 31)) & 1u);
-            const double a0 = rl_f64(tb[0], j), a1 = rl_f64(tb[1], j), a2 = rl_f64(tb[2], j);
-            const double d0 = rl_f64(tb[3], j), d1 = rl_f64(tb[4], j), d2 = rl_f64(tb[5], j);
-            A_chr += (t == 0) ? a0 : (t == 1 ? a1 : a2);
-            D_chr += (t == 0) ? d0 : (t == 1 ? d1 : d2);
+    for (u32 base = 0; base < Cn; base += AD_CHUNK) {
+        const u32 nj = min((u32)AD_CHUNK, Cn - base);
+        __syncthreads();                                         // rows staged / previous chunk consumed
+        for (u32 e = threadIdx.x; e < nj; e += IPB) s_col[e] = col_of_icv[base + e];
+        for (u32 e = threadIdx.x; e < nj * 6; e += IPB) s_tab[e] = tab[6 * (size_t)base + e];
+        __syncthreads();
+        // CVs in FILE order, sequential FP64 adds; the per-CV term is picked from the LDS table by the genotype t (0, 1, 2)
+        if (skip_d) {
+#pragma unroll 4
+            for (u32 j = 0; j < nj; j++) {
+                const u32 c = s_col[j];
+                const u32 t = ((r0[c >> 5] >> (c & 31)) & 1u) + ((r1[c >> 5] >> (c & 31)) & 1u);
+                A_chr += s_tab[6 * j + t];
+            }
+        } else {
+#pragma unroll 4
+            for (u32 j = 0; j < nj; j++) {
+                const u32 c = s_col[j];
+                const u32 t = ((r0[c >> 5] >> (c & 31)) & 1u) + ((r1[c >> 5] >> (c & 31)) & 1u);
+                A_chr += s_tab[6 * j + t];
+                D_chr += s_tab[6 * j + 3 + t];
+            }
         }
     }
     if (!live) return;

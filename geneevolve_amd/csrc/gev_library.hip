@@ -162,7 +162,7 @@ struct gev_ctx {
     // while sampling / sparse state of generation g+1 (stream) fill the other one
     struct Scratch {
         DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, ghist, goff, glist, status, slow_mut, slow_rec, chrwork, cvwork;
-        unsigned n_chrwork = 0, bpr_max = 1;
+        unsigned n_chrwork = 0, bpr_max = 1; bool long_rows = false;
         hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         bool timing_pending = false, stitch_pending = false;
         // gev_presample: the sampling kernels of the next gev_reproduce were already enqueued for exactly these inputs
@@ -894,6 +894,9 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     }
     const unsigned na = (unsigned)cw.size();
     sc.n_chrwork = na; sc.bpr_max = bpr_max;
+    size_t chunk_sum = 0;
+    for (const ChrWork& w : cw) chunk_sum += w.chunks / std::max(w.bpr, 1u);
+    sc.long_rows = na && chunk_sum / na >= 4096;
     if (na) {
         GEVC(upload_table(c, sc.chrwork, cw.data(), cw.size() * sizeof(ChrWork), st));
         GEVC(upload_table(c, sc.cvwork, vw.data(), vw.size() * sizeof(CvWork), st));
@@ -914,7 +917,7 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         const u32 nsub = 1 + c->rp_bits;
         size_t max_used = 0;
         for (const CvWork& v : vw) max_used = std::max<size_t>(max_used, (size_t)v.sub_w32 * nsub);
-        if (max_used) hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows * max_used, 256), (unsigned)vw.size()), dim3(256), 0, st, Vt, nsub, rows, nchr, sd);
+        if (max_used) hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows, SMALL_ROWS_PER_BLOCK), (unsigned)vw.size()), dim3(256), 0, st, Vt, nsub, rows, nchr, sd);
         KCHECK();
     }
     // ---- gamete grouping by source individual for the parent-major stitch (same for every chromosome)
@@ -948,8 +951,11 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         const size_t units = c->stitch_mode != 1 ? n_parent : rows;
         const size_t nblk = units * sc.bpr_max;
         if (nblk > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
-        if (c->stitch_mode == 0)
+        if (c->stitch_mode == 0 && sc.long_rows)          // 4 chunks per thread in flight pay off on long rows; short rows (< 4096 chunks = 64 KiB) lose lanes to the tail
             hipLaunchKernelGGL((k_stitch_regions<4, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
+                               sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd);
+        else if (c->stitch_mode == 0)
+            hipLaunchKernelGGL((k_stitch_regions<2, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
                                sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd);
         else if (c->stitch_mode == 2)
             hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
@@ -1033,6 +1039,8 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
         if (!(pre && attempt == 0)) GEVC(enqueue_sampling(c, sc, pop, n_people, has_mut, (u32)seed_reproduce));
         const double th1 = host_ms();
         GEVC(enqueue_sparse(c, sc, pop, n_people, has_mut));
+        // the dense stitch needs the sampling + sparse results only: it starts now, on its own stream, next to A/D (not waited for)
+        GEVC(enqueue_stitch(c, sc, pop, n_people));
         const double th2 = host_ms();
         c->ad_cached_pop = c->ad_host_set_pop = -1;
         if (c->eager_ad && c->pop[pop].cv[0][0].d_aptr.p) GEVC(enqueue_ad(c, pop, alt, n_people));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
@@ -1045,6 +1053,8 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
         for (int k = 0; k < nchr; k++) { P.st[k].mut_total[alt] = hstatus[ST_TOTALS + 2 * k]; P.st[k].parts_total[alt] = hstatus[ST_TOTALS + 2 * k + 1]; }
         if (!flags) break;
         if (attempt == 3) return fail(GEV_EDEVICE, "reproduce: buffers still too small after %d attempts (flags %u)", attempt + 1, flags);
+        HIPC(hipStreamSynchronize(c->stream_big));        // the stitch of the failed attempt still reads the records that are sampled again below
+        sc.timing_pending = false; sc.stitch_pending = false;   // (its kernel times are not counted)
         if (flags & FLAG_BK_OVF) c->bk_ovf_cap = std::max<size_t>(2 * c->bk_ovf_cap, (size_t)hstatus[ST_BK_OVF_USED] * 5 / 4 + 1024);
         if (flags & FLAG_NM_OVF) c->nm_ovf_cap = std::max<size_t>(2 * c->nm_ovf_cap, (size_t)hstatus[ST_NM_OVF_USED] * 5 / 4 + 1024);
         for (int k = 0; k < nchr; k++) {     // exact needs from the count passes (valid unless a record overflow zeroed some counts: then next attempt refines)
@@ -1057,7 +1067,6 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = ad_done;
     if (ad_done) c->ad_cached_pop = pop;
     if (sex_out) { HIPC(hipMemcpyAsync(sex_out, sc.sex.p, n_people, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st)); }
-    GEVC(enqueue_stitch(c, sc, pop, n_people));          // not waited for
     P.cur = alt; P.n_people = n_people; P.n_phys = n_people; P.logical.clear();
     c->gen_counter++;
     return GEV_OK;
@@ -1147,7 +1156,8 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
     // fast path: one root population and the block's rows fit LDS; else the general per-individual kernel
     const u32 S1 = sub_max | 1u;
     int ipb = 0;
-    if (c->rp_bits == 0 && all_have_cv) { for (int cand : {256, 128, 64}) if ((size_t)2 * cand * S1 * 4 <= 64 * 1024) { ipb = cand; break; } }
+    const size_t ad_tab_lds = AD_CHUNK * 4 + AD_CHUNK * 6 * 8 + 8;          // column + table chunk behind the rows
+    if (c->rp_bits == 0 && all_have_cv) { for (int cand : {256, 128, 64}) if ((size_t)2 * cand * S1 * 4 + ad_tab_lds <= 64 * 1024) { ipb = cand; break; } }
     size_t cvm_off = 0;
     for (int p = 0; p < nphen; p++)
         for (int k = 0; k < nchr; k++) {
@@ -1177,11 +1187,11 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
         }
         if (ipb) {
             hipLaunchKernelGGL(k_cv_table, dim3((unsigned)ceil_div(c_max, 256), nw), dim3(256), 0, st, At, n);
-            const size_t lds = (size_t)2 * ipb * S1 * 4;
+            const size_t lds = (size_t)2 * ipb * S1 * 4 + ad_tab_lds;
             const unsigned nb = (unsigned)ceil_div(n, ipb);
-            if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), lds, st, At, n, out_stride, c->d_flag.as<u32>());
-            else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb, nw), dim3(128), lds, st, At, n, out_stride, c->d_flag.as<u32>());
-            else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb, nw), dim3(64), lds, st, At, n, out_stride, c->d_flag.as<u32>());
+            if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>());
+            else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb, nw), dim3(128), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>());
+            else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb, nw), dim3(64), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>());
         } else {
             if (c_max) hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(c_max, 256), nw), dim3(256), 0, st, At, n);
             hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256), nw), dim3(256), 0, st, At, c->rp_bits, n, out_stride, c->d_flag.as<u32>());

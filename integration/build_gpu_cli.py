@@ -19,6 +19,8 @@ function signatures / the one marker comment, not by line numbers):
                   ras_write_hap_to_interval_format       body -> gevglue_write_interval  (--out_interval)
                   assort_mate               the two CommFunc::ras_rank calls -> gevglue_rank (gev_rank_f64: stable sort on the device)
                   sim_next_generation       + gevglue_presample before the mating of each population (gev_presample; random mating)
+                  ras_init_generation0 / sim_next_generation   population[ipop].ras_save_human_info(gen_num) -> gevglue_save_human_info
+                                            (the same .info bytes, written once instead of flushed per individual)
                   ras_scale_AD_compute_GEF  + first statement: with GEV_GEF_DEVICE=1 return gevglue_scale_gef (gev_scale_ad_compute_gef)
 """
 import os
@@ -82,6 +84,7 @@ def build(out_name, backend_link, extra_sources=()):
             "bool gevglue_hap_matrix(Simulation&, int, std::vector<Legend>&, int, Hap_SNP&);\n"
             "bool gevglue_plink_matrix(Simulation&, int, std::vector<Legend>&, int, std::vector<std::vector<bool> >&, plink_PED_ids&, plink_MAP&);\n"
             "bool gevglue_write_interval(Simulation&, int);\n"
+            "bool gevglue_save_human_info(Simulation&, int, int);\n"
             "bool gevglue_presample(Simulation&, int, int);\nstd::vector<unsigned long int> gevglue_rank(std::vector<double>&);\n"
             "bool gevglue_use_device_gef();\nbool gevglue_scale_gef(Simulation&, int, int, int, double, double);\n")
     inc = re.search(r'#include\s+"Simulation.h"', cpp)
@@ -107,6 +110,11 @@ def build(out_name, backend_link, extra_sources=()):
     # ras_scale_AD_compute_GEF (:3075): optional device version (GEV_GEF_DEVICE=1), else the function's own body
     i, j = body_span(cpp, r"^bool\s+Simulation::ras_scale_AD_compute_GEF\s*\(")
     cpp = cpp[:i + 1] + "\n    if (gevglue_use_device_gef()) return gevglue_scale_gef(*this, gen_num, ipop, iphen, s2_a_gen0, s2_d_gen0);\n" + cpp[i + 1:]
+    # Population::ras_save_human_info call sites (:610, :2018): same bytes, one write instead of one flush per individual
+    n_calls = cpp.count("population[ipop].ras_save_human_info(gen_num);")
+    if n_calls != 2:
+        raise SystemExit(f"build_gpu_cli: expected two ras_save_human_info call sites, found {n_calls}")
+    cpp = cpp.replace("population[ipop].ras_save_human_info(gen_num);", "gevglue_save_human_info(*this, ipop, gen_num);")
     i, j = body_span(cpp, r"^bool\s+Simulation::ras_do_migration\s*\(")
     body = cpp[i:j]
     k = body.index("// remove migrants from the origin population")

@@ -180,6 +180,41 @@ struct GevGlue {
         return true;
     }
 
+    // Population::ras_save_human_info (src/Population.cpp:510-568), the per-generation .info text dump -- after the GPU took over
+    // the genotype work this is the longest host phase of a generation (tools/cli_timing.py: 0.18 of 0.25 s at 100k individuals),
+    // because the reference ends every line with std::endl (one flush = one write() per individual).  Same bytes (default
+    // ostream formatting of a double = "%g", 6 significant digits; ids printed 1-based), built in memory and written once.
+    static bool save_human_info(Simulation& S, int ipop, int gen_num)
+    {
+        Population& P = S.population[ipop];
+        const int npheno = (int)P._pheno_scheme.size();
+        std::string out;
+        out.reserve(P.h.size() * (64 + 90 * (size_t)npheno) + 256);
+        out += "ID ID_Father ID_Mother ID_Fathers_Father ID_Fathers_Mother ID_Mothers_Father ID_Mothers_Mother sex ";
+        for (int j = 0; j < npheno; j++) {
+            const std::string ph = "ph" + std::to_string(j + 1);
+            for (const char* c : {"_A ", "_D ", "_G ", "_C ", "_E ", "_F ", "_P "}) out += ph + c;
+        }
+        out += "MV SV SV_f\n";
+        char buf[64];
+        auto num = [&](double v, char end) { const int n = snprintf(buf, sizeof buf, "%g", v); out.append(buf, (size_t)n); out.push_back(end); };
+        auto id = [&](unsigned long v) { const int n = snprintf(buf, sizeof buf, "%lu ", v); out.append(buf, (size_t)n); };
+        for (size_t i = 0; i < P.h.size(); i++) {
+            const Human& h = P.h[i];
+            id(h.ID + 1); id(h.ID_Father + 1); id(h.ID_Mother + 1); id(h.ID_Fathers_Father + 1); id(h.ID_Fathers_Mother + 1);
+            id(h.ID_Mothers_Father + 1); id(h.ID_Mothers_Mother + 1);
+            { const int n = snprintf(buf, sizeof buf, "%d ", (int)h.sex); out.append(buf, (size_t)n); }
+            for (int j = 0; j < npheno; j++) {
+                num(h.additive[j], ' '); num(h.dominance[j], ' '); num(h.bv[j], ' '); num(h.common_sibling[j], ' ');
+                num(h.e_noise[j], ' '); num(h.parental_effect[j], ' '); num(h.phen[j], ' ');
+            }
+            num(h.mating_value, ' '); num(h.selection_value, ' '); num(h.selection_value_func, '\n');
+        }
+        std::ofstream f((P._out_prefix + ".info.pop" + std::to_string(P._pop_num + 1) + ".gen" + std::to_string(gen_num) + ".txt").c_str(), std::ios::binary);
+        f.write(out.data(), (std::streamsize)out.size());
+        return true;
+    }
+
     // Simulation::ras_compute_AD (:2624-2749)
     static bool compute_AD(Simulation& S, int ipop, int /*gen_num*/)
     {
@@ -294,6 +329,7 @@ bool gevglue_compute_AD(Simulation& S, int ipop, int gen_num) { return GevGlue::
 bool gevglue_migrate(Simulation& S, const std::vector<std::vector<unsigned long int> >& a, const std::vector<std::vector<unsigned long int> >& b) { return GevGlue::migrate(S, a, b); }
 bool gevglue_hap_matrix(Simulation& S, int ipop, std::vector<Legend>& pops_legend, int ichr, Hap_SNP& hap_snp) { return GevGlue::hap_matrix(S, ipop, pops_legend, ichr, hap_snp); }
 bool gevglue_presample(Simulation& S, int ipop, int gen_num) { return GevGlue::presample(S, ipop, gen_num); }
+bool gevglue_save_human_info(Simulation& S, int ipop, int gen_num) { return GevGlue::save_human_info(S, ipop, gen_num); }
 std::vector<unsigned long int> gevglue_rank(std::vector<double>& x) { return GevGlue::rank(x); }
 bool gevglue_use_device_gef() { return GevGlue::use_device_gef(); }
 bool gevglue_scale_gef(Simulation& S, int gen_num, int ipop, int iphen, double s2_a_gen0, double s2_d_gen0) { return GevGlue::scale_gef(S, gen_num, ipop, iphen, s2_a_gen0, s2_d_gen0); }

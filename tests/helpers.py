@@ -45,7 +45,7 @@ def find_gen0_seeds(fx, oracle_lib):
     return seeds
 
 
-def setup_static(ctx, fx, only_chr=None):
+def setup_static(ctx, fx, only_chr=None, snp_founders=True):
     """ras_init_parameters equivalent: maps, SNP/CV grids, founder panels.  only_chr: the chromosomes whose genotype / CV
     inputs this context is given (locus-split populations); the others get their maps only."""
     n_pop, nchr, nphen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"])
@@ -60,7 +60,9 @@ def setup_static(ctx, fx, only_chr=None):
                 continue
             pos = fx[f"{pre}chr{ic}_snp_pos"]
             ctx.set_snps(ip, ic, pos)
-            if f"{pre}chr{ic}_founders" in fx:
+            if not snp_founders:                     # plane-less contexts keep no genotype matrix: founder tiles are passed to gev_materialize
+                pass
+            elif f"{pre}chr{ic}_founders" in fx:
                 ctx.upload_founders(ip, ic, bytes_to_words(fx[f"{pre}chr{ic}_founders"], len(pos)), len(pos))
             else:
                 ctx.upload_founders(ip, ic, synth_packed(int(fx[f"{pre}chr{ic}_founders_synth_seed"]), nh, len(pos)), len(pos))
@@ -80,8 +82,8 @@ def derive_moves(fx, g):
     return [tuple(int(x) for x in m) for m in fx[f"g{g}_moves"]]
 
 
-def compare_lists(ctx, fx, key_prefix, ip, nchr, label):
-    for ic in range(nchr):
+def compare_lists(ctx, fx, key_prefix, ip, nchr, label, chrs=None):
+    for ic in (range(nchr) if chrs is None else chrs):
         parts, off = ctx.download_intervals(ip, ic)
         muts, moff = ctx.download_mutations(ip, ic)
         got = np.stack([parts["st"].astype(np.int64), parts["en"].astype(np.int64), parts["hap_index"].astype(np.int64),
@@ -99,9 +101,9 @@ def compare_lists(ctx, fx, key_prefix, ip, nchr, label):
             assert np.array_equal(sha(muts), fx[k + "muts_sha"]), f"{label}: mutation lists hash (chr {ic})"
 
 
-def compare_dense(ctx, fx, g, ip, nchr, label):
+def compare_dense(ctx, fx, g, ip, nchr, label, chrs=None):
     checked = 0
-    for ic in range(nchr):
+    for ic in (range(nchr) if chrs is None else chrs):
         L = len(fx[f"pop{ip}_chr{ic}_snp_pos"])
         k = f"g{g}_pop{ip}_chr{ic}_dense"
         if k in fx or k + "_sha" in fx:
@@ -294,7 +296,7 @@ def check_ped_files(ctx, fx, ngen, ip, ic, label):
 from geneevolve_amd.host import comm_mean, comm_var, selection_func  # noqa: E402  (host mirror of CommFunc::mean/var, ras_selection_func)
 
 
-def closed_loop_case(lib, fx, label, device=-1, exact=True):
+def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at_end=None, info_texts=None):
     """Simulation::run for a single-population fixture, driven from the seed ALONE: ras_glob_seed() stream, gen-0 founders,
     ras_compute_AD, ras_scale_AD_compute_GEF (every phenotype, parental effect with the adjusted beta), mating / selection
     values, random_mate or assort_mate (device rank), reproduce -- every generation's couples, sexes, pedigree, raw A/D,
@@ -304,7 +306,9 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
     assert int(fx["n_pop"]) == 1
     nchr, nphen, ngen, rm = int(fx["nchr"]), int(fx["nphen"]), int(fx["n_gen"]), bool(int(fx["pop0_rm"]))
     ctx = lib.create(1, nchr, nphen, device) if lib.has_device_arg else lib.create(1, nchr, nphen)
-    setup_static(ctx, fx)
+    if plane_less:                                   # BASELINE config 5's mode: interval state only, genotypes materialised on demand
+        ctx.set_dense_state(False)
+    setup_static(ctx, fx, snp_founders=not plane_less)
     var = [[float(v) for v in fx[f"pop0_ph{p}_var"]] for p in range(nphen)]       # va, vd, ve, vf
     vc = [float(fx[f"pop0_ph{p}_vc"]) if f"pop0_ph{p}_vc" in fx else 0.0 for p in range(nphen)]
     beta = [1.0] * nphen                                                          # parameters.cpp default; adjusted after generation 0
@@ -348,6 +352,8 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
 
     def check_info_file(g, outs, mv, z, svf):
         """Population::ras_save_human_info: the reference's .info.popK.genG.txt, byte for byte (exact builds only)"""
+        if info_texts is not None:                    # the caller compares the texts of two builds field by field
+            info_texts.append(ras_save_human_info(sim.ped[0], sim.sex[0], outs, mv, z, svf))
         if exact and f"infofile_pop0_gen{g}_sha" in fx:
             txt = ras_save_human_info(sim.ped[0], sim.sex[0], outs, mv, z, svf)
             assert np.array_equal(np.frombuffer(hashlib.sha256(txt).digest(), dtype=np.uint8), fx[f"infofile_pop0_gen{g}_sha"]), f"{label}: .info file of generation {g} differs from the reference's"
@@ -394,7 +400,10 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True):
         z = (sv - sv_mean) / np.sqrt(sv_var) if sv_var > 0 else sv - sv_mean
         svf = selection_func(func, float(p1), float(p2), z)
         check_info_file(g, outs, mv, z, svf)
-    compare_dense(ctx, fx, ngen, 0, nchr, label)
+    if not plane_less:
+        compare_dense(ctx, fx, ngen, 0, nchr, label)
+    if at_end is not None:
+        at_end(ctx, sim)
     ctx.close()
 
 

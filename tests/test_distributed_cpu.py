@@ -20,3 +20,20 @@ def test_locus_split_population_two_ranks_oracle_backend():
     assert sorted(r for r, _ in res) == [0, 1]
     for r, msg in res:
         assert msg == "ok", f"rank {r}: {msg}"
+
+
+def test_two_populations_times_two_chromosome_shards_with_migration_oracle_backend():
+    """world_size 4 over gloo: 2 populations x 2 chromosome shards (fixture mig3c from the real reference): A/D all-reduce inside
+    each population, phenotype scaling from the all-reduced totals, migration between the ranks holding the same chromosomes"""
+    res = dist_worker.launch("oracle", world=4, target=dist_worker.run_split_migration)
+    assert sorted(r for r, _ in res) == [0, 1, 2, 3]
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
+def test_config4_in_miniature_22_chromosomes_assortative_mating_split_and_migration_oracle_backend():
+    """fixture c4mini (real reference): the 22 autosomes of Recom.Map.b37.50KbDiff, assortative mating, mutation map, two
+    populations with migration; each population split 11 | 11 chromosomes over two ranks"""
+    res = dist_worker.launch("oracle", world=4, target=dist_worker.run_split_migration_c4mini)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"

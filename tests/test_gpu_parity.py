@@ -236,6 +236,39 @@ def test_locus_split_population_on_gpu_matches_the_unsplit_reference_run():
         assert msg == "ok", f"rank {r}: {msg}"
 
 
+def test_rccl_backend_single_rank_collectives_drive_the_device_buffer_branch():
+    """The test box has ONE GPU, so RCCL cannot carry a two-rank exchange here; a single-rank "nccl" process group still runs the
+    collectives of the device-buffer branch for real (all_to_all_single of the size table on a device tensor, all_reduce of the
+    per-chromosome A/D on the GPU, the fences between torch's stream and the library's streams).  With one rank nobody can
+    emigrate, so the payload exchange is the empty case; the population must come out untouched.  Runs in a fresh process, as
+    a rank of a real job would (tests/rccl_single_rank.py)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_single_rank.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl single rank ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_two_populations_times_two_chromosome_shards_with_migration_on_gpu():
+    """BASELINE config 4's layout: 2 populations x 2 chromosome shards = 4 processes driving the HIP library (they share the test
+    box's GPU; gloo carries the A/D all-reduce and the migration all-to-all).  Split contexts exchange migrants (records hold
+    the active chromosomes only) and scale phenotypes from the all-reduced totals (gev_set_ad): everything equals the real
+    reference's unsplit run (fixture mig3c)."""
+    from tests import dist_worker
+    res = dist_worker.launch("gpu", world=4, target=dist_worker.run_split_migration)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
+def test_config4_in_miniature_on_gpu():
+    """composite of BASELINE config 4 at fixture scale (c4mini, from the real reference): 22 autosomes on the reference's own genetic
+    map, assortative mating (couples from the fixture), mutation map, two populations with migration, each population split
+    11 | 11 chromosomes over two processes"""
+    from tests import dist_worker
+    res = dist_worker.launch("gpu", world=4, target=dist_worker.run_split_migration_c4mini)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
 def test_baseline_config2_full_size_dense_state_equals_interval_state(gpu_lib):
     """BASELINE config 2 at FULL size (100k individuals x 1M SNPs; the oracle would need hours):
     after three generations the dense genotype rows produced by the stitch kernel must equal what the
@@ -788,6 +821,70 @@ def test_closed_loop_from_the_seed_alone_on_gpu(gpu_lib, case):
     """the same closed loop on the HIP library (A/D, intervals, genotypes, couples, sexes bit-exact; scaled phenotypes and what
     derives from them within 1e-9 relative: the device's parallel variance / log are not bit-identical to libm's)"""
     helpers.closed_loop_case(gpu_lib, helpers.load_fixture(case), f"gpu/{case}", device=0, exact=False)
+
+
+def test_config5_in_miniature_plane_less_selection_and_bed_output(gpu_lib):
+    """composite of BASELINE config 5 at fixture scale (syn1k from the real reference: logit selection on the phenotype, random
+    mating, mutation map, 10 generations): the WHOLE run is driven from --seed alone on a PLANE-LESS context (interval state
+    only, gev_set_dense_state 0) -- couples, sexes, pedigree, raw A/D and phenotypes are checked against the reference every
+    generation -- and at the end the genotype matrix and the PLINK .bed are assembled from the interval state in SNP tiles:
+    the matrix must have the reference's own hash, the .bed must equal the dense context's gev_format_bed."""
+    from tests.synth import synth_packed
+    from geneevolve_amd.capi import pack_rows, unpack_rows
+    fx = helpers.load_fixture("syn1k")
+    L = len(fx["pop0_chr0_snp_pos"]); nh = int(fx["pop0_n_founder_hap"]); ngen = int(fx["n_gen"])
+    founders = synth_packed(int(fx["pop0_chr0_founders_synth_seed"]), nh, L)
+    got = {}
+
+    def dense_end(ctx, sim):
+        got["bed"] = ctx.format_bed(0, 0)
+
+    def sparse_end(ctx, sim):
+        n = ctx.pop_size(0)
+        rows = []
+        beds = []
+        for s0 in range(0, L, 2048):                                 # SNP tiles: the full matrix is never resident
+            ns = min(2048, L - s0)
+            tile = pack_rows(unpack_rows(founders, L)[:, s0:s0 + ns])
+            rows.append(unpack_rows(ctx.materialize(0, 0, tile, 0, 2 * n, s0, ns), ns))
+            beds.append(ctx.materialize_bed(0, 0, [tile], s0, ns))
+        full = np.concatenate(rows, axis=1)
+        packed = np.packbits(full, axis=1, bitorder="little")
+        assert np.array_equal(helpers.sha(packed), fx[f"g{ngen}_pop0_chr0_dense_sha"]), "genotype matrix assembled from the interval state != the reference's"
+        got["bed_tiles"] = np.concatenate(beds)
+        with pytest.raises(capi.GevError):
+            ctx.download_haps(0, 0)                                  # no resident planes in this mode
+
+    helpers.closed_loop_case(gpu_lib, fx, "gpu/config5-mini dense", device=0, exact=False, at_end=dense_end)
+    helpers.closed_loop_case(gpu_lib, fx, "gpu/config5-mini plane-less", device=0, exact=False, plane_less=True, at_end=sparse_end)
+    assert np.array_equal(got["bed_tiles"], got["bed"]), ".bed from the interval state != .bed of the resident planes"
+
+
+def test_info_files_with_device_phenotype_scaling(gpu_lib, oracle_lib):
+    """gev_scale_ad_compute_gef agrees with the reference to ~1e-12 relative, not bit for bit (device log(), parallel variance).
+    What that means for the reference's own output: the .info.popK.genG.txt text (6 significant digits) produced from the
+    DEVICE's phenotype values is compared field by field with the text of the bit-exact oracle build (which equals the
+    reference's files byte for byte, tests/test_oracle_golden.py).  Reported: how many of the fields differ."""
+    total = differing = 0
+    for case in ("dense", "am1", "vc1", "syn1k"):
+        fx = helpers.load_fixture(case)
+        t_gpu, t_ref = [], []
+        helpers.closed_loop_case(gpu_lib, fx, f"gpu/{case}", device=0, exact=False, info_texts=t_gpu)
+        helpers.closed_loop_case(oracle_lib, fx, f"oracle/{case}", exact=True, info_texts=t_ref)
+        assert len(t_gpu) == len(t_ref) == int(fx["n_gen"]) + 1
+        for a, b in zip(t_gpu, t_ref):
+            la, lb = a.decode().splitlines(), b.decode().splitlines()
+            assert len(la) == len(lb)
+            for x, y in zip(la, lb):
+                fa, fb = x.split(), y.split()
+                assert len(fa) == len(fb)
+                total += len(fa)
+                for u, v in zip(fa, fb):
+                    if u != v:
+                        differing += 1
+                        assert abs(float(u) - float(v)) <= 2e-6 * max(abs(float(v)), 1e-300) + 1e-12, f"{case}: field {u} vs {v}"
+    print(f".info files from device phenotype scaling: {differing} of {total} text fields differ from the reference's (last printed digit)")
+    assert differing <= total * 1e-3
 
 
 def test_closed_loop_two_populations_with_migration_on_gpu(gpu_lib):

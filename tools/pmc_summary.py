@@ -49,13 +49,14 @@ def main():
     res = OrderedDict()
     res["FETCH_SIZE"] = per_kernel(fetch_dir, "FETCH_SIZE")
     res["WRITE_SIZE"] = per_kernel(write_dir, "WRITE_SIZE")
-    stitch = [k for k in res["FETCH_SIZE"] if "k_stitch_parent" in k]
+    stitch = [k for k in res["FETCH_SIZE"] if "k_stitch_regions" in k] or [k for k in res["FETCH_SIZE"] if "k_stitch_parent" in k]
     if stitch:
         k = stitch[0]
         fetch = res["FETCH_SIZE"][k]["avg_KiB"] * 1024.0
         write = res["WRITE_SIZE"][k]["avg_KiB"] * 1024.0
         traffic = 2.0 * fetch + write
-        res["k_stitch_parent_summary"] = {
+        res["stitch_summary"] = {
+            "kernel": k,
             "fetch_bytes_raw": fetch,
             "fetch_bytes_corrected_x2_gfx950_wide_stream": 2.0 * fetch,
             "write_bytes": write,
@@ -66,7 +67,7 @@ def main():
         }
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
-    print(json.dumps(res.get("k_stitch_parent_summary", {}), indent=1))
+    print(json.dumps(res.get("stitch_summary", {}), indent=1))
 
 
 if __name__ == "__main__":

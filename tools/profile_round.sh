@@ -16,3 +16,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o runc -- py
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one pass; no other trace domain)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch" -o runc -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --isolated-steps 0 > "$O/pmc_fetch.jsonl" 2> "$O/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write" -o runc -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --isolated-steps 0 > "$O/pmc_write.jsonl" 2> "$O/pmc_write.err"
+# 4. every kernel ALONE on the GPU (streams serialised): the sampling / sparse / A-D kernel times quoted in DESIGN.md
+GEV_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_serial" -o runc -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --isolated-steps 0 > "$O/serial.jsonl" 2> "$O/trace_serial.err"
+# 5. BASELINE config 4's per-GPU shard (125k individuals x 11 chromosomes x 227k SNPs = 156 GB resident): bench line + kernel stats, overlapped and serialised
+cd "$R" && python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline --nchr 11 --n-ind 125000 --n-loci 227000 > "$O/shard11_bench.jsonl" 2> "$O/shard11_bench.err"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_shard11" -o runc -- python3 "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --isolated-steps 0 --nchr 11 --n-ind 125000 --n-loci 227000 > "$O/shard11_under_rocprof.jsonl" 2> "$O/trace_shard11.err"
+GEV_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_shard11_serial" -o runc -- python3 "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --isolated-steps 0 --nchr 11 --n-ind 125000 --n-loci 227000 > "$O/shard11_serial.jsonl" 2> "$O/trace_shard11_serial.err"
+# 6. the drop-in PROGRAM (reference CLI bound to the library) next to the unmodified reference, 100k individuals
+cd "$R" && python3 tools/cli_timing.py --exe both --gens 3 > "$O/cli_dropin.json" 2> "$O/cli_dropin.err"
+python3 tools/cli_timing.py --exe gpu --gens 3 --assortative > "$O/cli_dropin_assortative.json" 2> "$O/cli_dropin_assortative.err" || true
+# 7. the multi-rank launcher on this one GPU (gloo rehearsal of the N>1 bench: both ranks share device 0)
+GEV_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 10 --warmup 3 > "$O/bench_n2_one_gpu.jsonl" 2> "$O/bench_n2_one_gpu.err"
+GEV_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 10 --warmup 3 --migration-rate 0.01 > "$O/bench_n2_migration_one_gpu.jsonl" 2> "$O/bench_n2_migration_one_gpu.err"
+ls "$O"
