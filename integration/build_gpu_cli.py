@@ -126,7 +126,7 @@ def build(out_name, backend_link, extra_sources=()):
         open(os.path.join(tmp, "Simulation.cpp"), "w").write(cpp)
         sg = os.path.join(REF, "Library", "libStatGen")
         asan = ["-fsanitize=address"] if os.environ.get("GEV_GLUE_ASAN") else []      # CPU-side debugging of the glue only
-        flags = (["-O1", "-g"] + asan if asan else ["-O3"]) + ["-std=c++11", "-w", "-D__ZLIB_AVAILABLE__", "-D_FILE_OFFSET_BITS=64", "-D__STDC_LIMIT_MACROS",
+        flags = (["-O1", "-g"] + asan if asan else ["-O3"]) + ["-std=c++11", "-pthread", "-w", "-D__ZLIB_AVAILABLE__", "-D_FILE_OFFSET_BITS=64", "-D__STDC_LIMIT_MACROS",
                  "-I" + tmp, "-I" + os.path.join(sg, "general"), "-I" + os.path.join(sg, "vcf"), "-I" + os.path.join(sg, "samtools"),
                  "-I" + os.path.join(REF, "Library", "eigen3"), "-I" + os.path.join(REF, "src"), "-I" + os.path.join(ROOT, "include"),
                  "-include", os.path.join(ROOT, "oracle", "ref_compat.h")]
@@ -136,7 +136,7 @@ def build(out_name, backend_link, extra_sources=()):
             subprocess.run(["g++"] + flags + ["-c", srcf, "-o", o], check=True)
             objs.append(o)
         exe = os.path.join(OUT, out_name)
-        subprocess.run(["g++", "-o", exe] + asan + objs + [f for f in need if f.endswith(".o")] + [os.path.join(OUT, "libStatGen.a"), "-lz"] + list(backend_link), check=True)
+        subprocess.run(["g++", "-o", exe] + asan + objs + [f for f in need if f.endswith(".o")] + [os.path.join(OUT, "libStatGen.a"), "-lz", "-pthread"] + list(backend_link), check=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     print("built", exe)

@@ -14,6 +14,7 @@
 #include <iostream>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 #include "Simulation.h"          // the EDITED copy: class Simulation has `friend struct GevGlue;`
 #include "CommFunc.h"
@@ -183,23 +184,15 @@ struct GevGlue {
     // Population::ras_save_human_info (src/Population.cpp:510-568), the per-generation .info text dump -- after the GPU took over
     // the genotype work this is the longest host phase of a generation (tools/cli_timing.py: 0.18 of 0.25 s at 100k individuals),
     // because the reference ends every line with std::endl (one flush = one write() per individual).  Same bytes (default
-    // ostream formatting of a double = "%g", 6 significant digits; ids printed 1-based), built in memory and written once.
-    static bool save_human_info(Simulation& S, int ipop, int gen_num)
+    // ostream formatting of a double = "%g", 6 significant digits; ids printed 1-based), built in memory by up to 8 host threads
+    // and written once.
+    static void format_humans(const Population& P, size_t i0, size_t i1, int npheno, std::string& out)
     {
-        Population& P = S.population[ipop];
-        const int npheno = (int)P._pheno_scheme.size();
-        std::string out;
-        out.reserve(P.h.size() * (64 + 90 * (size_t)npheno) + 256);
-        out += "ID ID_Father ID_Mother ID_Fathers_Father ID_Fathers_Mother ID_Mothers_Father ID_Mothers_Mother sex ";
-        for (int j = 0; j < npheno; j++) {
-            const std::string ph = "ph" + std::to_string(j + 1);
-            for (const char* c : {"_A ", "_D ", "_G ", "_C ", "_E ", "_F ", "_P "}) out += ph + c;
-        }
-        out += "MV SV SV_f\n";
         char buf[64];
         auto num = [&](double v, char end) { const int n = snprintf(buf, sizeof buf, "%g", v); out.append(buf, (size_t)n); out.push_back(end); };
         auto id = [&](unsigned long v) { const int n = snprintf(buf, sizeof buf, "%lu ", v); out.append(buf, (size_t)n); };
-        for (size_t i = 0; i < P.h.size(); i++) {
+        out.reserve((i1 - i0) * (64 + 90 * (size_t)npheno));
+        for (size_t i = i0; i < i1; i++) {
             const Human& h = P.h[i];
             id(h.ID + 1); id(h.ID_Father + 1); id(h.ID_Mother + 1); id(h.ID_Fathers_Father + 1); id(h.ID_Fathers_Mother + 1);
             id(h.ID_Mothers_Father + 1); id(h.ID_Mothers_Mother + 1);
@@ -210,8 +203,29 @@ struct GevGlue {
             }
             num(h.mating_value, ' '); num(h.selection_value, ' '); num(h.selection_value_func, '\n');
         }
+    }
+    static bool save_human_info(Simulation& S, int ipop, int gen_num)
+    {
+        Population& P = S.population[ipop];
+        const int npheno = (int)P._pheno_scheme.size();
+        std::string head = "ID ID_Father ID_Mother ID_Fathers_Father ID_Fathers_Mother ID_Mothers_Father ID_Mothers_Mother sex ";
+        for (int j = 0; j < npheno; j++) {
+            const std::string ph = "ph" + std::to_string(j + 1);
+            for (const char* c : {"_A ", "_D ", "_G ", "_C ", "_E ", "_F ", "_P "}) head += ph + c;
+        }
+        head += "MV SV SV_f\n";
+        // formatting is independent per individual: a few host threads each format a contiguous slice, the slices are written in order
+        const size_t n = P.h.size();
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), n / 4096 + 1));
+        std::vector<std::string> part(nt);
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; t++) th.emplace_back([&, t]() { format_humans(P, n * t / nt, n * (t + 1) / nt, npheno, part[t]); });
+        format_humans(P, 0, n / nt, npheno, part[0]);
+        for (auto& x : th) x.join();
         std::ofstream f((P._out_prefix + ".info.pop" + std::to_string(P._pop_num + 1) + ".gen" + std::to_string(gen_num) + ".txt").c_str(), std::ios::binary);
-        f.write(out.data(), (std::streamsize)out.size());
+        f.write(head.data(), (std::streamsize)head.size());
+        for (const std::string& p : part) f.write(p.data(), (std::streamsize)p.size());
         return true;
     }
 

@@ -74,3 +74,23 @@ def test_reference_cli_on_the_hip_library(case, tmp_path):
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/GeneEvolve_gpu not built (needs the reference tree at build time)")
     run_cli(exe, case, tmp_path)
+
+
+def test_multithreaded_info_writer_is_byte_identical_at_a_size_that_uses_several_threads(tmp_path):
+    """the glue's ras_save_human_info replacement formats slices of the population on several host threads (fixtures are too small
+    to start more than one): 10 000 individuals, the unmodified reference vs the bound program (oracle backend), .info files
+    of every generation byte for byte"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(helpers.GOLDEN), "..", "tools"))
+    from cli_timing import write_inputs
+    ref, glue = os.path.join(REFDIR, "GeneEvolve_ref"), os.path.join(REFDIR, "GeneEvolve_glue_on_oracle")
+    if not (os.path.exists(ref) and os.path.exists(glue)):
+        pytest.skip("oracle/_ref binaries not built (needs the reference tree at build time)")
+    wd = str(tmp_path)
+    args = write_inputs(wd, 10000, 40, 2, False)
+    for exe, tag in ((ref, "ref"), (glue, "glue")):
+        a = list(args); a[a.index("--prefix") + 1] = os.path.join(wd, tag)
+        assert subprocess.run([exe] + a, stdout=subprocess.DEVNULL, timeout=900).returncode == 0
+    for g in range(3):
+        x = open(os.path.join(wd, f"ref.info.pop1.gen{g}.txt"), "rb").read(); y = open(os.path.join(wd, f"glue.info.pop1.gen{g}.txt"), "rb").read()
+        assert len(x) > 500_000 and x == y, f".info file of generation {g} differs"
