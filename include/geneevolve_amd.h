@@ -130,7 +130,11 @@ int gev_init_gen0(gev_ctx*, int pop, size_t n_people, uint32_t seed_gen0, uint8_
  *                   ras_add_mutation (:2500), in call order (offspring-major, chromosome-minor)
  *  n_people       : sum of num_offspring over couples with inbreed==0 (checked)
  *  sex_out        : n_people bytes, Human::sex of each offspring (:2472), or NULL
- * Pedigree ids and common_sibling (:2473-2484) are pure host bookkeeping and stay with the host. */
+ * Pedigree ids and common_sibling (:2473-2484) are pure host bookkeeping and stay with the host.
+ * Cost note: with a mutation map every (offspring, chromosome) task restarts its rand() chain at srand(mut_seed), so all tasks are
+ * sampled in parallel.  WITHOUT one (mut_seeds == NULL) the reference's chain runs through every gamete in order (the seed of a
+ * gamete is the rand() output that follows the previous gamete's breakpoints): one wave walks it, about 10 us per gamete, i.e.
+ * seconds per generation beyond ~10^5 gametes -- a parity mode for Example1-sized inputs, not a production path. */
 int gev_reproduce(gev_ctx*, int pop, const gev_couple* couples, size_t n_couples,
                   uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds,
                   size_t n_people, uint8_t* sex_out);
