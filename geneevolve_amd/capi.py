@@ -420,10 +420,13 @@ class GevContext:
         self._call("materialize_bed", C.c_int(pop), C.c_int(chr), C.c_size_t(snp_begin), C.c_size_t(n_snps), ptrs, strides, rows, _p(out), C.c_size_t(nb))
         return out
 
-    def dbg_verify_planes(self, pop, chr, founder_seed):
-        """(mismatching plane words, bad parts) of the device-side full comparison plane == materialise(intervals, synthetic founders)"""
+    def dbg_verify_planes(self, pop, chr, founder_seeds):
+        """(mismatching plane words, bad parts) of the device-side full comparison plane == materialise(intervals, synthetic founders);
+        founder_seeds: the gev_synth_founders seed of every ROOT population's panel (a scalar for a single-population context)"""
+        seeds = np.atleast_1d(np.asarray(founder_seeds, dtype=np.uint64))
+        assert len(seeds) == self.n_pop
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)
-        self._call("dbg_verify_planes", C.c_int(pop), C.c_int(chr), C.c_uint64(int(founder_seed)), C.byref(a), C.byref(b))
+        self._call("dbg_verify_planes", C.c_int(pop), C.c_int(chr), _p(seeds), C.byref(a), C.byref(b))
         return int(a.value), int(b.value)
 
     def set_overlap(self, on):

@@ -1281,8 +1281,8 @@ __global__ void __launch_bounds__(256) k_materialize_tile(const u32* __restrict_
 // has to be resident.  Mutations are not in the plane (sparse overlay), so none are applied here.
 __global__ void __launch_bounds__(256) k_verify_plane(const u32* __restrict__ p_off, const gev_part* __restrict__ parts, size_t n_rows,
                                                       const u64* __restrict__ pos, u32 L, const u32* __restrict__ plane, size_t stride_w32,
-                                                      const u32* __restrict__ thr, u64 seed, int own_pop, size_t n_founder_rows,
-                                                      unsigned long long* __restrict__ n_bad /* [0] mismatching words, [1] parts with a foreign / out-of-range founder */)
+                                                      const u32* __restrict__ thr /* [n_pop][L] */, const u64* __restrict__ seeds /* [n_pop] */, int n_pop, const u64* __restrict__ n_founder_rows /* [n_pop] */,
+                                                      unsigned long long* __restrict__ n_bad /* [0] mismatching words, [1] parts with an unknown / out-of-range founder */)
 {
     const u32 words = (L + 31) / 32;
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1294,7 +1294,6 @@ __global__ void __launch_bounds__(256) k_verify_plane(const u32* __restrict__ p_
     u32 lo = p_off[r], hi = p_off[r + 1];
     const u32 end = hi;
     while (lo < hi) { const u32 m = (lo + hi) >> 1; if (parts[m].en <= x0) lo = m + 1; else hi = m; }
-    const u64 off = seed * 0xD1342543DE82EF95ull;
     u32 acc = 0;
     for (u32 i = lo; i < end && parts[i].st <= x1; i++) {
         const u64 st = parts[i].st, en = parts[i].en;
@@ -1302,11 +1301,14 @@ __global__ void __launch_bounds__(256) k_verify_plane(const u32* __restrict__ p_
         for (u32 t = 0; t < nb; t++) { a += wp[t] < st ? 1u : 0u; b += wp[t] < en ? 1u : 0u; }
         if (b <= a) continue;
         const u64 h = parts[i].hap_index;
-        if (parts[i].root_population != own_pop || h >= n_founder_rows) { atomicAdd(&n_bad[1], 1ull); continue; }
+        const int rp = parts[i].root_population;                                   // founder panel of the part's ROOT population (:1204)
+        if (rp < 0 || rp >= n_pop || h >= n_founder_rows[rp]) { atomicAdd(&n_bad[1], 1ull); continue; }
+        const u64 off = seeds[rp] * 0xD1342543DE82EF95ull;
+        const u32* __restrict__ th = thr + (size_t)rp * L;
         for (u32 t = a; t < b; t++) {
             const size_t ii = (size_t)32 * w + t;
             const u64 ctr = (((u64)h << 32) | (u64)ii) + off;
-            if ((u32)(mix64(ctr) >> 32) < thr[ii]) acc |= 1u << t;
+            if ((u32)(mix64(ctr) >> 32) < th[ii]) acc |= 1u << t;
         }
     }
     if (acc != plane[r * stride_w32 + w]) atomicAdd(&n_bad[0], 1ull);

@@ -2190,7 +2190,7 @@ __global__ void __launch_bounds__(64) k_dbg_sim_loc_rec(const GevRngTables* __re
     if (threadIdx.x == 0) { *n_out = h; next2[0] = (int)a; next2[1] = (int)b; }
 }
 // every word of the resident plane (dense stitch) against the interval state (k_parts) + the synthetic founder panel
-int gev_dbg_verify_planes(gev_ctx* c, int pop, int chr, uint64_t founder_seed, unsigned long long* n_bad_words, unsigned long long* n_bad_parts)
+int gev_dbg_verify_planes(gev_ctx* c, int pop, int chr, const uint64_t* founder_seeds, unsigned long long* n_bad_words, unsigned long long* n_bad_parts)
 {
     if (c) GEVC(check_dense(c, "dbg_verify_planes"));
     GEVC(check_idx(c, pop, chr));
@@ -2198,7 +2198,7 @@ int gev_dbg_verify_planes(gev_ctx* c, int pop, int chr, uint64_t founder_seed, u
     PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "dbg_verify_planes: population %d has no current generation", pop);
     if (!c->track_intervals) return fail(GEV_ESTATE, "dbg_verify_planes: interval tracking is disabled");
-    if (!n_bad_words || !n_bad_parts) return fail(GEV_EINVAL, "dbg_verify_planes: null output");
+    if (!founder_seeds || !n_bad_words || !n_bad_parts) return fail(GEV_EINVAL, "dbg_verify_planes: null argument");
     HIPC(hipSetDevice(c->device));
     GEVC(materialize_order(c, pop));
     GEVC(gev_sync(c));
@@ -2206,12 +2206,21 @@ int gev_dbg_verify_planes(gev_ctx* c, int pop, int chr, uint64_t founder_seed, u
     const size_t rows = 2 * P.n_people, words = ceil_div(S.L, 32);
     if (!rows || !words) { *n_bad_words = 0; *n_bad_parts = 0; return GEV_OK; }
     if (ceil_div(rows * words, 256) > 0x7fffffffull) return fail(GEV_EINVAL, "dbg_verify_planes: grid too large");
-    GEVC(c->d_thr32.ensure(S.L * sizeof(u32), st));
+    // per ROOT population: allele-frequency thresholds of its synthetic panel, its seed, its number of founder haplotypes
+    // (a population this context never generated founders for is taken to have as many as this one: same panel shape on every GPU)
+    const int np = c->n_pop;
+    GEVC(c->d_thr32.ensure((size_t)np * S.L * sizeof(u32), st));
+    std::vector<u64> meta(2 * (size_t)np);
+    for (int r = 0; r < np; r++) {
+        meta[r] = founder_seeds[r];
+        meta[np + r] = c->pop[r].cs[chr].founder_rows ? c->pop[r].cs[chr].founder_rows : S.founder_rows;
+        hipLaunchKernelGGL(k_synth_thresholds, dim3((unsigned)ceil_div(S.L, 256)), dim3(256), 0, st, c->d_thr32.as<u32>() + (size_t)r * S.L, S.L, founder_seeds[r]);
+    }
+    GEVC(h2d(c, c->d_map, meta.data(), meta.size() * sizeof(u64)));
     GEVC(c->d_flag.ensure(16, st));
     HIPC(hipMemsetAsync(c->d_flag.p, 0, 16, st));
-    hipLaunchKernelGGL(k_synth_thresholds, dim3((unsigned)ceil_div(S.L, 256)), dim3(256), 0, st, c->d_thr32.as<u32>(), S.L, founder_seed);
     hipLaunchKernelGGL(k_verify_plane, dim3((unsigned)ceil_div(rows * words, 256)), dim3(256), 0, st, cs.poff[P.cur].as<u32>(), cs.parts[P.cur].as<gev_part>(), rows,
-                       S.d_pos.as<u64>(), (u32)S.L, cs.plane[P.cur].as<u32>(), S.stride / 4, c->d_thr32.as<u32>(), founder_seed, pop, S.founder_rows,
+                       S.d_pos.as<u64>(), (u32)S.L, cs.plane[P.cur].as<u32>(), S.stride / 4, c->d_thr32.as<u32>(), c->d_map.as<u64>(), np, c->d_map.as<u64>() + np,
                        (unsigned long long*)c->d_flag.p);
     KCHECK();
     unsigned long long h[2] = {0, 0};

@@ -305,12 +305,13 @@ int gev_set_stitch_mode(gev_ctx*, int mode);
  * gev_dbg_tables / gev_dbg_threshold / gev_dbg_canonical run on the host (table and threshold
  * construction); gev_dbg_rand / gev_dbg_sim_loc_rec run the device generators:
  * glibc srand(seed);rand()xN and one Simulation::ras_sim_loc_rec call (src/Simulation.cpp:2973). */
-/* gev_dbg_verify_planes: full-coverage self-check of the dense state of a population whose founder panel came from
- * gev_synth_founders(seed = founder_seed): every 32-bit word of the resident genotype plane (written by the dense stitch from
- * breakpoints) is compared on the device with ras_convert_interval_to_hap_matrix (src/Simulation.cpp:1186-1230) applied to
- * the ancestry intervals (written by the interval kernel) -- two independent paths.  *n_bad_words = mismatching words,
- * *n_bad_parts = parts whose founder is foreign / out of range (both must be 0). */
-int    gev_dbg_verify_planes(gev_ctx*, int pop, int chr, uint64_t founder_seed, unsigned long long* n_bad_words, unsigned long long* n_bad_parts);
+/* gev_dbg_verify_planes: full-coverage self-check of the dense state of a population whose founder panels came from
+ * gev_synth_founders: every 32-bit word of the resident genotype plane (written by the dense stitch from breakpoints) is
+ * compared on the device with ras_convert_interval_to_hap_matrix (src/Simulation.cpp:1186-1230) applied to the ancestry
+ * intervals (written by the interval kernel) -- two independent paths.  founder_seeds[r] = the seed the panel of ROOT
+ * population r was generated with (n_pop entries: after migration a part may descend from another population's founders, on
+ * another GPU).  *n_bad_words = mismatching words, *n_bad_parts = parts whose founder is unknown / out of range (both must be 0). */
+int    gev_dbg_verify_planes(gev_ctx*, int pop, int chr, const uint64_t* founder_seeds, unsigned long long* n_bad_words, unsigned long long* n_bad_parts);
 int    gev_dbg_tables(void* out, size_t bytes);
 int    gev_dbg_threshold(double p, uint32_t out[4] /* a_lo, a_hi, b0, b1 */);
 double gev_dbg_canonical(uint32_t a, uint32_t b);

@@ -37,3 +37,11 @@ def test_config4_in_miniature_22_chromosomes_assortative_mating_split_and_migrat
     res = dist_worker.launch("oracle", world=4, target=dist_worker.run_split_migration_c4mini)
     for r, msg in res:
         assert msg == "ok", f"rank {r}: {msg}"
+
+
+def test_migration_beyond_fixture_size_host_logic_rehearsal():
+    """the worker of the GPU test `test_two_rank_migration_beyond_fixture_size_with_full_plane_verification`, with the CPU oracle in
+    both roles: checks the worker's own bookkeeping (who moves, sex arrays, collective order) where there is no GPU"""
+    res = dist_worker.launch("oracle", world=2, target=dist_worker.run_migration_at_scale)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"

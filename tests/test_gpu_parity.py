@@ -236,6 +236,14 @@ def test_locus_split_population_on_gpu_matches_the_unsplit_reference_run():
         assert msg == "ok", f"rank {r}: {msg}"
 
 
+def test_two_rank_migration_beyond_fixture_size_with_full_plane_verification():
+    """see tests/dist_worker.py:run_migration_at_scale"""
+    from tests import dist_worker
+    res = dist_worker.launch("gpu", world=2, target=dist_worker.run_migration_at_scale)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
 def test_rccl_backend_single_rank_collectives_drive_the_device_buffer_branch():
     """The test box has ONE GPU, so RCCL cannot carry a two-rank exchange here; a single-rank "nccl" process group still runs the
     collectives of the device-buffer branch for real (all_to_all_single of the size table on a device tensor, all_reduce of the
