@@ -356,6 +356,30 @@ def test_population_growth_without_intermediate_sync(gpu_lib, oracle_lib):
     g.close(); o.close()
 
 
+def test_baseline_config4_per_gpu_shard_full_size_dense_state_equals_interval_state(gpu_lib):
+    """BASELINE config 4's per-GPU share at FULL size: 125k individuals x 11 chromosomes x 227k SNPs = 156 GB of resident planes
+    (two sets), all chromosomes stitched by ONE launch per generation.  After two generations every word of all eleven planes
+    (2.75 M rows x 7 094 words) must equal the materialised interval state (gev_dbg_verify_planes); A/D must be finite and vary."""
+    n, L, nchr = 125_000, 227_000, 11
+    cfg = SyntheticConfig(n, L, nchr=nchr, seed=12345)
+    g = gpu_lib.create(1, nchr, 1)
+    cfg.apply_static(g)
+    for c in range(nchr):
+        g.synth_founders(0, c, 2 * n, 3000 + c); g.synth_cv_founders(0, 0, c, 2 * n, 4000 + c)
+    sim = Simulation(g, 404, nchr, True)
+    sim.ras_initial_human_gen0(0, n)
+    rng = np.random.default_rng(6)
+    for gen in (1, 2):
+        sim.couples[0] = synthetic_random_mate(sim.sex[0], n, rng)
+        sim.reproduce(0, gen)
+        add, _, addc, _ = sim.ras_compute_AD(0, gen, per_chr=True)
+        assert np.isfinite(add).all() and add.std() > 0 and all(addc[:, c, 0].std() > 0 for c in range(nchr))
+    for c in range(nchr):
+        assert g.dbg_verify_planes(0, c, 3000 + c) == (0, 0), f"chromosome {c}: dense state != interval state"
+    assert g.dbg_verify_planes(0, 3, 3004)[0] > 10 ** 8              # negative control: chromosome 3 against chromosome 4's founders
+    g.close()
+
+
 def test_cpp_host_drives_the_c_abi_like_the_python_host(gpu_lib):
     """tools/host_demo.cpp (C++ host, geneevolve_amd/host/gev_host.hpp, no Python) and the ctypes host
     run the same scenario through the same C-ABI: identical genotype / A / sex checksums."""
