@@ -686,8 +686,11 @@ __global__ void __launch_bounds__(256) k_stitch_parent(const ChrWork* __restrict
 // then costs a monotone pointer advance, one LDS read and the copies; only the (few) boundary chunks run the masked blend.
 template <int UNROLL, bool NT>
 __global__ void __launch_bounds__(256) k_stitch_regions(const ChrWork* __restrict__ Wt, u32 bpr_max, int nchr,
-                                                        const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd)
+                                                        const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd, int wave_prio)
 {
+    // instruction-issue priority of this kernel's waves inside a SIMD (s_setprio): the stitch shares the CUs with the ALU-bound
+    // sampling kernels of the next generation; its waves mostly wait for memory and should issue first when their data arrives
+    if (wave_prio == 3) __builtin_amdgcn_s_setprio(3); else if (wave_prio == 2) __builtin_amdgcn_s_setprio(2); else if (wave_prio == 1) __builtin_amdgcn_s_setprio(1);
     __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big, s_nd;
     __shared__ u32 s_bc[PM_KTOT + 1];        // distinct boundary chunks inside [q0, q1), ascending, then the sentinel 0xffffffff
     __shared__ u32 s_sel[PM_KTOT + 1];       // region r = pure chunks in front of boundary chunk r (r = nd: behind the last one)

@@ -380,6 +380,63 @@ def test_baseline_config4_per_gpu_shard_full_size_dense_state_equals_interval_st
     g.close()
 
 
+def test_baseline_config5_per_gpu_shape_full_size_tiles_from_intervals(gpu_lib):
+    """BASELINE config 5's per-GPU shape at FULL size: 125k individuals x 10M loci, no resident genotype planes (the matrix would
+    need 312 GB per generation): interval state + tiled materialisation.  The interval state does not depend on the SNP grid,
+    so a second, DENSE context that holds only a 16 384-SNP window of the same chromosome (same maps, CVs, seeds, couples) evolves
+    the same population: after two generations the tile gev_materialize assembles for that window from the plane-less context's
+    intervals (all 250 000 haplotype rows) must equal the dense context's resident rows, and gev_materialize_bed its .bed."""
+    n, L, s0, ns = 125_000, 10_000_000, 6_000_000, 16_384
+    big = SyntheticConfig(n, L, seed=12345)
+    sparse = gpu_lib.create(1, 1, 1); dense = gpu_lib.create(1, 1, 1)
+    sparse.set_dense_state(False)
+    big.apply_static(sparse)
+    big.apply_static(dense)
+    dense.set_snps(0, 0, big.snp_pos[s0:s0 + ns])                  # the window only
+    dense.synth_founders(0, 0, 2 * n, 808)                         # founder alleles of the window, generated on the device
+    for ctx in (sparse, dense):
+        ctx.synth_cv_founders(0, 0, 0, 2 * n, 809)
+    sims = [Simulation(ctx, 31, 1, True) for ctx in (sparse, dense)]
+    for sm in sims:
+        sm.ras_initial_human_gen0(0, n)
+    tile = dense.download_haps(0, 0)                                # generation 0 = the founder panel (row = founder haplotype): the tile gev_materialize is given
+    rng = np.random.default_rng(8)
+    for gen in (1, 2):
+        c = synthetic_random_mate(sims[0].sex[0], n, rng)
+        for sm in sims:
+            sm.couples[0] = c
+        assert np.array_equal(sims[0].reproduce(0, gen), sims[1].reproduce(0, gen))
+        a0 = sims[0].ras_compute_AD(0, gen); a1 = sims[1].ras_compute_AD(0, gen)
+        assert helpers.bits_equal(a0[0], a1[0])
+    got = sparse.materialize(0, 0, tile, 0, 2 * n, s0, ns)
+    want = dense.download_haps(0, 0)
+    assert np.array_equal(got, want), "tile assembled from the interval state != the dense context's rows"
+    assert np.array_equal(sparse.materialize_bed(0, 0, [tile], s0, ns), dense.format_bed(0, 0))
+    parts, off = sparse.download_intervals(0, 0)
+    assert off[-1] > 2 * n * 1.5
+    sparse.close(); dense.close()
+
+
+def test_work_table_ring_wraps_around(oracle_lib):
+    """the per-generation work tables (ChrWork / CvWork / AdWork) are staged through a ring of pinned host memory; with the ring
+    shrunk to a few entries it wraps every other generation (a wrap waits for the stream before slots are reused): 14 generations
+    of a 3-chromosome, 2-phenotype population against the oracle.  Runs in its own process (the ring size is read once)."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from geneevolve_amd.capi import GevLibrary\n"
+        "from oracle import oracle_api\n"
+        "from geneevolve_amd.host import SyntheticConfig\n"
+        "from tests.test_gpu_parity import run_pair\n"
+        "cfg = SyntheticConfig(150, 3000, nchr=3, chrom_bp=1_000_000, map_step=1000, rec_per_row=3e-3, mut_per_row=3e-3, n_cv=60, nphen=2, seed=19, vd=0.2)\n"
+        "run_pair(GevLibrary(), oracle_api.load(), cfg, n_gen=14, seed=5, check_every=7)\n"
+        "print('ring ok')\n")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, GEV_TABLE_RING_BYTES="2048", PYTHONPATH=root))
+    assert r.returncode == 0 and "ring ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_cpp_host_drives_the_c_abi_like_the_python_host(gpu_lib):
     """tools/host_demo.cpp (C++ host, geneevolve_amd/host/gev_host.hpp, no Python) and the ctypes host
     run the same scenario through the same C-ABI: identical genotype / A / sex checksums."""

@@ -128,7 +128,7 @@ int main(int argc, char** argv)
     ChrWork* dw; CK(hipMalloc(&dw, sizeof hw)); CK(hipMemcpy(dw, &hw, sizeof hw, hipMemcpyHostToDevice));
     ADD("rows (gamete-major)", hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)rows), dim3(256), 0, 0, dw, 1u, 1, sd));
 #define PM(name, U, NT, occ) ADD(name, hipLaunchKernelGGL((k_stitch_parent<U, NT>), dim3((unsigned)N), dim3(256), (occ) >= 8 ? 0 : std::min(160 * 1024 / (occ) - 3 * 1024, 64 * 1024 - 2048), 0, dw, 1u, 1, dgoff, dglist, sd))
-#define RG(name, U, NT, occ) ADD(name, hipLaunchKernelGGL((k_stitch_regions<U, NT>), dim3((unsigned)N), dim3(256), (occ) >= 8 ? 0 : std::min(160 * 1024 / (occ) - 6 * 1024, 64 * 1024 - 4096), 0, dw, 1u, 1, dgoff, dglist, sd))
+#define RG(name, U, NT, occ) ADD(name, hipLaunchKernelGGL((k_stitch_regions<U, NT>), dim3((unsigned)N), dim3(256), (occ) >= 8 ? 0 : std::min(160 * 1024 / (occ) - 6 * 1024, 64 * 1024 - 4096), 0, dw, 1u, 1, dgoff, dglist, sd, 0))
     PM("parent per-chunk U2 nt", 2, true, 8);
     RG("regions U2 nt", 2, true, 8);
     RG("regions U4 nt", 4, true, 8);
