@@ -3,8 +3,9 @@
 on BASELINE.json's config 2: 100k individuals x 1M biallelic SNPs, 1 chromosome of 100 Mb,
 uniform recombination map (2001 rows, 5e-4/row), mutation 1e-8/bp (5e-4/row), 1000 CVs.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]             (N > 1: starts its own N rank processes, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus 2 --migration-rate 0.01              (BASELINE config 3: two populations exchanging 1 % per generation)
 
 One process per GPU; each rank advances its OWN population of the full config-2 size (weak
 scaling: populations shard across GPUs); no data-path collective is
@@ -14,8 +15,9 @@ Simulation::ras_compute_AD run on the GPU through the C-ABI.  gev_reproduce retu
 small per-generation work is done; the HBM-bound dense stitch continues on the library's second
 stream and overlaps A/D, host mating and the next generation's sampling (every generation's
 stitch is complete before the timed region ends: the closing barrier synchronises the device).
-The ras_glob_seed() values of the next generation are pure draws of the host's stream, known before its couples
-are: they are handed over early (gev_presample) so the GPU samples while the host mates (--no-presample: hand
+The ras_glob_seed() values of the next generation (1 + N*nchr draws, src/Simulation.cpp:2398, :2500) are pure draws of the
+host's stream, known before its couples are: they are drawn INSIDE the timed loop, by a second host thread while the first
+waits in gev_reproduce, and handed over early (gev_presample) so the GPU samples while the host mates (--no-presample: hand
 seeds and couples over together).  The founder panel is generated on the device before the timed region, so
 genotype state is resident in HBM throughout.  --plane-less times BASELINE config 5's mode (interval state only,
 no per-generation genotype assembly) and is NOT the headline configuration.
@@ -24,7 +26,8 @@ Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_sti
 algorithmic bytes per launch = 2N rows x (L/8 read + L/8 written) = N*L/2, divided
 by its duration measured with HIP events on the library's own stream.  The kernel reads LESS than
 the algorithmic bytes (a parent's chunk is loaded once for all of its gametes), so `achieved` can
-exceed what a plain device copy of N*L/2 bytes reaches; `traffic` holds the measured HBM bytes.  `cpu_baseline` times the
+exceed what a plain device copy of N*L/2 bytes reaches; `traffic` holds the measured HBM bytes (newest committed rocprofv3
+PMC passes) and `hbm_actual_GBps` = traffic / kernel time, the rate the memory system really sustained.  `cpu_baseline` times the
 unmodified reference (oracle/_ref/ref_harness, kind "reference"; when it is absent the bit-exact CPU oracle, kind
 "port") on a bounded sample of the same workload on this box's host cores (1 thread: the reference is single threaded).
 """

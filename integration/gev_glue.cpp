@@ -1,7 +1,7 @@
 // integration/gev_glue.cpp -- the reference-side binding of INTEGRATION.md, for real: GeneEvolve's own host (Main.cpp,
 // parameters, every reader/writer, mating, phenotype scaling, migration decisions, summaries) with the reproduction hot
 // path running in libgeneevolve_amd.so.  integration/build_gpu_cli.py makes an edited build copy of the reference's
-// Simulation.{h,cpp} (six call sites rerouted to the functions below; nothing of the reference is stored in this repo)
+// Simulation.{h,cpp} (its call sites rerouted to the functions below, see the list in build_gpu_cli.py; nothing of the reference is stored in this repo)
 // and links it with this file, the reference's other objects and the library into oracle/_ref/GeneEvolve_gpu.
 // tests/test_gpu_parity.py runs that program on the reference's own kind of input files and compares its output files
 // with the unmodified reference's (hashes in tests/golden).
