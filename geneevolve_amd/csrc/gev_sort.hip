@@ -53,12 +53,18 @@ __global__ void __launch_bounds__(256) k_rank_scatter_nan(const uint32_t* __rest
 
 // d_x: n doubles on the device; d_rank: n results; d_tmp: caller-provided scratch of at least gev_rank_scratch_bytes(n) bytes.
 // Returns a hipError_t as int.
+// temporary storage of the library calls: the larger of the sort's and the (NaN path's) scan's
+static size_t rank_lib_tmp_bytes(size_t n)
+{
+    size_t t_sort = 0, t_scan = 0;
+    (void)rocprim::radix_sort_pairs((void*)nullptr, t_sort, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n);
+    (void)rocprim::exclusive_scan((void*)nullptr, t_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>());
+    return ((t_sort > t_scan ? t_sort : t_scan) + 255) & ~(size_t)255;
+}
 extern "C" size_t gev_rank_scratch_bytes(size_t n)
 {
-    size_t tmp = 0;
-    (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n);
     const size_t a = (n * 8 + 255) & ~(size_t)255, b = (n * 4 + 255) & ~(size_t)255;
-    return 2 * a + 3 * b + 256 + ((tmp + 255) & ~(size_t)255);
+    return 2 * a + 3 * b + 256 + rank_lib_tmp_bytes(n) + 256;
 }
 extern "C" int gev_rank_device(const double* d_x, size_t n, ull* d_rank, void* d_tmp, hipStream_t st)
 {
@@ -70,10 +76,8 @@ extern "C" int gev_rank_device(const double* d_x, size_t n, ull* d_rank, void* d
     uint32_t* idx_out = (uint32_t*)p; p += b;
     uint32_t* flags = (uint32_t*)p; p += b;
     uint32_t* n_nan = (uint32_t*)p; p += 256;
-    size_t tmp = 0;
-    hipError_t e = rocprim::radix_sort_pairs((void*)nullptr, tmp, key_in, key_out, idx_in, idx_out, n, 0, 64, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(n_nan, 0, 4, st);
+    size_t tmp = rank_lib_tmp_bytes(n);                   // what gev_rank_scratch_bytes reserved behind the arrays
+    hipError_t e = hipMemsetAsync(n_nan, 0, 4, st);
     if (e != hipSuccess) return (int)e;
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_rank_keys, dim3(nb), dim3(256), 0, st, d_x, n, key_in, idx_in, n_nan);
@@ -87,9 +91,7 @@ extern "C" int gev_rank_device(const double* d_x, size_t n, ull* d_rank, void* d
     if (h_nan == 0) hipLaunchKernelGGL(k_rank_scatter, dim3(nb), dim3(256), 0, st, idx_out, n, d_rank);
     else {
         hipLaunchKernelGGL(k_rank_nan_flags, dim3(nb), dim3(256), 0, st, d_x, n, flags);
-        e = rocprim::exclusive_scan((void*)nullptr, tmp, flags, idx_in, 0u, n, rocprim::plus<uint32_t>(), st);
-        if (e != hipSuccess) return (int)e;
-        e = rocprim::exclusive_scan((void*)p, tmp, flags, idx_in, 0u, n, rocprim::plus<uint32_t>(), st);   // scratch of the sort is larger than the scan's
+        e = rocprim::exclusive_scan((void*)p, tmp, flags, idx_in, 0u, n, rocprim::plus<uint32_t>(), st);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k_rank_scatter_nan, dim3(nb), dim3(256), 0, st, idx_out, d_x, idx_in, n, h_nan, d_rank);
     }
