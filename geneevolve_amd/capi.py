@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "csrc", "libgeneevolve_amd.so")
+DEFAULT_LIB = os.environ.get("GEV_LIBRARY_PATH") or os.path.join(_HERE, "csrc", "libgeneevolve_amd.so")   # (the variable: A/B builds of the same library)
 
 
 class GevError(RuntimeError):
@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "set_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
-    "dbg_verify_planes", "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
+    "dbg_verify_planes", "dbg_prefilter_sweep", "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
 
@@ -428,6 +428,11 @@ class GevContext:
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)
         self._call("dbg_verify_planes", C.c_int(pop), C.c_int(chr), _p(seeds), C.byref(a), C.byref(b))
         return int(a.value), int(b.value)
+
+    def dbg_prefilter_sweep(self, x_begin, x_end):
+        out = (C.c_ulonglong * 3)()
+        self._call("dbg_prefilter_sweep", C.c_uint32(int(x_begin)), C.c_uint32(int(x_end)), out)
+        return int(out[0]), int(out[1]), int(out[2])
 
     def set_overlap(self, on):
         """True (default) / False / 2 (sampling-only overlap), or None: decide from two timed serialised generations"""

@@ -1365,12 +1365,6 @@ __global__ void k_csr_gather_fill(const u32* __restrict__ s_off, const E* __rest
 // parallel (LCG jump-ahead) and compacted with a scan.  u = generate_canonical is computed in FP64
 // exactly as libstdc++ does (no contraction); log() is the device libm (<= 1 ulp from glibc's).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 powmod31(u32 a, u64 e)
-{
-    u32 r = 1;
-    while (e) { if (e & 1) r = mulmod31(r, a); a = mulmod31(a, a); e >>= 1; }
-    return r;
-}
 __device__ __forceinline__ double canonical_f64(u32 x1, u32 x2)
 {
     const double R = 2147483646.0, R2 = 0x1.fffffff000000p+61;

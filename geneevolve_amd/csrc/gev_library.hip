@@ -2234,6 +2234,46 @@ int gev_dbg_verify_planes(gev_ctx* c, int pop, int chr, const uint64_t* founder_
     *n_bad_words = h[0]; *n_bad_parts = h[1];
     return GEV_OK;
 }
+// Exhaustive check of the FP64 prefilter of the batched sampling kernels (gev_sample8.h:scan_candidates) over engine states
+// [x_begin, x_end) and all SB_J multipliers: with the exact high digit x2 = x * c_j mod M and F = floor(x2 * 2^20 / M), the 20 low
+// mantissa bits L of fma(x, fl(c_j / M), 1.5 * 2^32 + 4 u) must satisfy L - 4 - F in {-1, 0, 1, 2} (mod 2^20): then every draw
+// whose x2 is <= amax passes L < floor(amax * 2^20 / M) + 7, for every amax.  out[0] = violations, out[1] = largest (L - 4 - F),
+// out[2] = largest (F + 4 - L).
+__global__ void __launch_bounds__(256) k_dbg_prefilter_sweep(const GevRngTables* __restrict__ Tg, u32 x_begin, u32 x_end, unsigned long long* __restrict__ out)
+{
+    __shared__ double s_kd[SB_J]; __shared__ u32 s_ci[SB_J];
+    if (threadIdx.x < SB_J) { const u32 c = powmod31(Tg->pow128, threadIdx.x); s_ci[threadIdx.x] = c; s_kd[threadIdx.x] = (double)c / 2147483647.0; }
+    __syncthreads();
+    const double C = 6442450944.0 + 4.0 / 1048576.0;
+    unsigned long long bad = 0; int dpos = 0, dneg = 0;
+    for (u64 x = (u64)x_begin + (u64)blockIdx.x * 256 + threadIdx.x; x < x_end; x += (u64)gridDim.x * 256) {
+        const double xd = (double)(u32)x;
+        for (u32 j = 0; j < SB_J; j++) {
+            const u32 x2 = mulmod31((u32)x, s_ci[j]);
+            const u32 F = (u32)(((u64)x2 << 20) / 2147483647ull);
+            const u32 L = (u32)__double2loint(__fma_rn(xd, s_kd[j], C)) & 0xfffffu;
+            int d = (int)((L - 4u - F) & 0xfffffu);
+            if (d >= (1 << 19)) d -= (1 << 20);
+            if (d < -1 || d > 2) bad++;
+            dpos = max(dpos, d); dneg = max(dneg, -d);
+        }
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicMax(&out[1], (unsigned long long)dpos); atomicMax(&out[2], (unsigned long long)dneg);
+}
+int gev_dbg_prefilter_sweep(gev_ctx* c, uint32_t x_begin, uint32_t x_end, unsigned long long out[3])
+{
+    if (!c || !out) return fail(GEV_EINVAL, "null");
+    if (x_begin < 1 || x_end > 2147483647u || x_begin > x_end) return fail(GEV_EINVAL, "dbg_prefilter_sweep: engine states are 1 .. 2^31-2");
+    HIPC(hipSetDevice(c->device));
+    GEVC(c->d_flag.ensure(32, c->stream));
+    HIPC(hipMemsetAsync(c->d_flag.p, 0, 24, c->stream));
+    hipLaunchKernelGGL(k_dbg_prefilter_sweep, dim3(8192), dim3(256), 0, c->stream, c->d_tables.as<GevRngTables>(), x_begin, x_end, (unsigned long long*)c->d_flag.p);
+    KCHECK();
+    HIPC(hipMemcpyAsync(out, c->d_flag.p, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return GEV_OK;
+}
 int gev_dbg_tables(void* out, size_t bytes)
 {
     if (bytes != sizeof(GevRngTables)) return fail(GEV_EINVAL, "gev_dbg_tables: expected %zu bytes", sizeof(GevRngTables));

@@ -23,11 +23,14 @@
 #define SB_OUT 8            // rand() outputs per generator held in the lane grid
 #define SB_CAND 320         // candidate slots per wave: a flush is forced at >= 64, one scan step adds <= 256
 
-struct SmpTabs {            // constant tables, one copy per workgroup (LDS)
+#define SB_J 32             // draws per lane that are prefiltered from ONE exact engine state (64 * SB_J = 2048 draws per block)
+struct __attribute__((aligned(32))) SmpTabs {   // constant tables, one copy per workgroup (LDS)
+    double kd[SB_J];        // c_j / M with c_j = 16807^(128 j) mod M: draw (lane + 64 j)'s high digit = x_lane * c_j mod M
+    u32 ci[SB_J];           // c_j
     u32 pow_even[64];       // 16807^(2l+2): lane l's first high-digit engine output
     u32 w8[31 * SB_OUT];    // w_init[i][j], j < 8
     u32 pow_lcg[32];        // 16807^(i-1), i = 1..30
-    u32 pow128, pow512, inv16807, pad;
+    u32 pow128, pow_blk /* 16807^(128 SB_J): next block of draws */, inv16807, pad;
 };
 struct SmpWave {            // scratch of one wave (LDS)
     u32 r[SB_TASKS * 33];   // seed words r_0..r_30 of the 8 generators, odd stride
@@ -44,7 +47,11 @@ __device__ __forceinline__ void stage_smp_tabs(const GevRngTables* __restrict__ 
     for (u32 i = threadIdx.x; i < 64; i += blockDim.x) s->pow_even[i] = g->pow_even[i];
     for (u32 i = threadIdx.x; i < 31 * SB_OUT; i += blockDim.x) s->w8[i] = g->w_init[(i / SB_OUT) * 64 + (i % SB_OUT)];
     for (u32 i = threadIdx.x; i < 31; i += blockDim.x) s->pow_lcg[i] = g->pow_lcg[i];
-    if (threadIdx.x == 0) { s->pow_lcg[31] = 0; s->pow128 = g->pow128; s->pow512 = g->pow512; s->inv16807 = g->inv16807; s->pad = 0; }
+    if (threadIdx.x < SB_J) {
+        const u32 c = powmod31(g->pow128, threadIdx.x);              // (16807^128)^j
+        s->ci[threadIdx.x] = c; s->kd[threadIdx.x] = (double)c / 2147483647.0;
+    }
+    if (threadIdx.x == 0) { s->pow_lcg[31] = 0; s->pow128 = g->pow128; s->pow_blk = powmod31(g->pow128, SB_J); s->inv16807 = g->inv16807; s->pad = 0; }
     __syncthreads();
 }
 
@@ -76,8 +83,20 @@ __device__ __forceinline__ u32 srand8(const SmpTabs* __restrict__ T, volatile u3
 }
 
 // One Bernoulli scan (engine = minstd_rand0(engine_seed), draw d tests map row first_row + d) that only RECORDS candidates:
-// draws whose high digit is below `amax` (the largest a_hi of the map) go to the wave's candidate list tagged `tag`.
+// draws whose high digit x2 - 1 is below `amax` (the largest a_hi of the map) go to the wave's candidate list tagged `tag`.
 // `count` (wave-uniform) is the list length; `flush()` must consume the list and reset count when it reaches 64.
+//
+// FP64 prefilter.  Lane l holds ONE exact engine state x (the high digit of draw l of the current block of 64 * SB_J draws); the
+// high digit of its draw l + 64 j is x2 = x * c_j mod M, i.e. M * frac(T) with T = x * c_j / M < 2^31.  One FMA evaluates
+//     s = x * fl(c_j / M) + (1.5 * 2^32 + 4 u),   u = 2^-20 = ulp(s),
+// whose 20 low mantissa bits are  L = (frac(T) * 2^20 + e + 4) mod 2^20  with |e| < 1 (2^-22 from the rounded constant, 2^-21 from
+// the rounding of the FMA, in units of u = 2^-20 less than one unit together).  A draw with x2 <= amax has frac(T) * 2^20 in
+// (0, A], A = amax * 2^20 / M, hence L in [4, A + 5): it passes  L < ceil(A) + 6.  The test is a SUPERSET of the exact one
+// (a few thousand x2 values wide: ~0.4 % extra candidates at 5e-4 per row); every candidate's exact x2 is then computed with
+// the integer multiply and the exact threshold test runs in the resolve step, so the result is bit-identical.  Cost per 64 draws:
+// one v_fma_f64, one v_and, one v_cmp (the exact form needs a 10-instruction modular multiply per 64 draws), plus one uniform
+// 32-byte LDS read of the constants per 256 draws (broadcasting them from lanes with v_readlane measured 33 % slower).
+// gev_dbg_prefilter_sweep checks the bound exhaustively over all 2^31 - 2 engine states x 32 multipliers.
 template <class Flush>
 __device__ __forceinline__ void scan_candidates(const SmpTabs* __restrict__ T, SmpWave* __restrict__ W, u32 engine_seed, u32 amax,
                                                 u32 first_row, u32 n_draws, u32 tag, u32& count, Flush&& flush)
@@ -85,38 +104,42 @@ __device__ __forceinline__ void scan_candidates(const SmpTabs* __restrict__ T, S
     const u32 lane = threadIdx.x & 63;
     if (amax == 0) return;                                 // every row has probability 0: no draw can hit
     const u32 s0 = minstd_seed(engine_seed);
-    const u32 p128 = T->pow128, p512 = T->pow512;
-    // the four chains carry the engine state in the lazy form of mulmod31_lazy (2^31 stands for 1); a draw is a candidate if its
-    // canonical high digit a = x2 - 1 is below amax: lazy - 1 < amax, or lazy == 2^31 (x2 = 1, a = 0 < amax)
-    u32 xa = mulmod31(T->pow_even[lane], s0);
-    u32 xb = mulmod31(xa, p128), xc = mulmod31(xb, p128), xd = mulmod31(xc, p128);
-    auto push = [&](unsigned long long m, bool c, u32 x, u32 d) {
-        if (c) {
-            const u32 idx = count + mbcnt64(m);
-            W->cand_row[idx] = first_row + d; W->cand_x2[idx] = x == 0x80000000u ? 1u : x; W->cand_tag[idx] = (uint8_t)tag;
+    u32 x = mulmod31(T->pow_even[lane], s0);               // exact high digit (engine output 2 lane + 2) of draw `lane`
+    const double A = (double)amax * (1048576.0 / 2147483647.0);
+    const bool all_cand = A + 8.0 >= 1048576.0;            // thresholds near 1: every draw is a candidate
+    const u32 thr20 = all_cand ? 0xffffffffu : (u32)A + 7u;   // >= ceil(A) + 6
+    const double C = 6442450944.0 + 4.0 / 1048576.0;       // 1.5 * 2^32 + 4 u
+    for (u32 base = 0; base < n_draws; base += 64 * SB_J) {
+        const u32 n_here = min(64u * SB_J, n_draws - base);
+        const u32 jfull = n_here >> 6, jn = (n_here + 63u) >> 6;   // full groups of 64 draws / groups incl. a partial last one
+        const double xd = (double)x;
+        auto testk = [&](double k) -> bool { return ((u32)__double2loint(__fma_rn(xd, k, C)) & 0xfffffu) < thr20; };
+        auto push = [&](unsigned long long m, bool c, u32 j) {
+            if (c) {
+                const u32 idx = count + mbcnt64(m);
+                W->cand_row[idx] = first_row + base + 64u * j + lane;
+                W->cand_x2[idx] = mulmod31(x, T->ci[j]);  // the exact high digit of this draw
+                W->cand_tag[idx] = (uint8_t)tag;
+            }
+            count += (u32)__popcll(m);
+        };
+        // four groups (256 draws) per step; the constants c_j / M of a step are one uniform 32-byte LDS read
+        u32 j = 0;
+        for (; j + 4 <= jfull; j += 4) {                   // full groups: no bounds to check
+            const double4 kk = *reinterpret_cast<const double4*>(&T->kd[j]);
+            const bool c0 = testk(kk.x), c1 = testk(kk.y), c2 = testk(kk.z), c3 = testk(kk.w);
+            const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3);
+            if (m0 | m1 | m2 | m3) {
+                push(m0, c0, j); push(m1, c1, j + 1); push(m2, c2, j + 2); push(m3, c3, j + 3);
+                if (count >= 64) flush();
+            }
         }
-        count += (u32)__popcll(m);
-    };
-    auto is_cand = [&](u32 x) { return (x - 1 < amax) | (x == 0x80000000u); };
-    const u32 n_full = n_draws & ~255u;
-    u32 base = 0;
-    for (; base < n_full; base += 256) {
-        const bool ca = is_cand(xa), cb = is_cand(xb), cc = is_cand(xc), cd = is_cand(xd);
-        const unsigned long long ma = __ballot(ca), mb = __ballot(cb), mc = __ballot(cc), md = __ballot(cd);
-        if (ma | mb | mc | md) {
-            push(ma, ca, xa, base + lane); push(mb, cb, xb, base + 64 + lane); push(mc, cc, xc, base + 128 + lane); push(md, cd, xd, base + 192 + lane);
-            if (count >= 64) flush();
+        for (; j < jn; j++) {                              // the last (up to three full + one partial) groups of the block
+            const bool c0 = 64u * j + lane < n_here && testk(T->kd[j]);
+            const unsigned long long m0 = __ballot(c0);
+            if (m0) { push(m0, c0, j); if (count >= 64) flush(); }
         }
-        xa = mulmod31_lazy(xa, p512); xb = mulmod31_lazy(xb, p512); xc = mulmod31_lazy(xc, p512); xd = mulmod31_lazy(xd, p512);
-    }
-    if (base < n_draws) {                                  // last, partial step
-        const bool ca = base + lane < n_draws && is_cand(xa), cb = base + 64 + lane < n_draws && is_cand(xb);
-        const bool cc = base + 128 + lane < n_draws && is_cand(xc), cd = base + 192 + lane < n_draws && is_cand(xd);
-        const unsigned long long ma = __ballot(ca), mb = __ballot(cb), mc = __ballot(cc), md = __ballot(cd);
-        if (ma | mb | mc | md) {
-            push(ma, ca, xa, base + lane); push(mb, cb, xb, base + 64 + lane); push(mc, cc, xc, base + 128 + lane); push(md, cd, xd, base + 192 + lane);
-            if (count >= 64) flush();
-        }
+        if (base + 64 * SB_J < n_draws) x = mulmod31(x, T->pow_blk);
     }
 }
 

@@ -49,13 +49,22 @@ __device__ __forceinline__ uint32_t mulmod31(uint32_t a, uint32_t b)
     return r >= GEV_M31 ? r - GEV_M31 : r;
 }
 
-// Same product for a chain that is multiplied again: a <= 2^31, b < 2^31; the result is in [1, 2^31] and congruent to a*b, i.e.
-// canonical except that 2^31 may stand for 1 (the final conditional subtraction is left out; states are never 0 mod M).
-__device__ __forceinline__ uint32_t mulmod31_lazy(uint32_t a, uint32_t b)
+// The same product for CANONICAL operands (a, b in [0, M-1]): then p = a*b < M^2, r = floor(p / 2^31) + (p mod 2^31) <= 2M,
+// and the folded value (r & M) + (r >> 31) could only leave [0, M-1] for r = M or r = 2M, i.e. p = 0 (mod M) with p != 0, which a
+// prime modulus rules out: the conditional subtraction of mulmod31 is never taken.  Used by the scan loops, whose chains
+// multiply canonical engine states by canonical constants.
+__device__ __forceinline__ uint32_t mulmod31_canon(uint32_t a, uint32_t b)
 {
-    const uint32_t lo = a * b, hi = __umulhi(a, b);                  // hi <= 2^30
-    const uint32_t r = (hi << 1) + (lo >> 31) + (lo & GEV_M31);      // <= 2^32 - 2
+    const uint32_t lo = a * b, hi = __umulhi(a, b);
+    const uint32_t r = (hi << 1) + (lo >> 31) + (lo & GEV_M31);      // <= 2M
     return (r & GEV_M31) + (r >> 31);
+}
+
+__device__ __forceinline__ uint32_t powmod31(uint32_t a, uint64_t e)
+{
+    uint32_t r = 1;
+    while (e) { if (e & 1) r = mulmod31(r, a); a = mulmod31(a, a); e >>= 1; }
+    return r;
 }
 
 // std::minstd_rand0::seed(s): state = s mod (2^31-1), 0 -> 1.  `s` is the unsigned expression the

@@ -312,6 +312,11 @@ int gev_set_stitch_mode(gev_ctx*, int mode);
  * population r was generated with (n_pop entries: after migration a part may descend from another population's founders, on
  * another GPU).  *n_bad_words = mismatching words, *n_bad_parts = parts whose founder is unknown / out of range (both must be 0). */
 int    gev_dbg_verify_planes(gev_ctx*, int pop, int chr, const uint64_t* founder_seeds, unsigned long long* n_bad_words, unsigned long long* n_bad_parts);
+/* gev_dbg_prefilter_sweep: exhaustive check of the FP64 candidate prefilter of the batched sampling kernels over the engine states
+ * [x_begin, x_end) (the whole state space of minstd_rand0 is 1 .. 2^31-2) and all 32 per-lane multipliers: out[0] = states x multipliers
+ * for which the prefilter's 20-bit fraction deviates from the exact one by more than its proven bound (must be 0: the prefilter
+ * then flags a superset of the exact candidates for every threshold), out[1] / out[2] = largest deviations seen. */
+int    gev_dbg_prefilter_sweep(gev_ctx*, uint32_t x_begin, uint32_t x_end, unsigned long long out[3]);
 int    gev_dbg_tables(void* out, size_t bytes);
 int    gev_dbg_threshold(double p, uint32_t out[4] /* a_lo, a_hi, b0, b1 */);
 double gev_dbg_canonical(uint32_t a, uint32_t b);

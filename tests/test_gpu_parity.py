@@ -57,6 +57,17 @@ def test_device_sim_loc_rec_matches_reference_vectors(gpu_lib):
     ctx.close()
 
 
+def test_fp64_prefilter_of_the_sampling_scan_is_a_superset_for_every_engine_state(gpu_lib):
+    """the batched sampling kernels test most draws with one FP64 FMA instead of an exact modular multiply; the exact test runs
+    only for the draws the prefilter flags.  EXHAUSTIVE over the engine's whole state space (x = 1 .. 2^31-2) and all 32
+    per-lane multipliers (6.9e10 cases): the prefilter's 20-bit fraction never deviates from the exact one by more than the
+    bound its threshold allows for, so no draw the exact test would accept can be missed, whatever the map's probabilities."""
+    g = gpu_lib.create(1, 1, 1)
+    bad, dpos, dneg = g.dbg_prefilter_sweep(1, 2147483647)
+    assert bad == 0 and dpos <= 2 and dneg <= 1, (bad, dpos, dneg)
+    g.close()
+
+
 def test_synth_founders_match_specification(gpu_lib):
     cfg = SyntheticConfig(64, 1000, n_cv=77)
     ctx = gpu_lib.create(1, 1, 1)
