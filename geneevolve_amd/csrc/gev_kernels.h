@@ -684,8 +684,8 @@ __global__ void __launch_bounds__(256) k_stitch_parent(const ChrWork* __restrict
 // merged into the ascending list of distinct boundary CHUNKS of the span; between two consecutive boundary chunks every gamete
 // copies from ONE fixed parental row, so a region is described by one bit mask (bit j = gamete j takes row 1).  A pure chunk
 // then costs a monotone pointer advance, one LDS read and the copies; only the (few) boundary chunks run the masked blend.
-template <int UNROLL, bool NT>
-__global__ void __launch_bounds__(256) k_stitch_regions(const ChrWork* __restrict__ Wt, u32 bpr_max, int nchr,
+template <int UNROLL, bool NT, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS) k_stitch_regions(const ChrWork* __restrict__ Wt, u32 bpr_max, int nchr,
                                                         const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd, int wave_prio)
 {
     // instruction-issue priority of this kernel's waves inside a SIMD (s_setprio): the stitch shares the CUs with the ALU-bound
@@ -730,14 +730,14 @@ __global__ void __launch_bounds__(256) k_stitch_regions(const ChrWork* __restric
         const u32 n = s_n; const bool big = s_big != 0;
         if (!big)
             for (u32 j = 0; j < n; j++)
-                for (u32 m = threadIdx.x; m < s_k[j]; m += 256) s_idx[s_kb[j] + m] = sd.bk_idx[s_bkoff[j] + m];
+                for (u32 m = threadIdx.x; m < s_k[j]; m += THREADS) s_idx[s_kb[j] + m] = sd.bk_idx[s_bkoff[j] + m];
         __syncthreads();
         if (big) {
             // one gamete with more boundaries than LDS holds (> PM_KTOT crossovers): per-chunk bisection on the global index list
             const PmIdx I{s_idx, sd.bk_idx + s_bkoff[0], true};
             const u32 k = s_k[0];
             v4u* D = (v4u*)(dst + (size_t)s_row[0] * stride);
-            for (u32 q = q0 + threadIdx.x; q < q1; q += 256) {
+            for (u32 q = q0 + threadIdx.x; q < q1; q += THREADS) {
                 const u32 bit0 = q * 128u, bit1 = bit0 + 128u;
                 u32 cnt, nxt; pm_locate(I, k, bit0, cnt, nxt);
                 const u32 sel = s_start[0] ^ (cnt & 1u);
@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(256) k_stitch_regions(const ChrWork* __restric
         }
         __syncthreads();
         const u32 nd = s_nd;
-        for (u32 r = threadIdx.x; r <= nd; r += 256) {        // selection mask of every region
+        for (u32 r = threadIdx.x; r <= nd; r += THREADS) {        // selection mask of every region
             const u32 bit = (r == 0 ? q0 : s_bc[r - 1] + 1u) * 128u;
             u32 mask = 0;
             for (u32 j = 0; j < n; j++) {
@@ -787,12 +787,12 @@ __global__ void __launch_bounds__(256) k_stitch_regions(const ChrWork* __restric
         u32 reg[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) reg[u] = 0;
-        for (u32 q = q0 + threadIdx.x; q < q1; q += 256 * UNROLL) {
+        for (u32 q = q0 + threadIdx.x; q < q1; q += THREADS * UNROLL) {
             v4u a[UNROLL], b[UNROLL];
             u32 sel[UNROLL]; bool isb[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
-                const u32 qq = q + u * 256;
+                const u32 qq = q + u * THREADS;
                 sel[u] = 0; isb[u] = false;
                 if (qq >= q1) continue;
                 u32 r = reg[u];
@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(256) k_stitch_regions(const ChrWork* __restric
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
-                const u32 qq = q + u * 256;
+                const u32 qq = q + u * THREADS;
                 if (qq >= q1) continue;
                 if (!isb[u]) {
                     for (u32 j = 0; j < n; j++) {

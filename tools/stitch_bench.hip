@@ -134,6 +134,12 @@ int main(int argc, char** argv)
     RG("regions U4 nt", 4, true, 8);
     RG("regions U4 nt occ6", 4, true, 6);
     RG("regions U4 nt occ4", 4, true, 4);
+#define RGT(name, U, TH) ADD(name, hipLaunchKernelGGL((k_stitch_regions<U, true, TH>), dim3((unsigned)N), dim3(TH), 0, 0, dw, 1u, 1, dgoff, dglist, sd, 0))
+    RGT("regions U2 nt 128thr", 2, 128);
+    RGT("regions U4 nt 128thr", 4, 128);
+    RGT("regions U8 nt 128thr", 8, 128);
+    RGT("regions U4 nt 64thr", 4, 64);
+    RGT("regions U8 nt 64thr", 8, 64);
     RG("regions U8 nt", 8, true, 8);
     RG("regions U8 nt occ4", 8, true, 4);
     RG("regions U4 plain", 4, false, 8);
