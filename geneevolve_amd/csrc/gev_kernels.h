@@ -836,15 +836,15 @@ __global__ void __launch_bounds__(THREADS) k_stitch_regions(const ChrWork* __res
 // CV-column indices in parallel (one binary search per lane, 32 breakpoints per round) and share them with shuffles, then
 // every lane blends its own 32-bit words of the two parental rows; loads and stores are 128-byte coalesced per half-wave.
 #define SMALL_ROWS_PER_BLOCK 256         // 8 half-waves x 32 rounds: the block stages the CV position grid in LDS once
-#define SMALL_POS_LDS 4096               // CV positions held in LDS (32 KiB); longer grids are searched in global memory
-__global__ void __launch_bounds__(256) k_stitch_small(const CvWork* __restrict__ Vt, u32 nsub, size_t n_rows_out, int nchr, SampleDev sd)
+#define SMALL_POS_LDS 4096               // most CV positions held in LDS (32 KiB); longer grids are searched in global memory
+__global__ void __launch_bounds__(256) k_stitch_small(const CvWork* __restrict__ Vt, u32 nsub, size_t n_rows_out, int nchr, SampleDev sd, u32 pos_lds)
 {
-    __shared__ u64 s_pos[SMALL_POS_LDS];
+    extern __shared__ u64 s_pos[];                                        // min(largest CV grid of the launch, SMALL_POS_LDS) entries
     const CvWork& v = Vt[blockIdx.y];
     u32* __restrict__ dst = v.cvp_alt; const u32* __restrict__ src = v.cvp_cur;
     const u32 stride_w32 = v.stride_w32, sub_w32 = v.sub_w32, Cn = v.C;
     const int chr = v.chr;
-    const bool in_lds = Cn <= SMALL_POS_LDS;
+    const bool in_lds = Cn <= pos_lds;
     if (in_lds) for (u32 e = threadIdx.x; e < Cn; e += 256) s_pos[e] = v.pos_sorted[e];
     __syncthreads();
     const u64* __restrict__ pos = in_lds ? s_pos : v.pos_sorted;

@@ -922,7 +922,10 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         const u32 nsub = 1 + c->rp_bits;
         size_t max_used = 0;
         for (const CvWork& v : vw) max_used = std::max<size_t>(max_used, (size_t)v.sub_w32 * nsub);
-        if (max_used) hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows, SMALL_ROWS_PER_BLOCK), (unsigned)vw.size()), dim3(256), 0, st, Vt, nsub, rows, nchr, sd);
+        u32 cv_max = 0;
+        for (const CvWork& v : vw) if (v.C <= SMALL_POS_LDS) cv_max = std::max(cv_max, v.C);       // LDS copy of the CV grid: sized for the launch, not for the worst case (occupancy)
+        if (max_used) hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows, SMALL_ROWS_PER_BLOCK), (unsigned)vw.size()), dim3(256), (size_t)cv_max * sizeof(u64), st,
+                                         Vt, nsub, rows, nchr, sd, cv_max);
         KCHECK();
     }
     // ---- gamete grouping by source individual for the parent-major stitch (same for every chromosome)
