@@ -12,6 +12,7 @@
 //   GEV_SAMPLE_GRID=n         persistent workgroups of the sampling kernels (default 384 next to a stitch, 1024 alone)
 //   GEV_STITCH_WG_PER_CU=1..7 limit stitch workgroups per CU (default: wave-slot bound, 8)
 //   GEV_STITCH_PRIORITY=1|2   stitch stream high / all streams equal (default: small streams high, stitch low)
+//   GEV_STITCH_UNROLL=2|4|8    chunks per thread in flight in k_stitch_regions (default: 4 on rows >= 64 KiB, else 2; sweeps with fewer workgroups per CU lost)
 //   GEV_STITCH_WAVE_PRIO=0..3 s_setprio level of the stitch kernel's waves (default 0; measured: no effect next to the sampling kernels)
 //   GEV_TABLE_RING_BYTES=n    minimum size of the pinned ring the per-generation work tables are staged in (default 256 KiB)
 //   GEV_TRACE_HOST=1          stderr: host time per phase of gev_reproduce, allocations, deferred frees
@@ -194,6 +195,7 @@ struct gev_ctx {
     int overlap_mode = 1;          // 1 everything (default), 0 never, 2 sampling only, -1 decide after two serialised generations
     bool sparse_after_stitch = false;   // mode 2: the memory-bound sparse/CV/A-D kernels wait for the running stitch, only the ALU-bound sampling shares the GPU with it
     int auto_gens = 0; double auto_small_ms = 0, auto_stitch_ms = 0;
+    int stitch_unroll = 0;         // 0: chosen by row length; 2 / 4 / 8: forced (GEV_STITCH_UNROLL)
     int stitch_wave_prio = 0;      // s_setprio level of the stitch kernel's waves (GEV_STITCH_WAVE_PRIO)
     unsigned stitch_lds_pad = 0;   // unused dynamic LDS per stitch workgroup: limits workgroups per CU (160 KiB / CU)
     DevBuf d_snpmajor, d_text;
@@ -347,6 +349,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     c->serialize = c->overlap_mode <= 0;                             // auto starts serialised
     c->sparse_after_stitch = c->overlap_mode == 2;
     if (const char* e = getenv("GEV_SAMPLE_BATCHED")) c->sample_batched = atoi(e) != 0;
+    if (const char* e = getenv("GEV_STITCH_UNROLL")) c->stitch_unroll = atoi(e);
     if (const char* e = getenv("GEV_STITCH_WAVE_PRIO")) c->stitch_wave_prio = std::max(0, std::min(atoi(e), 3));
     if (const char* e = getenv("GEV_STITCH_MODE")) c->stitch_mode = std::max(0, std::min(atoi(e), 2));
     if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = c->sample_grid_shared = (unsigned)g; }
@@ -959,7 +962,11 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         const size_t units = c->stitch_mode != 1 ? n_parent : rows;
         const size_t nblk = units * sc.bpr_max;
         if (nblk > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
-        if (c->stitch_mode == 0 && sc.long_rows)          // 4 chunks per thread in flight pay off on long rows; short rows (< 4096 chunks = 64 KiB) lose lanes to the tail
+        const int su = c->stitch_unroll;                    // GEV_STITCH_UNROLL (experiments): 0 = by row length
+        if (c->stitch_mode == 0 && su == 8)
+            hipLaunchKernelGGL((k_stitch_regions<8, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
+                               sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd, c->stitch_wave_prio);
+        else if (c->stitch_mode == 0 && (su == 4 || (su == 0 && sc.long_rows)))          // 4 chunks per thread in flight pay off on long rows; short rows (< 4096 chunks = 64 KiB) lose lanes to the tail
             hipLaunchKernelGGL((k_stitch_regions<4, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
                                sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd, c->stitch_wave_prio);
         else if (c->stitch_mode == 0)
