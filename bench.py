@@ -23,10 +23,13 @@ genotype state is resident in HBM throughout.  --plane-less times BASELINE confi
 no per-generation genotype assembly) and is NOT the headline configuration.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_regions):
-algorithmic bytes per launch = 2N rows x (L/8 read + L/8 written) = N*L/2, divided
-by its duration measured with HIP events on the library's own stream.  The kernel reads LESS than
-the algorithmic bytes (a parent's chunk is loaded once for all of its gametes), so `achieved` can
-exceed what a plain device copy of N*L/2 bytes reaches; `traffic` holds the measured HBM bytes (newest committed rocprofv3
+algorithmic bytes per launch = gametes the launch copies x (L/8 read + L/8 written) (SURVEY.md 8(d)'s per-gamete figure),
+divided by its duration measured with HIP events on the library's own stream.  A gamete without a crossover is the parental
+haplotype unchanged; its slot shares the parent's row and the launch does not copy it (about e^-1 of the gametes on a 1-Morgan
+chromosome), so the units of a launch are the gametes WITH a crossover (gev_stitch_totals); `every_gamete_copied_equivalent_*`
+prices all 2N gametes (N*L/2 bytes, the definition of earlier rounds).  The kernel also reads LESS than the algorithmic bytes
+(a parent's chunk is loaded once for all of its gametes), so `achieved` can
+exceed what a plain device copy of the same bytes reaches; `traffic` holds the measured HBM bytes (newest committed rocprofv3
 PMC passes) and `hbm_actual_GBps` = traffic / kernel time, the rate the memory system really sustained.  `cpu_baseline` times the
 unmodified reference (oracle/_ref/ref_harness, kind "reference"; when it is absent the bit-exact CPU oracle, kind
 "port") on a bounded sample of the same workload on this box's host cores (1 thread: the reference is single threaded).
@@ -306,6 +309,7 @@ def main():
     del ad_ms[:], mate_ms[:], repro_ms[:], mig_ms[:], step_ms[:], seed_ms[:]
     mig_parts.clear()
     tot0, n0 = ctx.timing_totals()                       # (implies a sync of both library streams)
+    rows0 = (0, 0) if args.plane_less else ctx.stitch_totals()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
@@ -313,6 +317,7 @@ def main():
     barrier()                                            # torch.cuda.synchronize() waits for the last dense stitch too
     dt = time.perf_counter() - t0
     tot1, n1 = ctx.timing_totals()
+    rows1 = (0, 0) if args.plane_less else ctx.stitch_totals()
     assert n1 - n0 == args.steps
     sample_ms = [(tot1[0] - tot0[0]) / args.steps]; stitch_ms = [(tot1[1] - tot0[1]) / args.steps]; sparse_ms = [(tot1[2] - tot0[2]) / args.steps]
     if dist is not None:
@@ -335,9 +340,16 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         gens_per_s = world * args.steps / dt
-        alg_bytes = args.n_ind * args.n_loci / 2.0 * args.nchr   # per generation: one stitch launch per chromosome, N*L/2 bytes each
+        # Units one stitch launch processes = the gametes it copies.  A gamete without a crossover is its parent's haplotype
+        # unchanged (Simulation::recombine, src/Simulation.cpp:2910): its slot points at the parent's row and nothing is copied,
+        # so it is not a unit of the launch.  Per unit: L/8 bytes read + L/8 written.
+        full_bytes = args.n_ind * args.n_loci / 2.0 * args.nchr   # every gamete copied: N*L/2 per generation (the figure of earlier rounds)
+        rows_written, rows_total = rows1[0] - rows0[0], rows1[1] - rows0[1]
+        written_frac = rows_written / rows_total if rows_total else 1.0
+        alg_bytes = full_bytes * written_frac
         stitch = float(np.mean(stitch_ms))
         achieved = alg_bytes / (max(stitch, 1e-9) * 1e-3) / 1e9 if not args.plane_less else 0.0
+        full_equiv = full_bytes / (max(stitch, 1e-9) * 1e-3) / 1e9 if not args.plane_less else 0.0
         traffic, traffic_src = None, None                   # HBM bytes per launch from the committed PMC passes (same workload only)
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_config2_pmc_hbm.json")))       # newest round last
@@ -372,7 +384,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "hbm_actual_GBps": hbm_actual, "hbm_actual_frac": hbm_actual / HBM_PEAK_GBPS if hbm_actual else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": stitch,
-                         "note": "kernel time measured live with HIP events on the library's stitch stream inside the timed region, where the "
+                         "gametes_copied_per_launch": rows_written / max(args.steps, 1), "gametes_per_launch": rows_total / max(args.steps, 1),
+                         "copied_fraction": written_frac,
+                         "every_gamete_copied_equivalent_GBps": full_equiv, "every_gamete_copied_equivalent_frac": full_equiv / HBM_PEAK_GBPS,
+                         "note": "algorithmic bytes = gametes the launch copies x (L/8 read + L/8 written); crossover-free gametes share the parental "
+                                 "row and are not copied (every_gamete_copied_equivalent_* prices all 2N gametes, the definition of earlier rounds, "
+                                 "and can exceed the peak); kernel time measured live with HIP events on the library's stitch stream inside the timed region, where the "
                                  "kernel shares the GPU with the next generation's sampling/A-D kernels; isolated_* = same kernel with the two "
                                  "streams serialised (extra untimed generations); traffic = rocprofv3 PMC measurement committed under profiles/",
                          "isolated_kernel_ms": iso, "isolated_achieved": (alg_bytes / (iso * 1e-3) / 1e9) if iso else None,

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "set_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
-    "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "set_overlap",
+    "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "stitch_totals", "set_overlap",
     "dbg_verify_planes", "dbg_prefilter_sweep", "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -352,9 +352,16 @@ class GevContext:
         self._call("reserve", C.c_int(pop), C.c_size_t(max_people))
 
     def plane_ptr(self, pop, chr):
-        p = C.c_void_p(); s = C.c_size_t(); n = C.c_size_t()
-        self._call("plane_ptr", C.c_int(pop), C.c_int(chr), C.byref(p), C.byref(s), C.byref(n))
-        return p.value, s.value, n.value
+        """(pool pointer, row stride in bytes, number of haplotype slots, device pointer of the slot -> row table)"""
+        p = C.c_void_p(); s = C.c_size_t(); n = C.c_size_t(); t = C.c_void_p()
+        self._call("plane_ptr", C.c_int(pop), C.c_int(chr), C.byref(p), C.byref(s), C.byref(n), C.byref(t))
+        return p.value, s.value, n.value, t.value
+
+    def stitch_totals(self):
+        """(haplotype rows written by the dense stitch, rows of the generations produced) over all reproduce calls"""
+        w = C.c_ulonglong(); t = C.c_ulonglong()
+        self._call("stitch_totals", C.byref(w), C.byref(t))
+        return w.value, t.value
 
     def stream(self):
         p = C.c_void_p()

@@ -62,10 +62,21 @@ struct SampleDev {
 // Per-generation work tables: one entry per ACTIVE chromosome (ChrWork) / per (phenotype, active chromosome) (CvWork, AdWork).
 // Every per-chromosome kernel of a generation is ONE launch whose blockIdx.y (or .z) selects the entry, instead of one launch
 // per chromosome (a 22-chromosome genome used to cost ~300 launches per generation).
+// Genotype rows live in ONE pool per (population, chromosome): haplotype slot s (= 2*individual + chromatid) of a generation is
+// pool row phys[s].  An offspring gamete without a crossover IS its parent's haplotype (Simulation::recombine returns the
+// parental Hap unchanged when locs.size() < 3, src/Simulation.cpp:2910): its slot then points at the parent's pool row and no
+// byte is copied.  Every other gamete gets a row that no slot of the parents' generation points at (free list, rebuilt from the
+// parents' phys[] at the start of each generation: mark, collect).  Physical placement is arbitrary (atomics) and invisible:
+// every consumer goes through phys[].
+struct PoolWork {
+    uint8_t* pool; const u32* phys_cur; u32* phys_alt;      // rows, slot -> row of the parents / of the offspring
+    u32* live; u32* freel; u32* pctr;                       // [pool_rows] flags, [pool_rows] free rows, {n_free, n_taken, exhausted}
+    u32 pool_rows, alias;
+};
 struct ChrWork {
     const u32* moff_cur; const u64* mpos_cur; u32* moff_alt; u64* mpos_alt;                 // mutation lists (CSR), parents / offspring
     const u32* poff_cur; const gev_part* parts_cur; u32* poff_alt; gev_part* parts_alt;     // ancestry intervals
-    uint8_t* plane_alt; const uint8_t* plane_cur; const u64* snp_pos;                       // genotype planes
+    PoolWork pw; const u64* snp_pos;                                                        // genotype rows
     size_t stride;
     u64 bp0, bp_end;
     u32 mcap, pcap, chunks, bpr, L;
@@ -89,8 +100,9 @@ struct AdWork {
 #define GEV_NM_CAP 8
 // status words written by the kernels of one generation, read back once at its end
 enum { ST_BK_OVF_USED = 0, ST_NM_OVF_USED = 1, ST_FLAGS = 2, ST_SLOW_MUT = 3, ST_SLOW_REC = 4 /* tasks handed to the one-task-per-wave kernels */,
-       ST_TOTALS = 8 /* then per chr: mut_total, parts_total */ };
-enum { FLAG_BK_OVF = 1, FLAG_NM_OVF = 2, FLAG_MUT_CAP = 4, FLAG_PARTS_CAP = 8 };
+       ST_TOTALS = 8 /* then per chr: mut_total, parts_total, rows_written (gametes the dense stitch copies) */ };
+#define ST_PER_CHR 3
+enum { FLAG_BK_OVF = 1, FLAG_NM_OVF = 2, FLAG_MUT_CAP = 4, FLAG_PARTS_CAP = 8, FLAG_POOL = 16 };
 
 // The RNG tables (16 KB) are read 31 words at a time for every srand(); under a concurrently
 // running HBM-saturating stitch a dependent global read costs microseconds, so every sampling
@@ -180,7 +192,7 @@ __global__ void __launch_bounds__(256) k_scan_final_tab(const u32* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (base + j <= n) out[base + j] = ex;
-        if (base + j == n) status[ST_TOTALS + 2 * w.chr + (is_parts ? 1 : 0)] = ex;
+        if (base + j == n) status[ST_TOTALS + ST_PER_CHR * w.chr + (is_parts ? 1 : 0)] = ex;
         ex += v[j];
     }
 }
@@ -456,7 +468,7 @@ __global__ void __launch_bounds__(STITCH_THREADS) k_stitch_rows(const ChrWork* _
 {
     __shared__ u32 s_idx[STITCH_KMAX];
     const ChrWork& w = Wt[blockIdx.y];
-    uint8_t* __restrict__ dst = w.plane_alt; const uint8_t* __restrict__ src = w.plane_cur;
+    uint8_t* __restrict__ pool = w.pw.pool;
     const size_t stride = w.stride; const u32 chunks_per_row = w.chunks, blocks_per_row = w.bpr, L = w.L;
     const u64* __restrict__ pos = w.snp_pos; const int chr = w.chr;
     const u32 row = blockIdx.x / bpr_max;                 // output row = 2*offspring + s
@@ -468,9 +480,10 @@ __global__ void __launch_bounds__(STITCH_THREADS) k_stitch_rows(const ChrWork* _
     const u32 start = sd.start[G];
     const u32 k = sd.k[G];
     const u64* bk = sd.bk + sd.bk_off[G];
-    const uint4* __restrict__ A = (const uint4*)(src + (size_t)(2 * parent + start) * stride);
-    const uint4* __restrict__ B = (const uint4*)(src + (size_t)(2 * parent + (start ^ 1)) * stride);
-    uint4* __restrict__ D = (uint4*)(dst + (size_t)row * stride);
+    if (k == 0 && w.pw.alias) return;                        // the slot shares its parent's row (k_pool_assign)
+    const uint4* __restrict__ A = (const uint4*)(pool + (size_t)w.pw.phys_cur[2 * (size_t)parent + start] * stride);
+    const uint4* __restrict__ B = (const uint4*)(pool + (size_t)w.pw.phys_cur[2 * (size_t)parent + (start ^ 1)] * stride);
+    uint4* __restrict__ D = (uint4*)(pool + (size_t)w.pw.phys_alt[row] * stride);
     const u32 kk = k < STITCH_KMAX ? k : STITCH_KMAX;
     for (u32 m = threadIdx.x; m < kk; m += STITCH_THREADS) s_idx[m] = lower_bound_u64(pos, L, bk[m]);   // loci >= idx are past breakpoint m
     __syncthreads();
@@ -549,6 +562,87 @@ __global__ void __launch_bounds__(256) k_group_fill(const u32* __restrict__ fath
     const u32 p = (r & 1) ? mother[r >> 1] : father[r >> 1];
     glist[goff[p] + atomicAdd(&cursor[p], 1u)] = (u32)r;      // order inside a group is irrelevant: every gamete owns its output row
 }
+// ---- row pool (PoolWork): free rows of a generation = rows no parental slot points at ----------------------------------
+__device__ __forceinline__ void pool_clear(const PoolWork& pw)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pw.pool_rows; i += (size_t)gridDim.x * blockDim.x) pw.live[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 3) pw.pctr[threadIdx.x] = 0;        // n_free, n_taken, exhausted flag
+}
+__device__ __forceinline__ void pool_mark(const PoolWork& pw, size_t n_slots)
+{
+    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += (size_t)gridDim.x * blockDim.x) pw.live[pw.phys_cur[s]] = 1;
+}
+// wave-aggregated bump allocation: the lanes with `want` get consecutive indices from *ctr (one atomic per wave)
+__device__ __forceinline__ u32 wave_take(bool want, u32* ctr)
+{
+    const u64 b = __ballot(want);
+    if (!b) return 0;
+    const u32 lane = threadIdx.x & 63, leader = (u32)__ffsll((long long)b) - 1u;
+    u32 base = 0;
+    if (lane == leader) base = atomicAdd(ctr, (u32)__popcll(b));
+    base = __shfl(base, (int)leader);
+    return base + (u32)__popcll(b & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ void pool_collect(const PoolWork& pw)
+{
+    const size_t n = ((size_t)pw.pool_rows + 63) & ~(size_t)63;          // whole waves: wave_take needs every lane
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const bool fr = i < pw.pool_rows && !pw.live[i];
+        const u32 at = wave_take(fr, &pw.pctr[0]);
+        if (fr) pw.freel[at] = (u32)i;
+    }
+}
+__global__ void __launch_bounds__(256) k_pool_clear_tab(const ChrWork* __restrict__ Wt) { pool_clear(Wt[blockIdx.y].pw); }
+__global__ void __launch_bounds__(256) k_pool_mark_tab(const ChrWork* __restrict__ Wt, size_t n_slots) { pool_mark(Wt[blockIdx.y].pw, n_slots); }
+__global__ void __launch_bounds__(256) k_pool_collect_tab(const ChrWork* __restrict__ Wt) { pool_collect(Wt[blockIdx.y].pw); }
+__global__ void __launch_bounds__(256) k_pool_clear(PoolWork pw) { pool_clear(pw); }
+__global__ void __launch_bounds__(256) k_pool_mark(PoolWork pw, size_t n_slots) { pool_mark(pw, n_slots); }
+__global__ void __launch_bounds__(256) k_pool_collect(PoolWork pw) { pool_collect(pw); }
+// n fresh rows for slots [slot0, slot0 + n) of phys_alt (migration, order restoring); flag[0] set when the pool is exhausted
+__global__ void __launch_bounds__(256) k_pool_take(PoolWork pw, size_t slot0, size_t n, u32* __restrict__ flag)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const u32 n_free = pw.pctr[0];
+    const u32 at = pw.pctr[1] + (u32)r;
+    if (at >= n_free) { flag[0] = 1; pw.phys_alt[slot0 + r] = n_free ? pw.freel[at % n_free] : 0u; return; }
+    pw.phys_alt[slot0 + r] = pw.freel[at];
+}
+__global__ void k_pool_taken(PoolWork pw, u32 n) { if (threadIdx.x == 0 && blockIdx.x == 0) pw.pctr[1] += n; }
+__global__ void __launch_bounds__(256) k_iota_u32(u32* __restrict__ a, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (u32)i;
+}
+// pool rows of the offspring generation: a gamete without crossover shares its parent's row, every other one takes a free row
+__global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd)
+{
+    const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
+    const size_t n = (n_rows_out + 63) & ~(size_t)63;
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const bool valid = row < n_rows_out;
+    bool shared = false; u32 src = 0;
+    if (valid) {
+        const size_t i = row >> 1; const u32 s = (u32)(row & 1);
+        const size_t G = 2 * (i * nchr + w.chr) + s;
+        const u32 parent = s ? sd.mother[i] : sd.father[i];
+        shared = pw.alias && sd.k[G] == 0;
+        if (shared) src = pw.phys_cur[2 * (size_t)parent + sd.start[G]];
+    }
+    const bool fresh = valid && !shared;
+    const u32 at = wave_take(fresh, &pw.pctr[1]);
+    if (shared) pw.phys_alt[row] = src;
+    if (fresh) {
+        const u32 n_free = pw.pctr[0];
+        if (at < n_free) pw.phys_alt[row] = pw.freel[at];
+        else { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_POOL); pw.phys_alt[row] = n_free ? pw.freel[at % n_free] : 0u; }   // reported by the host; keep the stitch in bounds
+    }
+}
+__global__ void k_pool_report(const ChrWork* __restrict__ Wt, u32 na, SampleDev sd)
+{
+    for (u32 t = threadIdx.x; t < na; t += blockDim.x) sd.status[ST_TOTALS + ST_PER_CHR * Wt[t].chr + 2] = Wt[t].pw.pctr[1];
+}
 // breakpoint (base pairs) -> first locus index >= it, for every gamete of every chromosome: one fully parallel pass,
 // so that no stitch workgroup has to walk a 20-step dependent binary search before it can start streaming
 __global__ void __launch_bounds__(256) k_bk_to_idx(const ChrDev* __restrict__ chrs, int nchr, size_t n_gametes, SampleDev sd)
@@ -587,20 +681,21 @@ template <int UNROLL, bool NT>
 __global__ void __launch_bounds__(256) k_stitch_parent(const ChrWork* __restrict__ Wt, u32 bpr_max, int nchr,
                                                        const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd)
 {
-    __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big;
+    __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big, s_used;
     // Launched with a block of unused dynamic LDS: it caps the workgroups per CU so that wave slots stay free
     // for the small kernels of the next generation running concurrently on the other stream.
     // blockIdx.y = active chromosome (all chromosomes of a generation are one launch)
     const ChrWork& w = Wt[blockIdx.y];
-    uint8_t* __restrict__ dst = w.plane_alt; const uint8_t* __restrict__ src = w.plane_cur;
+    uint8_t* __restrict__ dst = w.pw.pool; const uint8_t* __restrict__ src = w.pw.pool;
+    const u32 alias = w.pw.alias;
     const size_t stride = w.stride; const u32 chunks_per_row = w.chunks, blocks_per_parent = w.bpr;
     const int chr = w.chr;
     const u32 parent = blockIdx.x / bpr_max, span = blockIdx.x % bpr_max;
     if (span >= blocks_per_parent) return;
     const u32 g0 = goff[parent], g1 = goff[parent + 1];
     if (g0 == g1) return;
-    const v4u* __restrict__ R0 = (const v4u*)(src + (size_t)(2 * parent) * stride);
-    const v4u* __restrict__ R1 = (const v4u*)(src + (size_t)(2 * parent + 1) * stride);
+    const v4u* __restrict__ R0 = (const v4u*)(src + (size_t)w.pw.phys_cur[2 * (size_t)parent] * stride);
+    const v4u* __restrict__ R1 = (const v4u*)(src + (size_t)w.pw.phys_cur[2 * (size_t)parent + 1] * stride);
     const u32 per_block = (chunks_per_row + blocks_per_parent - 1) / blocks_per_parent;
     const u32 q0 = span * per_block, q1 = min(q0 + per_block, chunks_per_row);
     u32 gb = g0;
@@ -611,21 +706,24 @@ __global__ void __launch_bounds__(256) k_stitch_parent(const ChrWork* __restrict
         if (threadIdx.x < cand) {
             const u32 row = glist[gb + threadIdx.x];
             const size_t G = 2 * ((size_t)(row >> 1) * nchr + chr) + (row & 1);
-            s_row[threadIdx.x] = row; s_start[threadIdx.x] = sd.start[G]; s_k[threadIdx.x] = sd.k[G]; s_bkoff[threadIdx.x] = sd.bk_off[G];
+            s_row[threadIdx.x] = w.pw.phys_alt[row]; s_start[threadIdx.x] = sd.start[G]; s_k[threadIdx.x] = sd.k[G]; s_bkoff[threadIdx.x] = sd.bk_off[G];
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            u32 n = 0, kt = 0, big = 0;
-            while (n < cand) {
-                const u32 k = s_k[n];
+        if (threadIdx.x == 0) {                            // serial prefix; gametes that share their parent's row are dropped (compaction in place)
+            u32 n = 0, kt = 0, big = 0, used = 0;
+            while (used < cand) {
+                const u32 k = s_k[used];
+                if (k == 0 && alias) { used++; continue; }
                 if (kt + k > PM_KTOT) { if (n == 0) big = 1; else break; }
-                s_kb[n] = kt; kt += k; n++;
+                s_row[n] = s_row[used]; s_start[n] = s_start[used]; s_bkoff[n] = s_bkoff[used]; s_k[n] = k;
+                s_kb[n] = kt; kt += k; n++; used++;
                 if (big) break;
             }
-            s_n = n; s_big = big;
+            s_n = n; s_big = big; s_used = used;
         }
         __syncthreads();
         const u32 n = s_n; const bool big = s_big != 0;
+        if (n == 0) { gb += s_used; continue; }
         if (!big)
             for (u32 j = 0; j < n; j++)
                 for (u32 m = threadIdx.x; m < s_k[j]; m += 256) s_idx[s_kb[j] + m] = sd.bk_idx[s_bkoff[j] + m];
@@ -675,7 +773,7 @@ __global__ void __launch_bounds__(256) k_stitch_parent(const ChrWork* __restrict
                 }
             }
         }
-        gb += n;
+        gb += s_used;
     }
 }
 
@@ -691,19 +789,20 @@ __global__ void __launch_bounds__(THREADS) k_stitch_regions(const ChrWork* __res
     // instruction-issue priority of this kernel's waves inside a SIMD (s_setprio): the stitch shares the CUs with the ALU-bound
     // sampling kernels of the next generation; its waves mostly wait for memory and should issue first when their data arrives
     if (wave_prio == 3) __builtin_amdgcn_s_setprio(3); else if (wave_prio == 2) __builtin_amdgcn_s_setprio(2); else if (wave_prio == 1) __builtin_amdgcn_s_setprio(1);
-    __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big, s_nd;
+    __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big, s_nd, s_used;
     __shared__ u32 s_bc[PM_KTOT + 1];        // distinct boundary chunks inside [q0, q1), ascending, then the sentinel 0xffffffff
     __shared__ u32 s_sel[PM_KTOT + 1];       // region r = pure chunks in front of boundary chunk r (r = nd: behind the last one)
     const ChrWork& w = Wt[blockIdx.y];
-    uint8_t* __restrict__ dst = w.plane_alt; const uint8_t* __restrict__ src = w.plane_cur;
+    uint8_t* __restrict__ dst = w.pw.pool; const uint8_t* __restrict__ src = w.pw.pool;
+    const u32 alias = w.pw.alias;
     const size_t stride = w.stride; const u32 chunks_per_row = w.chunks, blocks_per_parent = w.bpr;
     const int chr = w.chr;
     const u32 parent = blockIdx.x / bpr_max, span = blockIdx.x % bpr_max;
     if (span >= blocks_per_parent) return;
     const u32 g0 = goff[parent], g1 = goff[parent + 1];
     if (g0 == g1) return;
-    const v4u* __restrict__ R0 = (const v4u*)(src + (size_t)(2 * parent) * stride);
-    const v4u* __restrict__ R1 = (const v4u*)(src + (size_t)(2 * parent + 1) * stride);
+    const v4u* __restrict__ R0 = (const v4u*)(src + (size_t)w.pw.phys_cur[2 * (size_t)parent] * stride);
+    const v4u* __restrict__ R1 = (const v4u*)(src + (size_t)w.pw.phys_cur[2 * (size_t)parent + 1] * stride);
     const u32 per_block = (chunks_per_row + blocks_per_parent - 1) / blocks_per_parent;
     const u32 q0 = span * per_block, q1 = min(q0 + per_block, chunks_per_row);
     u32 gb = g0;
@@ -713,21 +812,24 @@ __global__ void __launch_bounds__(THREADS) k_stitch_regions(const ChrWork* __res
         if (threadIdx.x < cand) {
             const u32 row = glist[gb + threadIdx.x];
             const size_t G = 2 * ((size_t)(row >> 1) * nchr + chr) + (row & 1);
-            s_row[threadIdx.x] = row; s_start[threadIdx.x] = sd.start[G]; s_k[threadIdx.x] = sd.k[G]; s_bkoff[threadIdx.x] = sd.bk_off[G];
+            s_row[threadIdx.x] = w.pw.phys_alt[row]; s_start[threadIdx.x] = sd.start[G]; s_k[threadIdx.x] = sd.k[G]; s_bkoff[threadIdx.x] = sd.bk_off[G];
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            u32 n = 0, kt = 0, big = 0;
-            while (n < cand) {
-                const u32 k = s_k[n];
+        if (threadIdx.x == 0) {                            // serial prefix; gametes that share their parent's row are dropped (compaction in place)
+            u32 n = 0, kt = 0, big = 0, used = 0;
+            while (used < cand) {
+                const u32 k = s_k[used];
+                if (k == 0 && alias) { used++; continue; }
                 if (kt + k > PM_KTOT) { if (n == 0) big = 1; else break; }
-                s_kb[n] = kt; kt += k; n++;
+                s_row[n] = s_row[used]; s_start[n] = s_start[used]; s_bkoff[n] = s_bkoff[used]; s_k[n] = k;
+                s_kb[n] = kt; kt += k; n++; used++;
                 if (big) break;
             }
-            s_n = n; s_big = big;
+            s_n = n; s_big = big; s_used = used;
         }
         __syncthreads();
         const u32 n = s_n; const bool big = s_big != 0;
+        if (n == 0) { gb += s_used; continue; }
         if (!big)
             for (u32 j = 0; j < n; j++)
                 for (u32 m = threadIdx.x; m < s_k[j]; m += THREADS) s_idx[s_kb[j] + m] = sd.bk_idx[s_bkoff[j] + m];
@@ -750,7 +852,7 @@ __global__ void __launch_bounds__(THREADS) k_stitch_regions(const ChrWork* __res
                 }
                 D[q] = o;
             }
-            gb += n;
+            gb += s_used;
             continue;
         }
         // ---- merged boundary chunks of the span (thread 0: the lists are a handful of entries long)
@@ -828,7 +930,7 @@ __global__ void __launch_bounds__(THREADS) k_stitch_regions(const ChrWork* __res
                 }
             }
         }
-        gb += n;
+        gb += s_used;
     }
 }
 
@@ -1227,12 +1329,12 @@ __global__ void k_ad_sum_chr(const double* __restrict__ chr_vals /*[n][nchr][nph
 // ------------------------------------------------------------------------------------------
 // rows [row0, row0+n) already copied into `out` (stride out_w32 words); flip loci whose position is in the row's set
 __global__ void __launch_bounds__(256) k_snp_apply_mut(
-    const u32* __restrict__ plane, size_t stride_w32, u32* __restrict__ out, size_t out_w32, size_t row0, size_t n_rows,
+    const u32* __restrict__ plane, const u32* __restrict__ phys, size_t stride_w32, u32* __restrict__ out, size_t out_w32, size_t row0, size_t n_rows,
     const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ pos, u32 L)
 {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
-    const u32* in = plane + (row0 + r) * stride_w32;
+    const u32* in = plane + (size_t)phys[row0 + r] * stride_w32;
     u32* o = out + r * out_w32;
     for (u32 j = m_off[row0 + r]; j < m_off[row0 + r + 1]; j++) {
         const u64 x = m_pos[j];
@@ -1283,7 +1385,7 @@ __global__ void __launch_bounds__(256) k_materialize_tile(const u32* __restrict_
 // two independent paths.  The founder panel is the synthetic one (k_synth_rows), recomputed on the fly, so no founder copy
 // has to be resident.  Mutations are not in the plane (sparse overlay), so none are applied here.
 __global__ void __launch_bounds__(256) k_verify_plane(const u32* __restrict__ p_off, const gev_part* __restrict__ parts, size_t n_rows,
-                                                      const u64* __restrict__ pos, u32 L, const u32* __restrict__ plane, size_t stride_w32,
+                                                      const u64* __restrict__ pos, u32 L, const u32* __restrict__ plane, const u32* __restrict__ phys, size_t stride_w32,
                                                       const u32* __restrict__ thr /* [n_pop][L] */, const u64* __restrict__ seeds /* [n_pop] */, int n_pop, const u64* __restrict__ n_founder_rows /* [n_pop] */,
                                                       unsigned long long* __restrict__ n_bad /* [0] mismatching words, [1] parts with an unknown / out-of-range founder */)
 {
@@ -1314,7 +1416,7 @@ __global__ void __launch_bounds__(256) k_verify_plane(const u32* __restrict__ p_
             if ((u32)(mix64(ctr) >> 32) < th[ii]) acc |= 1u << t;
         }
     }
-    if (acc != plane[r * stride_w32 + w]) atomicAdd(&n_bad[0], 1ull);
+    if (acc != plane[(size_t)phys[r] * stride_w32 + w]) atomicAdd(&n_bad[0], 1ull);
 }
 // mutation overlay of a tile: out bit = !unmutated bit at every tile locus whose position is in the row's mutation list (:1212-1216)
 __global__ void __launch_bounds__(256) k_tile_apply_mut(const u32* __restrict__ plain, u32* __restrict__ out, size_t w32, size_t row0, size_t n_rows,
@@ -1340,6 +1442,18 @@ __global__ void __launch_bounds__(256) k_gather_rows16(uint4* __restrict__ dst, 
     if (q >= n_rows * chunks) return;
     const size_t r = q / chunks; const u32 c = (u32)(q % chunks);
     dst[r * dst_stride16 + c] = src[(size_t)map[r] * src_stride16 + c];
+}
+// the same between row pools: dst row dst_phys[r] (or r) <- src row src_phys[l] with l = map[r] (or base + r); null tables = identity
+__global__ void __launch_bounds__(256) k_copy_rows16(uint4* __restrict__ dst, size_t dst_stride16, const u32* __restrict__ dst_phys,
+                                                     const uint4* __restrict__ src, size_t src_stride16, const u32* __restrict__ src_phys,
+                                                     const u32* __restrict__ map, size_t base, size_t n_rows, u32 chunks)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_rows * chunks) return;
+    const size_t r = q / chunks; const u32 c = (u32)(q % chunks);
+    const size_t l = map ? (size_t)map[r] : base + r;
+    const size_t sr = src_phys ? (size_t)src_phys[l] : l, dr = dst_phys ? (size_t)dst_phys[r] : r;
+    dst[dr * dst_stride16 + c] = src[sr * src_stride16 + c];
 }
 // CSR gather: count / fill of rows selected by map (element size templated)
 __global__ void k_csr_gather_count(const u32* __restrict__ s_off, const u32* __restrict__ map, size_t n_rows, u32* __restrict__ cnt)
@@ -1440,7 +1554,7 @@ __global__ void __launch_bounds__(256) k_par_eff(const double* __restrict__ ff, 
 // plane is haplotype-major, so output = 64x64 bit-tile transposes (64 ballots per tile: lane b ends
 // up with SNP 64*sw+b across 64 haplotypes), then the sparse mutation overlay, then formatting.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_transpose_tiles(const u64* __restrict__ plane, size_t stride_w64, size_t n_rows, u32 L,
+__global__ void __launch_bounds__(256) k_transpose_tiles(const u64* __restrict__ plane, const u32* __restrict__ phys /* slot -> row, null = identity */, size_t stride_w64, size_t n_rows, u32 L,
                                                          u32 snp_begin, u32 n_snps, u64* __restrict__ out, size_t out_stride_w64, u32 words_per_wave)
 {
     const u32 lane = threadIdx.x & 63;
@@ -1449,8 +1563,9 @@ __global__ void __launch_bounds__(256) k_transpose_tiles(const u64* __restrict__
     const u32 sw_first = snp_begin >> 6, sw_last = (snp_begin + n_snps - 1) >> 6;
     const u32 sw0 = sw_first + wave * words_per_wave;
     const size_t row = hb * 64 + lane;
+    const size_t prow = row < n_rows && phys ? (size_t)phys[row] : row;
     for (u32 sw = sw0; sw < sw0 + words_per_wave && sw <= sw_last; sw++) {
-        const u64 v = row < n_rows ? plane[row * stride_w64 + sw] : 0ull;
+        const u64 v = row < n_rows ? plane[prow * stride_w64 + sw] : 0ull;
         u64 mine = 0;
 #pragma unroll 8
         for (u32 b = 0; b < 64; b++) {
@@ -1462,13 +1577,13 @@ __global__ void __launch_bounds__(256) k_transpose_tiles(const u64* __restrict__
     }
 }
 // flip (snp, hap) where the SNP position is in the haplotype's mutation set: value = !founder (idempotent)
-__global__ void __launch_bounds__(256) k_snpmajor_apply_mut(const u32* __restrict__ plane, size_t stride_w32, size_t n_rows,
+__global__ void __launch_bounds__(256) k_snpmajor_apply_mut(const u32* __restrict__ plane, const u32* __restrict__ phys, size_t stride_w32, size_t n_rows,
                                                             const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ pos, u32 L,
                                                             u32 snp_begin, u32 n_snps, unsigned long long* __restrict__ out, size_t out_stride_w64)
 {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
-    const u32* in = plane + r * stride_w32;
+    const u32* in = plane + (size_t)phys[r] * stride_w32;
     for (u32 j = m_off[r]; j < m_off[r + 1]; j++) {
         const u64 x = m_pos[j];
         u32 c = lower_bound_u64(pos, L, x);

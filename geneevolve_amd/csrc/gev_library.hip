@@ -131,7 +131,11 @@ struct CvStatic {                        // one population x phenotype x chromos
     bool frq_valid = false;
 };
 struct ChrState {
-    DevBuf plane[2], moff[2], mpos[2], poff[2], parts[2];
+    // genotype rows: one pool of 4 * cap_people rows (two generations' worth); slot s of the current generation is pool row
+    // phys[pcur][s] (gev_kernels.h, PoolWork).  phys has THREE buffers: the stitch of generation g (stream_big) still reads
+    // phys of g-1 and g while the small work of g+1 writes the next one.
+    DevBuf pool, phys[3], live, freel, pctr;
+    DevBuf moff[2], mpos[2], poff[2], parts[2];
     size_t mut_total[2] = {0, 0}, parts_total[2] = {0, 0};   // list sizes of the two buffers (known to the host after each generation)
     size_t mut_need = 0, parts_need = 0;                     // exact capacity demand after an overflowed attempt
 };
@@ -141,7 +145,7 @@ struct PopState {
     std::vector<ChrState> st;                          // [chr]
     std::vector<std::vector<std::array<DevBuf, 2>>> cvp; // [phen][chr][2]
     DevBuf d_chrdev;
-    int cur = 0;
+    int cur = 0, pcur = 0;                             // current buffer of the double-buffered lists / of phys[3]
     size_t n_people = 0, cap_people = 0;
     // After a cross-GPU migration the individuals of the current generation are not moved physically:
     // `logical[i]` = physical individual index of logical position i (empty = identity).  The next
@@ -197,7 +201,16 @@ struct gev_ctx {
     int auto_gens = 0; double auto_small_ms = 0, auto_stitch_ms = 0;
     int stitch_unroll = 0;         // 0: chosen by row length; 2 / 4 / 8: forced (GEV_STITCH_UNROLL)
     int stitch_wave_prio = 0;      // s_setprio level of the stitch kernel's waves (GEV_STITCH_WAVE_PRIO)
-    unsigned stitch_lds_pad = 0;   // unused dynamic LDS per stitch workgroup: limits workgroups per CU (160 KiB / CU)
+    bool alias_rows = true;        // crossover-free gametes share their parent's pool row instead of copying it (GEV_ALIAS_ROWS=0: copy every row)
+    unsigned long long rows_written_sum = 0, rows_total_sum = 0;   // over all generations and active chromosomes (gev_stitch_totals)
+    // Stitch workgroups per CU (8 = every wave slot).  The hardware queue priority does not let the small kernels of the next
+    // generation overtake a stitch grid that is still being dispatched: at 8 they start when the stitch is nearly over.  Slots
+    // left free (6 of 8 used) let them run next to it, at the price of a slightly slower stitch.  That pays when the small-kernel
+    // chain is the longer of the two: long rows (one 1M-SNP chromosome with shared rows: 6 -> +9 % generations/s), not when the
+    // stitch dominates anyway (11 chromosomes of 227k SNPs: 8).  Default: by row length; GEV_STITCH_WG_PER_CU=<n> fixes it,
+    // =auto measures it (a few generations per candidate, wall time between consecutive gev_reproduce returns).
+    int stitch_occ = 0 /* 0 = by row length */, stitch_occ_env = 0; bool stitch_occ_auto = false;
+    struct OccTune { int phase = 0 /* 0 idle, 1 measuring, 2 settled */, idx = 0, n = 0, best_occ = 8; double last = 0, cur_min = 0, best = 0; size_t people = 0; unsigned age = 0; } tune;
     DevBuf d_snpmajor, d_text;
     DevBuf d_sex0, d_gef_flag, d_gef_first, d_gef_red, d_gef_io;
     DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
@@ -350,12 +363,14 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     c->sparse_after_stitch = c->overlap_mode == 2;
     if (const char* e = getenv("GEV_SAMPLE_BATCHED")) c->sample_batched = atoi(e) != 0;
     if (const char* e = getenv("GEV_STITCH_UNROLL")) c->stitch_unroll = atoi(e);
+    if (const char* e = getenv("GEV_ALIAS_ROWS")) c->alias_rows = atoi(e) != 0;
     if (const char* e = getenv("GEV_STITCH_WAVE_PRIO")) c->stitch_wave_prio = std::max(0, std::min(atoi(e), 3));
     if (const char* e = getenv("GEV_STITCH_MODE")) c->stitch_mode = std::max(0, std::min(atoi(e), 2));
     if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = c->sample_grid_shared = (unsigned)g; }
-    if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // tuning knob: stitch workgroups per CU (default: unlimited = 8)
+    if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // fixed stitch workgroups per CU (default: measured, see OccTune)
         const int occ = atoi(e);
-        if (occ >= 1 && occ < 8) c->stitch_lds_pad = (unsigned)std::min(160 * 1024 / occ - 3 * 1024, 64 * 1024 - 2048);
+        if (!strcmp(e, "auto")) c->stitch_occ_auto = true;
+        else if (occ >= 1 && occ <= 8) c->stitch_occ = c->stitch_occ_env = occ;
     }
     *out = c.release();
     return GEV_OK;
@@ -467,6 +482,39 @@ int gev_set_cvs(gev_ctx* c, int pop, int phen, int chr, const u64* bp, const dou
 }
 
 static int wait_planes(gev_ctx* c);
+// pool descriptor of (population, chromosome); `alt` = the phys buffer a new generation / new slots are written to
+static PoolWork pool_work(const gev_ctx* c, const PopState& P, int chr, int alt)
+{
+    const ChrState& cs = P.st[chr];
+    PoolWork pw{};
+    pw.pool = cs.pool.as<uint8_t>(); pw.phys_cur = cs.phys[P.pcur].as<u32>(); pw.phys_alt = cs.phys[alt].as<u32>();
+    pw.live = cs.live.as<u32>(); pw.freel = cs.freel.as<u32>(); pw.pctr = cs.pctr.as<u32>();
+    pw.pool_rows = (u32)(4 * P.cap_people); pw.alias = c->alias_rows ? 1u : 0u;
+    return pw;
+}
+// free rows of the pool given the slots that are in use (the kernels of gev_reproduce do the same from the work table)
+static int pool_free_list(const PoolWork& pw, size_t n_slots, hipStream_t st)
+{
+    const unsigned blocks = (unsigned)std::min<size_t>(ceil_div(std::max<size_t>(pw.pool_rows, 1), 256), 1024);
+    hipLaunchKernelGGL(k_pool_clear, dim3(blocks), dim3(256), 0, st, pw);
+    hipLaunchKernelGGL(k_pool_mark, dim3(blocks), dim3(256), 0, st, pw, n_slots);
+    hipLaunchKernelGGL(k_pool_collect, dim3(blocks), dim3(256), 0, st, pw);
+    KCHECK();
+    return GEV_OK;
+}
+// fresh rows for slots [slot0, slot0 + n) of pw.phys_alt (synchronous: migration / order-restoring paths only)
+static int pool_take(const PoolWork& pw, size_t slot0, size_t n, hipStream_t st)
+{
+    if (!n) return GEV_OK;
+    hipLaunchKernelGGL(k_pool_take, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, pw, slot0, n, pw.pctr + 2);
+    hipLaunchKernelGGL(k_pool_taken, dim3(1), dim3(64), 0, st, pw, (u32)n);
+    KCHECK();
+    u32 flag = 0;
+    HIPC(hipMemcpyAsync(&flag, pw.pctr + 2, sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if (flag) return fail(GEV_EDEVICE, "genotype row pool exhausted (internal error)");
+    return GEV_OK;
+}
 static int ensure_capacity(gev_ctx* c, int pop, size_t people)
 {
     PopState& P = c->pop[pop];
@@ -479,8 +527,14 @@ static int ensure_capacity(gev_ctx* c, int pop, size_t people)
     for (int k = 0; k < c->nchr; k++) {
         if (!c->chr_active[k]) continue;
         if (!P.cs[k].stride) return fail(GEV_ESTATE, "set_snps must precede allocation (pop %d chr %d)", pop, k);
+        if (c->dense) {
+            ChrState& cs = P.st[k];
+            GEVC(cs.pool.ensure(2 * rows * P.cs[k].stride, c->stream, /*keep=*/true));          // row numbers stay valid: the pool grows at its end
+            for (int b = 0; b < 3; b++) GEVC(cs.phys[b].ensure(rows * sizeof(u32), c->stream, b == P.pcur));
+            GEVC(cs.live.ensure(2 * rows * sizeof(u32), c->stream)); GEVC(cs.freel.ensure(2 * rows * sizeof(u32), c->stream));
+            GEVC(cs.pctr.ensure(4 * sizeof(u32), c->stream));
+        }
         for (int b = 0; b < 2; b++) {
-            if (c->dense) GEVC(P.st[k].plane[b].ensure(rows * P.cs[k].stride, c->stream, /*keep=*/b == P.cur));
             GEVC(P.st[k].moff[b].ensure((rows + 1) * sizeof(u32), c->stream, b == P.cur));
             GEVC(P.st[k].poff[b].ensure((rows + 1) * sizeof(u32), c->stream, b == P.cur));
         }
@@ -537,13 +591,13 @@ int gev_upload_founders(gev_ctx* c, int pop, int chr, const u64* bits, size_t ro
     if (row_stride_words * 64 < L) return fail(GEV_EINVAL, "upload_founders: row stride too small");
     HIPC(hipSetDevice(c->device));
     GEVC(gev_sync(c));
-    GEVC(P.st[chr].plane[P.cur].ensure(nhap * S.stride, c->stream));
-    HIPC(hipMemsetAsync(P.st[chr].plane[P.cur].p, 0, nhap * S.stride, c->stream));
-    HIPC(hipMemcpy2DAsync(P.st[chr].plane[P.cur].p, S.stride, bits, row_stride_words * 8, ceil_div(L, 8), nhap, hipMemcpyHostToDevice, c->stream));
+    GEVC(P.st[chr].pool.ensure(nhap * S.stride, c->stream));
+    HIPC(hipMemsetAsync(P.st[chr].pool.p, 0, nhap * S.stride, c->stream));
+    HIPC(hipMemcpy2DAsync(P.st[chr].pool.p, S.stride, bits, row_stride_words * 8, ceil_div(L, 8), nhap, hipMemcpyHostToDevice, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     if (L % 8) {   // clear pad bits of the last byte (the contract says pad bits are zero; do not trust it)
         hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(nhap * (S.stride / 4), 256)), dim3(256), 0, c->stream,
-                           P.st[chr].plane[P.cur].as<u32>(), S.stride / 4, nhap, 0u, (u32)L);
+                           P.st[chr].pool.as<u32>(), S.stride / 4, nhap, 0u, (u32)L);
         KCHECK();
     }
     S.founder_rows = nhap; P.gen0 = false;
@@ -558,13 +612,13 @@ int gev_synth_founders(gev_ctx* c, int pop, int chr, size_t nhap, u64 seed)
     if (!S.L) return fail(GEV_ESTATE, "synth_founders: set_snps first");
     HIPC(hipSetDevice(c->device));
     GEVC(gev_sync(c));
-    GEVC(P.st[chr].plane[P.cur].ensure(nhap * S.stride, c->stream));
-    HIPC(hipMemsetAsync(P.st[chr].plane[P.cur].p, 0, nhap * S.stride, c->stream));
+    GEVC(P.st[chr].pool.ensure(nhap * S.stride, c->stream));
+    HIPC(hipMemsetAsync(P.st[chr].pool.p, 0, nhap * S.stride, c->stream));
     GEVC(c->d_thr32.ensure(S.L * sizeof(u32), c->stream));
     hipLaunchKernelGGL(k_synth_thresholds, dim3((unsigned)ceil_div(S.L, 256)), dim3(256), 0, c->stream, c->d_thr32.as<u32>(), S.L, seed);
     const size_t words = ceil_div(S.L, 64);
     hipLaunchKernelGGL(k_synth_rows, dim3((unsigned)ceil_div(nhap * words, 256)), dim3(256), 0, c->stream,
-                       P.st[chr].plane[P.cur].as<u64>(), S.stride / 8, nhap, S.L, c->d_thr32.as<u32>(), seed);
+                       P.st[chr].pool.as<u64>(), S.stride / 8, nhap, S.L, c->d_thr32.as<u32>(), seed);
     KCHECK();
     HIPC(hipStreamSynchronize(c->stream));
     S.founder_rows = nhap; P.gen0 = false;
@@ -691,9 +745,11 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     for (int k = 0; k < c->nchr; k++) {
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& st = P.st[k];
-        if (c->dense)
+        if (c->dense) {                                  // founder haplotype r is pool row r
             hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(rows * (S.stride / 4), 256)), dim3(256), 0, c->stream,
-                               st.plane[P.cur].as<u32>(), S.stride / 4, rows, S.idx_lo, S.idx_hi);
+                               st.pool.as<u32>(), S.stride / 4, rows, S.idx_lo, S.idx_hi);
+            hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, c->stream, st.phys[P.pcur].as<u32>(), rows);
+        }
         HIPC(hipMemsetAsync(st.moff[P.cur].p, 0, (rows + 1) * sizeof(u32), c->stream));
         GEVC(st.parts[P.cur].ensure(rows * sizeof(gev_part), c->stream));
         hipLaunchKernelGGL(k_init_parts, dim3((unsigned)ceil_div(rows + 1, 256)), dim3(256), 0, c->stream,
@@ -798,7 +854,7 @@ static int ensure_scratch(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, boo
 {
     hipStream_t st = c->stream;
     const size_t T = n_people * (size_t)c->nchr;
-    const size_t n_status = ST_TOTALS + 2 * (size_t)c->nchr;
+    const size_t n_status = ST_TOTALS + ST_PER_CHR * (size_t)c->nchr;
     GEVC(sc.father.ensure(n_people * sizeof(u32), st)); GEVC(sc.mother.ensure(n_people * sizeof(u32), st));
     GEVC(sc.seed_pat.ensure((T + 1) * sizeof(u32), st)); GEVC(sc.seed_mat.ensure(T * sizeof(u32), st));
     GEVC(sc.k.ensure(2 * T * sizeof(u32), st)); GEVC(sc.bk_off.ensure((2 * T + 1) * sizeof(u32), st));
@@ -823,7 +879,7 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
     GEVC(sc.bk.ensure((bk_fixed + c->bk_ovf_cap) * sizeof(u64), st));
     GEVC(sc.bk_idx.ensure((bk_fixed + c->bk_ovf_cap) * sizeof(u32), st));
     if (has_mut) { GEVC(sc.nm_pos.ensure((nm_fixed + c->nm_ovf_cap) * sizeof(u64), st)); GEVC(sc.nm_side.ensure(nm_fixed + c->nm_ovf_cap, st)); }
-    const size_t n_status = ST_TOTALS + 2 * (size_t)nchr;
+    const size_t n_status = ST_TOTALS + ST_PER_CHR * (size_t)nchr;
     HIPC(hipMemsetAsync(sc.status.p, 0, n_status * sizeof(u32), st));
     SampleDev sd = make_sd(c, sc, T);
 
@@ -886,7 +942,7 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         }
         w.bp0 = S.rbp.front(); w.bp_end = S.rbp.back(); w.chr = k;
         if (c->dense) {
-            w.plane_alt = cs.plane[alt].as<uint8_t>(); w.plane_cur = cs.plane[cur].as<uint8_t>(); w.snp_pos = S.d_pos.as<u64>();
+            w.pw = pool_work(c, P, k, (P.pcur + 1) % 3); w.snp_pos = S.d_pos.as<u64>();
             w.stride = S.stride; w.chunks = (u32)(S.stride / 16); w.L = (u32)S.L;
             // enough workgroups to fill 256 CUs even for small populations; one span >= 4 KiB
             const size_t units = c->stitch_mode != 1 ? n_parent : rows;
@@ -909,8 +965,17 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         GEVC(upload_table(c, sc.chrwork, cw.data(), cw.size() * sizeof(ChrWork), st));
         GEVC(upload_table(c, sc.cvwork, vw.data(), vw.size() * sizeof(CvWork), st));
         const ChrWork* Wt = sc.chrwork.as<ChrWork>(); const CvWork* Vt = sc.cvwork.as<CvWork>();
-        // ---- sparse state: mutation lists + ancestry intervals (count -> segmented scan -> fill), CV planes
         const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
+        // ---- pool rows of the offspring: free rows = rows no parental slot points at; crossover-free gametes share the parent's row
+        if (c->dense) {
+            const unsigned pool_blocks = (unsigned)std::min<size_t>(ceil_div(4 * P.cap_people, 256), 1024);
+            hipLaunchKernelGGL(k_pool_clear_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt);
+            hipLaunchKernelGGL(k_pool_mark_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt, 2 * P.n_phys);
+            hipLaunchKernelGGL(k_pool_collect_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt);
+            hipLaunchKernelGGL(k_pool_assign, dim3((unsigned)ceil_div(rows, 256), na), dim3(256), 0, st, Wt, rows, nchr, sd);
+            hipLaunchKernelGGL(k_pool_report, dim3(1), dim3(64), 0, st, Wt, na, sd);
+        }
+        // ---- sparse state: mutation lists + ancestry intervals (count -> segmented scan -> fill), CV planes
         const unsigned nseg = c->track_intervals ? 2 * na : na;            // segments [0, na): mutation lists, [na, 2 na): interval lists
         const size_t seg = rows + 1, nb = ceil_div(rows + 1, SCAN_ITEMS);
         GEVC(c->d_cnt.ensure((size_t)nseg * seg * sizeof(u32), st)); GEVC(c->d_sums.ensure((size_t)nseg * nb * sizeof(u32), st));
@@ -947,6 +1012,37 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     HIPC(hipEventRecord(sc.t[2], st));
     return GEV_OK;
 }
+// unused dynamic LDS per stitch workgroup that limits the workgroups per CU to `occ` (160 KiB of LDS per CU; the kernels'
+// own static LDS is 3.4 KiB, allocation granularity taken as 512 B)
+static unsigned stitch_lds_pad(int occ)
+{
+    if (occ >= 8) return 0;
+    const unsigned budget = (160u * 1024u / (unsigned)occ) / 512u * 512u;
+    return std::min(budget - 3584u, 64u * 1024u - 3584u);
+}
+static const int OCC_CAND[] = {8, 7, 6};
+// called at the end of every gev_reproduce: times the generations of each candidate and settles on the fastest
+static void occ_tune_step(gev_ctx* c, size_t n_people)
+{
+    gev_ctx::OccTune& t = c->tune;
+    if (!c->stitch_occ_auto || c->stitch_occ_env || !c->dense || c->serialize) return;
+    const double now = host_ms(), delta = now - t.last;
+    t.last = now;
+    const bool resized = c->n_pop == 1 && t.people && (n_people > t.people + t.people / 4 || n_people + n_people / 4 < t.people);
+    if (t.phase == 0 || resized || (t.phase == 2 && ++t.age >= 512)) {       // (re)start: first candidate, the first interval is a transition
+        t.phase = 1; t.idx = 0; t.n = 0; t.best = 0; t.people = n_people; t.age = 0; c->stitch_occ = OCC_CAND[0];
+        return;
+    }
+    if (t.phase != 1) return;
+    const int GENS = 4;                                       // intervals per candidate; the first still contains the previous candidate's stitch
+    if (t.n >= 1) t.cur_min = t.n == 1 ? delta : std::min(t.cur_min, delta);   // min: robust against a one-off host stall (a list buffer growing)
+    if (++t.n < GENS) return;
+    const bool better = t.idx == 0 || t.cur_min < t.best * 0.985;
+    if (better) { t.best = t.cur_min; t.best_occ = OCC_CAND[t.idx]; }
+    if (better && t.idx + 1 < (int)(sizeof OCC_CAND / sizeof OCC_CAND[0])) { t.idx++; t.n = 0; c->stitch_occ = OCC_CAND[t.idx]; return; }
+    t.phase = 2; c->stitch_occ = t.best_occ;
+    if (g_trace_host) fprintf(stderr, "[gev] stitch workgroups per CU: %d (best interval %.3f ms)\n", t.best_occ, t.best);
+}
 // the HBM-bound part, on stream_big, after the small work of the same generation: ONE launch over (parent, chromosome)
 static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people)
 {
@@ -964,16 +1060,16 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         if (nblk > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
         const int su = c->stitch_unroll;                    // GEV_STITCH_UNROLL (experiments): 0 = by row length
         if (c->stitch_mode == 0 && su == 8)
-            hipLaunchKernelGGL((k_stitch_regions<8, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
+            hipLaunchKernelGGL((k_stitch_regions<8, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : (sc.long_rows && !c->serialize ? 6 : 8)), sb,
                                sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd, c->stitch_wave_prio);
         else if (c->stitch_mode == 0 && (su == 4 || (su == 0 && sc.long_rows)))          // 4 chunks per thread in flight pay off on long rows; short rows (< 4096 chunks = 64 KiB) lose lanes to the tail
-            hipLaunchKernelGGL((k_stitch_regions<4, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
+            hipLaunchKernelGGL((k_stitch_regions<4, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : (sc.long_rows && !c->serialize ? 6 : 8)), sb,
                                sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd, c->stitch_wave_prio);
         else if (c->stitch_mode == 0)
-            hipLaunchKernelGGL((k_stitch_regions<2, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
+            hipLaunchKernelGGL((k_stitch_regions<2, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : (sc.long_rows && !c->serialize ? 6 : 8)), sb,
                                sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd, c->stitch_wave_prio);
         else if (c->stitch_mode == 2)
-            hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), c->stitch_lds_pad, sb,
+            hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : (sc.long_rows && !c->serialize ? 6 : 8)), sb,
                                sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd);
         else
             hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)nblk, sc.n_chrwork), dim3(STITCH_THREADS), 0, sb, sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sd);
@@ -1005,7 +1101,7 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     const bool has_mut = mut_seeds != nullptr;
     if (has_mut && n_mut_seeds != T) return fail(GEV_EINVAL, "reproduce: n_mut_seeds=%zu, expected n_people*nchr=%zu", n_mut_seeds, T);
     // pinned staging: [father | mother | mut_seeds | status], written by the host, copied asynchronously
-    const size_t n_status = ST_TOTALS + 2 * (size_t)nchr;
+    const size_t n_status = ST_TOTALS + ST_PER_CHR * (size_t)nchr;
     const size_t stage_words = 2 * n_people + (has_mut ? T : 0) + n_status;
     if (c->h_stage_bytes < stage_words * 4) {
         HIPC(hipDeviceSynchronize());
@@ -1065,7 +1161,8 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
         if (g_trace_host) fprintf(stderr, "[gev] gen %u attempt %d pre %d: enqueue sampling %.2f ms, sparse %.2f ms, A/D + wait %.2f ms, flags %u, graveyard %.1f MiB\n",
                                   c->gen_counter, attempt, (int)pre, th1 - th0, th2 - th1, host_ms() - th2, flags, g_graveyard.bytes / 1048576.0);
         if (g_trace_host && g_malloc_n) { fprintf(stderr, "[gev]   %zu hipMalloc calls, %.1f MiB, %.2f ms\n", g_malloc_n, g_malloc_bytes / 1048576.0, g_malloc_ms); g_malloc_ms = 0; g_malloc_n = 0; g_malloc_bytes = 0; }
-        for (int k = 0; k < nchr; k++) { P.st[k].mut_total[alt] = hstatus[ST_TOTALS + 2 * k]; P.st[k].parts_total[alt] = hstatus[ST_TOTALS + 2 * k + 1]; }
+        for (int k = 0; k < nchr; k++) { P.st[k].mut_total[alt] = hstatus[ST_TOTALS + ST_PER_CHR * k]; P.st[k].parts_total[alt] = hstatus[ST_TOTALS + ST_PER_CHR * k + 1]; }
+        if (flags & FLAG_POOL) return fail(GEV_EDEVICE, "reproduce: genotype row pool exhausted (internal error)");
         if (!flags) break;
         if (attempt == 3) return fail(GEV_EDEVICE, "reproduce: buffers still too small after %d attempts (flags %u)", attempt + 1, flags);
         HIPC(hipStreamSynchronize(c->stream_big));        // the stitch of the failed attempt still reads the records that are sampled again below
@@ -1078,12 +1175,14 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
         }
     }
     for (int k = 0; k < nchr; k++) { P.st[k].mut_need = 0; P.st[k].parts_need = 0; }
+    if (c->dense) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) { c->rows_written_sum += hstatus[ST_TOTALS + ST_PER_CHR * k + 2]; c->rows_total_sum += 2 * n_people; }
     const bool ad_done = c->eager_ad && c->pop[pop].cv[0][0].d_aptr.p;
     for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = ad_done;
     if (ad_done) c->ad_cached_pop = pop;
     if (sex_out) { HIPC(hipMemcpyAsync(sex_out, sc.sex.p, n_people, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st)); }
-    P.cur = alt; P.n_people = n_people; P.n_phys = n_people; P.logical.clear();
+    P.cur = alt; P.pcur = (P.pcur + 1) % 3; P.n_people = n_people; P.n_phys = n_people; P.logical.clear();
     c->gen_counter++;
+    occ_tune_step(c, n_people);
     return GEV_OK;
 }
 // Enqueue the sampling kernels of the NEXT gev_reproduce of `pop` now (they need the seeds and the offspring count, not the
@@ -1131,6 +1230,14 @@ int gev_sync(gev_ctx* c)
     for (auto& sc : c->sc) { GEVC(harvest_timing(c, sc)); sc.stitch_pending = false; }
     c->planes_pending = false;
     if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
+    return GEV_OK;
+}
+// haplotype rows the dense stitch wrote / rows of the new generations, summed over all gev_reproduce calls and active chromosomes
+// (the difference = crossover-free gametes, which share their parent's row)
+int gev_stitch_totals(gev_ctx* c, unsigned long long* rows_written, unsigned long long* rows_total)
+{
+    if (!c || !rows_written || !rows_total) return fail(GEV_EINVAL, "null");
+    *rows_written = c->rows_written_sum; *rows_total = c->rows_total_sum;
     return GEV_OK;
 }
 // cumulative kernel time per phase over all harvested generations: sampling, dense stitch, sparse, sum
@@ -1431,7 +1538,13 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
                 row0 += map.size();
             }
         }
-        // planes
+        // genotype rows: fresh pool rows of the destination, filled from the sources' pools
+        PoolWork dpw{};
+        if (c->dense) {
+            dpw = pool_work(c, D, k, (D.pcur + 1) % 3);
+            GEVC(pool_free_list(dpw, 2 * D.n_phys, st));
+            GEVC(pool_take(dpw, 0, rows_new, st));
+        }
         size_t row0 = 0;
         for (const Seg& sg : segs) {
             if (sg.people.empty()) continue;
@@ -1441,9 +1554,9 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
             GEVC(h2d(c, c->d_map, map.data(), map.size() * sizeof(u32)));
             const u32 chunks = (u32)(S.stride / 16);
             if (c->dense)
-                hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(map.size() * chunks, 256)), dim3(256), 0, st,
-                                   (uint4*)(ds.plane[alt].as<uint8_t>() + row0 * S.stride), S.stride / 16,
-                                   (const uint4*)Sp.st[k].plane[Sp.cur].p, Sp.cs[k].stride / 16, c->d_map.as<u32>(), map.size(), chunks);
+                hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(map.size() * chunks, 256)), dim3(256), 0, st,
+                                   (uint4*)dpw.pool, S.stride / 16, dpw.phys_alt + row0,
+                                   (const uint4*)Sp.st[k].pool.p, Sp.cs[k].stride / 16, Sp.st[k].phys[Sp.pcur].as<u32>(), c->d_map.as<u32>(), (size_t)0, map.size(), chunks);
             for (int p = 0; p < c->nphen; p++) {
                 CvStatic& V = D.cv[p][k];
                 const u32 cch = V.stride_w32 / 4;
@@ -1468,7 +1581,7 @@ static int materialize_order(gev_ctx* c, int pop)
     Seg all; all.src_pop = pop; all.people = P.logical;
     std::vector<Seg> segs; segs.push_back(std::move(all));
     GEVC(gather_population(c, pop, segs, P.n_people));
-    P.cur ^= 1; P.n_phys = P.n_people; P.logical.clear(); c->ad_cached_pop = c->ad_host_set_pop = -1;
+    P.cur ^= 1; P.pcur = (P.pcur + 1) % 3; P.n_phys = P.n_people; P.logical.clear(); c->ad_cached_pop = c->ad_host_set_pop = -1;
     return GEV_OK;
 }
 int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
@@ -1511,7 +1624,7 @@ int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
     // grow every destination first (capacity growth copies the current buffers), then gather
     for (int p = 0; p < c->n_pop; p++) if (n_new[p] > c->pop[p].cap_people) GEVC(ensure_capacity(c, p, n_new[p]));
     for (int p = 0; p < c->n_pop; p++) GEVC(gather_population(c, p, plan[p], n_new[p]));
-    for (int p = 0; p < c->n_pop; p++) { c->pop[p].cur ^= 1; c->pop[p].n_people = n_new[p]; c->pop[p].n_phys = n_new[p]; }
+    for (int p = 0; p < c->n_pop; p++) { c->pop[p].cur ^= 1; c->pop[p].pcur = (c->pop[p].pcur + 1) % 3; c->pop[p].n_people = n_new[p]; c->pop[p].n_phys = n_new[p]; }
     c->ad_cached_pop = c->ad_host_set_pop = -1;
     return GEV_OK;
 }
@@ -1604,8 +1717,8 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         const u32 chunks = (u32)(S.stride / 16);
         if (c->dense) {
-            hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, (uint4*)(out + po), S.stride / 16,
-                               (const uint4*)cs.plane[P.cur].p, S.stride / 16, c->d_map.as<u32>(), 2 * n, chunks);
+            hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, (uint4*)(out + po), S.stride / 16, (const u32*)nullptr,
+                               (const uint4*)cs.pool.p, S.stride / 16, cs.phys[P.pcur].as<u32>(), c->d_map.as<u32>(), (size_t)0, 2 * n, chunks);
             po = al16(po + 2 * n * S.stride);
         }
         for (int pass = 0; pass < 2; pass++) {
@@ -1676,7 +1789,13 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         if (c->dense) {
-            HIPC(hipMemcpyAsync(cs.plane[P.cur].as<uint8_t>() + r_old * S.stride, in + po, 2 * n * S.stride, hipMemcpyDeviceToDevice, st));
+            const PoolWork pw = pool_work(c, P, k, P.pcur);           // new slots of the CURRENT generation
+            GEVC(pool_free_list(pw, r_old, st));
+            GEVC(pool_take(pw, r_old, 2 * n, st));
+            const u32 chunks = (u32)(S.stride / 16);
+            hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, (uint4*)pw.pool, S.stride / 16, pw.phys_alt + r_old,
+                               (const uint4*)(in + po), S.stride / 16, (const u32*)nullptr, (const u32*)nullptr, (size_t)0, 2 * n, chunks);
+            KCHECK();
             po = al16(po + 2 * n * S.stride);
         }
         for (int pass = 0; pass < 2; pass++) {
@@ -1716,6 +1835,17 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
 }
 
 // ---- output materialisation ---------------------------------------------------------------
+// haplotype slots [slot0, slot0 + n) of the current generation, contiguous, into c->d_stage (already large enough)
+static int stage_rows(gev_ctx* c, PopState& P, int chr, size_t slot0, size_t n)
+{
+    ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
+    const u32 chunks = (u32)(S.stride / 16);
+    if (!n) return GEV_OK;
+    hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(n * chunks, 256)), dim3(256), 0, c->stream, (uint4*)c->d_stage.p, S.stride / 16, (const u32*)nullptr,
+                       (const uint4*)cs.pool.p, S.stride / 16, cs.phys[P.pcur].as<u32>(), (const u32*)nullptr, slot0, n, chunks);
+    KCHECK();
+    return GEV_OK;
+}
 int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_rows, u64* bits, size_t row_stride_words)
 {
     if (c) GEVC(check_dense(c, "download_haps"));
@@ -1734,9 +1864,9 @@ int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_r
     const size_t copy_bytes = std::min(row_stride_words * 8, S.stride);
     for (size_t r0 = 0; r0 < n_rows; r0 += max_rows) {
         const size_t nr = std::min(max_rows, n_rows - r0);
-        HIPC(hipMemcpyAsync(c->d_stage.p, cs.plane[P.cur].as<uint8_t>() + (row_begin + r0) * S.stride, nr * S.stride, hipMemcpyDeviceToDevice, st));
+        GEVC(stage_rows(c, P, chr, row_begin + r0, nr));
         hipLaunchKernelGGL(k_snp_apply_mut, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st,
-                           cs.plane[P.cur].as<u32>(), S.stride / 4, c->d_stage.as<u32>(), S.stride / 4, row_begin + r0, nr,
+                           cs.pool.as<u32>(), cs.phys[P.pcur].as<u32>(), S.stride / 4, c->d_stage.as<u32>(), S.stride / 4, row_begin + r0, nr,
                            cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)S.L);
         KCHECK();
         if (row_stride_words * 8 > copy_bytes)
@@ -1759,9 +1889,9 @@ static int snp_major_device(gev_ctx* c, int pop, int chr, size_t s0, size_t ns, 
     const u32 n_words = (u32)(((s0 + ns - 1) >> 6) - (s0 >> 6) + 1);
     const u32 wpw = 16;                                              // 16 words = one 128-byte line of every row per wave
     const unsigned gy = (unsigned)ceil_div(ceil_div(n_words, wpw), 4);
-    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)stride_w64, gy), dim3(256), 0, st, cs.plane[P.cur].as<u64>(), S.stride / 8, rows, (u32)S.L,
+    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)stride_w64, gy), dim3(256), 0, st, cs.pool.as<u64>(), cs.phys[P.pcur].as<u32>(), S.stride / 8, rows, (u32)S.L,
                        (u32)s0, (u32)ns, c->d_snpmajor.as<u64>(), stride_w64, wpw);
-    hipLaunchKernelGGL(k_snpmajor_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, cs.plane[P.cur].as<u32>(), S.stride / 4, rows,
+    hipLaunchKernelGGL(k_snpmajor_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, cs.pool.as<u32>(), cs.phys[P.pcur].as<u32>(), S.stride / 4, rows,
                        cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)S.L, (u32)s0, (u32)ns,
                        (unsigned long long*)c->d_snpmajor.p, stride_w64);
     KCHECK();
@@ -1826,9 +1956,9 @@ static int stage_individuals(gev_ctx* c, int pop, int chr, size_t ind0, size_t n
     hipStream_t st = c->stream;
     GEVC(c->d_stage.ensure(std::max<size_t>(2 * n * S.stride, 16), st));
     if (!n) return GEV_OK;
-    HIPC(hipMemcpyAsync(c->d_stage.p, cs.plane[P.cur].as<uint8_t>() + 2 * ind0 * S.stride, 2 * n * S.stride, hipMemcpyDeviceToDevice, st));
+    GEVC(stage_rows(c, P, chr, 2 * ind0, 2 * n));
     hipLaunchKernelGGL(k_snp_apply_mut, dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, st,
-                       cs.plane[P.cur].as<u32>(), S.stride / 4, c->d_stage.as<u32>(), S.stride / 4, 2 * ind0, 2 * n,
+                       cs.pool.as<u32>(), cs.phys[P.pcur].as<u32>(), S.stride / 4, c->d_stage.as<u32>(), S.stride / 4, 2 * ind0, 2 * n,
                        cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)S.L);
     KCHECK();
     return GEV_OK;
@@ -2026,7 +2156,7 @@ int gev_materialize_bed(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n
     u64* snpmajor = c->d_text.as<u64>(); uint8_t* bed = c->d_text.as<uint8_t>() + n_snps * stride_sm * 8;
     HIPC(hipMemsetAsync(snpmajor, 0, n_snps * stride_sm * 8, st));
     const u32 wpw = 16;
-    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)stride_sm, (unsigned)ceil_div(ceil_div(w64, wpw), 4)), dim3(256), 0, st, c->d_tmp.as<u64>(), w64, rows, (u32)n_snps,
+    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)stride_sm, (unsigned)ceil_div(ceil_div(w64, wpw), 4)), dim3(256), 0, st, c->d_tmp.as<u64>(), (const u32*)nullptr, w64, rows, (u32)n_snps,
                        0u, (u32)n_snps, snpmajor, stride_sm, wpw);
     hipLaunchKernelGGL(k_format_bed, dim3((unsigned)ceil_div(n_snps * bpl, 256)), dim3(256), 0, st, snpmajor, stride_sm, P.n_people, (u32)n_snps, bed);
     KCHECK();
@@ -2156,7 +2286,7 @@ int gev_download_mutations(gev_ctx* c, int pop, int chr, u64* out, u64* hap_offs
 
 // ---- introspection ------------------------------------------------------------------------
 int gev_pop_size(gev_ctx* c, int pop, size_t* n) { GEVC(check_idx(c, pop, 0)); if (!n) return fail(GEV_EINVAL, "null"); *n = c->pop[pop].n_people; return GEV_OK; }
-int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows)
+int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows, const uint32_t** row_of_slot)
 {
     if (c) GEVC(check_dense(c, "plane_ptr"));
     GEVC(check_idx(c, pop, chr));
@@ -2164,7 +2294,8 @@ int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_
     GEVC(gev_sync(c));
     if (c->pop[pop].gen0) GEVC(materialize_order(c, pop));
     PopState& P = c->pop[pop];
-    if (dptr) *dptr = P.st[chr].plane[P.cur].p;
+    if (dptr) *dptr = P.st[chr].pool.p;
+    if (row_of_slot) *row_of_slot = P.st[chr].phys[P.pcur].as<u32>();
     if (row_stride_bytes) *row_stride_bytes = P.cs[chr].stride;
     if (n_rows) *n_rows = 2 * P.n_people;
     return GEV_OK;
@@ -2235,7 +2366,7 @@ int gev_dbg_verify_planes(gev_ctx* c, int pop, int chr, const uint64_t* founder_
     GEVC(c->d_flag.ensure(16, st));
     HIPC(hipMemsetAsync(c->d_flag.p, 0, 16, st));
     hipLaunchKernelGGL(k_verify_plane, dim3((unsigned)ceil_div(rows * words, 256)), dim3(256), 0, st, cs.poff[P.cur].as<u32>(), cs.parts[P.cur].as<gev_part>(), rows,
-                       S.d_pos.as<u64>(), (u32)S.L, cs.plane[P.cur].as<u32>(), S.stride / 4, c->d_thr32.as<u32>(), c->d_map.as<u64>(), np, c->d_map.as<u64>() + np,
+                       S.d_pos.as<u64>(), (u32)S.L, cs.pool.as<u32>(), cs.phys[P.pcur].as<u32>(), S.stride / 4, c->d_thr32.as<u32>(), c->d_map.as<u64>(), np, c->d_map.as<u64>() + np,
                        (unsigned long long*)c->d_flag.p);
     KCHECK();
     unsigned long long h[2] = {0, 0};

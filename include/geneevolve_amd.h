@@ -264,9 +264,15 @@ int gev_download_mutations(gev_ctx*, int pop, int chr, uint64_t* out, uint64_t* 
 
 /* ---- introspection ------------------------------------------------------------------------ */
 int gev_pop_size(gev_ctx*, int pop, size_t* n_people);
-/* device pointer + stride of the resident genotype plane of the current generation (founder
- * alleles only: mutations are kept as a sparse overlay). */
-int gev_plane_ptr(gev_ctx*, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows);
+/* The resident genotype rows of the current generation (founder alleles only: mutations are kept as a sparse overlay, see
+ * DESIGN.md): haplotype slot s = 2*individual + chromatid is the row_stride_bytes bytes at dptr + row_of_slot[s] * row_stride_bytes
+ * (device pointers).  Rows live in a pool; a gamete without a crossover shares its parent's row, so several slots can name
+ * the same row.  Valid until the next call that changes the population. */
+int gev_plane_ptr(gev_ctx*, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows, const uint32_t** row_of_slot);
+/* Haplotype rows the dense stitch wrote and rows of the generations produced, summed over all gev_reproduce calls and active
+ * chromosomes of the context.  The difference is the number of crossover-free gametes (Simulation::recombine returns the
+ * parental Hap unchanged for them, src/Simulation.cpp:2910; here the slot points at the parent's row). */
+int gev_stitch_totals(gev_ctx*, unsigned long long* rows_written, unsigned long long* rows_total);
 /* Locus-split population: mark the chromosomes whose genotype / CV / list state THIS context holds (default: all).
  * Inactive chromosomes still need gev_set_rmap / gev_set_mutmap (the rand() seed chain of Simulation::reproduce,
  * src/Simulation.cpp:2447-2501, runs through every (offspring, chromosome) task), nothing else; their A/D entries come back

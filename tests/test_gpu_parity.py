@@ -153,6 +153,93 @@ def test_alternative_stitch_kernels_give_the_same_state(gpu_lib, oracle_lib, mod
     run_pair(gpu_lib, oracle_lib, cfg, n_gen=2, seed=7, stitch_mode=mode)
 
 
+def _read_device_u32(ptr, n):
+    """copy n uint32 from a device pointer (the library's slot -> row table)"""
+    hip = C.CDLL("libamdhip64.so")
+    out = np.empty(n, dtype=np.uint32)
+    rc = hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(4 * n), C.c_int(2))      # hipMemcpyDeviceToHost
+    assert rc == 0, f"hipMemcpy failed ({rc})"
+    return out
+
+
+@pytest.mark.parametrize("mode,alias", [(0, 1), (1, 1), (2, 1), (0, 0)])
+def test_crossover_free_gametes_share_the_parental_row(gpu_lib, oracle_lib, monkeypatch, mode, alias):
+    """Cold maps: ~0.3 crossovers per gamete, so most offspring haplotypes are a parent's haplotype unchanged
+    (Simulation::recombine returns the parental Hap, src/Simulation.cpp:2910).  The library then points the offspring slot at the
+    parent's pool row and copies nothing; after several generations rows are shared along chains of ancestors.  Everything
+    observable must equal the oracle in all three stitch kernels, and equal the run that copies every row (GEV_ALIAS_ROWS=0)."""
+    monkeypatch.setenv("GEV_ALIAS_ROWS", str(alias))
+    cfg = SyntheticConfig(400, 30000, nchr=3, chrom_bp=3_000_000, map_step=1000, rec_per_row=1e-4, mut_per_row=3e-4, n_cv=120, nphen=2, seed=41, vd=0.3)
+    g = gpu_lib.create(1, cfg.nchr, cfg.nphen); g.set_stitch_mode(mode)
+    o = oracle_lib.create(1, cfg.nchr, cfg.nphen)
+    cfg.apply_static(g); cfg.apply_static(o)
+    nh = 2 * cfg.n_ind
+    for c in range(cfg.nchr):
+        g.synth_founders(0, c, nh, cfg.seed + c); o.upload_founders(0, c, synth_packed(cfg.seed + c, nh, cfg.n_loci), cfg.n_loci)
+        for p in range(cfg.nphen):
+            ncv = len(cfg.cv[p][c][0])
+            g.synth_cv_founders(0, p, c, nh, cfg.seed + 100 + 7 * p + c); o.upload_cv_founders(0, p, c, synth_packed(cfg.seed + 100 + 7 * p + c, nh, ncv), ncv)
+    sg = Simulation(g, 77, cfg.nchr, True); so = Simulation(o, 77, cfg.nchr, True)
+    sg.ras_initial_human_gen0(0, cfg.n_ind); so.ras_initial_human_gen0(0, cfg.n_ind)
+    rng = np.random.default_rng(5)
+    sizes = [400, 400, 520, 520, 300, 300, 300, 300]          # growth (the pool is reallocated) and shrinkage on the way
+    shared_seen = 0
+    for gen, n in enumerate(sizes, 1):
+        couples = synthetic_random_mate(sg.sex[0], n, rng)
+        sg.couples[0] = couples; so.couples[0] = couples
+        before = [_read_device_u32(g.plane_ptr(0, c)[3], g.plane_ptr(0, c)[2]) for c in range(cfg.nchr)]
+        w0, t0 = g.stitch_totals()
+        assert np.array_equal(sg.reproduce(0, gen, n_people=n), so.reproduce(0, gen, n_people=n)), f"sex differs at generation {gen}"
+        w1, t1 = g.stitch_totals()
+        assert t1 - t0 == 2 * n * cfg.nchr
+        ag = sg.ras_compute_AD(0, gen, per_chr=True); ao = so.ras_compute_AD(0, gen, per_chr=True)
+        for x, y in zip(ag, ao):
+            assert helpers.bits_equal(x, y), f"A/D not bit-identical at generation {gen}"
+        n_shared = 0
+        for c in range(cfg.nchr):
+            _, stride, n_slots, tab = g.plane_ptr(0, c)
+            assert n_slots == 2 * n
+            after = _read_device_u32(tab, n_slots)
+            inherited = np.isin(after, before[c])
+            fresh = after[~inherited]
+            assert len(np.unique(fresh)) == len(fresh), "two copied gametes were given the same pool row"
+            n_shared += int(inherited.sum())
+            # a slot that names a parental row is exactly a gamete without crossover: its interval list is the parent's list
+            assert np.array_equal(g.download_haps(0, c), o.download_haps(0, c)), f"dense genotypes differ (gen {gen} chr {c})"
+            pg, og = g.download_intervals(0, c); po, oo = o.download_intervals(0, c)
+            assert np.array_equal(og, oo) and np.array_equal(pg, po)
+            mg, mog = g.download_mutations(0, c); mo, moo = o.download_mutations(0, c)
+            assert np.array_equal(mog, moo) and np.array_equal(mg, mo)
+            for ph in range(cfg.nphen):
+                assert np.array_equal(g.download_cv(0, ph, c), o.download_cv(0, ph, c))
+        assert (t1 - t0) - (w1 - w0) == n_shared, "rows reported as not copied != slots that name a parental row"
+        if alias:
+            assert n_shared > 0.5 * 2 * n * cfg.nchr, "expected most gametes to be crossover-free with this map"
+        else:
+            assert n_shared == 0
+        shared_seen += n_shared
+    assert g.dbg_verify_planes(0, 1, [cfg.seed + 1]) == (0, 0)
+    g.close(); o.close()
+
+
+def test_population_without_any_crossover(gpu_lib, oracle_lib):
+    """recombination probability 0 everywhere: every offspring haplotype is a parental one, the dense stitch has nothing to copy"""
+    cfg = SyntheticConfig(200, 10000, nchr=2, chrom_bp=1_000_000, map_step=1000, rec_per_row=0.0, mut_per_row=1e-3, n_cv=50, seed=43)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=4, seed=9)
+    g = gpu_lib.create(1, cfg.nchr, cfg.nphen)
+    cfg.apply_static(g)
+    for c in range(cfg.nchr):
+        g.synth_founders(0, c, 2 * cfg.n_ind, cfg.seed + c); g.synth_cv_founders(0, 0, c, 2 * cfg.n_ind, cfg.seed + 100 + c)
+    sg = Simulation(g, 9, cfg.nchr, True)
+    sg.ras_initial_human_gen0(0, cfg.n_ind)
+    rng = np.random.default_rng(9)
+    for gen in range(1, 4):
+        sg.couples[0] = synthetic_random_mate(sg.sex[0], cfg.n_ind, rng)
+        sg.reproduce(0, gen)
+    assert g.stitch_totals() == (0, 3 * 2 * cfg.n_ind * cfg.nchr)
+    g.close()
+
+
 def test_large_families_many_gametes_per_parent(gpu_lib, oracle_lib):
     # 40 offspring per couple: 40 gametes per parent -> several PM_GMAX batches in the parent-major kernel
     cfg = SyntheticConfig(240, 20000, nchr=1, chrom_bp=2_000_000, map_step=1000, rec_per_row=4e-3, mut_per_row=2e-3, n_cv=50, seed=13)

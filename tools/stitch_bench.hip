@@ -88,7 +88,9 @@ int main(int argc, char** argv)
     const size_t N = argc > 1 ? atol(argv[1]) : 100000, L = argc > 2 ? atol(argv[2]) : 1000000;
     const size_t stride = ((L + 7) / 8 + 127) / 128 * 128, rows = 2 * N;
     const u32 chunks = (u32)(stride / 16);
-    uint8_t *src, *dst; CK(hipMalloc(&src, rows * stride)); CK(hipMalloc(&dst, rows * stride));
+    // one row pool as in the library: the parents are rows [0, rows), the offspring rows [rows, 2 rows)
+    uint8_t* pool; CK(hipMalloc(&pool, 2 * rows * stride));
+    uint8_t *src = pool, *dst = pool + rows * stride;
     CK(hipMemset(src, 0x5a, rows * stride)); CK(hipMemset(dst, 0, rows * stride));
     std::mt19937_64 rng(1);
     std::vector<u32> father(N), mother(N), k(rows), off(rows + 1); std::vector<uint8_t> start(rows); std::vector<u64> bk, pos(L);
@@ -124,11 +126,30 @@ int main(int argc, char** argv)
     std::vector<Var> vars;
 #define ADD(name, ...) vars.push_back({name, [&]() { __VA_ARGS__; }, {}})
     // one-entry work table (the library builds one entry per active chromosome)
-    ChrWork hw = {}; hw.plane_alt = dst; hw.plane_cur = src; hw.snp_pos = dpos; hw.stride = stride; hw.chunks = chunks; hw.bpr = 1; hw.L = (u32)L; hw.chr = 0;
+    // slot -> row tables: parents identity; offspring either all fresh rows (every gamete copied) or, as the library does by
+    // default, crossover-free gametes sharing the parental row (nothing copied for them)
+    std::vector<u32> pc(rows), pa_copy(rows), pa_share(rows);
+    size_t n_shared = 0;
+    for (size_t r = 0; r < rows; r++) {
+        pc[r] = (u32)r; pa_copy[r] = (u32)(rows + r);
+        const u32 par = (r & 1) ? mother[r >> 1] : father[r >> 1];
+        if (k[r] == 0) { pa_share[r] = 2 * par + start[r]; n_shared++; } else pa_share[r] = (u32)(rows + r);
+    }
+    u32 *dpc, *dpa_copy, *dpa_share;
+    CK(hipMalloc(&dpc, rows * 4)); CK(hipMalloc(&dpa_copy, rows * 4)); CK(hipMalloc(&dpa_share, rows * 4));
+    CK(hipMemcpy(dpc, pc.data(), rows * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dpa_copy, pa_copy.data(), rows * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dpa_share, pa_share.data(), rows * 4, hipMemcpyHostToDevice));
+    ChrWork hw = {}; hw.pw.pool = pool; hw.pw.phys_cur = dpc; hw.pw.phys_alt = dpa_copy; hw.pw.alias = 0;
+    hw.snp_pos = dpos; hw.stride = stride; hw.chunks = chunks; hw.bpr = 1; hw.L = (u32)L; hw.chr = 0;
     ChrWork* dw; CK(hipMalloc(&dw, sizeof hw)); CK(hipMemcpy(dw, &hw, sizeof hw, hipMemcpyHostToDevice));
+    ChrWork hs = hw; hs.pw.phys_alt = dpa_share; hs.pw.alias = 1;
+    ChrWork* dws; CK(hipMalloc(&dws, sizeof hs)); CK(hipMemcpy(dws, &hs, sizeof hs, hipMemcpyHostToDevice));
     ADD("rows (gamete-major)", hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)rows), dim3(256), 0, 0, dw, 1u, 1, sd));
 #define PM(name, U, NT, occ) ADD(name, hipLaunchKernelGGL((k_stitch_parent<U, NT>), dim3((unsigned)N), dim3(256), (occ) >= 8 ? 0 : std::min(160 * 1024 / (occ) - 3 * 1024, 64 * 1024 - 2048), 0, dw, 1u, 1, dgoff, dglist, sd))
 #define RG(name, U, NT, occ) ADD(name, hipLaunchKernelGGL((k_stitch_regions<U, NT>), dim3((unsigned)N), dim3(256), (occ) >= 8 ? 0 : std::min(160 * 1024 / (occ) - 6 * 1024, 64 * 1024 - 4096), 0, dw, 1u, 1, dgoff, dglist, sd, 0))
+#define RGS(name, U) ADD(name, hipLaunchKernelGGL((k_stitch_regions<U, true>), dim3((unsigned)N), dim3(256), 0, 0, dws, 1u, 1, dgoff, dglist, sd, 0))
+    RGS("regions U4 nt SHARED rows", 4);
+    RGS("regions U2 nt SHARED rows", 2);
     PM("parent per-chunk U2 nt", 2, true, 8);
     RG("regions U2 nt", 2, true, 8);
     RG("regions U4 nt", 4, true, 8);
@@ -150,7 +171,8 @@ int main(int argc, char** argv)
             CK(hipEventRecord(e0, 0)); v.run(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (round) v.ms.push_back(ms);
         }
-    printf("N=%zu L=%zu rows=%zu stride=%zu  bytes moved per launch = %.2f GB\n", N, L, rows, stride, gbytes);
+    printf("N=%zu L=%zu rows=%zu stride=%zu  bytes moved per launch = %.2f GB (every gamete copied); SHARED: %zu of %zu gametes share the parental row, %.2f GB\n",
+           N, L, rows, stride, gbytes, n_shared, rows, (double)(rows - n_shared) * stride * 2 / 1e9);
     for (auto& v : vars) {
         std::sort(v.ms.begin(), v.ms.end());
         printf("%-26s median %7.3f ms  min %7.3f ms  -> %7.1f GB/s (median)\n", v.name, v.ms[v.ms.size() / 2], v.ms[0], gbytes / (v.ms[v.ms.size() / 2] * 1e-3));
