@@ -70,8 +70,8 @@ struct SampleDev {
 // every consumer goes through phys[].
 struct PoolWork {
     uint8_t* pool; const u32* phys_cur; u32* phys_alt;      // rows, slot -> row of the parents / of the offspring
-    u32* live; u32* freel; u32* pctr;                       // [pool_rows] flags, [pool_rows] free rows, {n_free, n_taken, exhausted}
-    u32 pool_rows, alias;
+    u32* live; u32* freel; u32* pctr;                       // [pool_rows] marks, [pool_rows] free rows, {n_free, n_taken, exhausted}
+    u32 pool_rows, alias, stamp;
 };
 struct ChrWork {
     const u32* moff_cur; const u64* mpos_cur; u32* moff_alt; u64* mpos_alt;                 // mutation lists (CSR), parents / offspring
@@ -192,7 +192,10 @@ __global__ void __launch_bounds__(256) k_scan_final_tab(const u32* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (base + j <= n) out[base + j] = ex;
-        if (base + j == n) status[ST_TOTALS + ST_PER_CHR * w.chr + (is_parts ? 1 : 0)] = ex;
+        if (base + j == n) {
+            status[ST_TOTALS + ST_PER_CHR * w.chr + (is_parts ? 1 : 0)] = ex;
+            if (!is_parts && w.pw.pctr) status[ST_TOTALS + ST_PER_CHR * w.chr + 2] = w.pw.pctr[1];    // gametes the dense stitch copies (k_pool_assign ran before)
+        }
         ex += v[j];
     }
 }
@@ -563,39 +566,35 @@ __global__ void __launch_bounds__(256) k_group_fill(const u32* __restrict__ fath
     glist[goff[p] + atomicAdd(&cursor[p], 1u)] = (u32)r;      // order inside a group is irrelevant: every gamete owns its output row
 }
 // ---- row pool (PoolWork): free rows of a generation = rows no parental slot points at ----------------------------------
-__device__ __forceinline__ void pool_clear(const PoolWork& pw)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pw.pool_rows; i += (size_t)gridDim.x * blockDim.x) pw.live[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < 3) pw.pctr[threadIdx.x] = 0;        // n_free, n_taken, exhausted flag
-}
+// live[row] == stamp <=> a slot of the parents' generation names the row; the stamp changes with every rebuild, so the marks of
+// earlier generations need no clearing (the buffer is zeroed when it is allocated, stamps start at 1)
 __device__ __forceinline__ void pool_mark(const PoolWork& pw, size_t n_slots)
 {
-    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += (size_t)gridDim.x * blockDim.x) pw.live[pw.phys_cur[s]] = 1;
+    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += (size_t)gridDim.x * blockDim.x) pw.live[pw.phys_cur[s]] = pw.stamp;
+    if (blockIdx.x == 0 && threadIdx.x < 3) pw.pctr[threadIdx.x] = 0;        // n_free, n_taken, exhausted flag
 }
-// wave-aggregated bump allocation: the lanes with `want` get consecutive indices from *ctr (one atomic per wave)
-__device__ __forceinline__ u32 wave_take(bool want, u32* ctr)
-{
-    const u64 b = __ballot(want);
-    if (!b) return 0;
-    const u32 lane = threadIdx.x & 63, leader = (u32)__ffsll((long long)b) - 1u;
-    u32 base = 0;
-    if (lane == leader) base = atomicAdd(ctr, (u32)__popcll(b));
-    base = __shfl(base, (int)leader);
-    return base + (u32)__popcll(b & ((1ull << lane) - 1ull));
-}
+// one atomic per 2048 rows: the block counts its free rows (8 per thread, coalesced), scans the counts, reserves a range
 __device__ __forceinline__ void pool_collect(const PoolWork& pw)
 {
-    const size_t n = ((size_t)pw.pool_rows + 63) & ~(size_t)63;          // whole waves: wave_take needs every lane
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const bool fr = i < pw.pool_rows && !pw.live[i];
-        const u32 at = wave_take(fr, &pw.pctr[0]);
-        if (fr) pw.freel[at] = (u32)i;
+    __shared__ u32 s_scan[8], s_base;
+    const u32 n_chunks = (pw.pool_rows + 2047u) / 2048u;
+    for (u32 chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const size_t i0 = (size_t)chunk * 2048 + threadIdx.x;
+        u32 mask = 0, c = 0;
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) { const size_t i = i0 + j * 256; const u32 fr = (i < pw.pool_rows && pw.live[i] != pw.stamp) ? 1u : 0u; mask |= fr << j; c += fr; }
+        u32 tot;
+        const u32 ex = block_exclusive_scan_256(c, s_scan, tot);
+        if (threadIdx.x == 0) s_base = tot ? atomicAdd(&pw.pctr[0], tot) : 0u;
+        __syncthreads();
+        u32 at = s_base + ex;
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) if ((mask >> j) & 1u) pw.freel[at++] = (u32)(i0 + j * 256);
+        __syncthreads();
     }
 }
-__global__ void __launch_bounds__(256) k_pool_clear_tab(const ChrWork* __restrict__ Wt) { pool_clear(Wt[blockIdx.y].pw); }
 __global__ void __launch_bounds__(256) k_pool_mark_tab(const ChrWork* __restrict__ Wt, size_t n_slots) { pool_mark(Wt[blockIdx.y].pw, n_slots); }
 __global__ void __launch_bounds__(256) k_pool_collect_tab(const ChrWork* __restrict__ Wt) { pool_collect(Wt[blockIdx.y].pw); }
-__global__ void __launch_bounds__(256) k_pool_clear(PoolWork pw) { pool_clear(pw); }
 __global__ void __launch_bounds__(256) k_pool_mark(PoolWork pw, size_t n_slots) { pool_mark(pw, n_slots); }
 __global__ void __launch_bounds__(256) k_pool_collect(PoolWork pw) { pool_collect(pw); }
 // n fresh rows for slots [slot0, slot0 + n) of phys_alt (migration, order restoring); flag[0] set when the pool is exhausted
@@ -615,33 +614,38 @@ __global__ void __launch_bounds__(256) k_iota_u32(u32* __restrict__ a, size_t n)
     if (i < n) a[i] = (u32)i;
 }
 // pool rows of the offspring generation: a gamete without crossover shares its parent's row, every other one takes a free row
+// (4 rows per thread, one atomic per block of 1024 rows)
 __global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd)
 {
+    __shared__ u32 s_scan[8], s_base;
     const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
-    const size_t n = (n_rows_out + 63) & ~(size_t)63;
-    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n) return;
-    const bool valid = row < n_rows_out;
-    bool shared = false; u32 src = 0;
-    if (valid) {
+    const size_t r0 = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    u32 mask = 0, c = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        const size_t row = r0 + j * 256;
+        if (row >= n_rows_out) continue;
         const size_t i = row >> 1; const u32 s = (u32)(row & 1);
         const size_t G = 2 * (i * nchr + w.chr) + s;
-        const u32 parent = s ? sd.mother[i] : sd.father[i];
-        shared = pw.alias && sd.k[G] == 0;
-        if (shared) src = pw.phys_cur[2 * (size_t)parent + sd.start[G]];
+        if (pw.alias && sd.k[G] == 0) {
+            const u32 parent = s ? sd.mother[i] : sd.father[i];
+            pw.phys_alt[row] = pw.phys_cur[2 * (size_t)parent + sd.start[G]];
+        } else { mask |= 1u << j; c++; }
     }
-    const bool fresh = valid && !shared;
-    const u32 at = wave_take(fresh, &pw.pctr[1]);
-    if (shared) pw.phys_alt[row] = src;
-    if (fresh) {
-        const u32 n_free = pw.pctr[0];
+    u32 tot;
+    const u32 ex = block_exclusive_scan_256(c, s_scan, tot);
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&pw.pctr[1], tot) : 0u;
+    __syncthreads();
+    u32 at = s_base + ex;
+    const u32 n_free = pw.pctr[0];
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        if (!((mask >> j) & 1u)) continue;
+        const size_t row = r0 + j * 256;
         if (at < n_free) pw.phys_alt[row] = pw.freel[at];
         else { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_POOL); pw.phys_alt[row] = n_free ? pw.freel[at % n_free] : 0u; }   // reported by the host; keep the stitch in bounds
+        at++;
     }
-}
-__global__ void k_pool_report(const ChrWork* __restrict__ Wt, u32 na, SampleDev sd)
-{
-    for (u32 t = threadIdx.x; t < na; t += blockDim.x) sd.status[ST_TOTALS + ST_PER_CHR * Wt[t].chr + 2] = Wt[t].pw.pctr[1];
 }
 // breakpoint (base pairs) -> first locus index >= it, for every gamete of every chromosome: one fully parallel pass,
 // so that no stitch workgroup has to walk a 20-step dependent binary search before it can start streaming

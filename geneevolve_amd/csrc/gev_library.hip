@@ -134,7 +134,7 @@ struct ChrState {
     // genotype rows: one pool of 4 * cap_people rows (two generations' worth); slot s of the current generation is pool row
     // phys[pcur][s] (gev_kernels.h, PoolWork).  phys has THREE buffers: the stitch of generation g (stream_big) still reads
     // phys of g-1 and g while the small work of g+1 writes the next one.
-    DevBuf pool, phys[3], live, freel, pctr;
+    DevBuf pool, phys[3], live, freel, pctr; u32 pool_stamp = 0;
     DevBuf moff[2], mpos[2], poff[2], parts[2];
     size_t mut_total[2] = {0, 0}, parts_total[2] = {0, 0};   // list sizes of the two buffers (known to the host after each generation)
     size_t mut_need = 0, parts_need = 0;                     // exact capacity demand after an overflowed attempt
@@ -483,20 +483,21 @@ int gev_set_cvs(gev_ctx* c, int pop, int phen, int chr, const u64* bp, const dou
 
 static int wait_planes(gev_ctx* c);
 // pool descriptor of (population, chromosome); `alt` = the phys buffer a new generation / new slots are written to
-static PoolWork pool_work(const gev_ctx* c, const PopState& P, int chr, int alt)
+static PoolWork pool_work(const gev_ctx* c, PopState& P, int chr, int alt)
 {
-    const ChrState& cs = P.st[chr];
+    ChrState& cs = P.st[chr];
     PoolWork pw{};
     pw.pool = cs.pool.as<uint8_t>(); pw.phys_cur = cs.phys[P.pcur].as<u32>(); pw.phys_alt = cs.phys[alt].as<u32>();
     pw.live = cs.live.as<u32>(); pw.freel = cs.freel.as<u32>(); pw.pctr = cs.pctr.as<u32>();
     pw.pool_rows = (u32)(4 * P.cap_people); pw.alias = c->alias_rows ? 1u : 0u;
+    if (++cs.pool_stamp == 0) cs.pool_stamp = 1;          // (a stale mark of 2^32 rebuilds ago could only keep a free row out of one free list)
+    pw.stamp = cs.pool_stamp;
     return pw;
 }
 // free rows of the pool given the slots that are in use (the kernels of gev_reproduce do the same from the work table)
 static int pool_free_list(const PoolWork& pw, size_t n_slots, hipStream_t st)
 {
     const unsigned blocks = (unsigned)std::min<size_t>(ceil_div(std::max<size_t>(pw.pool_rows, 1), 256), 1024);
-    hipLaunchKernelGGL(k_pool_clear, dim3(blocks), dim3(256), 0, st, pw);
     hipLaunchKernelGGL(k_pool_mark, dim3(blocks), dim3(256), 0, st, pw, n_slots);
     hipLaunchKernelGGL(k_pool_collect, dim3(blocks), dim3(256), 0, st, pw);
     KCHECK();
@@ -532,6 +533,7 @@ static int ensure_capacity(gev_ctx* c, int pop, size_t people)
             GEVC(cs.pool.ensure(2 * rows * P.cs[k].stride, c->stream, /*keep=*/true));          // row numbers stay valid: the pool grows at its end
             for (int b = 0; b < 3; b++) GEVC(cs.phys[b].ensure(rows * sizeof(u32), c->stream, b == P.pcur));
             GEVC(cs.live.ensure(2 * rows * sizeof(u32), c->stream)); GEVC(cs.freel.ensure(2 * rows * sizeof(u32), c->stream));
+            HIPC(hipMemsetAsync(cs.live.p, 0, cs.live.bytes, c->stream)); cs.pool_stamp = 0;   // marks are generation stamps: start from a clean buffer
             GEVC(cs.pctr.ensure(4 * sizeof(u32), c->stream));
         }
         for (int b = 0; b < 2; b++) {
@@ -969,11 +971,9 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         // ---- pool rows of the offspring: free rows = rows no parental slot points at; crossover-free gametes share the parent's row
         if (c->dense) {
             const unsigned pool_blocks = (unsigned)std::min<size_t>(ceil_div(4 * P.cap_people, 256), 1024);
-            hipLaunchKernelGGL(k_pool_clear_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt);
             hipLaunchKernelGGL(k_pool_mark_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt, 2 * P.n_phys);
             hipLaunchKernelGGL(k_pool_collect_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt);
-            hipLaunchKernelGGL(k_pool_assign, dim3((unsigned)ceil_div(rows, 256), na), dim3(256), 0, st, Wt, rows, nchr, sd);
-            hipLaunchKernelGGL(k_pool_report, dim3(1), dim3(64), 0, st, Wt, na, sd);
+            hipLaunchKernelGGL(k_pool_assign, dim3((unsigned)ceil_div(rows, 1024), na), dim3(256), 0, st, Wt, rows, nchr, sd);
         }
         // ---- sparse state: mutation lists + ancestry intervals (count -> segmented scan -> fill), CV planes
         const unsigned nseg = c->track_intervals ? 2 * na : na;            // segments [0, na): mutation lists, [na, 2 na): interval lists
