@@ -354,9 +354,13 @@ def main():
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_config2_pmc_hbm.json")))       # newest round last
         if pmcs and (args.n_ind, args.n_loci, args.nchr, args.map_step) == (100_000, 1_000_000, 1, 50_000) and not args.plane_less:
-            pm = json.load(open(pmcs[-1]))
-            traffic = (pm.get("stitch_summary") or pm["k_stitch_parent_summary"])["hbm_traffic_bytes_per_launch"]
-            traffic_src = os.path.relpath(pmcs[-1], ROOT)
+            # newest committed measurement of the SAME launch: its algorithmic bytes must be this run's (a measurement of the
+            # every-gamete-copied kernel does not describe the shared-row one, and vice versa)
+            for f in reversed(pmcs):
+                sm = json.load(open(f)).get("stitch_summary")
+                if sm and abs(sm["algorithmic_bytes_per_launch"] - alg_bytes) <= 0.02 * alg_bytes:
+                    traffic, traffic_src = sm["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+                    break
         # what the memory system really moved per second while the kernel ran: measured bytes / measured time.  The kernel reads a
         # parent chunk once for all of its gametes, so this is BELOW `achieved` (which prices the algorithmic N*L/2 bytes).
         hbm_actual = traffic / (max(stitch, 1e-9) * 1e-3) / 1e9 if traffic else None
