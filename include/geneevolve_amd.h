@@ -86,7 +86,14 @@ typedef struct gev_move {
 const char* gev_last_error(void);
 const char* gev_version(void);
 
-/* device < 0: use the current HIP device. */
+/* device < 0: use the current HIP device.
+ * Environment read here (tuning / cross-check knobs; none changes a result):
+ *   GEV_OVERLAP=0|1|2|-1        stream overlap mode (gev_set_overlap)
+ *   GEV_ALIAS_ROWS=0            copy every gamete row (default 1: a gamete without a crossover shares its parent's row)
+ *   GEV_STITCH_WG_PER_CU=n|auto dense-stitch workgroups per CU (default: 6 on rows >= 64 KiB, else 8; auto = measured at run time)
+ *   GEV_STITCH_MODE=0|1|2       stitch kernel (gev_set_stitch_mode)
+ *   GEV_SAMPLE_BATCHED=0        one sampling task per wave (the round-1 kernels) instead of eight
+ *   GEV_TABLE_RING_BYTES=n      minimum size of the pinned ring the per-generation work tables are staged through */
 int  gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen);
 void gev_destroy(gev_ctx* ctx);
 
