@@ -998,12 +998,6 @@ __global__ void __launch_bounds__(256) k_stitch_small(const CvWork* __restrict__
 // (recombine + modify_part_for_mutation_pos, :2903-2970) + new mutations of its side that fall
 // inside [bp0, bp_end) (ras_add_mutation only appends to a part that contains bp_mut, :2526-2545)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 parity_at(const u64* __restrict__ bk, u32 k, u64 x)   // #{c <= x} & 1
-{
-    u32 n = 0;
-    for (u32 m = 0; m < k; m++) n += (bk[m] <= x);
-    return n & 1u;
-}
 template <bool FILL>
 __global__ void __launch_bounds__(256) k_mutlist(const ChrWork* __restrict__ Wt, u32* __restrict__ cnt, size_t cnt_stride,
                                                  size_t n_rows_out, int nchr, int has_mut, SampleDev sd)
@@ -1022,24 +1016,32 @@ __global__ void __launch_bounds__(256) k_mutlist(const ChrWork* __restrict__ Wt,
     const u32 start = sd.start[G], k = sd.k[G];
     const u64* bk = sd.bk + sd.bk_off[G];
     const u32 a0 = p_off[2 * parent], a1 = p_off[2 * parent + 1], b1 = p_off[2 * parent + 2];   // hap0 = [a0,a1), hap1 = [a1,b1)
-    u32 ia = a0, ib = a1, in = 0, nn = 0;
+    u32 in = 0, nn = 0;
     const u64* npos = nullptr; const uint8_t* nside = nullptr;
     if (has_mut) { in = sd.nm_off[t]; nn = in + sd.nmut[t]; npos = sd.nm_pos; nside = sd.nm_side; }
     u32 n = 0;
     u64* out = FILL ? o_pos + o_off[row] : nullptr;
-    const u64 INF = ~0ull;
-    while (true) {
-        // advance each stream to its next qualifying element
-        while (ia < a1 && (start ^ parity_at(bk, k, p_pos[ia])) != 0u) ia++;
-        while (ib < b1 && (start ^ parity_at(bk, k, p_pos[ib])) != 1u) ib++;
-        while (in < nn && !(nside[in] == s && npos[in] >= bp0 && npos[in] < bp_end)) in++;
-        const u64 va = ia < a1 ? p_pos[ia] : INF, vb = ib < b1 ? p_pos[ib] : INF, vn = in < nn ? npos[in] : INF;
-        if (va == INF && vb == INF && vn == INF) break;
-        u64 v;
-        if (va <= vb && va <= vn) { v = va; ia++; } else if (vb <= vn) { v = vb; ib++; } else { v = vn; in++; }
-        if (FILL) out[n] = v;
-        n++;
+    // The breakpoints cut the positions into k+1 intervals [bk[j-1], bk[j]) that take hap start, start^1, start, ...: the inherited
+    // entries are k+1 contiguous ranges of the two sorted parental lists (two binary searches each), concatenated.  The new
+    // mutations of this side are merged in as a stream: everything inherited that is <= the next new position goes first (the
+    // reference's insertion keeps an equal old entry in front).
+#define NEXT_NEW() while (in < nn && !(nside[in] == s && npos[in] >= bp0 && npos[in] < bp_end)) in++
+    NEXT_NEW();
+    for (u32 j = 0; j <= k; j++) {
+        const u32 h = (start ^ j) & 1u;
+        const u32 L0 = h ? a1 : a0, L1 = h ? b1 : a1;
+        const u32 lo = j == 0 ? L0 : L0 + lower_bound_u64(p_pos + L0, L1 - L0, bk[j - 1]);
+        const u32 hi = j == k ? L1 : L0 + lower_bound_u64(p_pos + L0, L1 - L0, bk[j]);
+        if (hi <= lo) continue;
+        if (!FILL) { n += hi - lo; continue; }
+        for (u32 idx = lo; idx < hi; idx++) {
+            const u64 v = p_pos[idx];
+            while (in < nn && npos[in] < v) { out[n++] = npos[in]; in++; NEXT_NEW(); }
+            out[n++] = v;
+        }
     }
+    while (in < nn) { if (FILL) out[n] = npos[in]; n++; in++; NEXT_NEW(); }
+#undef NEXT_NEW
     if (!FILL) o_cnt[row] = n;
 }
 
@@ -1076,8 +1078,10 @@ __global__ void __launch_bounds__(256) k_parts(const ChrWork* __restrict__ Wt, u
         const u64 Lc = (i1 == 1) ? bp0 : bk[i1 - 2];
         const u64 Rc = (i1 == k + 1) ? bp_end : bk[i1 - 1];
         const u32 h0 = p_off[2 * parent + hap], h1 = p_off[2 * parent + hap + 1];
-        u32 i2 = h0;
-        while (i2 < h1 && p_parts[i2].en <= Lc) i2++;                                               // :2918
+        u32 i2;
+        { u32 lo = h0, hi = h1;                                                                     // :2918 -- parts tile the range, `en` ascends: the first part with en > Lc by bisection
+          while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (p_parts[mid].en <= Lc) lo = mid + 1; else hi = mid; }
+          i2 = lo; }
         if (i2 < h1 && p_parts[i2].st < Lc && Lc < p_parts[i2].en && Rc < p_parts[i2].en) {         // :2922
             if (FILL) { gev_part p = p_parts[i2]; p.st = Lc; p.en = Rc; out[n] = p; } n++; i2++;
         }
