@@ -998,7 +998,15 @@ __global__ void __launch_bounds__(256) k_stitch_small(const CvWork* __restrict__
 // (recombine + modify_part_for_mutation_pos, :2903-2970) + new mutations of its side that fall
 // inside [bp0, bp_end) (ras_add_mutation only appends to a part that contains bp_mut, :2526-2545)
 // ------------------------------------------------------------------------------------------
-template <bool FILL>
+__device__ __forceinline__ u32 upper_bound_u64(const u64* __restrict__ a, u32 n, u64 v)   // #{a[i] <= v}
+{
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// G lanes work on one output row: all of them walk the (short) control flow, the copies of inherited ranges are shared out
+// (G = 1 for the count pass, which only needs the range lengths; G = 8 for the fill pass: 64 contiguous bytes per step)
+template <bool FILL, int G>
 __global__ void __launch_bounds__(256) k_mutlist(const ChrWork* __restrict__ Wt, u32* __restrict__ cnt, size_t cnt_stride,
                                                  size_t n_rows_out, int nchr, int has_mut, SampleDev sd)
 {
@@ -1007,14 +1015,15 @@ __global__ void __launch_bounds__(256) k_mutlist(const ChrWork* __restrict__ Wt,
     u32* __restrict__ o_cnt = cnt + (size_t)blockIdx.y * cnt_stride;
     const u32* __restrict__ o_off = w.moff_alt; u64* __restrict__ o_pos = w.mpos_alt;
     const int chr = w.chr; const u64 bp0 = w.bp0, bp_end = w.bp_end; const u32 cap = w.mcap;
-    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t row = tid / G; const u32 sub = (u32)(tid % G);
     if (row >= n_rows_out) return;
-    if (FILL && o_off[row + 1] > cap) { if (o_off[row] <= cap) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_MUT_CAP); return; }   // host grows and redoes
+    if (FILL && o_off[row + 1] > cap) { if (o_off[row] <= cap && sub == 0) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_MUT_CAP); return; }   // host grows and redoes
     const u32 i = (u32)(row >> 1), s = (u32)(row & 1);
-    const size_t t = (size_t)i * nchr + chr, G = 2 * t + s;
+    const size_t t = (size_t)i * nchr + chr, G_ = 2 * t + s;
     const u32 parent = s ? sd.mother[i] : sd.father[i];
-    const u32 start = sd.start[G], k = sd.k[G];
-    const u64* bk = sd.bk + sd.bk_off[G];
+    const u32 start = sd.start[G_], k = sd.k[G_];
+    const u64* bk = sd.bk + sd.bk_off[G_];
     const u32 a0 = p_off[2 * parent], a1 = p_off[2 * parent + 1], b1 = p_off[2 * parent + 2];   // hap0 = [a0,a1), hap1 = [a1,b1)
     u32 in = 0, nn = 0;
     const u64* npos = nullptr; const uint8_t* nside = nullptr;
@@ -1023,9 +1032,10 @@ __global__ void __launch_bounds__(256) k_mutlist(const ChrWork* __restrict__ Wt,
     u64* out = FILL ? o_pos + o_off[row] : nullptr;
     // The breakpoints cut the positions into k+1 intervals [bk[j-1], bk[j]) that take hap start, start^1, start, ...: the inherited
     // entries are k+1 contiguous ranges of the two sorted parental lists (two binary searches each), concatenated.  The new
-    // mutations of this side are merged in as a stream: everything inherited that is <= the next new position goes first (the
-    // reference's insertion keeps an equal old entry in front).
+    // mutations of this side are merged in as a stream: a new position goes in front of the first inherited entry that is larger
+    // (the reference's insertion keeps an equal old entry in front).
 #define NEXT_NEW() while (in < nn && !(nside[in] == s && npos[in] >= bp0 && npos[in] < bp_end)) in++
+#define COPY_OLD(from, to) do { for (u32 q_ = (from) + sub; q_ < (to); q_ += G) out[n + (q_ - (from))] = p_pos[q_]; n += (to) - (from); } while (0)
     NEXT_NEW();
     for (u32 j = 0; j <= k; j++) {
         const u32 h = (start ^ j) & 1u;
@@ -1034,13 +1044,19 @@ __global__ void __launch_bounds__(256) k_mutlist(const ChrWork* __restrict__ Wt,
         const u32 hi = j == k ? L1 : L0 + lower_bound_u64(p_pos + L0, L1 - L0, bk[j]);
         if (hi <= lo) continue;
         if (!FILL) { n += hi - lo; continue; }
-        for (u32 idx = lo; idx < hi; idx++) {
-            const u64 v = p_pos[idx];
-            while (in < nn && npos[in] < v) { out[n++] = npos[in]; in++; NEXT_NEW(); }
-            out[n++] = v;
+        u32 cur = lo;
+        while (in < nn) {
+            const u64 vn = npos[in];
+            const u32 split = cur + upper_bound_u64(p_pos + cur, hi - cur, vn);      // first inherited entry > vn
+            if (split >= hi) break;                                                   // none in this interval: vn stays pending
+            COPY_OLD(cur, split);
+            if (sub == 0) out[n] = vn;
+            n++; in++; NEXT_NEW(); cur = split;
         }
+        COPY_OLD(cur, hi);
     }
-    while (in < nn) { if (FILL) out[n] = npos[in]; n++; in++; NEXT_NEW(); }
+    while (in < nn) { if (FILL && sub == 0) out[n] = npos[in]; n++; in++; NEXT_NEW(); }
+#undef COPY_OLD
 #undef NEXT_NEW
     if (!FILL) o_cnt[row] = n;
 }
@@ -1048,7 +1064,12 @@ __global__ void __launch_bounds__(256) k_mutlist(const ChrWork* __restrict__ Wt,
 // ------------------------------------------------------------------------------------------
 // K4: ancestry interval lists == Simulation::recombine (:2903-2958), statement by statement on CSR
 // ------------------------------------------------------------------------------------------
-template <bool FILL>
+// Simulation::recombine (:2903-2958) on the CSR interval lists.  The parts of a haplotype tile [bp0, bp_end) (st ascending,
+// en[i] = st[i+1]), so inside one interval [Lc, Rc) of the crossover pattern the reference's loop emits: at most one part clipped
+// at Lc (:2922 / :2931), then a RUN of whole parts -- everything up to the first part that ends behind Rc -- and at most one part
+// clipped at Rc (:2947).  The run is a contiguous range of the parent's list: found by bisection, counted by subtraction
+// (count pass, G = 1) or copied by G lanes together (fill pass, G = 8: 128 contiguous bytes per step).
+template <bool FILL, int G>
 __global__ void __launch_bounds__(256) k_parts(const ChrWork* __restrict__ Wt, u32* __restrict__ cnt, size_t cnt_stride,
                                                size_t n_rows_out, int nchr, SampleDev sd)
 {
@@ -1057,20 +1078,25 @@ __global__ void __launch_bounds__(256) k_parts(const ChrWork* __restrict__ Wt, u
     u32* __restrict__ o_cnt = cnt + (size_t)blockIdx.y * cnt_stride;
     const u32* __restrict__ o_off = w.poff_alt; gev_part* __restrict__ o_parts = w.parts_alt;
     const int chr = w.chr; const u64 bp0 = w.bp0, bp_end = w.bp_end; const u32 cap = w.pcap;
-    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t row = tid / G; const u32 sub = (u32)(tid % G);
     if (row >= n_rows_out) return;
-    if (FILL && o_off[row + 1] > cap) { if (o_off[row] <= cap) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_PARTS_CAP); return; }
+    if (FILL && o_off[row + 1] > cap) { if (o_off[row] <= cap && sub == 0) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_PARTS_CAP); return; }
     const u32 i = (u32)(row >> 1), s = (u32)(row & 1);
-    const size_t G = 2 * ((size_t)i * nchr + chr) + s;
+    const size_t G_ = 2 * ((size_t)i * nchr + chr) + s;
     const u32 parent = s ? sd.mother[i] : sd.father[i];
-    u32 hap = sd.start[G];
-    const u32 k = sd.k[G];
-    const u64* bk = sd.bk + sd.bk_off[G];
+    u32 hap = sd.start[G_];
+    const u32 k = sd.k[G_];
+    const u64* bk = sd.bk + sd.bk_off[G_];
     gev_part* out = FILL ? o_parts + o_off[row] : nullptr;
     u32 n = 0;
+    // whole parts [from, to) of the parent's list -> out[n ...], 16 bytes per lane and step
+#define COPY_RUN(from, to) do { if (FILL) { const uint4* s_ = (const uint4*)(p_parts + (from)); uint4* d_ = (uint4*)(out + n); \
+                                            for (u32 u_ = sub; u_ < 2u * ((to) - (from)); u_ += G) d_[u_] = s_[u_]; } n += (to) - (from); } while (0)
+#define FIRST_EN_GT(x, from, res) do { u32 lo_ = (from), hi_ = h1; while (lo_ < hi_) { const u32 mid_ = (lo_ + hi_) >> 1; if (p_parts[mid_].en <= (x)) lo_ = mid_ + 1; else hi_ = mid_; } res = lo_; } while (0)
     if (k == 0) {                                                       // locs.size() < 3, :2910
         const u32 h0 = p_off[2 * parent + hap], h1 = p_off[2 * parent + hap + 1];
-        for (u32 j = h0; j < h1; j++) { if (FILL) out[n] = p_parts[j]; n++; }
+        COPY_RUN(h0, h1);
         if (!FILL) o_cnt[row] = n;
         return;
     }
@@ -1079,23 +1105,28 @@ __global__ void __launch_bounds__(256) k_parts(const ChrWork* __restrict__ Wt, u
         const u64 Rc = (i1 == k + 1) ? bp_end : bk[i1 - 1];
         const u32 h0 = p_off[2 * parent + hap], h1 = p_off[2 * parent + hap + 1];
         u32 i2;
-        { u32 lo = h0, hi = h1;                                                                     // :2918 -- parts tile the range, `en` ascends: the first part with en > Lc by bisection
-          while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (p_parts[mid].en <= Lc) lo = mid + 1; else hi = mid; }
-          i2 = lo; }
+        FIRST_EN_GT(Lc, h0, i2);                                                                    // :2918
         if (i2 < h1 && p_parts[i2].st < Lc && Lc < p_parts[i2].en && Rc < p_parts[i2].en) {         // :2922
-            if (FILL) { gev_part p = p_parts[i2]; p.st = Lc; p.en = Rc; out[n] = p; } n++; i2++;
+            if (FILL && sub == 0) { gev_part p = p_parts[i2]; p.st = Lc; p.en = Rc; out[n] = p; } n++; i2++;
         }
         if (i2 < h1 && p_parts[i2].st < Lc && Lc < p_parts[i2].en && Rc >= p_parts[i2].en) {        // :2931
-            if (FILL) { gev_part p = p_parts[i2]; p.st = Lc; out[n] = p; } n++; i2++;
+            if (FILL && sub == 0) { gev_part p = p_parts[i2]; p.st = Lc; out[n] = p; } n++; i2++;
         }
-        while (i2 < h1 && p_parts[i2].en <= Rc && Lc <= p_parts[i2].st) {                           // :2939
-            if (FILL) out[n] = p_parts[i2]; n++; i2++;
+        // :2939 -- while (en <= Rc && Lc <= st): from here on every part starts at or behind Lc (the one that did not is handled
+        // above), so the loop runs up to the first part that ends behind Rc
+        if (i2 < h1 && Lc <= p_parts[i2].st) {
+            u32 iR;
+            FIRST_EN_GT(Rc, i2, iR);
+            COPY_RUN(i2, iR);
+            i2 = iR;
         }
         if (i2 < h1 && p_parts[i2].st < Rc && Rc < p_parts[i2].en) {                                 // :2947
-            if (FILL) { gev_part p = p_parts[i2]; p.en = Rc; out[n] = p; } n++;
+            if (FILL && sub == 0) { gev_part p = p_parts[i2]; p.en = Rc; out[n] = p; } n++;
         }
         hap ^= 1u;                                                                                   // :2955
     }
+#undef COPY_RUN
+#undef FIRST_EN_GT
     if (!FILL) o_cnt[row] = n;
 }
 
@@ -1131,28 +1162,53 @@ __global__ void __launch_bounds__(256) k_cv_apply_mut(
 // all (phenotype, chromosome) pairs of a population in one launch (blockIdx.y); also clears the column counters of the pair
 // Step 1 (coalesced): the allele sub-rows of the block's 256 haplotype rows are copied word by word (consecutive lanes =
 // consecutive words); step 2: one thread per row flips the CVs that are in the row's mutation set (few rows have any).
+// The mutation entries of the block's 256 rows are ONE contiguous range of the CSR array: the block scans it flat (coalesced,
+// independent of how the entries are spread over the rows) and drops every position that cannot be a CV position with one LDS
+// read (64-Kbit hash bitmap of the CV grid: 1000 CVs -> 1.5 % false positives); the few survivors are looked up exactly, their
+// row is found in the staged offsets, and the allele is set to !founder (idempotent: a position hit twice is still one flip).
+__device__ __forceinline__ u32 cv_hash16(u64 x) { return (u32)((x * 0x9E3779B97F4A7C15ull) >> 48); }
 __global__ void __launch_bounds__(256) k_cv_apply_mut_tab(const AdWork* __restrict__ At, size_t n_rows)
 {
+    __shared__ u32 s_bits[2048];
+    __shared__ u32 s_off[257];
     const AdWork& a = At[blockIdx.y];
     const size_t row0 = (size_t)blockIdx.x * 256;
     if (blockIdx.x == 0) for (u32 c = threadIdx.x; c < a.C; c += 256) a.counts[c] = 0;     // k_cv_count (next launch) accumulates into them
     const u32 sw = a.sub_w32;
-    const size_t n_here = min((size_t)256, n_rows - row0);
-    for (size_t e = threadIdx.x; e < n_here * sw; e += 256) {
+    const u32 n_here = (u32)min((size_t)256, n_rows - row0);
+    for (u32 q = threadIdx.x; q < 2048; q += 256) s_bits[q] = 0;
+    if (threadIdx.x <= n_here) s_off[threadIdx.x] = a.moff[row0 + threadIdx.x];
+    if (threadIdx.x == 0) s_off[n_here] = a.moff[row0 + n_here];
+    __syncthreads();
+    for (u32 c = threadIdx.x; c < a.C; c += 256) { const u32 h = cv_hash16(a.pos_sorted[c]); atomicOr(&s_bits[h >> 5], 1u << (h & 31)); }
+    for (size_t e = threadIdx.x; e < (size_t)n_here * sw; e += 256) {
         const size_t r = e / sw; const u32 w = (u32)(e - r * sw);
         a.cvm[(row0 + r) * sw + w] = a.cvp[(row0 + r) * a.stride_w32 + w];
     }
     __syncthreads();                                     // the flips below go to the rows this block has just written
-    const size_t row = row0 + threadIdx.x;
-    if (row >= n_rows) return;
-    const u32* in = a.cvp + row * a.stride_w32;
-    u32* o = a.cvm + row * sw;
-    for (u32 j = a.moff[row]; j < a.moff[row + 1]; j++) {
-        const u64 x = a.mpos[j];
+    const u32 e0 = s_off[0], e1 = s_off[n_here];
+    for (u32 eb = e0 + threadIdx.x; eb < e1; eb += 256 * 4) {
+        u64 xs[4];                                        // four independent loads in flight per lane
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const u32 e = eb + u * 256; xs[u] = e < e1 ? a.mpos[e] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+        const u32 e = eb + u * 256;
+        if (e >= e1) continue;
+        const u64 x = xs[u];
+        const u32 h = cv_hash16(x);
+        if (!((s_bits[h >> 5] >> (h & 31)) & 1u)) continue;
         u32 c = lower_bound_u64(a.pos_sorted, a.C, x);
+        if (c >= a.C || a.pos_sorted[c] != x) continue;
+        u32 lo = 0, hi = n_here;                          // row of entry e: the last r with s_off[r] <= e
+        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_off[mid] <= e) lo = mid; else hi = mid - 1; }
+        const size_t row = row0 + lo;
+        const u32* in = a.cvp + row * a.stride_w32;
+        u32* o = a.cvm + row * sw;
         for (; c < a.C && a.pos_sorted[c] == x; c++) {              // set semantics: flipped = !founder, idempotent
-            const u32 f = (in[c >> 5] >> (c & 31)) & 1u;
-            if (f) o[c >> 5] &= ~(1u << (c & 31)); else o[c >> 5] |= (1u << (c & 31));
+            const u32 f = (in[c >> 5] >> (c & 31)) & 1u, bit = 1u << (c & 31);
+            if (f) atomicAnd(&o[c >> 5], ~bit); else atomicOr(&o[c >> 5], bit);
+        }
         }
     }
 }

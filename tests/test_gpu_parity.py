@@ -162,6 +162,18 @@ def _read_device_u32(ptr, n):
     return out
 
 
+@pytest.mark.parametrize("lanes_from", [0, 1000000])
+def test_list_fill_kernels_thread_per_row_and_eight_lanes_per_row(gpu_lib, oracle_lib, monkeypatch, lanes_from):
+    """the mutation / interval list fill kernels exist in two forms (one thread per row; eight lanes per row copying the
+    inherited ranges together, used from GEV_LIST_LONG entries per row on): both forced in turn, hot maps (many crossovers and
+    new mutations per row: many short ranges, inserts inside ranges) and cold maps (long plain copies)"""
+    monkeypatch.setenv("GEV_LIST_LONG", str(lanes_from))
+    cfg = SyntheticConfig(200, 5000, nchr=2, chrom_bp=2_000_000, map_step=1000, rec_per_row=5e-3, mut_per_row=8e-3, n_cv=100, seed=61)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=6, seed=62)
+    cfg = SyntheticConfig(200, 5000, nchr=1, chrom_bp=2_000_000, map_step=1000, rec_per_row=2e-4, mut_per_row=2e-3, n_cv=100, seed=63)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=12, seed=64, check_every=3)
+
+
 @pytest.mark.parametrize("mode,alias", [(0, 1), (1, 1), (2, 1), (0, 0)])
 def test_crossover_free_gametes_share_the_parental_row(gpu_lib, oracle_lib, monkeypatch, mode, alias):
     """Cold maps: ~0.3 crossovers per gamete, so most offspring haplotypes are a parent's haplotype unchanged
@@ -220,6 +232,15 @@ def test_crossover_free_gametes_share_the_parental_row(gpu_lib, oracle_lib, monk
         shared_seen += n_shared
     assert g.dbg_verify_planes(0, 1, [cfg.seed + 1]) == (0, 0)
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("setting", ["auto", "8", "5"])
+def test_stitch_occupancy_settings_do_not_change_results(gpu_lib, oracle_lib, monkeypatch, setting):
+    """GEV_STITCH_WG_PER_CU limits the dense stitch's workgroups per CU (dynamic LDS padding); `auto` switches between 8, 7 and 6
+    while it measures.  Rows of 64 KiB (the long-row kernel), 16 generations so that the tuner walks through every candidate."""
+    monkeypatch.setenv("GEV_STITCH_WG_PER_CU", setting)
+    cfg = SyntheticConfig(150, 524288, nchr=1, chrom_bp=60_000_000, map_step=50_000, rec_per_row=8e-4, mut_per_row=5e-4, n_cv=64, seed=51)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=16 if setting == "auto" else 3, seed=52, check_every=8)
 
 
 def test_population_without_any_crossover(gpu_lib, oracle_lib):
