@@ -95,6 +95,7 @@ struct AdWork {
     double vd;
     u32 stride_w32, sub_w32, C;
     int own_pop;
+    u32 cols_sorted;      // the CV file is already in position order: CV j of the file is bit j of the rows
 };
 #define GEV_BK_CAP 8
 #define GEV_NM_CAP 8
@@ -1350,11 +1351,25 @@ __global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restr
     for (u32 base = 0; base < Cn; base += AD_CHUNK) {
         const u32 nj = min((u32)AD_CHUNK, Cn - base);
         __syncthreads();                                         // rows staged / previous chunk consumed
-        for (u32 e = threadIdx.x; e < nj; e += IPB) s_col[e] = col_of_icv[base + e];
+        if (!aw.cols_sorted) for (u32 e = threadIdx.x; e < nj; e += IPB) s_col[e] = col_of_icv[base + e];
         for (u32 e = threadIdx.x; e < nj * 6; e += IPB) s_tab[e] = tab[6 * (size_t)base + e];
         __syncthreads();
         // CVs in FILE order, sequential FP64 adds; the per-CV term is picked from the LDS table by the genotype t (0, 1, 2)
-        if (skip_d) {
+        if (aw.cols_sorted) {
+            // file order == column order (the usual case: CV files are written by position): one word of each row serves 32 CVs
+            for (u32 j0 = 0; j0 < nj; j0 += 32) {
+                u32 w0 = r0[(base + j0) >> 5], w1 = r1[(base + j0) >> 5];
+                const u32 m = min(32u, nj - j0);
+                const double* tj = s_tab + 6 * j0;
+                if (skip_d) {
+#pragma unroll 4
+                    for (u32 b = 0; b < m; b++) { const u32 t = (w0 & 1u) + (w1 & 1u); w0 >>= 1; w1 >>= 1; A_chr += tj[6 * b + t]; }
+                } else {
+#pragma unroll 4
+                    for (u32 b = 0; b < m; b++) { const u32 t = (w0 & 1u) + (w1 & 1u); w0 >>= 1; w1 >>= 1; A_chr += tj[6 * b + t]; D_chr += tj[6 * b + 3 + t]; }
+                }
+            }
+        } else if (skip_d) {
 #pragma unroll 4
             for (u32 j = 0; j < nj; j++) {
                 const u32 c = s_col[j];

@@ -131,6 +131,7 @@ struct CvStatic {                        // one population x phenotype x chromos
     u32 idx_lo = 0, idx_hi = 0;
     size_t founder_rows = 0;
     bool frq_valid = false;
+    bool cols_sorted = false;            // file order == position order (col_of_icv is the identity)
 };
 struct ChrState {
     // genotype rows: one pool of 4 * cap_people rows (two generations' worth); slot s of the current generation is pool row
@@ -466,6 +467,8 @@ int gev_set_cvs(gev_ctx* c, int pop, int phen, int chr, const u64* bp, const dou
     std::stable_sort(V.icv_of_col.begin(), V.icv_of_col.end(), [&](u32 x, u32 y) { return V.bp[x] < V.bp[y]; });
     V.col_of_icv.resize(C);
     for (u32 j = 0; j < C; j++) V.col_of_icv[V.icv_of_col[j]] = j;
+    V.cols_sorted = true;
+    for (u32 j = 0; j < C; j++) V.cols_sorted &= V.col_of_icv[j] == j;
     std::vector<u64> sorted(C);
     for (u32 j = 0; j < C; j++) sorted[j] = V.bp[V.icv_of_col[j]];
     V.sub_w32 = (u32)std::max<size_t>(ceil_div(C, 32), 1);
@@ -1308,7 +1311,7 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
             a.counts = V.d_counts.as<u32>(); a.frq = V.d_frq.as<double>(); a.tab = V.d_tab.as<double>();
             a.add_out = c->d_addchr.as<double>() + (size_t)k * nphen + p; a.dom_out = c->d_domchr.as<double>() + (size_t)k * nphen + p;
             a.bp0 = S.rbp.front(); a.bp_end = S.rbp.back(); a.vd = V.vd;
-            a.stride_w32 = V.stride_w32; a.sub_w32 = V.sub_w32; a.C = V.C; a.own_pop = pop;
+            a.stride_w32 = V.stride_w32; a.sub_w32 = V.sub_w32; a.C = V.C; a.own_pop = pop; a.cols_sorted = V.cols_sorted ? 1u : 0u;
             aw.push_back(a);
         }
     const unsigned nw = (unsigned)aw.size();
