@@ -1065,6 +1065,14 @@ __global__ void __launch_bounds__(256) k_mutlist(const ChrWork* __restrict__ Wt,
 // ------------------------------------------------------------------------------------------
 // K4: ancestry interval lists == Simulation::recombine (:2903-2958), statement by statement on CSR
 // ------------------------------------------------------------------------------------------
+// one part, optionally clipped, as two 16-byte register moves (a struct temporary would be placed in LDS: 14 KiB per block)
+__device__ __forceinline__ void put_part(gev_part* dst, const gev_part* src, bool set_st, u64 st, bool set_en, u64 en)
+{
+    uint4 a = ((const uint4*)src)[0]; const uint4 b = ((const uint4*)src)[1];        // a = {st, en}, b = {hap_index, root_population, reserved}
+    if (set_st) { a.x = (u32)st; a.y = (u32)(st >> 32); }
+    if (set_en) { a.z = (u32)en; a.w = (u32)(en >> 32); }
+    ((uint4*)dst)[0] = a; ((uint4*)dst)[1] = b;
+}
 // Simulation::recombine (:2903-2958) on the CSR interval lists.  The parts of a haplotype tile [bp0, bp_end) (st ascending,
 // en[i] = st[i+1]), so inside one interval [Lc, Rc) of the crossover pattern the reference's loop emits: at most one part clipped
 // at Lc (:2922 / :2931), then a RUN of whole parts -- everything up to the first part that ends behind Rc -- and at most one part
@@ -1108,10 +1116,10 @@ __global__ void __launch_bounds__(256) k_parts(const ChrWork* __restrict__ Wt, u
         u32 i2;
         FIRST_EN_GT(Lc, h0, i2);                                                                    // :2918
         if (i2 < h1 && p_parts[i2].st < Lc && Lc < p_parts[i2].en && Rc < p_parts[i2].en) {         // :2922
-            if (FILL && sub == 0) { gev_part p = p_parts[i2]; p.st = Lc; p.en = Rc; out[n] = p; } n++; i2++;
+            if (FILL && sub == 0) put_part(out + n, p_parts + i2, true, Lc, true, Rc); n++; i2++;
         }
         if (i2 < h1 && p_parts[i2].st < Lc && Lc < p_parts[i2].en && Rc >= p_parts[i2].en) {        // :2931
-            if (FILL && sub == 0) { gev_part p = p_parts[i2]; p.st = Lc; out[n] = p; } n++; i2++;
+            if (FILL && sub == 0) put_part(out + n, p_parts + i2, true, Lc, false, 0); n++; i2++;
         }
         // :2939 -- while (en <= Rc && Lc <= st): from here on every part starts at or behind Lc (the one that did not is handled
         // above), so the loop runs up to the first part that ends behind Rc
@@ -1122,7 +1130,7 @@ __global__ void __launch_bounds__(256) k_parts(const ChrWork* __restrict__ Wt, u
             i2 = iR;
         }
         if (i2 < h1 && p_parts[i2].st < Rc && Rc < p_parts[i2].en) {                                 // :2947
-            if (FILL && sub == 0) { gev_part p = p_parts[i2]; p.en = Rc; out[n] = p; } n++;
+            if (FILL && sub == 0) put_part(out + n, p_parts + i2, false, 0, true, Rc); n++;
         }
         hap ^= 1u;                                                                                   // :2955
     }
@@ -1325,8 +1333,11 @@ __global__ void k_cv_table(const AdWork* __restrict__ At, size_t n_human)
 // column reads).  col_of_icv / tab are wave-uniform (scalar loads); t selects per lane.
 #define AD_CHUNK 128          // CVs whose table entries sit in LDS at a time
 template <int IPB>
-__global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restrict__ At, u32 s1_max, size_t n_human, size_t out_stride, u32* __restrict__ nan_flag)
+__global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restrict__ At, u32 s1_max, size_t n_human, size_t out_stride, u32* __restrict__ nan_flag, int direct)
 {
+    // direct (every CV file of the launch is in position order): a thread walks its two rows word by word, 32 CVs per word, so
+    // it reads them straight from global memory (256 contiguous bytes per individual) and the launch passes s1_max = 0: only the
+    // 6.6 KiB table chunk sits in LDS, which lets the block run in the LDS a concurrent stitch leaves over
     extern __shared__ u32 s_rows[];                              // [2 * IPB * s1_max] rows | [AD_CHUNK] columns | [AD_CHUNK * 6] table (8-byte aligned)
     const AdWork& aw = At[blockIdx.y];
     const u32* __restrict__ cvm = aw.cvm; const u32 sub_w32 = aw.sub_w32; const u32* __restrict__ col_of_icv = aw.col_of_icv;
@@ -1338,13 +1349,14 @@ __global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restr
     const size_t n_here = min((size_t)IPB, n_human - ih0);
     const u32 words = (u32)(2 * n_here) * sub_w32;
     const u32* src = cvm + 2 * ih0 * sub_w32;
-    for (u32 e = threadIdx.x; e < words; e += IPB) {
-        const u32 row = e / sub_w32, w = e - row * sub_w32;     // row = 2*local_individual + hap
-        s_rows[((row & 1u) * IPB + (row >> 1)) * S1 + w] = src[e];
-    }
+    if (!direct)
+        for (u32 e = threadIdx.x; e < words; e += IPB) {
+            const u32 row = e / sub_w32, w = e - row * sub_w32;     // row = 2*local_individual + hap
+            s_rows[((row & 1u) * IPB + (row >> 1)) * S1 + w] = src[e];
+        }
     const bool live = threadIdx.x < n_here;
-    const u32* r0 = s_rows + (size_t)threadIdx.x * S1;
-    const u32* r1 = s_rows + ((size_t)IPB + threadIdx.x) * S1;
+    const u32* r0 = direct ? src + (live ? 2 * (size_t)threadIdx.x * sub_w32 : 0) : s_rows + (size_t)threadIdx.x * S1;
+    const u32* r1 = direct ? r0 + sub_w32 : s_rows + ((size_t)IPB + threadIdx.x) * S1;
     // vd == 0: the reference zeroes d (:2698-2699), every D-term is (+-0) * ... = +-0 and the running sum stays +0.0
     const bool skip_d = aw.vd == 0;
     double A_chr = 0, D_chr = 0;

@@ -1029,13 +1029,19 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     HIPC(hipEventRecord(sc.t[2], st));
     return GEV_OK;
 }
-// unused dynamic LDS per stitch workgroup that limits the workgroups per CU to `occ` (160 KiB of LDS per CU; the kernels'
-// own static LDS is 3.4 KiB, allocation granularity taken as 512 B)
+// Unused dynamic LDS per stitch workgroup that limits the workgroups per CU to `occ` (160 KiB of LDS per CU; the kernels' own
+// static LDS is 3.4 KiB, allocation granularity taken as 512 B): the SMALLEST padding with which occ + 1 workgroups no longer
+// fit, so that the rest of the LDS (about 20 KiB at occ = 6) stays available to the small kernels that run next to the stitch --
+// the sampling kernels stage 17.5 KiB of tables.  The largest padding that still admits `occ` workgroups leaves 2 KiB: a small
+// kernel then has to wait for a stitch workgroup to retire and displaces it (2.5 % fewer generations/s at config 2).
 static unsigned stitch_lds_pad(int occ)
 {
+    if (const char* e = getenv("GEV_STITCH_LDS_PAD")) return (unsigned)atoi(e);       // experiments
     if (occ >= 8) return 0;
-    const unsigned budget = (160u * 1024u / (unsigned)occ) / 512u * 512u;
-    return std::min(budget - 3584u, 64u * 1024u - 3584u);
+    const unsigned cu_lds = 160u * 1024u, own_min = 3072u, own_max = 3584u;            // the kernels' static LDS lies between these
+    const unsigned per_wg = cu_lds / (unsigned)(occ + 1) + 1u;                          // occ + 1 of these exceed the CU
+    const unsigned pad = (per_wg - own_min + 511u) / 512u * 512u;
+    return std::min(pad, 64u * 1024u - own_max);
 }
 static const int OCC_CAND[] = {8, 7, 6};
 // called at the end of every gev_reproduce: times the generations of each candidate and settles on the fastest
@@ -1326,11 +1332,18 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
         }
         if (ipb) {
             hipLaunchKernelGGL(k_cv_table, dim3((unsigned)ceil_div(c_max, 256), nw), dim3(256), 0, st, At, n);
-            const size_t lds = (size_t)2 * ipb * S1 * 4 + ad_tab_lds;
-            const unsigned nb = (unsigned)ceil_div(n, ipb);
-            if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>());
-            else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb, nw), dim3(128), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>());
-            else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb, nw), dim3(64), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>());
+            bool direct = true;                                  // every CV file in position order: rows are read from global memory, no row staging
+            for (const AdWork& a : aw) direct &= a.cols_sorted != 0;
+            if (direct) {
+                const unsigned nb = (unsigned)ceil_div(n, 256);
+                hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), ad_tab_lds, st, At, 0u, n, out_stride, c->d_flag.as<u32>(), 1);
+            } else {
+                const size_t lds = (size_t)2 * ipb * S1 * 4 + ad_tab_lds;
+                const unsigned nb = (unsigned)ceil_div(n, ipb);
+                if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>(), 0);
+                else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb, nw), dim3(128), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>(), 0);
+                else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb, nw), dim3(64), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>(), 0);
+            }
         } else {
             if (c_max) hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(c_max, 256), nw), dim3(256), 0, st, At, n);
             hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256), nw), dim3(256), 0, st, At, c->rp_bits, n, out_stride, c->d_flag.as<u32>());
