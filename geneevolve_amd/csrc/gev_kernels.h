@@ -1123,7 +1123,9 @@ __global__ void __launch_bounds__(256) k_parts(const ChrWork* __restrict__ Wt, u
         }
         // :2939 -- while (en <= Rc && Lc <= st): from here on every part starts at or behind Lc (the one that did not is handled
         // above), so the loop runs up to the first part that ends behind Rc
-        if (i2 < h1 && Lc <= p_parts[i2].st) {
+        if (FILL && G == 1) {                                       // short lists (one thread per row): copy while walking, as the reference does
+            while (i2 < h1 && p_parts[i2].en <= Rc && Lc <= p_parts[i2].st) { put_part(out + n, p_parts + i2, false, 0, false, 0); n++; i2++; }
+        } else if (i2 < h1 && Lc <= p_parts[i2].st) {
             u32 iR;
             FIRST_EN_GT(Rc, i2, iR);
             COPY_RUN(i2, iR);
@@ -1369,8 +1371,21 @@ __global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restr
         // CVs in FILE order, sequential FP64 adds; the per-CV term is picked from the LDS table by the genotype t (0, 1, 2)
         if (aw.cols_sorted) {
             // file order == column order (the usual case: CV files are written by position): one word of each row serves 32 CVs
-            for (u32 j0 = 0; j0 < nj; j0 += 32) {
-                u32 w0 = r0[(base + j0) >> 5], w1 = r1[(base + j0) >> 5];
+            // the chunk's (up to) four words of each row: one 16-byte load per row when the rows are 16-byte aligned (a 4-byte
+            // walk refetches each 128-byte line of the rows from L2 up to 32 times once the working set of the CU exceeds its L1)
+            u32 c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0};
+            const u32 wq = base >> 5;
+            if (direct && (sub_w32 & 3u) == 0 && wq + 4 <= sub_w32) {
+                const uint4 v0 = *(const uint4*)(r0 + wq), v1 = *(const uint4*)(r1 + wq);
+                c0[0] = v0.x; c0[1] = v0.y; c0[2] = v0.z; c0[3] = v0.w; c1[0] = v1.x; c1[1] = v1.y; c1[2] = v1.z; c1[3] = v1.w;
+            } else {
+#pragma unroll
+                for (u32 q = 0; q < 4; q++) if (wq + q < sub_w32) { c0[q] = r0[wq + q]; c1[q] = r1[wq + q]; }
+            }
+#pragma unroll
+            for (u32 j0 = 0; j0 < AD_CHUNK; j0 += 32) {
+                if (j0 >= nj) break;
+                u32 w0 = c0[j0 >> 5], w1 = c1[j0 >> 5];
                 const u32 m = min(32u, nj - j0);
                 const double* tj = s_tab + 6 * j0;
                 if (skip_d) {
