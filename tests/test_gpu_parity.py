@@ -446,6 +446,45 @@ def test_baseline_config2_full_size_dense_state_equals_interval_state(gpu_lib):
     g.close()
 
 
+def test_three_hundred_generations_of_shared_rows_dense_state_equals_interval_state(gpu_lib):
+    """A long run at a size where the stitch overlaps the next generation's kernels (20k individuals x 256k SNPs, no synchronisation
+    between generations): rows are handed down along chains of crossover-free gametes for many generations, the row pool is
+    rebuilt 300 times, the lists pass the length where the fill kernels switch to eight lanes per row, and the population size
+    wobbles (pool growth).  Every word of the final genotype rows must equal the materialised interval state, the list invariants
+    must hold, and a founder haplotype block that survived must still be there bit for bit."""
+    L = 262_144
+    cfg = SyntheticConfig(20_000, L, chrom_bp=100_000_000, n_cv=200, seed=71)
+    g = gpu_lib.create(1, 1, 1)
+    cfg.apply_static(g)
+    n = 20_000
+    g.synth_founders(0, 0, 2 * n, 8001); g.synth_cv_founders(0, 0, 0, 2 * n, 8002)
+    sim = Simulation(g, 4242, 1, True)
+    sim.ras_initial_human_gen0(0, n)
+    rng = np.random.default_rng(17)
+    copied = total = 0
+    for gen in range(1, 301):
+        n = 20_000 + (gen % 7) * 500 if gen % 50 else 24_000            # a few growth steps beyond the current capacity
+        sim.couples[0] = synthetic_random_mate(sim.sex[0], n, rng)
+        sim.reproduce(0, gen, n_people=n)
+        if gen % 100 == 0:
+            assert g.dbg_verify_planes(0, 0, 8001) == (0, 0), f"dense state != interval state after {gen} generations"
+    copied, total = g.stitch_totals()
+    assert 0.55 < copied / total < 0.70                                   # e^-1 of the gametes have no crossover at one Morgan
+    parts, off = g.download_intervals(0, 0)
+    muts, moff = g.download_mutations(0, 0)
+    assert len(off) == 2 * n + 1 and off[-1] == len(parts) and moff[-1] == len(muts)
+    st = parts["st"].astype(np.int64); en = parts["en"].astype(np.int64)
+    first = off[:-1].astype(np.int64); last = off[1:].astype(np.int64) - 1
+    assert (st[first] == int(cfg.rmap_bp[0])).all() and (en[last] == int(cfg.rmap_bp[-1])).all()      # every row tiles the map range
+    inner = np.ones(len(parts), dtype=bool); inner[last] = False
+    assert (en[inner] == st[1:][inner[:-1]]).all()
+    assert off[-1] / (2 * n) > 50                                          # ~ one new part per row and generation: the eight-lane fill form was in use
+    for r in range(0, 2 * n, 4001):
+        m = muts[int(moff[r]):int(moff[r + 1])]
+        assert (np.diff(m.astype(np.int64)) >= 0).all()
+    g.close()
+
+
 def test_population_growth_without_intermediate_sync(gpu_lib, oracle_lib):
     """The population grows every generation (capacity growth reallocates and copies the CURRENT planes) while the previous
     generation's dense stitch may still be running on the library's second stream: nothing between the generations waits
