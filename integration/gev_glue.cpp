@@ -14,6 +14,7 @@
 #include <iostream>
 #include <random>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 #include "Simulation.h"          // the EDITED copy: class Simulation has `friend struct GevGlue;`
@@ -79,6 +80,35 @@ struct GevGlue {
         return true;
     }
 
+    // Simulation::ras_allocate_memory_for_humans (:2366-2392): the same resizes (12 + 4 nchr heap allocations per individual), the
+    // individuals shared out over a few host threads -- with the genotype work on the GPU this was the longest part of
+    // Simulation::reproduce at 100k individuals.  Same stdout text.
+    static void allocate_humans(std::vector<Human>& h, unsigned long n_people, int nchr, int nphen)
+    {
+        std::cout << "        Allocating memory: " << std::flush;
+        h.resize(n_people);
+        auto fill = [&h, nchr, nphen](size_t b, size_t e) {
+            for (size_t it = b; it < e; it++) {
+                h[it].chr.resize(nchr);
+                for (int ichr = 0; ichr < nchr; ichr++) {
+                    h[it].chr[ichr].Hap.resize(2);
+                    h[it].chr[ichr].bv_chr.resize(nphen);
+                    h[it].chr[ichr].additive_chr.resize(nphen);
+                    h[it].chr[ichr].dominance_chr.resize(nphen);
+                }
+                h[it].additive.resize(nphen); h[it].dominance.resize(nphen); h[it].common_sibling.resize(nphen);
+                h[it].bv.resize(nphen); h[it].e_noise.resize(nphen); h[it].parental_effect.resize(nphen); h[it].phen.resize(nphen);
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), n_people / 4096 + 1));
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; t++) th.emplace_back(fill, n_people * t / nt, n_people * (t + 1) / nt);
+        fill(0, n_people / nt);
+        for (auto& x : th) x.join();
+        std::cout << "done." << std::endl;
+    }
+
     // Simulation::reproduce (:2394-2493): same ras_glob_seed() draws, same host bookkeeping, genotype work in the library
     static std::vector<Human> reproduce(Simulation& S, int ipop, int gen_num)
     {
@@ -90,7 +120,11 @@ struct GevGlue {
         for (unsigned long i = 0; i < n_couples; i++) if (!P._couples_info[i].inbreed) n_people += P._couples_info[i].num_offspring;
         const int nchr = (int)P.h[0].chr.size(), nphen = (int)P._pheno_scheme.size();
         std::vector<Human> h_ret;
-        S.ras_allocate_memory_for_humans(h_ret, n_people, nchr, nphen);
+        const bool trace = getenv("GEV_GLUE_TRACE") != NULL;
+        const auto tr0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) { if (trace) fprintf(stderr, "[glue] reproduce: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count()); };
+        allocate_humans(h_ret, n_people, nchr, nphen);
+        lap("records allocated");
         std::default_random_engine generator(seed + 1);                            // common effect, :2417-2429
         std::vector<std::vector<double> > val_common(nphen, std::vector<double>(n_couples, 0));
         for (int iphen = 0; iphen < nphen; iphen++)
@@ -107,9 +141,11 @@ struct GevGlue {
             for (size_t t = 0; t < mut_seeds.size(); t++) mut_seeds[t] = S.ras_glob_seed();
         }
         std::vector<uint8_t> sex(n_people);
+        lap("couples and seeds ready");
         if (gev_reproduce(ctx(), ipop, cpl.data(), n_couples, seed, mut_seeds.empty() ? NULL : mut_seeds.data(), mut_seeds.size(), n_people, sex.data())) {
             fail("gev_reproduce"); return std::vector<Human>();
         }
+        lap("gev_reproduce returned");
         unsigned long i_people = 0;
         for (unsigned long it = 0; it < n_couples; it++) {
             if (P._couples_info[it].inbreed) continue;
@@ -123,7 +159,31 @@ struct GevGlue {
                 i_people++;
             }
         }
+        lap("pedigree fields set");
+        release_humans(P.h);              // the caller replaces P.h with the return value (:1929): nothing reads the parents any more
+        lap("parents released");
         return h_ret;
+    }
+    // The parents' records are destroyed by the assignment `population[ipop].h = reproduce(...)` (src/Simulation.cpp:1929), one
+    // individual after the other on the calling thread (16 frees each).  Their inner vectors are released here first, by a few
+    // threads; the assignment then destroys empty shells.
+    static void release_humans(std::vector<Human>& h)
+    {
+        const size_t n = h.size();
+        auto drop = [&h](size_t b, size_t e) {
+            for (size_t it = b; it < e; it++) {
+                Human& x = h[it];
+                std::vector<chromosome>().swap(x.chr);
+                std::vector<double>().swap(x.additive); std::vector<double>().swap(x.dominance); std::vector<double>().swap(x.common_sibling);
+                std::vector<double>().swap(x.bv); std::vector<double>().swap(x.e_noise); std::vector<double>().swap(x.parental_effect); std::vector<double>().swap(x.phen);
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), n / 4096 + 1));
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; t++) th.emplace_back(drop, n * t / nt, n * (t + 1) / nt);
+        drop(0, n / nt);
+        for (auto& x : th) x.join();
     }
 
     // Simulation::sim_next_generation, just before the mating of population ipop (:1907): under random mating (one child per

@@ -133,7 +133,7 @@ def main():
     args = ap.parse_args()
     out = {"workload": f"{args.n_ind} individuals, 1 chromosome of 100 Mb, 2001 map rows, 1000 CVs, {args.n_snps} SNPs, "
                        f"{'assortative (mat_cor 0.4)' if args.assortative else 'random'} mating, {args.gens} generations",
-           "host_cores_used": 1}
+           "host_cores_used": "reference: 1 (single threaded); bound program: 1 + up to 7 helper threads inside the glue (record allocation / release, .info formatting)"}
     with tempfile.TemporaryDirectory(prefix="gev_cli_") as wd:
         t0 = time.perf_counter()
         a = write_inputs(wd, args.n_ind, args.n_snps, args.gens, args.assortative)
