@@ -10,7 +10,10 @@
 //   GEV_SAMPLE_BATCHED=0|1    sampling kernels: one task per wave | eight tasks per wave (default)
 //   GEV_STITCH_MODE=0|1|2     dense stitch kernel: k_stitch_regions (default) | k_stitch_rows | k_stitch_parent (same results)
 //   GEV_SAMPLE_GRID=n         persistent workgroups of the sampling kernels (default 384 next to a stitch, 1024 alone)
-//   GEV_STITCH_WG_PER_CU=1..7 limit stitch workgroups per CU (default: wave-slot bound, 8)
+//   GEV_STITCH_WG_PER_CU=n|auto stitch workgroups per CU, by dynamic LDS padding (default: 6 on rows >= 64 KiB, else unlimited; auto: measured at run time)
+//   GEV_STITCH_LDS_PAD=bytes  (experiments) that padding directly
+//   GEV_ALIAS_ROWS=0|1        copy every gamete row | crossover-free gametes share the parental row (default)
+//   GEV_LIST_LONG=n           average list entries per row from which the list fill kernels put eight lanes on a row (default 20)
 //   GEV_STITCH_PRIORITY=1|2   stitch stream high / all streams equal (default: small streams high, stitch low)
 //   GEV_STITCH_UNROLL=2|4|8    chunks per thread in flight in k_stitch_regions (default: 4 on rows >= 64 KiB, else 2; sweeps with fewer workgroups per CU lost)
 //   GEV_STITCH_WAVE_PRIO=0..3 s_setprio level of the stitch kernel's waves (default 0; measured: no effect next to the sampling kernels)

@@ -92,6 +92,7 @@ const char* gev_version(void);
  *   GEV_ALIAS_ROWS=0            copy every gamete row (default 1: a gamete without a crossover shares its parent's row)
  *   GEV_STITCH_WG_PER_CU=n|auto dense-stitch workgroups per CU (default: 6 on rows >= 64 KiB, else 8; auto = measured at run time)
  *   GEV_STITCH_MODE=0|1|2       stitch kernel (gev_set_stitch_mode)
+ *   GEV_STITCH_LDS_PAD=bytes    (experiments) dynamic LDS padding of the stitch workgroups, overriding the one derived from WG_PER_CU
  *   GEV_SAMPLE_BATCHED=0        one sampling task per wave (the round-1 kernels) instead of eight
  *   GEV_LIST_LONG=n             average list entries per row from which the list fill kernels put 8 lanes on a row (default 20)
  *   GEV_TABLE_RING_BYTES=n      minimum size of the pinned ring the per-generation work tables are staged through */
