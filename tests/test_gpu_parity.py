@@ -195,7 +195,6 @@ def test_crossover_free_gametes_share_the_parental_row(gpu_lib, oracle_lib, monk
     sg.ras_initial_human_gen0(0, cfg.n_ind); so.ras_initial_human_gen0(0, cfg.n_ind)
     rng = np.random.default_rng(5)
     sizes = [400, 400, 520, 520, 300, 300, 300, 300]          # growth (the pool is reallocated) and shrinkage on the way
-    shared_seen = 0
     for gen, n in enumerate(sizes, 1):
         couples = synthetic_random_mate(sg.sex[0], n, rng)
         sg.couples[0] = couples; so.couples[0] = couples
@@ -229,7 +228,6 @@ def test_crossover_free_gametes_share_the_parental_row(gpu_lib, oracle_lib, monk
             assert n_shared > 0.5 * 2 * n * cfg.nchr, "expected most gametes to be crossover-free with this map"
         else:
             assert n_shared == 0
-        shared_seen += n_shared
     assert g.dbg_verify_planes(0, 1, [cfg.seed + 1]) == (0, 0)
     g.close(); o.close()
 
@@ -461,7 +459,6 @@ def test_three_hundred_generations_of_shared_rows_dense_state_equals_interval_st
     sim = Simulation(g, 4242, 1, True)
     sim.ras_initial_human_gen0(0, n)
     rng = np.random.default_rng(17)
-    copied = total = 0
     for gen in range(1, 301):
         n = 20_000 + (gen % 7) * 500 if gen % 50 else 24_000            # a few growth steps beyond the current capacity
         sim.couples[0] = synthetic_random_mate(sim.sex[0], n, rng)
