@@ -22,14 +22,12 @@ seeds and couples over together).  The founder panel is generated on the device 
 genotype state is resident in HBM throughout.  --plane-less times BASELINE config 5's mode (interval state only,
 no per-generation genotype assembly) and is NOT the headline configuration.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_regions):
-algorithmic bytes per launch = gametes the launch copies x (L/8 read + L/8 written) (SURVEY.md 8(d)'s per-gamete figure),
-divided by its duration measured with HIP events on the library's own stream.  A gamete without a crossover is the parental
-haplotype unchanged; its slot shares the parent's row and the launch does not copy it (about e^-1 of the gametes on a 1-Morgan
-chromosome), so the units of a launch are the gametes WITH a crossover (gev_stitch_totals); `every_gamete_copied_equivalent_*`
-prices all 2N gametes (N*L/2 bytes, the definition of earlier rounds).  The kernel also reads LESS than the algorithmic bytes
-(a parent's chunk is loaded once for all of its gametes), so `achieved` can
-exceed what a plain device copy of the same bytes reaches; `traffic` holds the measured HBM bytes (newest committed rocprofv3
+Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_segments): a genotype row is kept as 16 KiB
+segments, and in a segment that contains none of its crossover boundaries an offspring gamete is one parental haplotype unchanged:
+that segment names the parent's unit and is not copied.  The units of a launch are the segments it WRITES (about one per crossover;
+gev_stitch_totals), algorithmic bytes per launch = bytes written x 2 (read once, written once; SURVEY.md 8(d)'s per-gamete figure
+restricted to the bytes that change hands), divided by the kernel's duration measured with HIP events on the library's own stream.
+`every_gamete_copied_equivalent_*` prices all 2N whole rows (N*L/2 bytes, the definition of round 1).  `traffic` holds the measured HBM bytes (newest committed rocprofv3
 PMC passes) and `hbm_actual_GBps` = traffic / kernel time, the rate the memory system really sustained.  `cpu_baseline` times the
 unmodified reference (oracle/_ref/ref_harness, kind "reference"; when it is absent the bit-exact CPU oracle, kind
 "port") on a bounded sample of the same workload on this box's host cores (1 thread: the reference is single threaded).
@@ -309,7 +307,7 @@ def main():
     del ad_ms[:], mate_ms[:], repro_ms[:], mig_ms[:], step_ms[:], seed_ms[:]
     mig_parts.clear()
     tot0, n0 = ctx.timing_totals()                       # (implies a sync of both library streams)
-    rows0 = (0, 0) if args.plane_less else ctx.stitch_totals()
+    rows0 = (0, 0, 0, 0) if args.plane_less else ctx.stitch_totals()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
@@ -317,7 +315,7 @@ def main():
     barrier()                                            # torch.cuda.synchronize() waits for the last dense stitch too
     dt = time.perf_counter() - t0
     tot1, n1 = ctx.timing_totals()
-    rows1 = (0, 0) if args.plane_less else ctx.stitch_totals()
+    rows1 = (0, 0, 0, 0) if args.plane_less else ctx.stitch_totals()
     assert n1 - n0 == args.steps
     sample_ms = [(tot1[0] - tot0[0]) / args.steps]; stitch_ms = [(tot1[1] - tot0[1]) / args.steps]; sparse_ms = [(tot1[2] - tot0[2]) / args.steps]
     if dist is not None:
@@ -344,9 +342,10 @@ def main():
         # unchanged (Simulation::recombine, src/Simulation.cpp:2910): its slot points at the parent's row and nothing is copied,
         # so it is not a unit of the launch.  Per unit: L/8 bytes read + L/8 written.
         full_bytes = args.n_ind * args.n_loci / 2.0 * args.nchr   # every gamete copied: N*L/2 per generation (the figure of earlier rounds)
-        rows_written, rows_total = rows1[0] - rows0[0], rows1[1] - rows0[1]
-        written_frac = rows_written / rows_total if rows_total else 1.0
-        alg_bytes = full_bytes * written_frac
+        bytes_written, bytes_total = rows1[0] - rows0[0], rows1[1] - rows0[1]
+        segs_written, segs_total = rows1[2] - rows0[2], rows1[3] - rows0[3]
+        written_frac = bytes_written / bytes_total if bytes_total else 1.0
+        alg_bytes = 2.0 * bytes_written / max(args.steps, 1)         # per generation: every written byte is read once and written once
         stitch = float(np.mean(stitch_ms))
         achieved = alg_bytes / (max(stitch, 1e-9) * 1e-3) / 1e9 if not args.plane_less else 0.0
         full_equiv = full_bytes / (max(stitch, 1e-9) * 1e-3) / 1e9 if not args.plane_less else 0.0
@@ -384,16 +383,17 @@ def main():
                          "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None,
                          "migration_steps": {k: v / args.steps for k, v in mig_parts.items()} if mig_parts else None},
                "host_step_ms": [round(x, 2) for x in step_ms[:args.steps]],
-            "roofline": {"bound": "hbm", "kernel": "k_stitch_regions", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_stitch_segments", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "hbm_actual_GBps": hbm_actual, "hbm_actual_frac": hbm_actual / HBM_PEAK_GBPS if hbm_actual else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": stitch,
-                         "gametes_copied_per_launch": rows_written / max(args.steps, 1), "gametes_per_launch": rows_total / max(args.steps, 1),
-                         "copied_fraction": written_frac,
+                         "segments_written_per_launch": segs_written / max(args.steps, 1), "segments_per_launch": segs_total / max(args.steps, 1),
+                         "written_fraction_of_row_bytes": written_frac,
                          "every_gamete_copied_equivalent_GBps": full_equiv, "every_gamete_copied_equivalent_frac": full_equiv / HBM_PEAK_GBPS,
-                         "note": "algorithmic bytes = gametes the launch copies x (L/8 read + L/8 written); crossover-free gametes share the parental "
-                                 "row and are not copied (every_gamete_copied_equivalent_* prices all 2N gametes, the definition of earlier rounds, "
-                                 "and can exceed the peak); kernel time measured live with HIP events on the library's stitch stream inside the timed region, where the "
+                         "note": "units of a launch = the row segments it writes (16 KiB each; those that contain a crossover boundary -- every other segment "
+                                 "of an offspring row names the parental unit and is not copied); algorithmic bytes = bytes written x 2 (each is read once "
+                                 "and written once); every_gamete_copied_equivalent_* prices all 2N whole rows (N*L/2 bytes, the definition of round 1) "
+                                 "and can exceed the peak; kernel time measured live with HIP events on the library's stitch stream inside the timed region, where the "
                                  "kernel shares the GPU with the next generation's sampling/A-D kernels; isolated_* = same kernel with the two "
                                  "streams serialised (extra untimed generations); traffic = rocprofv3 PMC measurement committed under profiles/",
                          "isolated_kernel_ms": iso, "isolated_achieved": (alg_bytes / (iso * 1e-3) / 1e9) if iso else None,

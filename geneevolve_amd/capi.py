@@ -352,16 +352,16 @@ class GevContext:
         self._call("reserve", C.c_int(pop), C.c_size_t(max_people))
 
     def plane_ptr(self, pop, chr):
-        """(pool pointer, row stride in bytes, number of haplotype slots, device pointer of the slot -> row table)"""
-        p = C.c_void_p(); s = C.c_size_t(); n = C.c_size_t(); t = C.c_void_p()
-        self._call("plane_ptr", C.c_int(pop), C.c_int(chr), C.byref(p), C.byref(s), C.byref(n), C.byref(t))
-        return p.value, s.value, n.value, t.value
+        """(pool pointer, unit bytes, number of haplotype slots, device pointer of the (slot, segment) -> unit table, segments per row)"""
+        p = C.c_void_p(); s = C.c_size_t(); n = C.c_size_t(); t = C.c_void_p(); g = C.c_uint32()
+        self._call("plane_ptr", C.c_int(pop), C.c_int(chr), C.byref(p), C.byref(s), C.byref(n), C.byref(t), C.byref(g))
+        return p.value, s.value, n.value, t.value, g.value
 
     def stitch_totals(self):
-        """(haplotype rows written by the dense stitch, rows of the generations produced) over all reproduce calls"""
-        w = C.c_ulonglong(); t = C.c_ulonglong()
-        self._call("stitch_totals", C.byref(w), C.byref(t))
-        return w.value, t.value
+        """(bytes written by the dense stitch, bytes of the rows of the generations produced, segments written, segments) over all reproduce calls"""
+        w = C.c_ulonglong(); t = C.c_ulonglong(); sw = C.c_ulonglong(); st = C.c_ulonglong()
+        self._call("stitch_totals", C.byref(w), C.byref(t), C.byref(sw), C.byref(st))
+        return w.value, t.value, sw.value, st.value
 
     def stream(self):
         p = C.c_void_p()

@@ -62,22 +62,37 @@ struct SampleDev {
 // Per-generation work tables: one entry per ACTIVE chromosome (ChrWork) / per (phenotype, active chromosome) (CvWork, AdWork).
 // Every per-chromosome kernel of a generation is ONE launch whose blockIdx.y (or .z) selects the entry, instead of one launch
 // per chromosome (a 22-chromosome genome used to cost ~300 launches per generation).
-// Genotype rows live in ONE pool per (population, chromosome): haplotype slot s (= 2*individual + chromatid) of a generation is
-// pool row phys[s].  An offspring gamete without a crossover IS its parent's haplotype (Simulation::recombine returns the
-// parental Hap unchanged when locs.size() < 3, src/Simulation.cpp:2910): its slot then points at the parent's pool row and no
-// byte is copied.  Every other gamete gets a row that no slot of the parents' generation points at (free list, rebuilt from the
-// parents' phys[] at the start of each generation: mark, collect).  Physical placement is arbitrary (atomics) and invisible:
-// every consumer goes through phys[].
+// Genotype rows live in ONE pool of SEGMENTS per (population, chromosome).  A haplotype row (slot s = 2*individual + chromatid)
+// is cut into nseg segments of 2^seg_shift 16-byte chunks (16 KiB by default); segment g of slot s is pool unit
+// phys[s * nseg + g].  In a segment that contains none of its crossover boundaries an offspring gamete IS one parental haplotype
+// (Simulation::recombine copies the parent's parts unchanged between two crossovers, src/Simulation.cpp:2939-2946; without any
+// crossover it returns the parental Hap itself, :2910): that segment of the offspring slot then names the parent's unit and no
+// byte is copied.  Only the segments that contain a boundary get a unit of their own -- one that no segment of the parents'
+// generation names (free list, rebuilt from the parents' table at the start of every generation: mark, collect) -- and are
+// written by the dense stitch.  Units are written once and never modified (mutations are a sparse overlay of the slot).
+// Physical placement is arbitrary (atomics) and invisible: every consumer goes through the table (RowMap).
 struct PoolWork {
-    uint8_t* pool; const u32* phys_cur; u32* phys_alt;      // rows, slot -> row of the parents / of the offspring
-    u32* live; u32* freel; u32* pctr;                       // [pool_rows] marks, [pool_rows] free rows, {n_free, n_taken, exhausted}
-    u32 pool_rows, alias, stamp;
+    uint8_t* pool; const u32* phys_cur; u32* phys_alt;      // units; (slot, segment) -> unit of the parents / of the offspring
+    u32* live; u32* freel; u32* pctr;                       // [pool_units] marks, [pool_units] free units, {n_free, n_taken, exhausted, last segments taken}
+    u32* items;                                             // [n_taken] (slot * nseg + segment) of every unit handed out = the stitch's work list; items[items_cap] = n_taken
+    u32 pool_units, alias, stamp, nseg, seg_shift, items_cap;
+};
+// read access to the rows of one generation
+struct RowMap {
+    const uint8_t* pool; const u32* phys; u32 nseg, seg_shift;
+    __device__ __forceinline__ const uint4* chunk(size_t slot, u32 q) const
+    {
+        const u32 unit = phys[slot * nseg + (q >> seg_shift)];
+        return (const uint4*)(pool + ((size_t)unit << (seg_shift + 4))) + (q & ((1u << seg_shift) - 1u));
+    }
+    __device__ __forceinline__ u32 word32(size_t slot, u32 w) const { return ((const u32*)chunk(slot, w >> 2))[w & 3u]; }
+    __device__ __forceinline__ u64 word64(size_t slot, u32 w) const { return ((const u64*)chunk(slot, w >> 1))[w & 1u]; }
 };
 struct ChrWork {
     const u32* moff_cur; const u64* mpos_cur; u32* moff_alt; u64* mpos_alt;                 // mutation lists (CSR), parents / offspring
     const u32* poff_cur; const gev_part* parts_cur; u32* poff_alt; gev_part* parts_alt;     // ancestry intervals
     PoolWork pw; const u64* snp_pos;                                                        // genotype rows
-    size_t stride;
+    size_t stride;                                                                          // bytes of a whole row (host-side layouts)
     u64 bp0, bp_end;
     u32 mcap, pcap, chunks, bpr, L;
     int chr;
@@ -101,8 +116,8 @@ struct AdWork {
 #define GEV_NM_CAP 8
 // status words written by the kernels of one generation, read back once at its end
 enum { ST_BK_OVF_USED = 0, ST_NM_OVF_USED = 1, ST_FLAGS = 2, ST_SLOW_MUT = 3, ST_SLOW_REC = 4 /* tasks handed to the one-task-per-wave kernels */,
-       ST_TOTALS = 8 /* then per chr: mut_total, parts_total, rows_written (gametes the dense stitch copies) */ };
-#define ST_PER_CHR 3
+       ST_TOTALS = 8 /* then per chr: mut_total, parts_total, segments the dense stitch writes, how many of them are last (partial) segments */ };
+#define ST_PER_CHR 4
 enum { FLAG_BK_OVF = 1, FLAG_NM_OVF = 2, FLAG_MUT_CAP = 4, FLAG_PARTS_CAP = 8, FLAG_POOL = 16 };
 
 // The RNG tables (16 KB) are read 31 words at a time for every srand(); under a concurrently
@@ -195,7 +210,11 @@ __global__ void __launch_bounds__(256) k_scan_final_tab(const u32* __restrict__ 
         if (base + j <= n) out[base + j] = ex;
         if (base + j == n) {
             status[ST_TOTALS + ST_PER_CHR * w.chr + (is_parts ? 1 : 0)] = ex;
-            if (!is_parts && w.pw.pctr) status[ST_TOTALS + ST_PER_CHR * w.chr + 2] = w.pw.pctr[1];    // gametes the dense stitch copies (k_pool_assign ran before)
+            if (!is_parts && w.pw.pctr) {                                                           // k_pool_assign ran before
+                status[ST_TOTALS + ST_PER_CHR * w.chr + 2] = w.pw.pctr[1];                          // segments the dense stitch writes
+                status[ST_TOTALS + ST_PER_CHR * w.chr + 3] = w.pw.pctr[3];                          // ... of which last (partial) segments
+                w.pw.items[w.pw.items_cap] = min(w.pw.pctr[1], w.pw.items_cap);                     // length of the stitch's work list
+            }
         }
         ex += v[j];
     }
@@ -450,13 +469,16 @@ __global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict
 #include "gev_sample8.h"
 
 // ------------------------------------------------------------------------------------------
-// K5: dense stitch -- the HBM-roofline kernel.
+// K5: dense stitch -- the HBM-bound kernel.
 // Dense equivalent of Simulation::recombine (:2903-2958) applied to the materialised haplotypes
 // (ras_convert_interval_to_hap_matrix, :1186-1230): at locus position x the offspring gamete
 // copies parental haplotype  start ^ parity(#{breakpoints c : c <= x}).  In locus-index space a
 // gamete row is a concatenation of bit ranges of the parent's two rows AT THE SAME OFFSETS, so
-// all but <= k 16-byte chunks per row are plain 16-byte copies from ONE parent row: algorithmic
-// traffic = L/8 read + L/8 written per gamete.
+// between two boundaries it IS one parental row.  Rows are stored as segments (PoolWork): a segment
+// without a boundary is not copied at all -- the offspring's table entry names the parent's unit
+// (k_pool_assign) -- and the stitch writes only the segments that contain a boundary: about one
+// 16 KiB segment per crossover instead of the whole row.  Per unit of work (one written segment):
+// segment bytes read + segment bytes written.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 lower_bound_u64(const u64* __restrict__ a, u32 n, u64 v)   // #{a[i] < v}
 {
@@ -464,126 +486,48 @@ __device__ __forceinline__ u32 lower_bound_u64(const u64* __restrict__ a, u32 n,
     while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
     return lo;
 }
-#define STITCH_THREADS 256
-#define STITCH_KMAX 256          // boundaries staged in LDS per row; more spill to a global-memory walk
-#define STITCH_UNROLL 4
-// one workgroup = one output row x one span of chunks; 16 B per lane per access
-__global__ void __launch_bounds__(STITCH_THREADS) k_stitch_rows(const ChrWork* __restrict__ Wt, u32 bpr_max, int nchr, SampleDev sd)
+__device__ __forceinline__ u32 count_le_u32(const u32* __restrict__ a, u32 n, u32 v)      // #{a[i] <= v}, a ascending
 {
-    __shared__ u32 s_idx[STITCH_KMAX];
-    const ChrWork& w = Wt[blockIdx.y];
-    uint8_t* __restrict__ pool = w.pw.pool;
-    const size_t stride = w.stride; const u32 chunks_per_row = w.chunks, blocks_per_row = w.bpr, L = w.L;
-    const u64* __restrict__ pos = w.snp_pos; const int chr = w.chr;
-    const u32 row = blockIdx.x / bpr_max;                 // output row = 2*offspring + s
-    const u32 span = blockIdx.x % bpr_max;
-    if (span >= blocks_per_row) return;
-    const u32 i = row >> 1, s = row & 1;
-    const size_t G = 2 * ((size_t)i * nchr + chr) + s;
-    const u32 parent = s ? sd.mother[i] : sd.father[i];
-    const u32 start = sd.start[G];
-    const u32 k = sd.k[G];
-    const u64* bk = sd.bk + sd.bk_off[G];
-    if (k == 0 && w.pw.alias) return;                        // the slot shares its parent's row (k_pool_assign)
-    const uint4* __restrict__ A = (const uint4*)(pool + (size_t)w.pw.phys_cur[2 * (size_t)parent + start] * stride);
-    const uint4* __restrict__ B = (const uint4*)(pool + (size_t)w.pw.phys_cur[2 * (size_t)parent + (start ^ 1)] * stride);
-    uint4* __restrict__ D = (uint4*)(pool + (size_t)w.pw.phys_alt[row] * stride);
-    const u32 kk = k < STITCH_KMAX ? k : STITCH_KMAX;
-    for (u32 m = threadIdx.x; m < kk; m += STITCH_THREADS) s_idx[m] = lower_bound_u64(pos, L, bk[m]);   // loci >= idx are past breakpoint m
-    __syncthreads();
-    const u32 per_block = (chunks_per_row + blocks_per_row - 1) / blocks_per_row;
-    const u32 q0 = span * per_block;
-    const u32 q1 = min(q0 + per_block, chunks_per_row);
-    if (k == 0) {                                           // locs.size()<3: the parent's haplotype unchanged (:2910)
-        for (u32 q = q0 + threadIdx.x; q < q1; q += STITCH_THREADS * STITCH_UNROLL) {
-            uint4 v[STITCH_UNROLL];
-#pragma unroll
-            for (int u = 0; u < STITCH_UNROLL; u++) { const u32 qq = q + u * STITCH_THREADS; if (qq < q1) v[u] = A[qq]; }
-#pragma unroll
-            for (int u = 0; u < STITCH_UNROLL; u++) { const u32 qq = q + u * STITCH_THREADS; if (qq < q1) D[qq] = v[u]; }
-        }
-        return;
-    }
-    for (u32 q = q0 + threadIdx.x; q < q1; q += STITCH_THREADS) {
-        const u32 bit0 = q * 128u, bit1 = bit0 + 128u;
-        // boundaries <= bit0 decide the source at the chunk's first locus
-        u32 cnt = 0;
-        if (k <= STITCH_KMAX) {
-            if (k <= 8) { for (u32 m = 0; m < k; m++) cnt += (s_idx[m] <= bit0); }
-            else { u32 lo = 0, hi = k; while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (s_idx[mid] <= bit0) lo = mid + 1; else hi = mid; } cnt = lo; }
-        } else {
-            for (u32 m = 0; m < k; m++) cnt += (lower_bound_u64(pos, L, bk[m]) <= bit0);
-        }
-        u32 nxt = 0xffffffffu;                               // first boundary inside (bit0, bit1)
-        if (cnt < k) nxt = (k <= STITCH_KMAX) ? s_idx[cnt] : lower_bound_u64(pos, L, bk[cnt]);
-        if (nxt >= bit1) {
-            D[q] = (cnt & 1) ? B[q] : A[q];
-        } else {
-            const uint4 a = A[q], b = B[q];
-            u32 aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, ow[4];
-            u32 mask[4];                                     // 1 = take B
-            const u32 init = (cnt & 1) ? 0xffffffffu : 0u;
-#pragma unroll
-            for (int w = 0; w < 4; w++) mask[w] = init;
-            for (u32 m = cnt; m < k; m++) {
-                const u32 id = (k <= STITCH_KMAX) ? s_idx[m] : lower_bound_u64(pos, L, bk[m]);
-                if (id >= bit1) break;
-                const u32 rel = id - bit0;                   // toggle every bit >= rel
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    const u32 wb = w * 32u;
-                    u32 t = 0;
-                    if (rel <= wb) t = 0xffffffffu; else if (rel < wb + 32u) t = 0xffffffffu << (rel - wb);
-                    mask[w] ^= t;
-                }
-            }
-#pragma unroll
-            for (int w = 0; w < 4; w++) ow[w] = (aw[w] & ~mask[w]) | (bw[w] & mask[w]);
-            D[q] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-        }
-    }
+    if (n <= 8) { u32 c = 0; for (u32 m = 0; m < n; m++) c += (a[m] <= v); return c; }
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+    return lo;
 }
-// ------------------------------------------------------------------------------------------
-// K5, parent-major form (the production path).  Every gamete of one parent reads the same two
-// rows and needs, in expectation, half of each.  One workgroup per PARENT: per 16-byte chunk it
-// loads row0 and/or row1 only if some gamete of the group needs it, then writes every gamete's
-// chunk.  With g gametes per parent the fraction of the parent's 2*L/8 bytes that is read is
-// 1-2^-g in expectation, so HBM reads fall below the per-gamete algorithmic L/8 (random mating,
-// g ~ Poisson(2): 0.63 of it) while the algorithmic work per generation is unchanged.
-// Grouping (gametes by source individual) is a counting sort: k_group_hist -> scan -> k_group_fill.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_group_hist(const u32* __restrict__ father, const u32* __restrict__ mother, size_t n_rows_out, u32* __restrict__ hist)
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4u mask_from(u32 rel)           // ones at bit positions >= rel of a 128-bit chunk
 {
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows_out) return;
-    atomicAdd(&hist[(r & 1) ? mother[r >> 1] : father[r >> 1]], 1u);
+    v4u t;
+    t.x = rel < 32 ? 0xffffffffu << rel : 0u;
+    t.y = rel <= 32 ? 0xffffffffu : (rel < 64 ? 0xffffffffu << (rel - 32) : 0u);
+    t.z = rel <= 64 ? 0xffffffffu : (rel < 96 ? 0xffffffffu << (rel - 64) : 0u);
+    t.w = rel <= 96 ? 0xffffffffu : (rel < 128 ? 0xffffffffu << (rel - 96) : 0u);
+    return t;
 }
-__global__ void __launch_bounds__(256) k_group_fill(const u32* __restrict__ father, const u32* __restrict__ mother, size_t n_rows_out,
-                                                    const u32* __restrict__ goff, u32* __restrict__ cursor, u32* __restrict__ glist)
+// one 16-byte chunk of a gamete: `cnt` boundaries lie at or before its first locus bit0, `in[c], in[c+1], ...` are the following ones
+__device__ __forceinline__ v4u blend_chunk(v4u a, v4u b, u32 sel, const u32* in, u32 c, u32 n, u32 bit0)
 {
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows_out) return;
-    const u32 p = (r & 1) ? mother[r >> 1] : father[r >> 1];
-    glist[goff[p] + atomicAdd(&cursor[p], 1u)] = (u32)r;      // order inside a group is irrelevant: every gamete owns its output row
+    v4u mask = sel ? (v4u)(0xffffffffu) : (v4u)(0u);       // 1 = take row 1
+    for (u32 m = c; m < n; m++) { const u32 id = in[m]; if (id >= bit0 + 128u) break; mask ^= mask_from(id - bit0); }
+    return (a & ~mask) | (b & mask);
 }
-// ---- row pool (PoolWork): free rows of a generation = rows no parental slot points at ----------------------------------
-// live[row] == stamp <=> a slot of the parents' generation names the row; the stamp changes with every rebuild, so the marks of
+// ---- unit pool (PoolWork): free units of a generation = units no (slot, segment) of the parents names -----------------
+// live[unit] == stamp <=> an entry of the parents' table names the unit; the stamp changes with every rebuild, so the marks of
 // earlier generations need no clearing (the buffer is zeroed when it is allocated, stamps start at 1)
-__device__ __forceinline__ void pool_mark(const PoolWork& pw, size_t n_slots)
+__device__ __forceinline__ void pool_mark(const PoolWork& pw, size_t n_entries)
 {
-    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += (size_t)gridDim.x * blockDim.x) pw.live[pw.phys_cur[s]] = pw.stamp;
-    if (blockIdx.x == 0 && threadIdx.x < 3) pw.pctr[threadIdx.x] = 0;        // n_free, n_taken, exhausted flag
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += (size_t)gridDim.x * blockDim.x) pw.live[pw.phys_cur[e]] = pw.stamp;
+    if (blockIdx.x == 0 && threadIdx.x < 4) pw.pctr[threadIdx.x] = 0;        // n_free, n_taken, exhausted flag, last segments taken
 }
-// one atomic per 2048 rows: the block counts its free rows (8 per thread, coalesced), scans the counts, reserves a range
+// one atomic per 2048 units: the block counts its free units (8 per thread, coalesced), scans the counts, reserves a range
 __device__ __forceinline__ void pool_collect(const PoolWork& pw)
 {
     __shared__ u32 s_scan[8], s_base;
-    const u32 n_chunks = (pw.pool_rows + 2047u) / 2048u;
+    const u32 n_chunks = (pw.pool_units + 2047u) / 2048u;
     for (u32 chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const size_t i0 = (size_t)chunk * 2048 + threadIdx.x;
         u32 mask = 0, c = 0;
 #pragma unroll
-        for (u32 j = 0; j < 8; j++) { const size_t i = i0 + j * 256; const u32 fr = (i < pw.pool_rows && pw.live[i] != pw.stamp) ? 1u : 0u; mask |= fr << j; c += fr; }
+        for (u32 j = 0; j < 8; j++) { const size_t i = i0 + j * 256; const u32 fr = (i < pw.pool_units && pw.live[i] != pw.stamp) ? 1u : 0u; mask |= fr << j; c += fr; }
         u32 tot;
         const u32 ex = block_exclusive_scan_256(c, s_scan, tot);
         if (threadIdx.x == 0) s_base = tot ? atomicAdd(&pw.pctr[0], tot) : 0u;
@@ -594,44 +538,49 @@ __device__ __forceinline__ void pool_collect(const PoolWork& pw)
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(256) k_pool_mark_tab(const ChrWork* __restrict__ Wt, size_t n_slots) { pool_mark(Wt[blockIdx.y].pw, n_slots); }
+__global__ void __launch_bounds__(256) k_pool_mark_tab(const ChrWork* __restrict__ Wt, size_t n_slots) { const PoolWork& pw = Wt[blockIdx.y].pw; pool_mark(pw, n_slots * pw.nseg); }
 __global__ void __launch_bounds__(256) k_pool_collect_tab(const ChrWork* __restrict__ Wt) { pool_collect(Wt[blockIdx.y].pw); }
-__global__ void __launch_bounds__(256) k_pool_mark(PoolWork pw, size_t n_slots) { pool_mark(pw, n_slots); }
+__global__ void __launch_bounds__(256) k_pool_mark(PoolWork pw, size_t n_slots) { pool_mark(pw, n_slots * pw.nseg); }
 __global__ void __launch_bounds__(256) k_pool_collect(PoolWork pw) { pool_collect(pw); }
-// n fresh rows for slots [slot0, slot0 + n) of phys_alt (migration, order restoring); flag[0] set when the pool is exhausted
+// fresh units for every segment of slots [slot0, slot0 + n) of pw.phys_alt (migration, order restoring); flag[0] set when the pool is exhausted
 __global__ void __launch_bounds__(256) k_pool_take(PoolWork pw, size_t slot0, size_t n, u32* __restrict__ flag)
 {
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * pw.nseg) return;
     const u32 n_free = pw.pctr[0];
-    const u32 at = pw.pctr[1] + (u32)r;
-    if (at >= n_free) { flag[0] = 1; pw.phys_alt[slot0 + r] = n_free ? pw.freel[at % n_free] : 0u; return; }
-    pw.phys_alt[slot0 + r] = pw.freel[at];
+    const u32 at = pw.pctr[1] + (u32)e;
+    u32* dst = pw.phys_alt + slot0 * pw.nseg + e;
+    if (at >= n_free) { flag[0] = 1; *dst = n_free ? pw.freel[at % n_free] : 0u; return; }
+    *dst = pw.freel[at];
 }
-__global__ void k_pool_taken(PoolWork pw, u32 n) { if (threadIdx.x == 0 && blockIdx.x == 0) pw.pctr[1] += n; }
+__global__ void k_pool_taken(PoolWork pw, u32 n_units) { if (threadIdx.x == 0 && blockIdx.x == 0) pw.pctr[1] += n_units; }
 __global__ void __launch_bounds__(256) k_iota_u32(u32* __restrict__ a, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = (u32)i;
 }
-// pool rows of the offspring generation: a gamete without crossover shares its parent's row, every other one takes a free row
-// (4 rows per thread, one atomic per block of 1024 rows)
+// Units of the offspring generation.  Per output row (thread): which segments contain one of the gamete's boundaries (bk_idx =
+// first locus index at or behind the breakpoint; its 16-byte chunk decides the segment)?  Those get a free unit and an entry
+// in the stitch's work list; every other segment names the unit of the parental haplotype that is being copied there:
+// start ^ parity(#boundaries at or before the segment's first locus).  One atomic per block of 256 rows.
+#define POOL_SEG_MAX 64          // segments per row handled with a 64-bit flag word (16 KiB segments: rows up to 1 MiB = 8M loci); longer rows use larger segments
 __global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd)
 {
-    __shared__ u32 s_scan[8], s_base;
+    __shared__ u32 s_scan[8], s_base, s_last;
     const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
-    const size_t r0 = (size_t)blockIdx.x * 1024 + threadIdx.x;
-    u32 mask = 0, c = 0;
-#pragma unroll
-    for (u32 j = 0; j < 4; j++) {
-        const size_t row = r0 + j * 256;
-        if (row >= n_rows_out) continue;
+    const u32 S = pw.nseg, sh = pw.seg_shift;
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x == 0) s_last = 0;
+    u64 flags = 0; u32 c = 0, parent = 0, start = 0, k = 0;
+    const u32* idx = nullptr;
+    if (row < n_rows_out) {
         const size_t i = row >> 1; const u32 s = (u32)(row & 1);
         const size_t G = 2 * (i * nchr + w.chr) + s;
-        if (pw.alias && sd.k[G] == 0) {
-            const u32 parent = s ? sd.mother[i] : sd.father[i];
-            pw.phys_alt[row] = pw.phys_cur[2 * (size_t)parent + sd.start[G]];
-        } else { mask |= 1u << j; c++; }
+        parent = s ? sd.mother[i] : sd.father[i];
+        start = sd.start[G]; k = sd.k[G]; idx = sd.bk_idx + sd.bk_off[G];
+        if (!pw.alias) flags = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+        else for (u32 m = 0; m < k; m++) { const u32 g = (idx[m] >> 7) >> sh; if (g < S) flags |= 1ull << g; }
+        c = (u32)__popcll(flags);
     }
     u32 tot;
     const u32 ex = block_exclusive_scan_256(c, s_scan, tot);
@@ -639,14 +588,23 @@ __global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__
     __syncthreads();
     u32 at = s_base + ex;
     const u32 n_free = pw.pctr[0];
-#pragma unroll
-    for (u32 j = 0; j < 4; j++) {
-        if (!((mask >> j) & 1u)) continue;
-        const size_t row = r0 + j * 256;
-        if (at < n_free) pw.phys_alt[row] = pw.freel[at];
-        else { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_POOL); pw.phys_alt[row] = n_free ? pw.freel[at % n_free] : 0u; }   // reported by the host; keep the stitch in bounds
-        at++;
+    u32* out = pw.phys_alt + row * S;
+    u32 m = 0, cnt = 0;                                       // boundaries with idx <= first locus of the segment: ascending list, one sweep
+    for (u32 g = 0; g < S && row < n_rows_out; g++) {
+        const u32 bit0 = (g << sh) << 7;
+        while (m < k && idx[m] <= bit0) { m++; cnt++; }
+        if ((flags >> g) & 1ull) {
+            if (at < n_free) { out[g] = pw.freel[at]; if (at < pw.items_cap) pw.items[at] = (u32)(row * S + g); }
+            else { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_POOL); out[g] = n_free ? pw.freel[at % n_free] : 0u; }   // reported by the host; keeps the stitch in bounds
+            if (g == S - 1) atomicAdd(&s_last, 1u);
+            at++;
+        } else {
+            const u32 sel = (start ^ cnt) & 1u;
+            out[g] = pw.phys_cur[(2 * (size_t)parent + sel) * S + g];
+        }
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_last) atomicAdd(&pw.pctr[3], s_last);
 }
 // breakpoint (base pairs) -> first locus index >= it, for every gamete of every chromosome: one fully parallel pass,
 // so that no stitch workgroup has to walk a 20-step dependent binary search before it can start streaming
@@ -658,284 +616,116 @@ __global__ void __launch_bounds__(256) k_bk_to_idx(const ChrDev* __restrict__ ch
     const u32 k = sd.k[G], off = sd.bk_off[G];
     for (u32 m = 0; m < k; m++) sd.bk_idx[off + m] = lower_bound_u64(C.snp_pos, C.L, sd.bk[off + m]);
 }
-#define PM_GMAX 16           // gametes of one parent handled per pass
-#define PM_KTOT 256          // their boundaries staged in LDS
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4u mask_from(u32 rel)           // ones at bit positions >= rel of a 128-bit chunk
+// K5, production form: one workgroup per entry of the work list k_pool_assign wrote (one written segment of one gamete),
+// persistent grid.  The boundaries inside the segment (usually one) are staged in LDS; a chunk before / behind / between them is
+// a plain 16-byte copy from ONE parental unit, the chunk that contains one is blended by mask.  Four chunks per thread in flight.
+#define SEG_KMAX 128         // boundaries of one gamete inside one segment held in LDS; more are read from global memory
+template <bool NT>
+__global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restrict__ Wt, int nchr, SampleDev sd)
 {
-    v4u t;
-    t.x = rel < 32 ? 0xffffffffu << rel : 0u;
-    t.y = rel <= 32 ? 0xffffffffu : (rel < 64 ? 0xffffffffu << (rel - 32) : 0u);
-    t.z = rel <= 64 ? 0xffffffffu : (rel < 96 ? 0xffffffffu << (rel - 64) : 0u);
-    t.w = rel <= 96 ? 0xffffffffu : (rel < 128 ? 0xffffffffu << (rel - 96) : 0u);
-    return t;
-}
-// boundary m of a staged gamete as a locus index: from LDS, or (one oversize gamete) from global memory
-struct PmIdx {
-    const u32* lds; const u32* glob; bool big;
-    __device__ __forceinline__ u32 at(u32 m) const { return big ? glob[m] : lds[m]; }
-};
-// #{boundaries <= bit0} and the first boundary after them
-__device__ __forceinline__ void pm_locate(const PmIdx& I, u32 k, u32 bit0, u32& cnt, u32& nxt)
-{
-    if (k <= 8 && !I.big) { cnt = 0; for (u32 m = 0; m < k; m++) cnt += (I.lds[m] <= bit0); }
-    else { u32 lo = 0, hi = k; while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (I.at(mid) <= bit0) lo = mid + 1; else hi = mid; } cnt = lo; }
-    nxt = cnt < k ? I.at(cnt) : 0xffffffffu;
-}
-template <int UNROLL, bool NT>
-__global__ void __launch_bounds__(256) k_stitch_parent(const ChrWork* __restrict__ Wt, u32 bpr_max, int nchr,
-                                                       const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd)
-{
-    __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big, s_used;
-    // Launched with a block of unused dynamic LDS: it caps the workgroups per CU so that wave slots stay free
-    // for the small kernels of the next generation running concurrently on the other stream.
-    // blockIdx.y = active chromosome (all chromosomes of a generation are one launch)
-    const ChrWork& w = Wt[blockIdx.y];
-    uint8_t* __restrict__ dst = w.pw.pool; const uint8_t* __restrict__ src = w.pw.pool;
-    const u32 alias = w.pw.alias;
-    const size_t stride = w.stride; const u32 chunks_per_row = w.chunks, blocks_per_parent = w.bpr;
-    const int chr = w.chr;
-    const u32 parent = blockIdx.x / bpr_max, span = blockIdx.x % bpr_max;
-    if (span >= blocks_per_parent) return;
-    const u32 g0 = goff[parent], g1 = goff[parent + 1];
-    if (g0 == g1) return;
-    const v4u* __restrict__ R0 = (const v4u*)(src + (size_t)w.pw.phys_cur[2 * (size_t)parent] * stride);
-    const v4u* __restrict__ R1 = (const v4u*)(src + (size_t)w.pw.phys_cur[2 * (size_t)parent + 1] * stride);
-    const u32 per_block = (chunks_per_row + blocks_per_parent - 1) / blocks_per_parent;
-    const u32 q0 = span * per_block, q1 = min(q0 + per_block, chunks_per_row);
-    u32 gb = g0;
-    while (gb < g1) {
-        __syncthreads();                                   // previous batch consumed
-        // descriptors of up to PM_GMAX gametes, one thread each (parallel loads), then a short serial prefix in LDS
-        const u32 cand = min(g1 - gb, (u32)PM_GMAX);
-        if (threadIdx.x < cand) {
-            const u32 row = glist[gb + threadIdx.x];
-            const size_t G = 2 * ((size_t)(row >> 1) * nchr + chr) + (row & 1);
-            s_row[threadIdx.x] = w.pw.phys_alt[row]; s_start[threadIdx.x] = sd.start[G]; s_k[threadIdx.x] = sd.k[G]; s_bkoff[threadIdx.x] = sd.bk_off[G];
-        }
+    __shared__ u32 s_in[SEG_KMAX];
+    const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
+    const u32 S = pw.nseg, sh = pw.seg_shift, SC = 1u << sh;
+    const u32 n_items = pw.items[pw.items_cap];
+    for (u32 it = blockIdx.x; it < n_items; it += gridDim.x) {
+        __syncthreads();                                    // LDS of the previous item consumed
+        const u32 e = pw.items[it];
+        const u32 row = e / S, g = e - row * S;
+        const u32 i = row >> 1, s = row & 1u;
+        const size_t G = 2 * ((size_t)i * nchr + w.chr) + s;
+        const u32 parent = s ? sd.mother[i] : sd.father[i];
+        const u32 start = sd.start[G], k = sd.k[G];
+        const u32* __restrict__ idx = sd.bk_idx + sd.bk_off[G];
+        const u32 q0 = g << sh, nq = min(SC, w.chunks - q0);
+        const u32 bit_lo = q0 << 7, bit_hi = (q0 + nq) << 7;
+        const u32 m0 = count_le_u32(idx, k, bit_lo);        // boundaries at or before the segment's first locus
+        const u32 m1 = bit_hi ? count_le_u32(idx, k, bit_hi - 1u) : 0u;
+        const u32 nin = m1 - m0;                            // boundaries inside
+        const bool in_lds = nin <= SEG_KMAX;
+        if (in_lds) for (u32 m = threadIdx.x; m < nin; m += 256) s_in[m] = idx[m0 + m];
         __syncthreads();
-        if (threadIdx.x == 0) {                            // serial prefix; gametes that share their parent's row are dropped (compaction in place)
-            u32 n = 0, kt = 0, big = 0, used = 0;
-            while (used < cand) {
-                const u32 k = s_k[used];
-                if (k == 0 && alias) { used++; continue; }
-                if (kt + k > PM_KTOT) { if (n == 0) big = 1; else break; }
-                s_row[n] = s_row[used]; s_start[n] = s_start[used]; s_bkoff[n] = s_bkoff[used]; s_k[n] = k;
-                s_kb[n] = kt; kt += k; n++; used++;
-                if (big) break;
-            }
-            s_n = n; s_big = big; s_used = used;
-        }
-        __syncthreads();
-        const u32 n = s_n; const bool big = s_big != 0;
-        if (n == 0) { gb += s_used; continue; }
-        if (!big)
-            for (u32 j = 0; j < n; j++)
-                for (u32 m = threadIdx.x; m < s_k[j]; m += 256) s_idx[s_kb[j] + m] = sd.bk_idx[s_bkoff[j] + m];
-        __syncthreads();
-        for (u32 q = q0 + threadIdx.x; q < q1; q += 256 * UNROLL) {
-            bool need0[UNROLL], need1[UNROLL];
-            v4u a[UNROLL], b[UNROLL];
+        const u32* in = in_lds ? s_in : idx + m0;
+        const v4u* __restrict__ R0 = (const v4u*)(pw.pool + ((size_t)pw.phys_cur[(2 * (size_t)parent) * S + g] << (sh + 4)));
+        const v4u* __restrict__ R1 = (const v4u*)(pw.pool + ((size_t)pw.phys_cur[(2 * (size_t)parent + 1) * S + g] << (sh + 4)));
+        v4u* __restrict__ D = (v4u*)(pw.pool + ((size_t)pw.phys_alt[(size_t)row * S + g] << (sh + 4)));
+        const u32 sel0 = (start ^ m0) & 1u;
+        for (u32 q = threadIdx.x; q < nq; q += 256 * 4) {
+            v4u a[4], b[4]; u32 c[4]; bool mixed[4];
 #pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                need0[u] = false; need1[u] = false;
+            for (int u = 0; u < 4; u++) {
                 const u32 qq = q + u * 256;
-                if (qq >= q1) continue;
-                const u32 bit0 = qq * 128u, bit1 = bit0 + 128u;
-                for (u32 j = 0; j < n; j++) {
-                    const PmIdx I{s_idx + s_kb[j], sd.bk_idx + s_bkoff[j], big};
-                    u32 cnt, nxt; pm_locate(I, s_k[j], bit0, cnt, nxt);
-                    const u32 sel = s_start[j] ^ (cnt & 1u);
-                    const bool mixed = nxt < bit1;
-                    need0[u] |= mixed || sel == 0u; need1[u] |= mixed || sel == 1u;
-                }
+                c[u] = 0; mixed[u] = false;
+                if (qq >= nq) continue;
+                const u32 bit0 = bit_lo + (qq << 7);
+                c[u] = count_le_u32(in, nin, bit0);
+                mixed[u] = c[u] < nin && in[c[u]] < bit0 + 128u;
+                const u32 sel = (sel0 ^ c[u]) & 1u;
+                if (mixed[u] || sel == 0u) a[u] = NT ? __builtin_nontemporal_load(&R0[qq]) : R0[qq];
+                if (mixed[u] || sel == 1u) b[u] = NT ? __builtin_nontemporal_load(&R1[qq]) : R1[qq];
             }
 #pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
+            for (int u = 0; u < 4; u++) {
                 const u32 qq = q + u * 256;
-                if (need0[u]) a[u] = NT ? __builtin_nontemporal_load(&R0[qq]) : R0[qq];
-                if (need1[u]) b[u] = NT ? __builtin_nontemporal_load(&R1[qq]) : R1[qq];
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const u32 qq = q + u * 256;
-                if (qq >= q1) continue;
-                const u32 bit0 = qq * 128u, bit1 = bit0 + 128u;
-                for (u32 j = 0; j < n; j++) {
-                    const PmIdx I{s_idx + s_kb[j], sd.bk_idx + s_bkoff[j], big};
-                    const u32 k = s_k[j];
-                    u32 cnt, nxt; pm_locate(I, k, bit0, cnt, nxt);
-                    const u32 sel = s_start[j] ^ (cnt & 1u);
-                    v4u o;
-                    if (nxt >= bit1) o = sel ? b[u] : a[u];
-                    else {
-                        v4u mask = sel ? (v4u)(0xffffffffu) : (v4u)(0u);       // 1 = take row1
-                        for (u32 m = cnt; m < k; m++) { const u32 id = I.at(m); if (id >= bit1) break; mask ^= mask_from(id - bit0); }
-                        o = (a[u] & ~mask) | (b[u] & mask);
-                    }
-                    v4u* D = (v4u*)(dst + (size_t)s_row[j] * stride);
-                    if (NT) __builtin_nontemporal_store(o, &D[qq]); else D[qq] = o;
-                }
+                if (qq >= nq) continue;
+                const u32 sel = (sel0 ^ c[u]) & 1u;
+                const v4u o = mixed[u] ? blend_chunk(a[u], b[u], sel, in, c[u], nin, bit_lo + (qq << 7)) : (sel ? b[u] : a[u]);
+                if (NT) __builtin_nontemporal_store(o, &D[qq]); else D[qq] = o;
             }
         }
-        gb += s_used;
     }
 }
-
-// K5, parent-major, REGION form (the production kernel).  Same workgroup = parent mapping and the same read sharing as
-// k_stitch_parent, but the per-chunk bookkeeping is hoisted out of the streaming loop: the boundaries of all staged gametes are
-// merged into the ascending list of distinct boundary CHUNKS of the span; between two consecutive boundary chunks every gamete
-// copies from ONE fixed parental row, so a region is described by one bit mask (bit j = gamete j takes row 1).  A pure chunk
-// then costs a monotone pointer advance, one LDS read and the copies; only the (few) boundary chunks run the masked blend.
-template <int UNROLL, bool NT, int THREADS = 256>
-__global__ void __launch_bounds__(THREADS) k_stitch_regions(const ChrWork* __restrict__ Wt, u32 bpr_max, int nchr,
-                                                        const u32* __restrict__ goff, const u32* __restrict__ glist, SampleDev sd, int wave_prio)
+// K5, gamete-major form (cross-check, gev_set_stitch_mode(1)): one workgroup per OUTPUT ROW walks all its chunks and decides
+// for itself which segments are its own (those that contain a boundary chunk; all of them when rows are never shared) and,
+// per chunk, the source by bisection over the gamete's whole boundary list -- no work list, no per-segment staging.
+#define STITCH_THREADS 256
+#define STITCH_KMAX 256          // boundaries staged in LDS per row; more are read from global memory
+__global__ void __launch_bounds__(STITCH_THREADS) k_stitch_rows(const ChrWork* __restrict__ Wt, int nchr, SampleDev sd)
 {
-    // instruction-issue priority of this kernel's waves inside a SIMD (s_setprio): the stitch shares the CUs with the ALU-bound
-    // sampling kernels of the next generation; its waves mostly wait for memory and should issue first when their data arrives
-    if (wave_prio == 3) __builtin_amdgcn_s_setprio(3); else if (wave_prio == 2) __builtin_amdgcn_s_setprio(2); else if (wave_prio == 1) __builtin_amdgcn_s_setprio(1);
-    __shared__ u32 s_row[PM_GMAX], s_start[PM_GMAX], s_k[PM_GMAX], s_kb[PM_GMAX], s_bkoff[PM_GMAX], s_idx[PM_KTOT], s_n, s_big, s_nd, s_used;
-    __shared__ u32 s_bc[PM_KTOT + 1];        // distinct boundary chunks inside [q0, q1), ascending, then the sentinel 0xffffffff
-    __shared__ u32 s_sel[PM_KTOT + 1];       // region r = pure chunks in front of boundary chunk r (r = nd: behind the last one)
-    const ChrWork& w = Wt[blockIdx.y];
-    uint8_t* __restrict__ dst = w.pw.pool; const uint8_t* __restrict__ src = w.pw.pool;
-    const u32 alias = w.pw.alias;
-    const size_t stride = w.stride; const u32 chunks_per_row = w.chunks, blocks_per_parent = w.bpr;
-    const int chr = w.chr;
-    const u32 parent = blockIdx.x / bpr_max, span = blockIdx.x % bpr_max;
-    if (span >= blocks_per_parent) return;
-    const u32 g0 = goff[parent], g1 = goff[parent + 1];
-    if (g0 == g1) return;
-    const v4u* __restrict__ R0 = (const v4u*)(src + (size_t)w.pw.phys_cur[2 * (size_t)parent] * stride);
-    const v4u* __restrict__ R1 = (const v4u*)(src + (size_t)w.pw.phys_cur[2 * (size_t)parent + 1] * stride);
-    const u32 per_block = (chunks_per_row + blocks_per_parent - 1) / blocks_per_parent;
-    const u32 q0 = span * per_block, q1 = min(q0 + per_block, chunks_per_row);
-    u32 gb = g0;
-    while (gb < g1) {
-        __syncthreads();                                   // previous batch consumed
-        const u32 cand = min(g1 - gb, (u32)PM_GMAX);
-        if (threadIdx.x < cand) {
-            const u32 row = glist[gb + threadIdx.x];
-            const size_t G = 2 * ((size_t)(row >> 1) * nchr + chr) + (row & 1);
-            s_row[threadIdx.x] = w.pw.phys_alt[row]; s_start[threadIdx.x] = sd.start[G]; s_k[threadIdx.x] = sd.k[G]; s_bkoff[threadIdx.x] = sd.bk_off[G];
+    __shared__ u32 s_idx[STITCH_KMAX];
+    const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
+    const u32 S = pw.nseg, sh = pw.seg_shift;
+    const u32 row = blockIdx.x;                           // output row = 2*offspring + s
+    const u32 i = row >> 1, s = row & 1u;
+    const size_t G = 2 * ((size_t)i * nchr + w.chr) + s;
+    const u32 parent = s ? sd.mother[i] : sd.father[i];
+    const u32 start = sd.start[G], k = sd.k[G];
+    const u32* __restrict__ gidx = sd.bk_idx + sd.bk_off[G];
+    const bool in_lds = k <= STITCH_KMAX;
+    if (in_lds) for (u32 m = threadIdx.x; m < k; m += STITCH_THREADS) s_idx[m] = gidx[m];
+    __syncthreads();
+    const u32* idx = in_lds ? s_idx : gidx;
+    for (u32 q = threadIdx.x; q < w.chunks; q += STITCH_THREADS) {
+        const u32 g = q >> sh, ql = q & ((1u << sh) - 1u);
+        if (pw.alias) {                                     // is segment g one of the row's own?  (some boundary chunk lies in it)
+            const u32 first_bit = (g << sh) << 7, last_chunk_end = ((g + 1u) << sh) << 7;
+            const u32 c0 = first_bit ? count_le_u32(idx, k, first_bit - 1u) : 0u;                                                     // #{idx < first_bit}
+            const u32 c1 = count_le_u32(idx, k, last_chunk_end - 1u);                                                                   // #{idx < end}
+            if (c1 == c0) continue;                         // shared with the parent: nothing to write
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {                            // serial prefix; gametes that share their parent's row are dropped (compaction in place)
-            u32 n = 0, kt = 0, big = 0, used = 0;
-            while (used < cand) {
-                const u32 k = s_k[used];
-                if (k == 0 && alias) { used++; continue; }
-                if (kt + k > PM_KTOT) { if (n == 0) big = 1; else break; }
-                s_row[n] = s_row[used]; s_start[n] = s_start[used]; s_bkoff[n] = s_bkoff[used]; s_k[n] = k;
-                s_kb[n] = kt; kt += k; n++; used++;
-                if (big) break;
-            }
-            s_n = n; s_big = big; s_used = used;
-        }
-        __syncthreads();
-        const u32 n = s_n; const bool big = s_big != 0;
-        if (n == 0) { gb += s_used; continue; }
-        if (!big)
-            for (u32 j = 0; j < n; j++)
-                for (u32 m = threadIdx.x; m < s_k[j]; m += THREADS) s_idx[s_kb[j] + m] = sd.bk_idx[s_bkoff[j] + m];
-        __syncthreads();
-        if (big) {
-            // one gamete with more boundaries than LDS holds (> PM_KTOT crossovers): per-chunk bisection on the global index list
-            const PmIdx I{s_idx, sd.bk_idx + s_bkoff[0], true};
-            const u32 k = s_k[0];
-            v4u* D = (v4u*)(dst + (size_t)s_row[0] * stride);
-            for (u32 q = q0 + threadIdx.x; q < q1; q += THREADS) {
-                const u32 bit0 = q * 128u, bit1 = bit0 + 128u;
-                u32 cnt, nxt; pm_locate(I, k, bit0, cnt, nxt);
-                const u32 sel = s_start[0] ^ (cnt & 1u);
-                v4u o;
-                if (nxt >= bit1) o = sel ? R1[q] : R0[q];
-                else {
-                    v4u mask = sel ? (v4u)(0xffffffffu) : (v4u)(0u);
-                    for (u32 m = cnt; m < k; m++) { const u32 id = I.at(m); if (id >= bit1) break; mask ^= mask_from(id - bit0); }
-                    o = (R0[q] & ~mask) | (R1[q] & mask);
-                }
-                D[q] = o;
-            }
-            gb += s_used;
-            continue;
-        }
-        // ---- merged boundary chunks of the span (thread 0: the lists are a handful of entries long)
-        if (threadIdx.x == 0) {
-            u32 nd = 0;
-            const u32 kt = s_kb[n - 1] + s_k[n - 1];
-            for (u32 m = 0; m < kt; m++) {
-                const u32 c = s_idx[m] >> 7;
-                if (c < q0 || c >= q1) continue;
-                u32 p = nd;                                   // insertion into the ascending distinct list
-                while (p > 0 && s_bc[p - 1] > c) p--;
-                if (p > 0 && s_bc[p - 1] == c) continue;
-                for (u32 t = nd; t > p; t--) s_bc[t] = s_bc[t - 1];
-                s_bc[p] = c; nd++;
-            }
-            s_bc[nd] = 0xffffffffu;
-            s_nd = nd;
-        }
-        __syncthreads();
-        const u32 nd = s_nd;
-        for (u32 r = threadIdx.x; r <= nd; r += THREADS) {        // selection mask of every region
-            const u32 bit = (r == 0 ? q0 : s_bc[r - 1] + 1u) * 128u;
-            u32 mask = 0;
-            for (u32 j = 0; j < n; j++) {
-                const u32* id = s_idx + s_kb[j]; const u32 k = s_k[j];
-                u32 cnt = 0;
-                for (u32 m = 0; m < k; m++) cnt += (id[m] <= bit);
-                mask |= ((s_start[j] ^ cnt) & 1u) << j;
-            }
-            s_sel[r] = mask;
-        }
-        __syncthreads();
-        const u32 full = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
-        u32 reg[UNROLL];
+        const u32 bit0 = q << 7;
+        const u32 cnt = count_le_u32(idx, k, bit0);
+        const u32 sel = (start ^ cnt) & 1u;
+        const uint4* A = (const uint4*)(pw.pool + ((size_t)pw.phys_cur[(2 * (size_t)parent + sel) * S + g] << (sh + 4))) + ql;
+        uint4* Dq = (uint4*)(pw.pool + ((size_t)pw.phys_alt[(size_t)row * S + g] << (sh + 4))) + ql;
+        if (cnt >= k || idx[cnt] >= bit0 + 128u) { *Dq = *A; continue; }
+        const uint4* B = (const uint4*)(pw.pool + ((size_t)pw.phys_cur[(2 * (size_t)parent + (sel ^ 1u)) * S + g] << (sh + 4))) + ql;
+        const uint4 av = *A, bv = *B;
+        u32 aw[4] = {av.x, av.y, av.z, av.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w}, ow[4], mask[4] = {0, 0, 0, 0};      // 1 = take B (the other haplotype)
+        for (u32 m = cnt; m < k; m++) {
+            const u32 id = idx[m];
+            if (id >= bit0 + 128u) break;
+            const u32 rel = id - bit0;                       // toggle every bit >= rel
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) reg[u] = 0;
-        for (u32 q = q0 + threadIdx.x; q < q1; q += THREADS * UNROLL) {
-            v4u a[UNROLL], b[UNROLL];
-            u32 sel[UNROLL]; bool isb[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const u32 qq = q + u * THREADS;
-                sel[u] = 0; isb[u] = false;
-                if (qq >= q1) continue;
-                u32 r = reg[u];
-                while (s_bc[r] < qq) r++;                    // sentinel-terminated
-                reg[u] = r;
-                isb[u] = s_bc[r] == qq;
-                sel[u] = s_sel[r];
-                if (isb[u] || sel[u] != full) a[u] = NT ? __builtin_nontemporal_load(&R0[qq]) : R0[qq];
-                if (isb[u] || sel[u] != 0u) b[u] = NT ? __builtin_nontemporal_load(&R1[qq]) : R1[qq];
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const u32 qq = q + u * THREADS;
-                if (qq >= q1) continue;
-                if (!isb[u]) {
-                    for (u32 j = 0; j < n; j++) {
-                        const v4u o = ((sel[u] >> j) & 1u) ? b[u] : a[u];
-                        v4u* D = (v4u*)(dst + (size_t)s_row[j] * stride);
-                        if (NT) __builtin_nontemporal_store(o, &D[qq]); else D[qq] = o;
-                    }
-                } else {
-                    const u32 bit0 = qq * 128u, bit1 = bit0 + 128u;
-                    for (u32 j = 0; j < n; j++) {
-                        const u32* id = s_idx + s_kb[j]; const u32 k = s_k[j];
-                        u32 cnt = 0;
-                        for (u32 m = 0; m < k; m++) cnt += (id[m] <= bit0);
-                        v4u mask = ((s_start[j] ^ cnt) & 1u) ? (v4u)(0xffffffffu) : (v4u)(0u);       // 1 = take row1
-                        for (u32 m = cnt; m < k; m++) { if (id[m] >= bit1) break; mask ^= mask_from(id[m] - bit0); }
-                        const v4u o = (a[u] & ~mask) | (b[u] & mask);
-                        v4u* D = (v4u*)(dst + (size_t)s_row[j] * stride);
-                        if (NT) __builtin_nontemporal_store(o, &D[qq]); else D[qq] = o;
-                    }
-                }
+            for (int x = 0; x < 4; x++) {
+                const u32 wb = x * 32u;
+                u32 t = 0;
+                if (rel <= wb) t = 0xffffffffu; else if (rel < wb + 32u) t = 0xffffffffu << (rel - wb);
+                mask[x] ^= t;
             }
         }
-        gb += s_used;
+#pragma unroll
+        for (int x = 0; x < 4; x++) ow[x] = (aw[x] & ~mask[x]) | (bw[x] & mask[x]);
+        *Dq = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
 }
 
@@ -1435,18 +1225,17 @@ __global__ void k_ad_sum_chr(const double* __restrict__ chr_vals /*[n][nchr][nph
 // ------------------------------------------------------------------------------------------
 // rows [row0, row0+n) already copied into `out` (stride out_w32 words); flip loci whose position is in the row's set
 __global__ void __launch_bounds__(256) k_snp_apply_mut(
-    const u32* __restrict__ plane, const u32* __restrict__ phys, size_t stride_w32, u32* __restrict__ out, size_t out_w32, size_t row0, size_t n_rows,
+    RowMap rm, u32* __restrict__ out, size_t out_w32, size_t row0, size_t n_rows,
     const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ pos, u32 L)
 {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
-    const u32* in = plane + (size_t)phys[row0 + r] * stride_w32;
     u32* o = out + r * out_w32;
     for (u32 j = m_off[row0 + r]; j < m_off[row0 + r + 1]; j++) {
         const u64 x = m_pos[j];
         u32 c = lower_bound_u64(pos, L, x);
         for (; c < L && pos[c] == x; c++) {
-            const u32 f = (in[c >> 5] >> (c & 31)) & 1u;
+            const u32 f = (rm.word32(row0 + r, c >> 5) >> (c & 31)) & 1u;
             if (f) o[c >> 5] &= ~(1u << (c & 31)); else o[c >> 5] |= (1u << (c & 31));
         }
     }
@@ -1491,7 +1280,7 @@ __global__ void __launch_bounds__(256) k_materialize_tile(const u32* __restrict_
 // two independent paths.  The founder panel is the synthetic one (k_synth_rows), recomputed on the fly, so no founder copy
 // has to be resident.  Mutations are not in the plane (sparse overlay), so none are applied here.
 __global__ void __launch_bounds__(256) k_verify_plane(const u32* __restrict__ p_off, const gev_part* __restrict__ parts, size_t n_rows,
-                                                      const u64* __restrict__ pos, u32 L, const u32* __restrict__ plane, const u32* __restrict__ phys, size_t stride_w32,
+                                                      const u64* __restrict__ pos, u32 L, RowMap rm,
                                                       const u32* __restrict__ thr /* [n_pop][L] */, const u64* __restrict__ seeds /* [n_pop] */, int n_pop, const u64* __restrict__ n_founder_rows /* [n_pop] */,
                                                       unsigned long long* __restrict__ n_bad /* [0] mismatching words, [1] parts with an unknown / out-of-range founder */)
 {
@@ -1522,7 +1311,7 @@ __global__ void __launch_bounds__(256) k_verify_plane(const u32* __restrict__ p_
             if ((u32)(mix64(ctr) >> 32) < th[ii]) acc |= 1u << t;
         }
     }
-    if (acc != plane[(size_t)phys[r] * stride_w32 + w]) atomicAdd(&n_bad[0], 1ull);
+    if (acc != rm.word32(r, w)) atomicAdd(&n_bad[0], 1ull);
 }
 // mutation overlay of a tile: out bit = !unmutated bit at every tile locus whose position is in the row's mutation list (:1212-1216)
 __global__ void __launch_bounds__(256) k_tile_apply_mut(const u32* __restrict__ plain, u32* __restrict__ out, size_t w32, size_t row0, size_t n_rows,
@@ -1549,17 +1338,25 @@ __global__ void __launch_bounds__(256) k_gather_rows16(uint4* __restrict__ dst, 
     const size_t r = q / chunks; const u32 c = (u32)(q % chunks);
     dst[r * dst_stride16 + c] = src[(size_t)map[r] * src_stride16 + c];
 }
-// the same between row pools: dst row dst_phys[r] (or r) <- src row src_phys[l] with l = map[r] (or base + r); null tables = identity
-__global__ void __launch_bounds__(256) k_copy_rows16(uint4* __restrict__ dst, size_t dst_stride16, const u32* __restrict__ dst_phys,
-                                                     const uint4* __restrict__ src, size_t src_stride16, const u32* __restrict__ src_phys,
-                                                     const u32* __restrict__ map, size_t base, size_t n_rows, u32 chunks)
+// rows between the segment pool and flat buffers (migration, order restoring, download staging): one side or both can be a
+// flat array of whole rows (phys == null: row r at base + r * stride16 chunks) or a pool addressed through a unit table
+struct RowRef {
+    uint8_t* base; const u32* phys; size_t stride16; u32 nseg, seg_shift;
+    __device__ __forceinline__ uint4* chunk(size_t r, u32 q) const
+    {
+        if (!phys) return (uint4*)base + r * stride16 + q;
+        const u32 unit = phys[r * nseg + (q >> seg_shift)];
+        return (uint4*)(base + ((size_t)unit << (seg_shift + 4))) + (q & ((1u << seg_shift) - 1u));
+    }
+};
+// dst row r <- src row (map ? map[r] : base + r)
+__global__ void __launch_bounds__(256) k_copy_rows16(RowRef dst, RowRef src, const u32* __restrict__ map, size_t base, size_t n_rows, u32 chunks)
 {
-    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n_rows * chunks) return;
-    const size_t r = q / chunks; const u32 c = (u32)(q % chunks);
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rows * chunks) return;
+    const size_t r = e / chunks; const u32 q = (u32)(e % chunks);
     const size_t l = map ? (size_t)map[r] : base + r;
-    const size_t sr = src_phys ? (size_t)src_phys[l] : l, dr = dst_phys ? (size_t)dst_phys[r] : r;
-    dst[dr * dst_stride16 + c] = src[sr * src_stride16 + c];
+    *dst.chunk(r, q) = *src.chunk(l, q);
 }
 // CSR gather: count / fill of rows selected by map (element size templated)
 __global__ void k_csr_gather_count(const u32* __restrict__ s_off, const u32* __restrict__ map, size_t n_rows, u32* __restrict__ cnt)
@@ -1660,7 +1457,7 @@ __global__ void __launch_bounds__(256) k_par_eff(const double* __restrict__ ff, 
 // plane is haplotype-major, so output = 64x64 bit-tile transposes (64 ballots per tile: lane b ends
 // up with SNP 64*sw+b across 64 haplotypes), then the sparse mutation overlay, then formatting.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_transpose_tiles(const u64* __restrict__ plane, const u32* __restrict__ phys /* slot -> row, null = identity */, size_t stride_w64, size_t n_rows, u32 L,
+__global__ void __launch_bounds__(256) k_transpose_tiles(const u64* __restrict__ plane /* flat rows, or null: */, RowMap rm /* segment pool */, size_t stride_w64, size_t n_rows, u32 L,
                                                          u32 snp_begin, u32 n_snps, u64* __restrict__ out, size_t out_stride_w64, u32 words_per_wave)
 {
     const u32 lane = threadIdx.x & 63;
@@ -1669,9 +1466,8 @@ __global__ void __launch_bounds__(256) k_transpose_tiles(const u64* __restrict__
     const u32 sw_first = snp_begin >> 6, sw_last = (snp_begin + n_snps - 1) >> 6;
     const u32 sw0 = sw_first + wave * words_per_wave;
     const size_t row = hb * 64 + lane;
-    const size_t prow = row < n_rows && phys ? (size_t)phys[row] : row;
     for (u32 sw = sw0; sw < sw0 + words_per_wave && sw <= sw_last; sw++) {
-        const u64 v = row < n_rows ? plane[prow * stride_w64 + sw] : 0ull;
+        const u64 v = row < n_rows ? (plane ? plane[row * stride_w64 + sw] : rm.word64(row, sw)) : 0ull;
         u64 mine = 0;
 #pragma unroll 8
         for (u32 b = 0; b < 64; b++) {
@@ -1683,19 +1479,18 @@ __global__ void __launch_bounds__(256) k_transpose_tiles(const u64* __restrict__
     }
 }
 // flip (snp, hap) where the SNP position is in the haplotype's mutation set: value = !founder (idempotent)
-__global__ void __launch_bounds__(256) k_snpmajor_apply_mut(const u32* __restrict__ plane, const u32* __restrict__ phys, size_t stride_w32, size_t n_rows,
+__global__ void __launch_bounds__(256) k_snpmajor_apply_mut(RowMap rm, size_t n_rows,
                                                             const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ pos, u32 L,
                                                             u32 snp_begin, u32 n_snps, unsigned long long* __restrict__ out, size_t out_stride_w64)
 {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
-    const u32* in = plane + (size_t)phys[r] * stride_w32;
     for (u32 j = m_off[r]; j < m_off[r + 1]; j++) {
         const u64 x = m_pos[j];
         u32 c = lower_bound_u64(pos, L, x);
         for (; c < L && pos[c] == x; c++) {
             if (c < snp_begin || c >= snp_begin + n_snps) continue;
-            const u32 f = (in[c >> 5] >> (c & 31)) & 1u;
+            const u32 f = (rm.word32(r, c >> 5) >> (c & 31)) & 1u;
             unsigned long long* w = out + (size_t)(c - snp_begin) * out_stride_w64 + (r >> 6);
             const unsigned long long bit = 1ull << (r & 63);
             if (f) atomicAnd(w, ~bit); else atomicOr(w, bit);

@@ -8,14 +8,15 @@
 //   GEV_OVERLAP=0|1|2|-1      stream overlap: never | everything (default) | sampling only | decide from two timed generations
 //   GEV_SERIALIZE=1           same as GEV_OVERLAP=0
 //   GEV_SAMPLE_BATCHED=0|1    sampling kernels: one task per wave | eight tasks per wave (default)
-//   GEV_STITCH_MODE=0|1|2     dense stitch kernel: k_stitch_regions (default) | k_stitch_rows | k_stitch_parent (same results)
+//   GEV_STITCH_MODE=0|1       dense stitch kernel: k_stitch_segments (default) | k_stitch_rows (same results)
 //   GEV_SAMPLE_GRID=n         persistent workgroups of the sampling kernels (default 384 next to a stitch, 1024 alone)
-//   GEV_STITCH_WG_PER_CU=n|auto stitch workgroups per CU, by dynamic LDS padding (default: 6 on rows >= 64 KiB, else unlimited; auto: measured at run time)
+//   GEV_STITCH_WG_PER_CU=n|auto stitch workgroups per CU, by dynamic LDS padding (default: unlimited; auto: measured at run time)
 //   GEV_STITCH_LDS_PAD=bytes  (experiments) that padding directly
-//   GEV_ALIAS_ROWS=0|1        copy every gamete row | crossover-free gametes share the parental row (default)
+//   GEV_ALIAS_ROWS=0|1        write every segment of every gamete row | segments without a crossover boundary share the parental unit (default)
 //   GEV_LIST_LONG=n           average list entries per row from which the list fill kernels put eight lanes on a row (default 20)
 //   GEV_STITCH_PRIORITY=1|2   stitch stream high / all streams equal (default: small streams high, stitch low)
-//   GEV_STITCH_UNROLL=2|4|8    chunks per thread in flight in k_stitch_regions (default: 4 on rows >= 64 KiB, else 2; sweeps with fewer workgroups per CU lost)
+//   GEV_STITCH_GRID=n         persistent workgroups of the segment stitch per chromosome (default 16384)
+//   GEV_SEG_CHUNKS=2^k        16-byte chunks per row segment (default 1024 = 16 KiB)
 //   GEV_STITCH_WAVE_PRIO=0..3 s_setprio level of the stitch kernel's waves (default 0; measured: no effect next to the sampling kernels)
 //   GEV_TABLE_RING_BYTES=n    minimum size of the pinned ring the per-generation work tables are staged in (default 256 KiB)
 //   GEV_TRACE_HOST=1          stderr: host time per phase of gev_reproduce, allocations, deferred frees
@@ -120,7 +121,10 @@ struct ChrStatic {                       // one population x one chromosome
     std::vector<u64> mbp; std::vector<double> mrate; bool mut_set = false;
     std::vector<u64> pos;                // Legend.pos
     DevBuf d_rthr, d_rbp, d_mthr, d_mbp, d_pos;
-    size_t L = 0, stride = 0;            // plane row stride in bytes (multiple of 128)
+    size_t L = 0, stride = 0;            // bytes of a whole genotype row in flat (host-side / staging) layouts, multiple of 128
+    u32 nseg = 1, seg_shift = 10;        // the device keeps a row as nseg segments of 2^seg_shift 16-byte chunks (gev_kernels.h, PoolWork)
+    size_t unit_bytes() const { return (size_t)16 << seg_shift; }
+    size_t pitch() const { return (size_t)nseg * unit_bytes(); }      // founder rows: row r = units r*nseg .. r*nseg+nseg-1 = a flat row of this pitch
     u32 idx_lo = 0, idx_hi = 0;          // loci inside [bp0, bp_end)
     u32 r_amax = 0, m_amax = 0;
     size_t founder_rows = 0;
@@ -140,7 +144,7 @@ struct ChrState {
     // genotype rows: one pool of 4 * cap_people rows (two generations' worth); slot s of the current generation is pool row
     // phys[pcur][s] (gev_kernels.h, PoolWork).  phys has THREE buffers: the stitch of generation g (stream_big) still reads
     // phys of g-1 and g while the small work of g+1 writes the next one.
-    DevBuf pool, phys[3], live, freel, pctr; u32 pool_stamp = 0;
+    DevBuf pool, phys[3], live, freel, pctr, items[2]; u32 pool_stamp = 0;
     DevBuf moff[2], mpos[2], poff[2], parts[2];
     size_t mut_total[2] = {0, 0}, parts_total[2] = {0, 0};   // list sizes of the two buffers (known to the host after each generation)
     size_t mut_need = 0, parts_need = 0;                     // exact capacity demand after an overflowed attempt
@@ -174,8 +178,8 @@ struct gev_ctx {
     // per-generation scratch: two sets, because the dense stitch of generation g (stream_big) still reads set g%2
     // while sampling / sparse state of generation g+1 (stream) fill the other one
     struct Scratch {
-        DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, ghist, goff, glist, status, slow_mut, slow_rec, chrwork, cvwork;
-        unsigned n_chrwork = 0, bpr_max = 1; bool long_rows = false;
+        DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, status, slow_mut, slow_rec, chrwork, cvwork;
+        unsigned n_chrwork = 0;
         hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         bool timing_pending = false, stitch_pending = false;
         // gev_presample: the sampling kernels of the next gev_reproduce were already enqueued for exactly these inputs
@@ -196,7 +200,7 @@ struct gev_ctx {
     int ad_cached_pop = -1;                                  // population whose current-generation A/D sits in h_ad
     int ad_host_set_pop = -1;                                // population whose raw A/D totals on the device were supplied by gev_set_ad (locus-split: all-reduced)
     bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
-    int stitch_mode = 0;           // 0 = parent-major region form (production, k_stitch_regions), 1 = gamete-major (k_stitch_rows), 2 = parent-major per-chunk form (k_stitch_parent)
+    int stitch_mode = 0;           // 0 = work-list form (production, k_stitch_segments), 1 = gamete-major (k_stitch_rows)
     bool sample_batched = true;               // K1-K3 as eight tasks per wave (gev_sample8.h); GEV_SAMPLE_BATCHED=0: one task per wave
     unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels when they have the GPU to themselves (GEV_SAMPLE_GRID)
     unsigned sample_grid_shared = 384;        // ... and next to a running stitch: 6 waves per CU take fewer of the stitch's slots for longer, which costs
@@ -205,11 +209,12 @@ struct gev_ctx {
     int overlap_mode = 1;          // 1 everything (default), 0 never, 2 sampling only, -1 decide after two serialised generations
     bool sparse_after_stitch = false;   // mode 2: the memory-bound sparse/CV/A-D kernels wait for the running stitch, only the ALU-bound sampling shares the GPU with it
     int auto_gens = 0; double auto_small_ms = 0, auto_stitch_ms = 0;
-    int stitch_unroll = 0;         // 0: chosen by row length; 2 / 4 / 8: forced (GEV_STITCH_UNROLL)
+    size_t stitch_grid = 16384;    // persistent workgroups of the segment stitch per chromosome (GEV_STITCH_GRID)
     int stitch_wave_prio = 0;      // s_setprio level of the stitch kernel's waves (GEV_STITCH_WAVE_PRIO)
     size_t list_long = LIST_LONG;  // average list entries per row from which the list fill kernels use LIST_LANES lanes per row (GEV_LIST_LONG)
+    u32 seg_shift = 10;            // log2(16-byte chunks per row segment): 16 KiB (GEV_SEG_CHUNKS=<power of two> for tests / experiments)
     bool alias_rows = true;        // crossover-free gametes share their parent's pool row instead of copying it (GEV_ALIAS_ROWS=0: copy every row)
-    unsigned long long rows_written_sum = 0, rows_total_sum = 0;   // over all generations and active chromosomes (gev_stitch_totals)
+    unsigned long long chunks_written_sum = 0, chunks_total_sum = 0, segments_written_sum = 0, segments_total_sum = 0;   // over all generations and active chromosomes (gev_stitch_totals)
     // Stitch workgroups per CU (8 = every wave slot).  The hardware queue priority does not let the small kernels of the next
     // generation overtake a stitch grid that is still being dispatched: at 8 they start when the stitch is nearly over.  Slots
     // left free (6 of 8 used) let them run next to it, at the price of a slightly slower stitch.  That pays when the small-kernel
@@ -369,11 +374,12 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     c->serialize = c->overlap_mode <= 0;                             // auto starts serialised
     c->sparse_after_stitch = c->overlap_mode == 2;
     if (const char* e = getenv("GEV_SAMPLE_BATCHED")) c->sample_batched = atoi(e) != 0;
-    if (const char* e = getenv("GEV_STITCH_UNROLL")) c->stitch_unroll = atoi(e);
+    if (const char* e = getenv("GEV_STITCH_GRID")) c->stitch_grid = (size_t)std::max(1, atoi(e));
     if (const char* e = getenv("GEV_LIST_LONG")) c->list_long = (size_t)std::max(0, atoi(e));
+    if (const char* e = getenv("GEV_SEG_CHUNKS")) { const int v = atoi(e); u32 sh = 0; while ((1 << (sh + 1)) <= v) sh++; if (v >= 1 && sh <= 20) c->seg_shift = sh; }
     if (const char* e = getenv("GEV_ALIAS_ROWS")) c->alias_rows = atoi(e) != 0;
     if (const char* e = getenv("GEV_STITCH_WAVE_PRIO")) c->stitch_wave_prio = std::max(0, std::min(atoi(e), 3));
-    if (const char* e = getenv("GEV_STITCH_MODE")) c->stitch_mode = std::max(0, std::min(atoi(e), 2));
+    if (const char* e = getenv("GEV_STITCH_MODE")) c->stitch_mode = std::max(0, std::min(atoi(e), 1));
     if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = c->sample_grid_shared = (unsigned)g; }
     if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // fixed stitch workgroups per CU (default: measured, see OccTune)
         const int occ = atoi(e);
@@ -452,6 +458,9 @@ int gev_set_snps(gev_ctx* c, int pop, int chr, const u64* pos, size_t L)
     ChrStatic& S = c->pop[pop].cs[chr];
     S.pos.assign(pos, pos + L); S.L = L;
     S.stride = std::max<size_t>(round_up(ceil_div(L, 8), 128), 128);
+    S.seg_shift = c->seg_shift;                                    // 16 KiB segments unless the row would need more than 64 of them
+    while (ceil_div(S.stride / 16, (size_t)1 << S.seg_shift) > POOL_SEG_MAX) S.seg_shift++;
+    S.nseg = (u32)ceil_div(S.stride / 16, (size_t)1 << S.seg_shift);
     HIPC(hipSetDevice(c->device));
     GEVC(h2d(c, S.d_pos, pos, L * sizeof(u64)));
     c->pop[pop].finalized = false;
@@ -497,17 +506,32 @@ static PoolWork pool_work(const gev_ctx* c, PopState& P, int chr, int alt)
 {
     ChrState& cs = P.st[chr];
     PoolWork pw{};
+    const ChrStatic& S = P.cs[chr];
     pw.pool = cs.pool.as<uint8_t>(); pw.phys_cur = cs.phys[P.pcur].as<u32>(); pw.phys_alt = cs.phys[alt].as<u32>();
     pw.live = cs.live.as<u32>(); pw.freel = cs.freel.as<u32>(); pw.pctr = cs.pctr.as<u32>();
-    pw.pool_rows = (u32)(4 * P.cap_people); pw.alias = c->alias_rows ? 1u : 0u;
+    pw.nseg = S.nseg; pw.seg_shift = S.seg_shift;
+    pw.pool_units = (u32)(4 * P.cap_people * S.nseg); pw.alias = c->alias_rows ? 1u : 0u;
+    pw.items = cs.items[P.cur ^ 1].as<u32>(); pw.items_cap = (u32)(2 * P.cap_people * S.nseg);
     if (++cs.pool_stamp == 0) cs.pool_stamp = 1;          // (a stale mark of 2^32 rebuilds ago could only keep a free row out of one free list)
     pw.stamp = cs.pool_stamp;
     return pw;
 }
+// read access to the current generation's rows / a flat buffer of whole rows, for the kernels that move or read rows
+static RowMap row_map(const PopState& P, int chr)
+{
+    const ChrStatic& S = P.cs[chr]; const ChrState& cs = P.st[chr];
+    return RowMap{cs.pool.as<uint8_t>(), cs.phys[P.pcur].as<u32>(), S.nseg, S.seg_shift};
+}
+static RowRef pool_rows(const PopState& P, int chr, const u32* table)
+{
+    const ChrStatic& S = P.cs[chr];
+    return RowRef{P.st[chr].pool.as<uint8_t>(), table, 0, S.nseg, S.seg_shift};
+}
+static RowRef flat_rows(void* base, size_t stride_bytes) { return RowRef{(uint8_t*)base, nullptr, stride_bytes / 16, 1, 0}; }
 // free rows of the pool given the slots that are in use (the kernels of gev_reproduce do the same from the work table)
 static int pool_free_list(const PoolWork& pw, size_t n_slots, hipStream_t st)
 {
-    const unsigned blocks = (unsigned)std::min<size_t>(ceil_div(std::max<size_t>(pw.pool_rows, 1), 256), 1024);
+    const unsigned blocks = (unsigned)std::min<size_t>(ceil_div(std::max<size_t>(pw.pool_units, 1), 256), 1024);
     hipLaunchKernelGGL(k_pool_mark, dim3(blocks), dim3(256), 0, st, pw, n_slots);
     hipLaunchKernelGGL(k_pool_collect, dim3(blocks), dim3(256), 0, st, pw);
     KCHECK();
@@ -517,8 +541,8 @@ static int pool_free_list(const PoolWork& pw, size_t n_slots, hipStream_t st)
 static int pool_take(const PoolWork& pw, size_t slot0, size_t n, hipStream_t st)
 {
     if (!n) return GEV_OK;
-    hipLaunchKernelGGL(k_pool_take, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, pw, slot0, n, pw.pctr + 2);
-    hipLaunchKernelGGL(k_pool_taken, dim3(1), dim3(64), 0, st, pw, (u32)n);
+    hipLaunchKernelGGL(k_pool_take, dim3((unsigned)ceil_div(n * pw.nseg, 256)), dim3(256), 0, st, pw, slot0, n, pw.pctr + 2);
+    hipLaunchKernelGGL(k_pool_taken, dim3(1), dim3(64), 0, st, pw, (u32)(n * pw.nseg));
     KCHECK();
     u32 flag = 0;
     HIPC(hipMemcpyAsync(&flag, pw.pctr + 2, sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -540,9 +564,11 @@ static int ensure_capacity(gev_ctx* c, int pop, size_t people)
         if (!P.cs[k].stride) return fail(GEV_ESTATE, "set_snps must precede allocation (pop %d chr %d)", pop, k);
         if (c->dense) {
             ChrState& cs = P.st[k];
-            GEVC(cs.pool.ensure(2 * rows * P.cs[k].stride, c->stream, /*keep=*/true));          // row numbers stay valid: the pool grows at its end
-            for (int b = 0; b < 3; b++) GEVC(cs.phys[b].ensure(rows * sizeof(u32), c->stream, b == P.pcur));
-            GEVC(cs.live.ensure(2 * rows * sizeof(u32), c->stream)); GEVC(cs.freel.ensure(2 * rows * sizeof(u32), c->stream));
+            const size_t units = rows * P.cs[k].nseg;                                          // per generation
+            GEVC(cs.pool.ensure(2 * units * P.cs[k].unit_bytes(), c->stream, /*keep=*/true));   // unit numbers stay valid: the pool grows at its end
+            for (int b = 0; b < 3; b++) GEVC(cs.phys[b].ensure(units * sizeof(u32), c->stream, b == P.pcur));
+            for (int b = 0; b < 2; b++) GEVC(cs.items[b].ensure((units + 1) * sizeof(u32), c->stream));
+            GEVC(cs.live.ensure(2 * units * sizeof(u32), c->stream)); GEVC(cs.freel.ensure(2 * units * sizeof(u32), c->stream));
             HIPC(hipMemsetAsync(cs.live.p, 0, cs.live.bytes, c->stream)); cs.pool_stamp = 0;   // marks are generation stamps: start from a clean buffer
             GEVC(cs.pctr.ensure(4 * sizeof(u32), c->stream));
         }
@@ -603,13 +629,13 @@ int gev_upload_founders(gev_ctx* c, int pop, int chr, const u64* bits, size_t ro
     if (row_stride_words * 64 < L) return fail(GEV_EINVAL, "upload_founders: row stride too small");
     HIPC(hipSetDevice(c->device));
     GEVC(gev_sync(c));
-    GEVC(P.st[chr].pool.ensure(nhap * S.stride, c->stream));
-    HIPC(hipMemsetAsync(P.st[chr].pool.p, 0, nhap * S.stride, c->stream));
-    HIPC(hipMemcpy2DAsync(P.st[chr].pool.p, S.stride, bits, row_stride_words * 8, ceil_div(L, 8), nhap, hipMemcpyHostToDevice, c->stream));
+    GEVC(P.st[chr].pool.ensure(nhap * S.pitch(), c->stream));                       // founder haplotype r = units r*nseg ..: flat rows of pitch()
+    HIPC(hipMemsetAsync(P.st[chr].pool.p, 0, nhap * S.pitch(), c->stream));
+    HIPC(hipMemcpy2DAsync(P.st[chr].pool.p, S.pitch(), bits, row_stride_words * 8, ceil_div(L, 8), nhap, hipMemcpyHostToDevice, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     if (L % 8) {   // clear pad bits of the last byte (the contract says pad bits are zero; do not trust it)
-        hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(nhap * (S.stride / 4), 256)), dim3(256), 0, c->stream,
-                           P.st[chr].pool.as<u32>(), S.stride / 4, nhap, 0u, (u32)L);
+        hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(nhap * (S.pitch() / 4), 256)), dim3(256), 0, c->stream,
+                           P.st[chr].pool.as<u32>(), S.pitch() / 4, nhap, 0u, (u32)L);
         KCHECK();
     }
     S.founder_rows = nhap; P.gen0 = false;
@@ -624,13 +650,13 @@ int gev_synth_founders(gev_ctx* c, int pop, int chr, size_t nhap, u64 seed)
     if (!S.L) return fail(GEV_ESTATE, "synth_founders: set_snps first");
     HIPC(hipSetDevice(c->device));
     GEVC(gev_sync(c));
-    GEVC(P.st[chr].pool.ensure(nhap * S.stride, c->stream));
-    HIPC(hipMemsetAsync(P.st[chr].pool.p, 0, nhap * S.stride, c->stream));
+    GEVC(P.st[chr].pool.ensure(nhap * S.pitch(), c->stream));
+    HIPC(hipMemsetAsync(P.st[chr].pool.p, 0, nhap * S.pitch(), c->stream));
     GEVC(c->d_thr32.ensure(S.L * sizeof(u32), c->stream));
     hipLaunchKernelGGL(k_synth_thresholds, dim3((unsigned)ceil_div(S.L, 256)), dim3(256), 0, c->stream, c->d_thr32.as<u32>(), S.L, seed);
     const size_t words = ceil_div(S.L, 64);
     hipLaunchKernelGGL(k_synth_rows, dim3((unsigned)ceil_div(nhap * words, 256)), dim3(256), 0, c->stream,
-                       P.st[chr].pool.as<u64>(), S.stride / 8, nhap, S.L, c->d_thr32.as<u32>(), seed);
+                       P.st[chr].pool.as<u64>(), S.pitch() / 8, nhap, S.L, c->d_thr32.as<u32>(), seed);
     KCHECK();
     HIPC(hipStreamSynchronize(c->stream));
     S.founder_rows = nhap; P.gen0 = false;
@@ -758,9 +784,9 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& st = P.st[k];
         if (c->dense) {                                  // founder haplotype r is pool row r
-            hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(rows * (S.stride / 4), 256)), dim3(256), 0, c->stream,
-                               st.pool.as<u32>(), S.stride / 4, rows, S.idx_lo, S.idx_hi);
-            hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, c->stream, st.phys[P.pcur].as<u32>(), rows);
+            hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(rows * (S.pitch() / 4), 256)), dim3(256), 0, c->stream,
+                               st.pool.as<u32>(), S.pitch() / 4, rows, S.idx_lo, S.idx_hi);
+            hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)ceil_div(rows * S.nseg, 256)), dim3(256), 0, c->stream, st.phys[P.pcur].as<u32>(), rows * S.nseg);
         }
         HIPC(hipMemsetAsync(st.moff[P.cur].p, 0, (rows + 1) * sizeof(u32), c->stream));
         GEVC(st.parts[P.cur].ensure(rows * sizeof(gev_part), c->stream));
@@ -932,9 +958,7 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     // ---- work tables of this generation
     const int cur = P.cur, alt = P.cur ^ 1;
     const double grow = (double)rows / (double)std::max<size_t>(2 * P.n_people, 1);
-    const size_t n_parent = P.n_phys;
     std::vector<ChrWork> cw; std::vector<CvWork> vw;
-    unsigned bpr_max = 1;
     for (int k = 0; k < nchr; k++) {
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
@@ -956,11 +980,6 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         if (c->dense) {
             w.pw = pool_work(c, P, k, (P.pcur + 1) % 3); w.snp_pos = S.d_pos.as<u64>();
             w.stride = S.stride; w.chunks = (u32)(S.stride / 16); w.L = (u32)S.L;
-            // enough workgroups to fill 256 CUs even for small populations; one span >= 4 KiB
-            const size_t units = c->stitch_mode != 1 ? n_parent : rows;
-            u32 bpr = 1;
-            while (units * bpr < 4096 && w.chunks / (bpr * 2) >= 256) bpr *= 2;
-            w.bpr = bpr; bpr_max = std::max(bpr_max, bpr);
         }
         cw.push_back(w);
         for (int p = 0; p < c->nphen; p++) {
@@ -969,10 +988,7 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         }
     }
     const unsigned na = (unsigned)cw.size();
-    sc.n_chrwork = na; sc.bpr_max = bpr_max;
-    size_t chunk_sum = 0;
-    for (const ChrWork& w : cw) chunk_sum += w.chunks / std::max(w.bpr, 1u);
-    sc.long_rows = na && chunk_sum / na >= 4096;
+    sc.n_chrwork = na;
     if (na) {
         GEVC(upload_table(c, sc.chrwork, cw.data(), cw.size() * sizeof(ChrWork), st));
         GEVC(upload_table(c, sc.cvwork, vw.data(), vw.size() * sizeof(CvWork), st));
@@ -980,10 +996,12 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
         // ---- pool rows of the offspring: free rows = rows no parental slot points at; crossover-free gametes share the parent's row
         if (c->dense) {
-            const unsigned pool_blocks = (unsigned)std::min<size_t>(ceil_div(4 * P.cap_people, 256), 1024);
+            size_t nseg_max = 1;
+            for (const ChrWork& w : cw) nseg_max = std::max<size_t>(nseg_max, w.pw.nseg);
+            const unsigned pool_blocks = (unsigned)std::min<size_t>(ceil_div(4 * P.cap_people * nseg_max, 256), 1024);
             hipLaunchKernelGGL(k_pool_mark_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt, 2 * P.n_phys);
             hipLaunchKernelGGL(k_pool_collect_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt);
-            hipLaunchKernelGGL(k_pool_assign, dim3((unsigned)ceil_div(rows, 1024), na), dim3(256), 0, st, Wt, rows, nchr, sd);
+            hipLaunchKernelGGL(k_pool_assign, dim3((unsigned)ceil_div(rows, 256), na), dim3(256), 0, st, Wt, rows, nchr, sd);
         }
         // ---- sparse state: mutation lists + ancestry intervals (count -> segmented scan -> fill), CV planes
         const unsigned nseg = c->track_intervals ? 2 * na : na;            // segments [0, na): mutation lists, [na, 2 na): interval lists
@@ -1014,19 +1032,6 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         for (const CvWork& v : vw) if (v.C <= SMALL_POS_LDS) cv_max = std::max(cv_max, v.C);       // LDS copy of the CV grid: sized for the launch, not for the worst case (occupancy)
         if (max_used) hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows, SMALL_ROWS_PER_BLOCK), (unsigned)vw.size()), dim3(256), (size_t)cv_max * sizeof(u64), st,
                                          Vt, nsub, rows, nchr, sd, cv_max);
-        KCHECK();
-    }
-    // ---- gamete grouping by source individual for the parent-major stitch (same for every chromosome)
-    if (c->stitch_mode != 1) {
-        const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
-        GEVC(sc.ghist.ensure((n_parent + 1) * sizeof(u32), st)); GEVC(sc.goff.ensure((n_parent + 1) * sizeof(u32), st));
-        GEVC(sc.glist.ensure(rows * sizeof(u32), st));
-        HIPC(hipMemsetAsync(sc.ghist.p, 0, (n_parent + 1) * sizeof(u32), st));
-        hipLaunchKernelGGL(k_group_hist, dim3(row_blocks), dim3(256), 0, st, sd.father, sd.mother, rows, sc.ghist.as<u32>());
-        KCHECK();
-        GEVC(scan_u32(c, sc.ghist.as<u32>(), n_parent, sc.goff.as<u32>(), nullptr));
-        HIPC(hipMemsetAsync(sc.ghist.p, 0, (n_parent + 1) * sizeof(u32), st));
-        hipLaunchKernelGGL(k_group_fill, dim3(row_blocks), dim3(256), 0, st, sd.father, sd.mother, rows, sc.goff.as<u32>(), sc.ghist.as<u32>(), sc.glist.as<u32>());
         KCHECK();
     }
     HIPC(hipEventRecord(sc.t[2], st));
@@ -1070,35 +1075,23 @@ static void occ_tune_step(gev_ctx* c, size_t n_people)
     if (g_trace_host) fprintf(stderr, "[gev] stitch workgroups per CU: %d (best interval %.3f ms)\n", t.best_occ, t.best);
 }
 // the HBM-bound part, on stream_big, after the small work of the same generation: ONE launch over (parent, chromosome)
-static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people)
+static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int /*pop*/, size_t n_people)
 {
-    PopState& P = c->pop[pop];
     const int nchr = c->nchr;
-    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people, n_parent = P.n_phys;
+    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
     hipStream_t sb = c->stream_big;
     SampleDev sd = make_sd(c, sc, T);
     HIPC(hipEventRecord(sc.ev_small_done, c->stream));
     HIPC(hipStreamWaitEvent(sb, sc.ev_small_done, 0));
     HIPC(hipEventRecord(sc.t[4], sb));
     if (c->dense && sc.n_chrwork) {
-        const size_t units = c->stitch_mode != 1 ? n_parent : rows;
-        const size_t nblk = units * sc.bpr_max;
-        if (nblk > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
-        const int su = c->stitch_unroll;                    // GEV_STITCH_UNROLL (experiments): 0 = by row length
-        if (c->stitch_mode == 0 && su == 8)
-            hipLaunchKernelGGL((k_stitch_regions<8, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : (sc.long_rows && !c->serialize ? 6 : 8)), sb,
-                               sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd, c->stitch_wave_prio);
-        else if (c->stitch_mode == 0 && (su == 4 || (su == 0 && sc.long_rows)))          // 4 chunks per thread in flight pay off on long rows; short rows (< 4096 chunks = 64 KiB) lose lanes to the tail
-            hipLaunchKernelGGL((k_stitch_regions<4, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : (sc.long_rows && !c->serialize ? 6 : 8)), sb,
-                               sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd, c->stitch_wave_prio);
-        else if (c->stitch_mode == 0)
-            hipLaunchKernelGGL((k_stitch_regions<2, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : (sc.long_rows && !c->serialize ? 6 : 8)), sb,
-                               sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd, c->stitch_wave_prio);
-        else if (c->stitch_mode == 2)
-            hipLaunchKernelGGL((k_stitch_parent<2, true>), dim3((unsigned)nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : (sc.long_rows && !c->serialize ? 6 : 8)), sb,
-                               sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sc.goff.as<u32>(), sc.glist.as<u32>(), sd);
-        else
-            hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)nblk, sc.n_chrwork), dim3(STITCH_THREADS), 0, sb, sc.chrwork.as<ChrWork>(), sc.bpr_max, nchr, sd);
+        if (rows > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
+        if (c->stitch_mode == 0) {
+            // persistent grid over the work list (its length is known to the device only): enough workgroups to fill every CU
+            const unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(rows, 1), c->stitch_grid);
+            hipLaunchKernelGGL((k_stitch_segments<true>), dim3(nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : 8), sb, sc.chrwork.as<ChrWork>(), nchr, sd);
+        } else
+            hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)rows, sc.n_chrwork), dim3(STITCH_THREADS), 0, sb, sc.chrwork.as<ChrWork>(), nchr, sd);
         KCHECK();
     }
     HIPC(hipEventRecord(sc.t[3], sb));
@@ -1201,7 +1194,13 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
         }
     }
     for (int k = 0; k < nchr; k++) { P.st[k].mut_need = 0; P.st[k].parts_need = 0; }
-    if (c->dense) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) { c->rows_written_sum += hstatus[ST_TOTALS + ST_PER_CHR * k + 2]; c->rows_total_sum += 2 * n_people; }
+    if (c->dense) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) {            // 16-byte chunks the stitch wrote / chunks of the generation's rows
+        const ChrStatic& S = P.cs[k];
+        const unsigned long long units = hstatus[ST_TOTALS + ST_PER_CHR * k + 2], last = hstatus[ST_TOTALS + ST_PER_CHR * k + 3];
+        const unsigned long long chunks = S.stride / 16, seg = 1ull << S.seg_shift, last_chunks = chunks - (S.nseg - 1) * seg;
+        c->chunks_written_sum += (units - last) * seg + last * last_chunks; c->chunks_total_sum += 2ull * n_people * chunks;
+        c->segments_written_sum += units; c->segments_total_sum += 2ull * n_people * S.nseg;
+    }
     const bool ad_done = c->eager_ad && c->pop[pop].cv[0][0].d_aptr.p;
     for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = ad_done;
     if (ad_done) c->ad_cached_pop = pop;
@@ -1258,12 +1257,15 @@ int gev_sync(gev_ctx* c)
     if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
     return GEV_OK;
 }
-// haplotype rows the dense stitch wrote / rows of the new generations, summed over all gev_reproduce calls and active chromosomes
-// (the difference = crossover-free gametes, which share their parent's row)
-int gev_stitch_totals(gev_ctx* c, unsigned long long* rows_written, unsigned long long* rows_total)
+// what the dense stitch wrote, summed over all gev_reproduce calls and active chromosomes: bytes written and bytes of the rows
+// of the generations produced (the difference = row segments without a crossover boundary, which share the parental unit),
+// and the same in segments
+int gev_stitch_totals(gev_ctx* c, unsigned long long* bytes_written, unsigned long long* bytes_total, unsigned long long* segments_written, unsigned long long* segments_total)
 {
-    if (!c || !rows_written || !rows_total) return fail(GEV_EINVAL, "null");
-    *rows_written = c->rows_written_sum; *rows_total = c->rows_total_sum;
+    if (!c || !bytes_written || !bytes_total) return fail(GEV_EINVAL, "null");
+    *bytes_written = 16ull * c->chunks_written_sum; *bytes_total = 16ull * c->chunks_total_sum;
+    if (segments_written) *segments_written = c->segments_written_sum;
+    if (segments_total) *segments_total = c->segments_total_sum;
     return GEV_OK;
 }
 // cumulative kernel time per phase over all harvested generations: sampling, dense stitch, sparse, sum
@@ -1588,8 +1590,7 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
             const u32 chunks = (u32)(S.stride / 16);
             if (c->dense)
                 hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(map.size() * chunks, 256)), dim3(256), 0, st,
-                                   (uint4*)dpw.pool, S.stride / 16, dpw.phys_alt + row0,
-                                   (const uint4*)Sp.st[k].pool.p, Sp.cs[k].stride / 16, Sp.st[k].phys[Sp.pcur].as<u32>(), c->d_map.as<u32>(), (size_t)0, map.size(), chunks);
+                                   pool_rows(D, k, dpw.phys_alt + row0 * S.nseg), pool_rows(Sp, k, Sp.st[k].phys[Sp.pcur].as<u32>()), c->d_map.as<u32>(), (size_t)0, map.size(), chunks);
             for (int p = 0; p < c->nphen; p++) {
                 CvStatic& V = D.cv[p][k];
                 const u32 cch = V.stride_w32 / 4;
@@ -1750,8 +1751,8 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         const u32 chunks = (u32)(S.stride / 16);
         if (c->dense) {
-            hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, (uint4*)(out + po), S.stride / 16, (const u32*)nullptr,
-                               (const uint4*)cs.pool.p, S.stride / 16, cs.phys[P.pcur].as<u32>(), c->d_map.as<u32>(), (size_t)0, 2 * n, chunks);
+            hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, flat_rows(out + po, S.stride),
+                               pool_rows(P, k, cs.phys[P.pcur].as<u32>()), c->d_map.as<u32>(), (size_t)0, 2 * n, chunks);
             po = al16(po + 2 * n * S.stride);
         }
         for (int pass = 0; pass < 2; pass++) {
@@ -1826,8 +1827,8 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
             GEVC(pool_free_list(pw, r_old, st));
             GEVC(pool_take(pw, r_old, 2 * n, st));
             const u32 chunks = (u32)(S.stride / 16);
-            hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, (uint4*)pw.pool, S.stride / 16, pw.phys_alt + r_old,
-                               (const uint4*)(in + po), S.stride / 16, (const u32*)nullptr, (const u32*)nullptr, (size_t)0, 2 * n, chunks);
+            hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, pool_rows(P, k, pw.phys_alt + r_old * S.nseg),
+                               flat_rows((void*)(in + po), S.stride), (const u32*)nullptr, (size_t)0, 2 * n, chunks);
             KCHECK();
             po = al16(po + 2 * n * S.stride);
         }
@@ -1874,8 +1875,8 @@ static int stage_rows(gev_ctx* c, PopState& P, int chr, size_t slot0, size_t n)
     ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
     const u32 chunks = (u32)(S.stride / 16);
     if (!n) return GEV_OK;
-    hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(n * chunks, 256)), dim3(256), 0, c->stream, (uint4*)c->d_stage.p, S.stride / 16, (const u32*)nullptr,
-                       (const uint4*)cs.pool.p, S.stride / 16, cs.phys[P.pcur].as<u32>(), (const u32*)nullptr, slot0, n, chunks);
+    hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(n * chunks, 256)), dim3(256), 0, c->stream, flat_rows(c->d_stage.p, S.stride),
+                       pool_rows(P, chr, cs.phys[P.pcur].as<u32>()), (const u32*)nullptr, slot0, n, chunks);
     KCHECK();
     return GEV_OK;
 }
@@ -1899,7 +1900,7 @@ int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_r
         const size_t nr = std::min(max_rows, n_rows - r0);
         GEVC(stage_rows(c, P, chr, row_begin + r0, nr));
         hipLaunchKernelGGL(k_snp_apply_mut, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st,
-                           cs.pool.as<u32>(), cs.phys[P.pcur].as<u32>(), S.stride / 4, c->d_stage.as<u32>(), S.stride / 4, row_begin + r0, nr,
+                           row_map(P, chr), c->d_stage.as<u32>(), S.stride / 4, row_begin + r0, nr,
                            cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)S.L);
         KCHECK();
         if (row_stride_words * 8 > copy_bytes)
@@ -1922,9 +1923,9 @@ static int snp_major_device(gev_ctx* c, int pop, int chr, size_t s0, size_t ns, 
     const u32 n_words = (u32)(((s0 + ns - 1) >> 6) - (s0 >> 6) + 1);
     const u32 wpw = 16;                                              // 16 words = one 128-byte line of every row per wave
     const unsigned gy = (unsigned)ceil_div(ceil_div(n_words, wpw), 4);
-    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)stride_w64, gy), dim3(256), 0, st, cs.pool.as<u64>(), cs.phys[P.pcur].as<u32>(), S.stride / 8, rows, (u32)S.L,
+    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)stride_w64, gy), dim3(256), 0, st, (const u64*)nullptr, row_map(P, chr), S.stride / 8, rows, (u32)S.L,
                        (u32)s0, (u32)ns, c->d_snpmajor.as<u64>(), stride_w64, wpw);
-    hipLaunchKernelGGL(k_snpmajor_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, cs.pool.as<u32>(), cs.phys[P.pcur].as<u32>(), S.stride / 4, rows,
+    hipLaunchKernelGGL(k_snpmajor_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, row_map(P, chr), rows,
                        cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)S.L, (u32)s0, (u32)ns,
                        (unsigned long long*)c->d_snpmajor.p, stride_w64);
     KCHECK();
@@ -1991,7 +1992,7 @@ static int stage_individuals(gev_ctx* c, int pop, int chr, size_t ind0, size_t n
     if (!n) return GEV_OK;
     GEVC(stage_rows(c, P, chr, 2 * ind0, 2 * n));
     hipLaunchKernelGGL(k_snp_apply_mut, dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, st,
-                       cs.pool.as<u32>(), cs.phys[P.pcur].as<u32>(), S.stride / 4, c->d_stage.as<u32>(), S.stride / 4, 2 * ind0, 2 * n,
+                       row_map(P, chr), c->d_stage.as<u32>(), S.stride / 4, 2 * ind0, 2 * n,
                        cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), S.d_pos.as<u64>(), (u32)S.L);
     KCHECK();
     return GEV_OK;
@@ -2189,7 +2190,7 @@ int gev_materialize_bed(gev_ctx* c, int pop, int chr, size_t snp_begin, size_t n
     u64* snpmajor = c->d_text.as<u64>(); uint8_t* bed = c->d_text.as<uint8_t>() + n_snps * stride_sm * 8;
     HIPC(hipMemsetAsync(snpmajor, 0, n_snps * stride_sm * 8, st));
     const u32 wpw = 16;
-    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)stride_sm, (unsigned)ceil_div(ceil_div(w64, wpw), 4)), dim3(256), 0, st, c->d_tmp.as<u64>(), (const u32*)nullptr, w64, rows, (u32)n_snps,
+    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)stride_sm, (unsigned)ceil_div(ceil_div(w64, wpw), 4)), dim3(256), 0, st, c->d_tmp.as<u64>(), RowMap{}, w64, rows, (u32)n_snps,
                        0u, (u32)n_snps, snpmajor, stride_sm, wpw);
     hipLaunchKernelGGL(k_format_bed, dim3((unsigned)ceil_div(n_snps * bpl, 256)), dim3(256), 0, st, snpmajor, stride_sm, P.n_people, (u32)n_snps, bed);
     KCHECK();
@@ -2319,7 +2320,7 @@ int gev_download_mutations(gev_ctx* c, int pop, int chr, u64* out, u64* hap_offs
 
 // ---- introspection ------------------------------------------------------------------------
 int gev_pop_size(gev_ctx* c, int pop, size_t* n) { GEVC(check_idx(c, pop, 0)); if (!n) return fail(GEV_EINVAL, "null"); *n = c->pop[pop].n_people; return GEV_OK; }
-int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows, const uint32_t** row_of_slot)
+int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* unit_bytes, size_t* n_slots, const uint32_t** unit_of, uint32_t* segments_per_row)
 {
     if (c) GEVC(check_dense(c, "plane_ptr"));
     GEVC(check_idx(c, pop, chr));
@@ -2328,9 +2329,10 @@ int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* row_stride_
     if (c->pop[pop].gen0) GEVC(materialize_order(c, pop));
     PopState& P = c->pop[pop];
     if (dptr) *dptr = P.st[chr].pool.p;
-    if (row_of_slot) *row_of_slot = P.st[chr].phys[P.pcur].as<u32>();
-    if (row_stride_bytes) *row_stride_bytes = P.cs[chr].stride;
-    if (n_rows) *n_rows = 2 * P.n_people;
+    if (unit_of) *unit_of = P.st[chr].phys[P.pcur].as<u32>();
+    if (unit_bytes) *unit_bytes = P.cs[chr].unit_bytes();
+    if (segments_per_row) *segments_per_row = P.cs[chr].nseg;
+    if (n_slots) *n_slots = 2 * P.n_people;
     return GEV_OK;
 }
 int gev_stream(gev_ctx* c, void** s) { if (!c || !s) return fail(GEV_EINVAL, "null"); *s = (void*)c->stream; return GEV_OK; }
@@ -2345,7 +2347,7 @@ int gev_set_overlap(gev_ctx* c, int on)
     if (c->overlap_mode >= 0) c->serialize = c->overlap_mode == 0; else { c->serialize = true; c->auto_gens = 0; c->auto_small_ms = c->auto_stitch_ms = 0; }
     return GEV_OK;
 }
-int gev_set_stitch_mode(gev_ctx* c, int mode) { if (!c || mode < 0 || mode > 2) return fail(GEV_EINVAL, "stitch mode must be 0 (parent-major, region form), 1 (gamete-major) or 2 (parent-major, per-chunk form)"); c->stitch_mode = mode; return GEV_OK; }
+int gev_set_stitch_mode(gev_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return fail(GEV_EINVAL, "stitch mode must be 0 (work list of the segments to write) or 1 (gamete-major)"); c->stitch_mode = mode; return GEV_OK; }
 
 // ---- diagnostics (tests only; no simulation state involved) --------------------------------
 __global__ void __launch_bounds__(64) k_dbg_rand(const GevRngTables* __restrict__ T, u32 seed, u32 n, int* __restrict__ out)
@@ -2399,7 +2401,7 @@ int gev_dbg_verify_planes(gev_ctx* c, int pop, int chr, const uint64_t* founder_
     GEVC(c->d_flag.ensure(16, st));
     HIPC(hipMemsetAsync(c->d_flag.p, 0, 16, st));
     hipLaunchKernelGGL(k_verify_plane, dim3((unsigned)ceil_div(rows * words, 256)), dim3(256), 0, st, cs.poff[P.cur].as<u32>(), cs.parts[P.cur].as<gev_part>(), rows,
-                       S.d_pos.as<u64>(), (u32)S.L, cs.pool.as<u32>(), cs.phys[P.pcur].as<u32>(), S.stride / 4, c->d_thr32.as<u32>(), c->d_map.as<u64>(), np, c->d_map.as<u64>() + np,
+                       S.d_pos.as<u64>(), (u32)S.L, row_map(P, chr), c->d_thr32.as<u32>(), c->d_map.as<u64>(), np, c->d_map.as<u64>() + np,
                        (unsigned long long*)c->d_flag.p);
     KCHECK();
     unsigned long long h[2] = {0, 0};

@@ -89,9 +89,10 @@ const char* gev_version(void);
 /* device < 0: use the current HIP device.
  * Environment read here (tuning / cross-check knobs; none changes a result):
  *   GEV_OVERLAP=0|1|2|-1        stream overlap mode (gev_set_overlap)
- *   GEV_ALIAS_ROWS=0            copy every gamete row (default 1: a gamete without a crossover shares its parent's row)
- *   GEV_STITCH_WG_PER_CU=n|auto dense-stitch workgroups per CU (default: 6 on rows >= 64 KiB, else 8; auto = measured at run time)
- *   GEV_STITCH_MODE=0|1|2       stitch kernel (gev_set_stitch_mode)
+ *   GEV_ALIAS_ROWS=0            write every segment of every gamete row (default 1: a segment without a crossover boundary shares the parental unit)
+ *   GEV_STITCH_WG_PER_CU=n|auto dense-stitch workgroups per CU (default: unlimited; auto = measured at run time)
+ *   GEV_SEG_CHUNKS=2^k          16-byte chunks per row segment (default 1024 = 16 KiB; small values exercise many segments on small rows)
+ *   GEV_STITCH_MODE=0|1         stitch kernel (gev_set_stitch_mode)
  *   GEV_STITCH_LDS_PAD=bytes    (experiments) dynamic LDS padding of the stitch workgroups, overriding the one derived from WG_PER_CU
  *   GEV_SAMPLE_BATCHED=0        one sampling task per wave (the round-1 kernels) instead of eight
  *   GEV_LIST_LONG=n             average list entries per row from which the list fill kernels put 8 lanes on a row (default 20)
@@ -274,14 +275,16 @@ int gev_download_mutations(gev_ctx*, int pop, int chr, uint64_t* out, uint64_t* 
 /* ---- introspection ------------------------------------------------------------------------ */
 int gev_pop_size(gev_ctx*, int pop, size_t* n_people);
 /* The resident genotype rows of the current generation (founder alleles only: mutations are kept as a sparse overlay, see
- * DESIGN.md): haplotype slot s = 2*individual + chromatid is the row_stride_bytes bytes at dptr + row_of_slot[s] * row_stride_bytes
- * (device pointers).  Rows live in a pool; a gamete without a crossover shares its parent's row, so several slots can name
- * the same row.  Valid until the next call that changes the population. */
-int gev_plane_ptr(gev_ctx*, int pop, int chr, void** dptr, size_t* row_stride_bytes, size_t* n_rows, const uint32_t** row_of_slot);
-/* Haplotype rows the dense stitch wrote and rows of the generations produced, summed over all gev_reproduce calls and active
- * chromosomes of the context.  The difference is the number of crossover-free gametes (Simulation::recombine returns the
- * parental Hap unchanged for them, src/Simulation.cpp:2910; here the slot points at the parent's row). */
-int gev_stitch_totals(gev_ctx*, unsigned long long* rows_written, unsigned long long* rows_total);
+ * DESIGN.md).  A row is kept as segments_per_row segments of unit_bytes bytes; segment g of haplotype slot s = 2*individual +
+ * chromatid is the unit_bytes bytes at dptr + unit_of[s * segments_per_row + g] * unit_bytes (device pointers; the last segment of
+ * a row is used up to the row's length).  A segment without a crossover boundary shares the parental unit, so several entries can
+ * name the same unit.  Valid until the next call that changes the population. */
+int gev_plane_ptr(gev_ctx*, int pop, int chr, void** dptr, size_t* unit_bytes, size_t* n_slots, const uint32_t** unit_of, uint32_t* segments_per_row);
+/* Bytes the dense stitch wrote and bytes of the rows of the generations produced, summed over all gev_reproduce calls and active
+ * chromosomes of the context, and the same in row segments (the last two may be NULL).  The difference: segments that contain no
+ * crossover boundary -- Simulation::recombine copies the parental parts unchanged there (src/Simulation.cpp:2939-2946, :2910) --
+ * name the parent's unit instead of being copied. */
+int gev_stitch_totals(gev_ctx*, unsigned long long* bytes_written, unsigned long long* bytes_total, unsigned long long* segments_written, unsigned long long* segments_total);
 /* Locus-split population: mark the chromosomes whose genotype / CV / list state THIS context holds (default: all).
  * Inactive chromosomes still need gev_set_rmap / gev_set_mutmap (the rand() seed chain of Simulation::reproduce,
  * src/Simulation.cpp:2447-2501, runs through every (offspring, chromosome) task), nothing else; their A/D entries come back
@@ -312,8 +315,8 @@ int gev_last_reproduce_ms(gev_ctx*, float ms[4]);
 int gev_timing_totals(gev_ctx*, double ms_sum[4], unsigned long long* n_generations);
 /* enable/disable keeping the ancestry interval state on the device (default on) */
 int gev_set_track_intervals(gev_ctx*, int on);
-/* dense-stitch kernel: 0 = parent-major, region form k_stitch_regions (default), 1 = gamete-major k_stitch_rows, 2 = parent-major,
- * per-chunk form k_stitch_parent.  Same results; kept selectable for A/B measurement and parity cross-checks. */
+/* dense-stitch kernel: 0 = k_stitch_segments (default: one workgroup per entry of the list of segments to write), 1 = gamete-major
+ * k_stitch_rows (every output row finds its own segments and sources).  Same results; kept for parity cross-checks. */
 int gev_set_stitch_mode(gev_ctx*, int mode);
 
 /* ---- diagnostics: RNG building blocks exposed for the parity tests (no simulation state) ----

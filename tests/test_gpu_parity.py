@@ -142,10 +142,10 @@ def test_gpu_vs_oracle_task_parallel_mode(gpu_lib, oracle_lib):
     run_pair(gpu_lib, oracle_lib, cfg, n_gen=5, seed=2024)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1])
 def test_alternative_stitch_kernels_give_the_same_state(gpu_lib, oracle_lib, mode):
-    """the production stitch is k_stitch_regions (mode 0, every other test); the gamete-major (1) and per-chunk parent-major (2)
-    kernels are independent formulations of the same rule"""
+    """the production stitch is k_stitch_segments (mode 0, every other test: one workgroup per entry of the list of segments to
+    write); the gamete-major k_stitch_rows (1) finds its segments and sources itself -- an independent formulation of the same rule"""
     cfg = SyntheticConfig(300, 5000, nchr=2, chrom_bp=2_000_000, map_step=1000, rec_per_row=5e-3, mut_per_row=5e-3, n_cv=100, seed=12)
     run_pair(gpu_lib, oracle_lib, cfg, n_gen=3, seed=31, stitch_mode=mode)
     # many boundaries per row and > 256 boundaries for single gametes (the LDS list of the parent-major kernels overflows)
@@ -174,13 +174,16 @@ def test_list_fill_kernels_thread_per_row_and_eight_lanes_per_row(gpu_lib, oracl
     run_pair(gpu_lib, oracle_lib, cfg, n_gen=12, seed=64, check_every=3)
 
 
-@pytest.mark.parametrize("mode,alias", [(0, 1), (1, 1), (2, 1), (0, 0)])
-def test_crossover_free_gametes_share_the_parental_row(gpu_lib, oracle_lib, monkeypatch, mode, alias):
-    """Cold maps: ~0.3 crossovers per gamete, so most offspring haplotypes are a parent's haplotype unchanged
-    (Simulation::recombine returns the parental Hap, src/Simulation.cpp:2910).  The library then points the offspring slot at the
-    parent's pool row and copies nothing; after several generations rows are shared along chains of ancestors.  Everything
-    observable must equal the oracle in all three stitch kernels, and equal the run that copies every row (GEV_ALIAS_ROWS=0)."""
-    monkeypatch.setenv("GEV_ALIAS_ROWS", str(alias))
+@pytest.mark.parametrize("mode,alias,seg_chunks", [(0, 1, 16), (1, 1, 16), (0, 0, 16), (1, 0, 64), (0, 1, 1024), (0, 1, 4)])
+def test_segments_without_a_crossover_share_the_parental_unit(gpu_lib, oracle_lib, monkeypatch, mode, alias, seg_chunks):
+    """Cold maps: ~0.3 crossovers per gamete.  A row is kept as segments; in a segment that contains none of its boundaries an
+    offspring gamete is one parental haplotype unchanged (Simulation::recombine copies the parent's parts between two crossovers,
+    src/Simulation.cpp:2939-2946, and returns the parental Hap when there is none, :2910), so the offspring's table entry names
+    the parent's unit and nothing is copied; after several generations units are shared along chains of ancestors.  Everything
+    observable must equal the oracle in both stitch kernels, for tiny segments (16 chunks = 2048 loci: 15 segments per row, many
+    boundaries on segment edges), whole-row segments and 64-byte segments (60 per row, the 64-segment limit), and equal the run that writes every segment
+    (GEV_ALIAS_ROWS=0)."""
+    monkeypatch.setenv("GEV_ALIAS_ROWS", str(alias)); monkeypatch.setenv("GEV_SEG_CHUNKS", str(seg_chunks))
     cfg = SyntheticConfig(400, 30000, nchr=3, chrom_bp=3_000_000, map_step=1000, rec_per_row=1e-4, mut_per_row=3e-4, n_cv=120, nphen=2, seed=41, vd=0.3)
     g = gpu_lib.create(1, cfg.nchr, cfg.nphen); g.set_stitch_mode(mode)
     o = oracle_lib.create(1, cfg.nchr, cfg.nphen)
@@ -198,24 +201,25 @@ def test_crossover_free_gametes_share_the_parental_row(gpu_lib, oracle_lib, monk
     for gen, n in enumerate(sizes, 1):
         couples = synthetic_random_mate(sg.sex[0], n, rng)
         sg.couples[0] = couples; so.couples[0] = couples
-        before = [_read_device_u32(g.plane_ptr(0, c)[3], g.plane_ptr(0, c)[2]) for c in range(cfg.nchr)]
-        w0, t0 = g.stitch_totals()
+        before = []
+        for c in range(cfg.nchr):
+            _, _, n_slots, tab, nseg = g.plane_ptr(0, c)
+            before.append(_read_device_u32(tab, n_slots * nseg))
+        _, _, sw0, st0 = g.stitch_totals()
         assert np.array_equal(sg.reproduce(0, gen, n_people=n), so.reproduce(0, gen, n_people=n)), f"sex differs at generation {gen}"
-        w1, t1 = g.stitch_totals()
-        assert t1 - t0 == 2 * n * cfg.nchr
+        bw1, bt1, sw1, st1 = g.stitch_totals()
         ag = sg.ras_compute_AD(0, gen, per_chr=True); ao = so.ras_compute_AD(0, gen, per_chr=True)
         for x, y in zip(ag, ao):
             assert helpers.bits_equal(x, y), f"A/D not bit-identical at generation {gen}"
-        n_shared = 0
+        n_shared = n_units = 0
         for c in range(cfg.nchr):
-            _, stride, n_slots, tab = g.plane_ptr(0, c)
-            assert n_slots == 2 * n
-            after = _read_device_u32(tab, n_slots)
+            _, unit_bytes, n_slots, tab, nseg = g.plane_ptr(0, c)
+            assert n_slots == 2 * n and unit_bytes == 16 * seg_chunks and nseg == -(-3840 // unit_bytes)      # rows of 30000 bits = 3840 bytes
+            after = _read_device_u32(tab, n_slots * nseg)
             inherited = np.isin(after, before[c])
             fresh = after[~inherited]
-            assert len(np.unique(fresh)) == len(fresh), "two copied gametes were given the same pool row"
-            n_shared += int(inherited.sum())
-            # a slot that names a parental row is exactly a gamete without crossover: its interval list is the parent's list
+            assert len(np.unique(fresh)) == len(fresh), "two written segments were given the same pool unit"
+            n_shared += int(inherited.sum()); n_units += len(after)
             assert np.array_equal(g.download_haps(0, c), o.download_haps(0, c)), f"dense genotypes differ (gen {gen} chr {c})"
             pg, og = g.download_intervals(0, c); po, oo = o.download_intervals(0, c)
             assert np.array_equal(og, oo) and np.array_equal(pg, po)
@@ -223,11 +227,13 @@ def test_crossover_free_gametes_share_the_parental_row(gpu_lib, oracle_lib, monk
             assert np.array_equal(mog, moo) and np.array_equal(mg, mo)
             for ph in range(cfg.nphen):
                 assert np.array_equal(g.download_cv(0, ph, c), o.download_cv(0, ph, c))
-        assert (t1 - t0) - (w1 - w0) == n_shared, "rows reported as not copied != slots that name a parental row"
+        assert st1 - st0 == n_units
+        assert (st1 - st0) - (sw1 - sw0) == n_shared, "segments reported as not written != table entries that name a parental unit"
         if alias:
-            assert n_shared > 0.5 * 2 * n * cfg.nchr, "expected most gametes to be crossover-free with this map"
+            assert n_shared > 0.5 * n_units, "expected most segments to be boundary-free with this map"
         else:
             assert n_shared == 0
+    assert 0 < bw1 <= bt1
     assert g.dbg_verify_planes(0, 1, [cfg.seed + 1]) == (0, 0)
     g.close(); o.close()
 
@@ -255,7 +261,8 @@ def test_population_without_any_crossover(gpu_lib, oracle_lib):
     for gen in range(1, 4):
         sg.couples[0] = synthetic_random_mate(sg.sex[0], cfg.n_ind, rng)
         sg.reproduce(0, gen)
-    assert g.stitch_totals() == (0, 3 * 2 * cfg.n_ind * cfg.nchr)
+    bw, bt, sw, st = g.stitch_totals()
+    assert (bw, sw) == (0, 0) and st == 3 * 2 * cfg.n_ind * cfg.nchr and bt == st * 1280          # one 1280-byte segment per row of 10000 loci
     g.close()
 
 
@@ -465,8 +472,8 @@ def test_three_hundred_generations_of_shared_rows_dense_state_equals_interval_st
         sim.reproduce(0, gen, n_people=n)
         if gen % 100 == 0:
             assert g.dbg_verify_planes(0, 0, 8001) == (0, 0), f"dense state != interval state after {gen} generations"
-    copied, total = g.stitch_totals()
-    assert 0.55 < copied / total < 0.70                                   # e^-1 of the gametes have no crossover at one Morgan
+    copied, total, _, _ = g.stitch_totals()
+    assert 0.30 < copied / total < 0.50                                   # two 16 KiB segments per row, half a Morgan each: 1 - e^-0.5 = 0.39 of them hold a boundary
     parts, off = g.download_intervals(0, 0)
     muts, moff = g.download_mutations(0, 0)
     assert len(off) == 2 * n + 1 and off[-1] == len(parts) and moff[-1] == len(muts)

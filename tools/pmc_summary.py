@@ -49,7 +49,8 @@ def main():
     res = OrderedDict()
     res["FETCH_SIZE"] = per_kernel(fetch_dir, "FETCH_SIZE")
     res["WRITE_SIZE"] = per_kernel(write_dir, "WRITE_SIZE")
-    stitch = [k for k in res["FETCH_SIZE"] if "k_stitch_regions" in k] or [k for k in res["FETCH_SIZE"] if "k_stitch_parent" in k]
+    stitch = ([k for k in res["FETCH_SIZE"] if "k_stitch_segments" in k] or [k for k in res["FETCH_SIZE"] if "k_stitch_regions" in k]
+              or [k for k in res["FETCH_SIZE"] if "k_stitch_parent" in k])
     if stitch:
         k = stitch[0]
         fetch = res["FETCH_SIZE"][k]["avg_KiB"] * 1024.0
