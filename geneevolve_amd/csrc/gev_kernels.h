@@ -616,19 +616,22 @@ __global__ void __launch_bounds__(256) k_bk_to_idx(const ChrDev* __restrict__ ch
     const u32 k = sd.k[G], off = sd.bk_off[G];
     for (u32 m = 0; m < k; m++) sd.bk_idx[off + m] = lower_bound_u64(C.snp_pos, C.L, sd.bk[off + m]);
 }
-// K5, production form: one workgroup per entry of the work list k_pool_assign wrote (one written segment of one gamete),
-// persistent grid.  The boundaries inside the segment (usually one) are staged in LDS; a chunk before / behind / between them is
-// a plain 16-byte copy from ONE parental unit, the chunk that contains one is blended by mask.  Four chunks per thread in flight.
-#define SEG_KMAX 128         // boundaries of one gamete inside one segment held in LDS; more are read from global memory
+// K5, production form: one WAVE per entry of the work list k_pool_assign wrote (one written segment of one gamete), persistent
+// grid.  The entry's descriptors (gamete, parent, the boundaries inside the segment -- usually one) are wave-uniform: the wave
+// index is made scalar so they come through the scalar cache, and up to eight inside boundaries sit in registers.  A chunk
+// before / behind / between them is a plain 16-byte copy from ONE parental unit, the chunk that contains one is blended by mask;
+// four chunks per lane in flight, 4 KiB per wave and step.  Thousands of entries are in flight per chip (8 waves per SIMD), which
+// is what hides the five dependent descriptor loads in front of every 16 KiB copy.
+#define SEG_KREG 8           // boundaries of one gamete inside one segment held in registers; more are read from global memory
 template <bool NT>
 __global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restrict__ Wt, int nchr, SampleDev sd)
 {
-    __shared__ u32 s_in[SEG_KMAX];
     const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
     const u32 S = pw.nseg, sh = pw.seg_shift, SC = 1u << sh;
     const u32 n_items = pw.items[pw.items_cap];
-    for (u32 it = blockIdx.x; it < n_items; it += gridDim.x) {
-        __syncthreads();                                    // LDS of the previous item consumed
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    for (u32 it = wave0; it < n_items; it += gridDim.x * 4u) {
         const u32 e = pw.items[it];
         const u32 row = e / S, g = e - row * S;
         const u32 i = row >> 1, s = row & 1u;
@@ -639,37 +642,57 @@ __global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restri
         const u32 q0 = g << sh, nq = min(SC, w.chunks - q0);
         const u32 bit_lo = q0 << 7, bit_hi = (q0 + nq) << 7;
         const u32 m0 = count_le_u32(idx, k, bit_lo);        // boundaries at or before the segment's first locus
-        const u32 m1 = bit_hi ? count_le_u32(idx, k, bit_hi - 1u) : 0u;
+        const u32 m1 = count_le_u32(idx, k, bit_hi - 1u);
         const u32 nin = m1 - m0;                            // boundaries inside
-        const bool in_lds = nin <= SEG_KMAX;
-        if (in_lds) for (u32 m = threadIdx.x; m < nin; m += 256) s_in[m] = idx[m0 + m];
-        __syncthreads();
-        const u32* in = in_lds ? s_in : idx + m0;
         const v4u* __restrict__ R0 = (const v4u*)(pw.pool + ((size_t)pw.phys_cur[(2 * (size_t)parent) * S + g] << (sh + 4)));
         const v4u* __restrict__ R1 = (const v4u*)(pw.pool + ((size_t)pw.phys_cur[(2 * (size_t)parent + 1) * S + g] << (sh + 4)));
         v4u* __restrict__ D = (v4u*)(pw.pool + ((size_t)pw.phys_alt[(size_t)row * S + g] << (sh + 4)));
         const u32 sel0 = (start ^ m0) & 1u;
-        for (u32 q = threadIdx.x; q < nq; q += 256 * 4) {
-            v4u a[4], b[4]; u32 c[4]; bool mixed[4];
+        if (nin <= SEG_KREG) {
+            u32 in[SEG_KREG];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const u32 qq = q + u * 256;
-                c[u] = 0; mixed[u] = false;
-                if (qq >= nq) continue;
-                const u32 bit0 = bit_lo + (qq << 7);
-                c[u] = count_le_u32(in, nin, bit0);
-                mixed[u] = c[u] < nin && in[c[u]] < bit0 + 128u;
-                const u32 sel = (sel0 ^ c[u]) & 1u;
-                if (mixed[u] || sel == 0u) a[u] = NT ? __builtin_nontemporal_load(&R0[qq]) : R0[qq];
-                if (mixed[u] || sel == 1u) b[u] = NT ? __builtin_nontemporal_load(&R1[qq]) : R1[qq];
+            for (int m = 0; m < SEG_KREG; m++) in[m] = (u32)m < nin ? idx[m0 + m] : 0xffffffffu;
+            for (u32 q = lane; q < nq; q += 64 * 4) {
+                v4u a[4], b[4]; u32 c[4]; bool mixed[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const u32 qq = q + u * 64;
+                    c[u] = 0; mixed[u] = false;
+                    if (qq >= nq) continue;
+                    const u32 bit0 = bit_lo + (qq << 7);
+                    u32 cc = 0; bool mx = false;
+#pragma unroll
+                    for (int m = 0; m < SEG_KREG; m++) { cc += (in[m] <= bit0); mx |= (in[m] > bit0 && in[m] < bit0 + 128u); }
+                    c[u] = cc; mixed[u] = mx;
+                    const u32 sel = (sel0 ^ cc) & 1u;
+                    if (mx || sel == 0u) a[u] = NT ? __builtin_nontemporal_load(&R0[qq]) : R0[qq];
+                    if (mx || sel == 1u) b[u] = NT ? __builtin_nontemporal_load(&R1[qq]) : R1[qq];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const u32 qq = q + u * 64;
+                    if (qq >= nq) continue;
+                    const u32 sel = (sel0 ^ c[u]) & 1u;
+                    v4u o;
+                    if (!mixed[u]) o = sel ? b[u] : a[u];
+                    else {
+                        const u32 bit0 = bit_lo + (qq << 7);
+                        v4u mask = sel ? (v4u)(0xffffffffu) : (v4u)(0u);       // 1 = take row 1
+#pragma unroll
+                        for (int m = 0; m < SEG_KREG; m++) if (in[m] > bit0 && in[m] < bit0 + 128u) mask ^= mask_from(in[m] - bit0);
+                        o = (a[u] & ~mask) | (b[u] & mask);
+                    }
+                    if (NT) __builtin_nontemporal_store(o, &D[qq]); else D[qq] = o;
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const u32 qq = q + u * 256;
-                if (qq >= nq) continue;
-                const u32 sel = (sel0 ^ c[u]) & 1u;
-                const v4u o = mixed[u] ? blend_chunk(a[u], b[u], sel, in, c[u], nin, bit_lo + (qq << 7)) : (sel ? b[u] : a[u]);
-                if (NT) __builtin_nontemporal_store(o, &D[qq]); else D[qq] = o;
+        } else {
+            const u32* in = idx + m0;                       // many boundaries in one segment (hot maps): bisection on the global list
+            for (u32 qq = lane; qq < nq; qq += 64) {
+                const u32 bit0 = bit_lo + (qq << 7);
+                const u32 c = count_le_u32(in, nin, bit0);
+                const u32 sel = (sel0 ^ c) & 1u;
+                const bool mx = c < nin && in[c] < bit0 + 128u;
+                D[qq] = mx ? blend_chunk(R0[qq], R1[qq], sel, in, c, nin, bit0) : (sel ? R1[qq] : R0[qq]);
             }
         }
     }
