@@ -63,7 +63,7 @@ struct SampleDev {
 // Every per-chromosome kernel of a generation is ONE launch whose blockIdx.y (or .z) selects the entry, instead of one launch
 // per chromosome (a 22-chromosome genome used to cost ~300 launches per generation).
 // Genotype rows live in ONE pool of SEGMENTS per (population, chromosome).  A haplotype row (slot s = 2*individual + chromatid)
-// is cut into nseg segments of 2^seg_shift 16-byte chunks (16 KiB by default); segment g of slot s is pool unit
+// is cut into nseg segments of 2^seg_shift 16-byte chunks (8 KiB by default); segment g of slot s is pool unit
 // phys[s * nseg + g].  In a segment that contains none of its crossover boundaries an offspring gamete IS one parental haplotype
 // (Simulation::recombine copies the parent's parts unchanged between two crossovers, src/Simulation.cpp:2939-2946; without any
 // crossover it returns the parental Hap itself, :2910): that segment of the offspring slot then names the parent's unit and no
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict
 // between two boundaries it IS one parental row.  Rows are stored as segments (PoolWork): a segment
 // without a boundary is not copied at all -- the offspring's table entry names the parent's unit
 // (k_pool_assign) -- and the stitch writes only the segments that contain a boundary: about one
-// 16 KiB segment per crossover instead of the whole row.  Per unit of work (one written segment):
+// 8 KiB segment per crossover instead of the whole row.  Per unit of work (one written segment):
 // segment bytes read + segment bytes written.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 lower_bound_u64(const u64* __restrict__ a, u32 n, u64 v)   // #{a[i] < v}
@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(256) k_iota_u32(u32* __restrict__ a, size_t n)
 // first locus index at or behind the breakpoint; its 16-byte chunk decides the segment)?  Those get a free unit and an entry
 // in the stitch's work list; every other segment names the unit of the parental haplotype that is being copied there:
 // start ^ parity(#boundaries at or before the segment's first locus).  One atomic per block of 256 rows.
-#define POOL_SEG_MAX 64          // segments per row handled with a 64-bit flag word (16 KiB segments: rows up to 1 MiB = 8M loci); longer rows use larger segments
+#define POOL_SEG_MAX 64          // segments per row handled with a 64-bit flag word (8 KiB segments: rows up to 512 KiB = 4M loci); longer rows use larger segments
 __global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd)
 {
     __shared__ u32 s_scan[8], s_base, s_last;

@@ -16,7 +16,7 @@
 //   GEV_LIST_LONG=n           average list entries per row from which the list fill kernels put eight lanes on a row (default 20)
 //   GEV_STITCH_PRIORITY=1|2   stitch stream high / all streams equal (default: small streams high, stitch low)
 //   GEV_STITCH_GRID=n         persistent workgroups of the segment stitch per chromosome (default 16384)
-//   GEV_SEG_CHUNKS=2^k        16-byte chunks per row segment (default 1024 = 16 KiB)
+//   GEV_SEG_CHUNKS=2^k        16-byte chunks per row segment (default 512 = 8 KiB)
 //   GEV_STITCH_WAVE_PRIO=0..3 s_setprio level of the stitch kernel's waves (default 0; measured: no effect next to the sampling kernels)
 //   GEV_TABLE_RING_BYTES=n    minimum size of the pinned ring the per-generation work tables are staged in (default 256 KiB)
 //   GEV_TRACE_HOST=1          stderr: host time per phase of gev_reproduce, allocations, deferred frees
@@ -122,7 +122,7 @@ struct ChrStatic {                       // one population x one chromosome
     std::vector<u64> pos;                // Legend.pos
     DevBuf d_rthr, d_rbp, d_mthr, d_mbp, d_pos;
     size_t L = 0, stride = 0;            // bytes of a whole genotype row in flat (host-side / staging) layouts, multiple of 128
-    u32 nseg = 1, seg_shift = 10;        // the device keeps a row as nseg segments of 2^seg_shift 16-byte chunks (gev_kernels.h, PoolWork)
+    u32 nseg = 1, seg_shift = 9;         // the device keeps a row as nseg segments of 2^seg_shift 16-byte chunks (gev_kernels.h, PoolWork)
     size_t unit_bytes() const { return (size_t)16 << seg_shift; }
     size_t pitch() const { return (size_t)nseg * unit_bytes(); }      // founder rows: row r = units r*nseg .. r*nseg+nseg-1 = a flat row of this pitch
     u32 idx_lo = 0, idx_hi = 0;          // loci inside [bp0, bp_end)
@@ -212,7 +212,8 @@ struct gev_ctx {
     size_t stitch_grid = 16384;    // persistent workgroups of the segment stitch per chromosome (GEV_STITCH_GRID)
     int stitch_wave_prio = 0;      // s_setprio level of the stitch kernel's waves (GEV_STITCH_WAVE_PRIO)
     size_t list_long = LIST_LONG;  // average list entries per row from which the list fill kernels use LIST_LANES lanes per row (GEV_LIST_LONG)
-    u32 seg_shift = 10;            // log2(16-byte chunks per row segment): 16 KiB (GEV_SEG_CHUNKS=<power of two> for tests / experiments)
+    u32 seg_shift = 9;             // log2(16-byte chunks per row segment): 8 KiB -- sweep at config 2 / the config-4 shard: 256 chunks 370 / 72, 512: 457 / 72, 1024: 450 / 58,
+                                   // 2048: 375 generations/s (smaller: more table entries to manage; larger: more bytes copied per crossover); GEV_SEG_CHUNKS=<power of two>
     bool alias_rows = true;        // crossover-free gametes share their parent's pool row instead of copying it (GEV_ALIAS_ROWS=0: copy every row)
     unsigned long long chunks_written_sum = 0, chunks_total_sum = 0, segments_written_sum = 0, segments_total_sum = 0;   // over all generations and active chromosomes (gev_stitch_totals)
     // Stitch workgroups per CU (8 = every wave slot).  The hardware queue priority does not let the small kernels of the next

@@ -91,7 +91,7 @@ const char* gev_version(void);
  *   GEV_OVERLAP=0|1|2|-1        stream overlap mode (gev_set_overlap)
  *   GEV_ALIAS_ROWS=0            write every segment of every gamete row (default 1: a segment without a crossover boundary shares the parental unit)
  *   GEV_STITCH_WG_PER_CU=n|auto dense-stitch workgroups per CU (default: unlimited; auto = measured at run time)
- *   GEV_SEG_CHUNKS=2^k          16-byte chunks per row segment (default 1024 = 16 KiB; small values exercise many segments on small rows)
+ *   GEV_SEG_CHUNKS=2^k          16-byte chunks per row segment (default 512 = 8 KiB; small values exercise many segments on small rows)
  *   GEV_STITCH_MODE=0|1         stitch kernel (gev_set_stitch_mode)
  *   GEV_STITCH_LDS_PAD=bytes    (experiments) dynamic LDS padding of the stitch workgroups, overriding the one derived from WG_PER_CU
  *   GEV_SAMPLE_BATCHED=0        one sampling task per wave (the round-1 kernels) instead of eight

@@ -473,7 +473,7 @@ def test_three_hundred_generations_of_shared_rows_dense_state_equals_interval_st
         if gen % 100 == 0:
             assert g.dbg_verify_planes(0, 0, 8001) == (0, 0), f"dense state != interval state after {gen} generations"
     copied, total, _, _ = g.stitch_totals()
-    assert 0.30 < copied / total < 0.50                                   # two 16 KiB segments per row, half a Morgan each: 1 - e^-0.5 = 0.39 of them hold a boundary
+    assert 0.15 < copied / total < 0.30                                   # four 8 KiB segments per row, a quarter of a Morgan each: 1 - e^-0.25 = 0.22 of them hold a boundary
     parts, off = g.download_intervals(0, 0)
     muts, moff = g.download_mutations(0, 0)
     assert len(off) == 2 * n + 1 and off[-1] == len(parts) and moff[-1] == len(muts)
