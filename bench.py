@@ -191,6 +191,7 @@ def main():
                     help="N>1 only: fraction of each population that moves to EACH other population every generation "
                          "(BASELINE config 3 uses 0.01); rows travel by all_to_all over RCCL")
     ap.add_argument("--spawn", action="store_true", help="go through the worker launcher even for --gpus 1 (checks that the launcher costs nothing)")
+    ap.add_argument("--no-pipeline", action="store_true", help="mate, then gev_reproduce, strictly one after the other (default: the host forms the next couples between gev_reproduce_begin and _end)")
     ap.add_argument("--isolated-steps", type=int, default=3, help="extra untimed generations without stream overlap for roofline.isolated")
     args = ap.parse_args()
 
@@ -266,7 +267,40 @@ def main():
         v = sim.ras_glob_seed(n_seeds)
         return v, (time.perf_counter() - ts) * 1e3
 
+    # Pipelined host loop (default): the sexes of a generation come out of the sampling kernels' rand() chain, which the head start
+    # (gev_presample) has already run when the generation is handed over, and random mating reads nothing else -- so the host forms
+    # the NEXT generation's couples between gev_reproduce_begin and gev_reproduce_end, while the device builds lists, CV planes,
+    # genotype rows and A/D of this one.  --no-pipeline: mate, then gev_reproduce, one after the other.
+    pipeline = presample and not migrate and not args.no_pipeline
+    state = {}
+
+    def step_pipelined(i):
+        t0 = time.perf_counter()
+        if "couples" not in state:                               # first step: the head start and the first couples
+            sim.presample(P, seeds[i], args.n_ind)
+            state["couples"] = synthetic_random_mate(sim.sex[P], args.n_ind, rng)
+            seeds[i + 1] = sim.ras_glob_seed(n_seeds)
+        sd = seeds.pop(i)
+        sex_new = ctx.presample_sex(P, args.n_ind)              # this generation's sexes: its sampling ran during the previous step
+        ctx.reproduce_begin(P, state["couples"], int(sd[0]), sd[1:], n_people=args.n_ind)   # Simulation::reproduce, first half
+        sim.presample(P, seeds[i + 1], args.n_ind)               # head start of the next generation, queued behind this one's lists and A/D
+        fut = seed_pool.submit(timed_draw)                       # one generation's worth of ras_glob_seed() draws per step, second host thread
+        t1 = time.perf_counter()
+        state["couples"] = synthetic_random_mate(sex_new, args.n_ind, rng, out=state["couples"])    # host mating of the NEXT generation
+        t2 = time.perf_counter()
+        ctx.reproduce_end(want_sex=False)                        # ... second half (the sexes are sex_new)
+        sim.sex[P] = sex_new
+        sim.last_seed_reproduce = int(sd[0])
+        t3 = time.perf_counter()
+        sim.ras_compute_AD(P, i + 1)                             # Simulation::ras_compute_AD
+        seeds[i + 2], dms = fut.result()
+        seed_ms.append(dms)
+        t4 = time.perf_counter()
+        mate_ms.append((t2 - t1) * 1e3); repro_ms.append((t1 - t0 + t3 - t2) * 1e3); ad_ms.append((t4 - t3) * 1e3); step_ms.append((t4 - t0) * 1e3)
+
     def step(i):
+        if pipeline:
+            return step_pipelined(i)
         t0 = time.perf_counter()
         sim.couples[P] = synthetic_random_mate(sim.sex[P], args.n_ind, rng, out=sim.couples.get(P))   # host mating (outside the hot path)
         t1 = time.perf_counter()
@@ -330,7 +364,7 @@ def main():
         ta, na = ctx.timing_totals()
         for j in range(args.isolated_steps):
             sim.couples[P] = synthetic_random_mate(sim.sex[P], args.n_ind, rng, out=sim.couples.get(P))
-            sim.reproduce(P, total + j + 1, seeds=seeds.pop(total) if j == 0 else sim.ras_glob_seed(n_seeds), n_people=args.n_ind)
+            sim.reproduce(P, total + j + 1, seeds=seeds.pop(total + j) if (total + j) in seeds else sim.ras_glob_seed(n_seeds), n_people=args.n_ind)
         tb, nb = ctx.timing_totals()
         iso = (tb[1] - ta[1]) / max(nb - na, 1)
         ctx.set_overlap(True)
@@ -376,7 +410,8 @@ def main():
                        "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_chromosomes": args.nchr, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
                        "interval_state_tracked": not args.no_intervals, "resident_genotype_planes": not args.plane_less,
                        "seeds_handed_over_before_couples": presample,
-                       "ras_glob_seed_draws": "inside the timed loop, one generation's worth per step, by a second host thread while the first waits in gev_reproduce (phase_ms.host_seed_draws)"},
+                       "host_mating_overlaps_device_work": pipeline,
+                       "ras_glob_seed_draws": "inside the timed loop, one generation's worth per step, by a second host thread (phase_ms.host_seed_draws)"},
             "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci * args.nchr / dt,
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
                          "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "host_seed_draws": float(np.mean(seed_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "upload_founders", "upload_cv_founders", "synth_founders", "synth_cv_founders", "init_gen0",
     "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "set_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
-    "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "stitch_totals", "set_overlap",
+    "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "stitch_totals", "reproduce_begin", "reproduce_end", "presample_sex", "set_overlap",
     "dbg_verify_planes", "dbg_prefilter_sweep", "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -201,6 +201,29 @@ class GevContext:
         sex = np.zeros(n_people, dtype=np.uint8) if want_sex else None
         self._call("reproduce", C.c_int(pop), _p(couples), C.c_size_t(len(couples)), C.c_uint32(int(seed_reproduce)),
                    _p(ms), C.c_size_t(0 if ms is None else len(ms)), C.c_size_t(n_people), _p(sex))
+        return sex
+
+    def reproduce_begin(self, pop, couples, seed_reproduce, mut_seeds=None, n_people=None):
+        """first half of reproduce(): stage the inputs and enqueue the generation's device work (returns without waiting)"""
+        couples = np.ascontiguousarray(couples)
+        assert couples.dtype == COUPLE_DTYPE
+        if n_people is None:
+            n_people = int(couples["num_offspring"][couples["inbreed"] == 0].sum())
+        ms = None if mut_seeds is None else _arr(mut_seeds, np.uint32)
+        self._call("reproduce_begin", C.c_int(pop), _p(couples), C.c_size_t(len(couples)), C.c_uint32(int(seed_reproduce)),
+                   _p(ms), C.c_size_t(0 if ms is None else len(ms)), C.c_size_t(n_people))
+        self._pending_people = n_people
+
+    def reproduce_end(self, want_sex=True):
+        """second half: wait, redo with larger buffers if needed, publish the generation; returns the sexes"""
+        sex = np.zeros(self._pending_people, dtype=np.uint8) if want_sex else None
+        self._call("reproduce_end", _p(sex))
+        return sex
+
+    def presample_sex(self, pop, n_people):
+        """sexes of the generation whose sampling presample() has enqueued (waits for the sampling kernels only)"""
+        sex = np.zeros(n_people, dtype=np.uint8)
+        self._call("presample_sex", C.c_int(pop), _p(sex), C.c_size_t(n_people))
         return sex
 
     def presample(self, pop, seed_reproduce, mut_seeds, n_people):

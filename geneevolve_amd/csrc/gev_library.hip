@@ -169,7 +169,7 @@ struct PopState {
 struct gev_ctx {
     int device = 0, n_pop = 0, nchr = 0, nphen = 0;
     u32 rp_bits = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream_samp = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};
     bool track_intervals = true;
@@ -179,8 +179,8 @@ struct gev_ctx {
     // while sampling / sparse state of generation g+1 (stream) fill the other one
     struct Scratch {
         DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, status, slow_mut, slow_rec, chrwork, cvwork;
-        unsigned n_chrwork = 0;
-        hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        unsigned n_chrwork = 0; float sampling_ms_saved = -1;
+        hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_status = nullptr, ev_sampled = nullptr;   // the generation's status block (and A/D results) have arrived on the host
         bool timing_pending = false, stitch_pending = false;
         // gev_presample: the sampling kernels of the next gev_reproduce were already enqueued for exactly these inputs
         bool presampled = false; int ps_pop = -1; u32 ps_seed = 0; size_t ps_n_people = 0; bool ps_has_mut = false;
@@ -223,6 +223,7 @@ struct gev_ctx {
     // stitch dominates anyway (11 chromosomes of 227k SNPs: 8).  Default: by row length; GEV_STITCH_WG_PER_CU=<n> fixes it,
     // =auto measures it (a few generations per candidate, wall time between consecutive gev_reproduce returns).
     int stitch_occ = 0 /* 0 = by row length */, stitch_occ_env = 0; bool stitch_occ_auto = false;
+    struct PendingRepro { bool active = false, has_mut = false, pre = false; int pop = 0, attempt = 0; size_t n_people = 0, n_status = 0; u32 seed = 0; u32* hstatus = nullptr; double th0 = 0, th1 = 0, th2 = 0; } pend;
     struct OccTune { int phase = 0 /* 0 idle, 1 measuring, 2 settled */, idx = 0, n = 0, best_occ = 8; double last = 0, cur_min = 0, best = 0; size_t people = 0; unsigned age = 0; } tune;
     DevBuf d_snpmajor, d_text;
     DevBuf d_sex0, d_gef_flag, d_gef_first, d_gef_red, d_gef_io;
@@ -279,6 +280,7 @@ static int make_thresholds(gev_ctx* c, const std::vector<double>& p, std::vector
 static int check_idx(gev_ctx* c, int pop, int chr, int phen = 0)
 {
     if (!c) return fail(GEV_EINVAL, "null context");
+    if (c->pend.active) return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first");
     if (pop < 0 || pop >= c->n_pop) return fail(GEV_EINVAL, "population index %d out of range", pop);
     if (chr < 0 || chr >= c->nchr) return fail(GEV_EINVAL, "chromosome index %d out of range", chr);
     if (phen < 0 || phen >= c->nphen) return fail(GEV_EINVAL, "phenotype index %d out of range", phen);
@@ -353,6 +355,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
         if (atoi(e) == 1) std::swap(prio_least, prio_greatest); else if (atoi(e) == 2) prio_least = prio_greatest = (prio_least + prio_greatest) / 2;
     }
     HIPC(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
+    HIPC(hipStreamCreateWithPriority(&c->stream_samp, hipStreamNonBlocking, prio_greatest));
     for (auto& ev : c->ev) HIPC(hipEventCreate(&ev));
     HIPC(hipStreamCreateWithPriority(&c->stream_big, hipStreamNonBlocking, prio_least));
     HIPC(hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming));
@@ -360,6 +363,8 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     for (auto& sc : c->sc) {
         HIPC(hipEventCreateWithFlags(&sc.ev_small_done, hipEventDisableTiming));
         HIPC(hipEventCreateWithFlags(&sc.ev_stitch_done, hipEventDisableTiming));
+        HIPC(hipEventCreateWithFlags(&sc.ev_status, hipEventDisableTiming));
+        HIPC(hipEventCreateWithFlags(&sc.ev_sampled, hipEventDisableTiming));
         for (auto& e : sc.t) HIPC(hipEventCreate(&e));
     }
     c->pop.resize(n_pop);
@@ -396,10 +401,11 @@ void gev_destroy(gev_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     if (c->stream_big) { (void)hipStreamSynchronize(c->stream_big); (void)hipStreamDestroy(c->stream_big); }
+    if (c->stream_samp) { (void)hipStreamSynchronize(c->stream_samp); (void)hipStreamDestroy(c->stream_samp); }
     if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
-    for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
+    for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); if (sc.ev_status) (void)hipEventDestroy(sc.ev_status); if (sc.ev_sampled) (void)hipEventDestroy(sc.ev_sampled); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
     hipStream_t s = c->stream;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_seeds) (void)hipHostFree(c->h_seeds);
@@ -833,12 +839,23 @@ static int wait_planes(gev_ctx* c)
     if (c->planes_pending) HIPC(hipStreamWaitEvent(c->stream, c->ev_planes, 0));
     return GEV_OK;
 }
+// the sampling time of the set's previous generation, read before a head start records the sampling events again (never blocks:
+// that sampling is long over; the stitch of that generation may still run, its time is collected later by harvest_timing)
+static int harvest_sampling_time(gev_ctx::Scratch& sc)
+{
+    if (!sc.timing_pending || sc.sampling_ms_saved >= 0) return GEV_OK;
+    float t;
+    HIPC(hipEventElapsedTime(&t, sc.t[0], sc.t[1]));
+    sc.sampling_ms_saved = t;
+    return GEV_OK;
+}
 static int harvest_timing(gev_ctx* c, gev_ctx::Scratch& sc)
 {
     if (!sc.timing_pending) return GEV_OK;
     HIPC(hipEventSynchronize(sc.t[3]));
     float t; float ms[4];
-    HIPC(hipEventElapsedTime(&t, sc.t[0], sc.t[1])); ms[0] = t;
+    if (sc.sampling_ms_saved >= 0) { ms[0] = sc.sampling_ms_saved; sc.sampling_ms_saved = -1; }
+    else { HIPC(hipEventElapsedTime(&t, sc.t[0], sc.t[1])); ms[0] = t; }
     HIPC(hipEventElapsedTime(&t, sc.t[4], sc.t[3])); ms[1] = t;
     HIPC(hipEventElapsedTime(&t, sc.t[5], sc.t[2])); ms[2] = t;
     ms[3] = ms[0] + ms[1] + ms[2];
@@ -905,10 +922,9 @@ static int ensure_scratch(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, boo
     return GEV_OK;
 }
 // K1-K3: crossover / mutation sampling and the rand() seed chain; depends on the seeds and n_people only, not on the couples
-static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut, u32 seed_reproduce)
+static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut, u32 seed_reproduce, hipStream_t st)
 {
     PopState& P = c->pop[pop];
-    hipStream_t st = c->stream;
     const int nchr = c->nchr;
     const size_t T = n_people * (size_t)nchr;
     const GevRngTables* Tb = c->d_tables.as<GevRngTables>();
@@ -1106,8 +1122,31 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int /*pop*/, size_t 
     return GEV_OK;
 }
 
-int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_couples, uint32_t seed_reproduce,
-                  const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people, uint8_t* sex_out)
+// One attempt of a generation: sampling (unless the head start covers it), lists + CV planes + unit table, the dense stitch on its
+// own stream, A/D, and the status block on its way back -- everything enqueued, nothing waited for.
+static int enqueue_attempt(gev_ctx* c, int attempt)
+{
+    gev_ctx::PendingRepro& q = c->pend;
+    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    q.th0 = host_ms();
+    if (attempt == 0) GEVC(harvest_timing(c, sc));          // kernel times of the set's previous generation, before its events are recorded again
+    if (!(q.pre && attempt == 0)) GEVC(enqueue_sampling(c, sc, q.pop, q.n_people, q.has_mut, q.seed, c->stream));
+    q.th1 = host_ms();
+    GEVC(enqueue_sparse(c, sc, q.pop, q.n_people, q.has_mut));
+    // the dense stitch needs the sampling + sparse results only: it starts now, on its own stream, next to A/D (not waited for)
+    GEVC(enqueue_stitch(c, sc, q.pop, q.n_people));
+    q.th2 = host_ms();
+    c->ad_cached_pop = c->ad_host_set_pop = -1;
+    if (c->eager_ad && c->pop[q.pop].cv[0][0].d_aptr.p) GEVC(enqueue_ad(c, q.pop, c->pop[q.pop].cur ^ 1, q.n_people));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
+    HIPC(hipMemcpyAsync(q.hstatus, sc.status.p, q.n_status * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipEventRecord(sc.ev_status, c->stream));          // gev_reproduce_end waits for THIS, not for whatever a head start queued behind it
+    return GEV_OK;
+}
+// gev_reproduce in two halves: _begin checks and stages the inputs and enqueues the generation's device work, _end waits for it,
+// repeats it with larger buffers if a capacity was exceeded, and publishes the new generation.  Between the two the host is free
+// (the bench forms the next generation's couples there); no other call on the context is allowed in between.
+int gev_reproduce_begin(gev_ctx* c, int pop, const gev_couple* couples, size_t n_couples, uint32_t seed_reproduce,
+                        const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people)
 {
     GEVC(check_idx(c, pop, 0));
     PopState& P = c->pop[pop];
@@ -1154,6 +1193,8 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     const bool pre = sc.presampled && sc.ps_pop == pop && sc.ps_seed == (u32)seed_reproduce && sc.ps_n_people == n_people && sc.ps_has_mut == has_mut &&
                      (!has_mut || (c->h_seeds && memcmp(c->h_seeds, mut_seeds, T * sizeof(u32)) == 0));
     sc.presampled = false;
+    if (pre) HIPC(hipStreamWaitEvent(st, sc.ev_sampled, 0));     // the head start ran on its own stream
+    else HIPC(hipStreamSynchronize(c->stream_samp));            // a head start that does not match must not write into the set any more
     if (!pre) {
         // the stitch that last read this scratch set must be over before the set is refilled
         GEVC(harvest_timing(c, sc));
@@ -1164,22 +1205,31 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     HIPC(hipMemcpyAsync(sc.father.p, father, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
     HIPC(hipMemcpyAsync(sc.mother.p, mother, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
 
+    gev_ctx::PendingRepro& q = c->pend;
+    q.pop = pop; q.n_people = n_people; q.has_mut = has_mut; q.pre = pre; q.seed = (u32)seed_reproduce; q.attempt = 0; q.n_status = n_status; q.hstatus = hstatus;
+    GEVC(enqueue_attempt(c, 0));
+    q.active = true;
+    return GEV_OK;
+}
+int gev_reproduce_end(gev_ctx* c, uint8_t* sex_out)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    gev_ctx::PendingRepro& q = c->pend;
+    if (!q.active) return fail(GEV_ESTATE, "reproduce_end: no gev_reproduce_begin is pending");
+    q.active = false;                                       // whatever happens below, the generation is no longer pending
+    HIPC(hipSetDevice(c->device));
+    const int pop = q.pop, nchr = c->nchr; const size_t n_people = q.n_people;
+    PopState& P = c->pop[pop];
+    hipStream_t st = c->stream;
+    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    u32* hstatus = q.hstatus;
     const int alt = P.cur ^ 1;
-    for (int attempt = 0;; attempt++) {
-        const double th0 = host_ms();
-        if (!(pre && attempt == 0)) GEVC(enqueue_sampling(c, sc, pop, n_people, has_mut, (u32)seed_reproduce));
-        const double th1 = host_ms();
-        GEVC(enqueue_sparse(c, sc, pop, n_people, has_mut));
-        // the dense stitch needs the sampling + sparse results only: it starts now, on its own stream, next to A/D (not waited for)
-        GEVC(enqueue_stitch(c, sc, pop, n_people));
-        const double th2 = host_ms();
-        c->ad_cached_pop = c->ad_host_set_pop = -1;
-        if (c->eager_ad && c->pop[pop].cv[0][0].d_aptr.p) GEVC(enqueue_ad(c, pop, alt, n_people));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
-        HIPC(hipMemcpyAsync(hstatus, sc.status.p, n_status * sizeof(u32), hipMemcpyDeviceToHost, st));
-        HIPC(hipStreamSynchronize(st));
+    for (int attempt = q.attempt;; attempt++) {
+        if (attempt > 0) GEVC(enqueue_attempt(c, attempt));
+        HIPC(hipEventSynchronize(sc.ev_status));
         const u32 flags = hstatus[ST_FLAGS];
         if (g_trace_host) fprintf(stderr, "[gev] gen %u attempt %d pre %d: enqueue sampling %.2f ms, sparse %.2f ms, A/D + wait %.2f ms, flags %u, graveyard %.1f MiB\n",
-                                  c->gen_counter, attempt, (int)pre, th1 - th0, th2 - th1, host_ms() - th2, flags, g_graveyard.bytes / 1048576.0);
+                                  c->gen_counter, attempt, (int)q.pre, q.th1 - q.th0, q.th2 - q.th1, host_ms() - q.th2, flags, g_graveyard.bytes / 1048576.0);
         if (g_trace_host && g_malloc_n) { fprintf(stderr, "[gev]   %zu hipMalloc calls, %.1f MiB, %.2f ms\n", g_malloc_n, g_malloc_bytes / 1048576.0, g_malloc_ms); g_malloc_ms = 0; g_malloc_n = 0; g_malloc_bytes = 0; }
         for (int k = 0; k < nchr; k++) { P.st[k].mut_total[alt] = hstatus[ST_TOTALS + ST_PER_CHR * k]; P.st[k].parts_total[alt] = hstatus[ST_TOTALS + ST_PER_CHR * k + 1]; }
         if (flags & FLAG_POOL) return fail(GEV_EDEVICE, "reproduce: genotype row pool exhausted (internal error)");
@@ -1187,6 +1237,7 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
         if (attempt == 3) return fail(GEV_EDEVICE, "reproduce: buffers still too small after %d attempts (flags %u)", attempt + 1, flags);
         HIPC(hipStreamSynchronize(c->stream_big));        // the stitch of the failed attempt still reads the records that are sampled again below
         sc.timing_pending = false; sc.stitch_pending = false;   // (its kernel times are not counted)
+        c->sc[(c->gen_counter + 1) & 1].presampled = false;     // a head start taken meanwhile used the old record capacities: sample again
         if (flags & FLAG_BK_OVF) c->bk_ovf_cap = std::max<size_t>(2 * c->bk_ovf_cap, (size_t)hstatus[ST_BK_OVF_USED] * 5 / 4 + 1024);
         if (flags & FLAG_NM_OVF) c->nm_ovf_cap = std::max<size_t>(2 * c->nm_ovf_cap, (size_t)hstatus[ST_NM_OVF_USED] * 5 / 4 + 1024);
         for (int k = 0; k < nchr; k++) {     // exact needs from the count passes (valid unless a record overflow zeroed some counts: then next attempt refines)
@@ -1211,12 +1262,34 @@ int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_coupl
     occ_tune_step(c, n_people);
     return GEV_OK;
 }
+int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_couples, uint32_t seed_reproduce,
+                  const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people, uint8_t* sex_out)
+{
+    GEVC(gev_reproduce_begin(c, pop, couples, n_couples, seed_reproduce, mut_seeds, n_mut_seeds, n_people));
+    return gev_reproduce_end(c, sex_out);
+}
+// The sexes of the generation whose sampling gev_presample has enqueued (they come out of the rand() chain of the sampling
+// kernels, src/Simulation.cpp:2472, and need nothing else): lets a host that mates at random form the NEXT couples while the
+// device still works on this generation.  Waits for the sampling kernels only.
+int gev_presample_sex(gev_ctx* c, int pop, uint8_t* sex_out, size_t n_people)
+{
+    GEVC(check_idx(c, pop, 0));
+    if (!sex_out) return fail(GEV_EINVAL, "presample_sex: null output");
+    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    if (!sc.presampled || sc.ps_pop != pop || sc.ps_n_people != n_people) return fail(GEV_ESTATE, "presample_sex: no matching gev_presample is pending");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t st = c->serialize ? c->stream : c->stream_samp;
+    HIPC(hipMemcpyAsync(sex_out, sc.sex.p, n_people, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    return GEV_OK;
+}
 // Enqueue the sampling kernels of the NEXT gev_reproduce of `pop` now (they need the seeds and the offspring count, not the
 // couples) and return at once: the host can form the couples while the GPU samples.  gev_reproduce recognises the
 // same (seed, mutation seeds, n_people) and skips its own sampling; anything else simply samples again.
 int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people)
 {
-    GEVC(check_idx(c, pop, 0));
+    if (!c) return fail(GEV_EINVAL, "null context");
+    if (pop < 0 || pop >= c->n_pop) return fail(GEV_EINVAL, "population index %d out of range", pop);   // (allowed between gev_reproduce_begin and _end)
     PopState& P = c->pop[pop];
     if (!P.gen0) return fail(GEV_ESTATE, "presample: population %d has no current generation (call gev_init_gen0)", pop);
     HIPC(hipSetDevice(c->device));
@@ -1226,13 +1299,12 @@ int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* 
     const bool has_mut = mut_seeds != nullptr;
     if (has_mut && n_mut_seeds != T) return fail(GEV_EINVAL, "presample: n_mut_seeds=%zu, expected n_people*nchr=%zu", n_mut_seeds, T);
     GEVC(finalize_static(c, pop));
-    hipStream_t st = c->stream;
-    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    hipStream_t st = c->serialize ? c->stream : c->stream_samp;   // the head start has a stream of its own: it runs next to the lists / A-D of the generation in flight
+    // the scratch set of the generation AFTER the one in flight when called between gev_reproduce_begin and _end
+    gev_ctx::Scratch& sc = c->sc[(c->gen_counter + (c->pend.active ? 1u : 0u)) & 1];
     sc.presampled = false;
-    GEVC(harvest_timing(c, sc));
-    if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); sc.stitch_pending = false; }
-    GEVC(ensure_scratch(c, sc, n_people, has_mut));
-    if (has_mut) {
+    const bool seeds_in_place = has_mut && mut_seeds == (const uint32_t*)c->h_seeds;
+    if (has_mut && !seeds_in_place) {
         if (c->h_seeds_bytes < T * sizeof(u32)) {
             HIPC(hipStreamSynchronize(st));              // an earlier copy out of the old buffer may be in flight
             if (c->h_seeds) (void)hipHostFree(c->h_seeds);
@@ -1241,9 +1313,17 @@ int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* 
             c->h_seeds_bytes = T * sizeof(u32) * 5 / 4 + 4096;
         }
         memcpy(c->h_seeds, mut_seeds, T * sizeof(u32));
+    }
+    // Called while a generation is in flight, the stitch that last used this scratch set may still be running: nothing here waits
+    // for it on the host (its kernel time is collected when the set's next generation is enqueued); the sampling stream does.
+    if (c->pend.active) GEVC(harvest_sampling_time(sc)); else GEVC(harvest_timing(c, sc));
+    if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); if (!c->pend.active) sc.stitch_pending = false; }
+    GEVC(ensure_scratch(c, sc, n_people, has_mut));
+    if (has_mut) {
         HIPC(hipMemcpyAsync(sc.mutseeds.p, c->h_seeds, T * sizeof(u32), hipMemcpyHostToDevice, st));
     }
-    GEVC(enqueue_sampling(c, sc, pop, n_people, has_mut, seed_reproduce));
+    GEVC(enqueue_sampling(c, sc, pop, n_people, has_mut, seed_reproduce, st));
+    HIPC(hipEventRecord(sc.ev_sampled, st));
     sc.presampled = true; sc.ps_pop = pop; sc.ps_seed = seed_reproduce; sc.ps_n_people = n_people; sc.ps_has_mut = has_mut;
     return GEV_OK;
 }
@@ -1252,7 +1332,7 @@ int gev_sync(gev_ctx* c)
 {
     if (!c) return fail(GEV_EINVAL, "null context");
     HIPC(hipSetDevice(c->device));
-    HIPC(hipStreamSynchronize(c->stream)); HIPC(hipStreamSynchronize(c->stream_big));
+    HIPC(hipStreamSynchronize(c->stream)); HIPC(hipStreamSynchronize(c->stream_big)); HIPC(hipStreamSynchronize(c->stream_samp));
     for (auto& sc : c->sc) { GEVC(harvest_timing(c, sc)); sc.stitch_pending = false; }
     c->planes_pending = false;
     if (g_graveyard.bytes) g_graveyard.drain(c->device, false);

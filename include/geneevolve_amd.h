@@ -155,6 +155,18 @@ int gev_reproduce(gev_ctx*, int pop, const gev_couple* couples, size_t n_couples
  * Returns without waiting.  gev_reproduce called next with the same seed_reproduce, mut_seeds and n_people uses the
  * results; with anything else it samples again.  Same argument checks / errors as gev_reproduce. */
 int gev_presample(gev_ctx*, int pop, uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people);
+/* gev_reproduce in two halves.  _begin checks and stages the inputs and enqueues the generation's device work; _end waits for it
+ * (repeating it with larger buffers if a list capacity was exceeded), publishes the new generation and returns the sexes.
+ * gev_reproduce = _begin + _end.  Between the two the host is free -- bench.py forms the next generation's couples there -- but no
+ * other call on the context is allowed (GEV_ESTATE). */
+int gev_reproduce_begin(gev_ctx*, int pop, const gev_couple* couples, size_t n_couples, uint32_t seed_reproduce,
+                        const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people);
+int gev_reproduce_end(gev_ctx*, uint8_t* sex_out);
+/* The sexes of the generation whose sampling gev_presample has enqueued: they come out of the rand() chain of the sampling
+ * (src/Simulation.cpp:2472) and depend on nothing else, so a host that mates at random (Simulation::random_mate reads nothing but
+ * the sexes) can form the couples of the generation AFTER the one it is about to hand over.  Waits for the sampling kernels only;
+ * call it after gev_presample and before the gev_reproduce(_begin) of that generation. */
+int gev_presample_sex(gev_ctx*, int pop, uint8_t* sex_out, size_t n_people);
 /* ---- Simulation::ras_compute_AD + ras_find_cv (src/Simulation.cpp:2624-2815) --------------
  * additive/dominance : [n_people * nphen], index ih*nphen + iphen  (Human::additive/dominance, raw)
  * add_chr/dom_chr    : [n_people * nchr * nphen], index (ih*nchr + ichr)*nphen + iphen, or NULL

@@ -955,6 +955,53 @@ def test_presample_gives_the_same_generation_and_falls_back_on_any_mismatch(gpu_
         g.close()
 
 
+def test_reproduce_in_two_halves_with_early_sexes_gives_the_same_generations(gpu_lib, oracle_lib):
+    """gev_reproduce_begin / gev_reproduce_end with the head start and gev_presample_sex -- the pipelined host loop of bench.py,
+    where the NEXT generation's couples are formed between the two halves from the sexes the sampling already produced -- against
+    the oracle driven the plain way with the same couples; any other call between the two halves is refused."""
+    cfg = SyntheticConfig(300, 20000, nchr=2, chrom_bp=4_000_000, map_step=2000, rec_per_row=6e-4, mut_per_row=8e-4, n_cv=80, seed=81)
+    g = gpu_lib.create(1, cfg.nchr, cfg.nphen); o = oracle_lib.create(1, cfg.nchr, cfg.nphen)
+    cfg.apply_static(g); cfg.apply_static(o)
+    nh = 2 * cfg.n_ind
+    for c in range(cfg.nchr):
+        g.synth_founders(0, c, nh, cfg.seed + c); o.upload_founders(0, c, synth_packed(cfg.seed + c, nh, cfg.n_loci), cfg.n_loci)
+        g.synth_cv_founders(0, 0, c, nh, cfg.seed + 100 + c); o.upload_cv_founders(0, 0, c, synth_packed(cfg.seed + 100 + c, nh, 80), 80)
+    sg = Simulation(g, 5, cfg.nchr, True); so = Simulation(o, 5, cfg.nchr, True)
+    sg.ras_initial_human_gen0(0, cfg.n_ind); so.ras_initial_human_gen0(0, cfg.n_ind)
+    rng = np.random.default_rng(3)
+    n, n_seeds = cfg.n_ind, 1 + cfg.n_ind * cfg.nchr
+    seeds = sg.ras_glob_seed(n_seeds)
+    sg.presample(0, seeds, n)
+    couples = synthetic_random_mate(sg.sex[0], n, rng)
+    for gen in range(1, 7):
+        sex_early = g.presample_sex(0, n)
+        seeds_next = sg.ras_glob_seed(n_seeds)
+        g.reproduce_begin(0, couples, int(seeds[0]), seeds[1:], n_people=n)
+        with pytest.raises(capi.GevError):
+            g.download_cv(0, 0, 0)                                              # nothing else is allowed between the halves ...
+        if gen % 2:
+            sg.presample(0, seeds_next, n)                                      # ... but the head start of the next generation (bench.py's order)
+        next_couples = synthetic_random_mate(sex_early, n, rng)              # what bench.py does here
+        sex = g.reproduce_end(want_sex=bool(gen % 3))
+        assert sex is None or np.array_equal(sex, sex_early)
+        so.couples[0] = couples
+        assert np.array_equal(so.reproduce(0, gen, seeds=seeds, n_people=n), sex_early), f"sex differs at generation {gen}"
+        if not gen % 2:
+            sg.presample(0, seeds_next, n)                                      # or after the generation is complete
+        seeds = seeds_next
+        ag = g.compute_ad(0); ao = o.compute_ad(0)
+        for x, y in zip(ag, ao):
+            assert helpers.bits_equal(x, y), f"A/D not bit-identical at generation {gen}"
+        for c in range(cfg.nchr):
+            assert np.array_equal(g.download_haps(0, c), o.download_haps(0, c)), f"dense genotypes differ (gen {gen} chr {c})"
+            pg, og = g.download_intervals(0, c); po, oo = o.download_intervals(0, c)
+            assert np.array_equal(og, oo) and np.array_equal(pg, po)
+        couples = next_couples
+    with pytest.raises(capi.GevError):
+        g.reproduce_end()                                                     # nothing pending
+    g.close(); o.close()
+
+
 def slice_bits(packed, L, s0, ns):
     """columns [s0, s0+ns) of a bit matrix packed in uint64 words -> packed again (bit j = column s0 + j)"""
     u = capi.unpack_rows(packed, L)[:, s0:s0 + ns]
