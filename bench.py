@@ -9,16 +9,19 @@ uniform recombination map (2001 rows, 5e-4/row), mutation 1e-8/bp (5e-4/row), 10
 
 One process per GPU; each rank advances its OWN population of the full config-2 size (weak
 scaling: populations shard across GPUs); no data-path collective is
-needed without migration.  A step = one generation: host makes the couples list from the
-returned sexes (mating is outside the hot path), then Simulation::reproduce and
-Simulation::ras_compute_AD run on the GPU through the C-ABI.  gev_reproduce returns once the
-small per-generation work is done; the HBM-bound dense stitch continues on the library's second
-stream and overlaps A/D, host mating and the next generation's sampling (every generation's
-stitch is complete before the timed region ends: the closing barrier synchronises the device).
+needed without migration.  A step = one generation: the host makes the couples list from the
+sexes (mating is outside the hot path), Simulation::reproduce and Simulation::ras_compute_AD run
+on the GPU through the C-ABI.  The host loop is software-pipelined (default; --no-pipeline: mate, then
+gev_reproduce, strictly one after the other): the sexes of a generation come out of the sampling
+kernels' rand() chain, which the head start (gev_presample) has run before the generation is handed over,
+and random mating reads nothing but the sexes -- so every step hands generation g over with
+gev_reproduce_begin, issues the head start of g+1, forms the couples of g+1 on the host from
+gev_presample_sex's result while the device builds g, and collects g with gev_reproduce_end.  The dense stitch
+runs on the library's own stream and overlaps all of that (every generation's stitch is complete before the
+timed region ends: the closing barrier synchronises the device).
 The ras_glob_seed() values of the next generation (1 + N*nchr draws, src/Simulation.cpp:2398, :2500) are pure draws of the
-host's stream, known before its couples are: they are drawn INSIDE the timed loop, by a second host thread while the first
-waits in gev_reproduce, and handed over early (gev_presample) so the GPU samples while the host mates (--no-presample: hand
-seeds and couples over together).  The founder panel is generated on the device before the timed region, so
+host's stream, known before its couples are: they are drawn INSIDE the timed loop, one generation's worth per step, by a second
+host thread, and handed over early (gev_presample) (--no-presample: hand seeds and couples over together, no pipelining).  The founder panel is generated on the device before the timed region, so
 genotype state is resident in HBM throughout.  --plane-less times BASELINE config 5's mode (interval state only,
 no per-generation genotype assembly) and is NOT the headline configuration.
 
