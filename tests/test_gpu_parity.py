@@ -1114,6 +1114,48 @@ def test_long_run_exercises_list_growth_and_redo_paths(gpu_lib, oracle_lib):
     g.close(); o.close()
 
 
+def test_pipelined_host_loop_through_list_growth_and_redo_paths(gpu_lib, oracle_lib):
+    """bench.py's order of calls -- gev_presample_sex, gev_reproduce_begin, the head start of the NEXT generation, the next couples on
+    the host, gev_reproduce_end -- for 40 generations in which the lists outgrow their buffers several times: a generation is redone
+    inside gev_reproduce_end while the next head start is already queued (it is then sampled again), and the population size
+    changes (a head start for another size does not match and is dropped).  Against the oracle driven the plain way."""
+    cfg = SyntheticConfig(120, 1500, nchr=2, chrom_bp=1_000_000, map_step=5_000, rec_per_row=0.025, mut_per_row=0.015, n_cv=25, seed=35)
+    g = gpu_lib.create(1, 2, 1); o = oracle_lib.create(1, 2, 1)
+    cfg.apply_static(g); cfg.apply_static(o)
+    for c in range(2):
+        g.synth_founders(0, c, 240, 70 + c); o.upload_founders(0, c, synth_packed(70 + c, 240, 1500), 1500)
+        g.synth_cv_founders(0, 0, c, 240, 80 + c); o.upload_cv_founders(0, 0, c, synth_packed(80 + c, 240, 25), 25)
+    sg, so = Simulation(g, 3, 2, True), Simulation(o, 3, 2, True)
+    sg.ras_initial_human_gen0(0, 120); so.ras_initial_human_gen0(0, 120)
+    rng = np.random.default_rng(6)
+    size = lambda gen: 120 if gen % 9 else 150
+    seeds = sg.ras_glob_seed(1 + 2 * size(1))
+    sg.presample(0, seeds, size(1))
+    couples = synthetic_random_mate(sg.sex[0], size(1), rng)
+    for gen in range(1, 41):
+        n = size(gen)
+        sex_early = g.presample_sex(0, n)
+        seeds_next = sg.ras_glob_seed(1 + 2 * size(gen + 1))
+        g.reproduce_begin(0, couples, int(seeds[0]), seeds[1:], n_people=n)
+        sg.presample(0, seeds_next, size(gen + 1))
+        next_couples = synthetic_random_mate(sex_early, size(gen + 1), rng)
+        sex = g.reproduce_end()
+        assert np.array_equal(sex, sex_early)
+        so.couples[0] = couples
+        assert np.array_equal(so.reproduce(0, gen, seeds=seeds, n_people=n), sex), f"sex gen {gen}"
+        xa, xo = g.compute_ad(0), o.compute_ad(0)
+        assert helpers.bits_equal(xa[0], xo[0]), f"A gen {gen}"
+        if gen % 10 == 0:
+            for c in range(2):
+                assert np.array_equal(g.download_haps(0, c), o.download_haps(0, c)), f"dense gen {gen} chr {c}"
+                pg, og = g.download_intervals(0, c); po, oo = o.download_intervals(0, c)
+                assert np.array_equal(og, oo) and np.array_equal(pg, po), f"intervals gen {gen} chr {c}"
+                mg, mog = g.download_mutations(0, c); mo, moo = o.download_mutations(0, c)
+                assert np.array_equal(mog, moo) and np.array_equal(mg, mo), f"mutations gen {gen} chr {c}"
+        couples, seeds = next_couples, seeds_next
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1", "ex1full"])
 def test_closed_loop_from_the_seed_alone_on_gpu(gpu_lib, case):
     """the same closed loop on the HIP library (A/D, intervals, genotypes, couples, sexes bit-exact; scaled phenotypes and what
