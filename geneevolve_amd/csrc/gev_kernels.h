@@ -620,10 +620,11 @@ __global__ void __launch_bounds__(256) k_bk_to_idx(const ChrDev* __restrict__ ch
 // grid.  The entry's descriptors (gamete, parent, the boundaries inside the segment -- usually one) are wave-uniform: the wave
 // index is made scalar so they come through the scalar cache, and up to eight inside boundaries sit in registers.  A chunk
 // before / behind / between them is a plain 16-byte copy from ONE parental unit, the chunk that contains one is blended by mask;
-// four chunks per lane in flight, 4 KiB per wave and step.  Thousands of entries are in flight per chip (8 waves per SIMD), which
-// is what hides the five dependent descriptor loads in front of every 16 KiB copy.
+// U chunks per lane in flight (2: 2 KiB per wave and step -- with 4 or 8 the kernel needs more registers, fewer waves fit and the
+// launch gets slower: 0.64 / 0.69 ms against 0.60 ms at config 2).  Thousands of entries are in flight per chip, which is what
+// hides the five dependent descriptor loads in front of every 8 KiB copy.
 #define SEG_KREG 8           // boundaries of one gamete inside one segment held in registers; more are read from global memory
-template <bool NT>
+template <bool NT, int U = 2>
 __global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restrict__ Wt, int nchr, SampleDev sd)
 {
     const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
@@ -652,10 +653,10 @@ __global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restri
             u32 in[SEG_KREG];
 #pragma unroll
             for (int m = 0; m < SEG_KREG; m++) in[m] = (u32)m < nin ? idx[m0 + m] : 0xffffffffu;
-            for (u32 q = lane; q < nq; q += 64 * 4) {
-                v4u a[4], b[4]; u32 c[4]; bool mixed[4];
+            for (u32 q = lane; q < nq; q += 64 * U) {
+                v4u a[U], b[U]; u32 c[U]; bool mixed[U];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < U; u++) {
                     const u32 qq = q + u * 64;
                     c[u] = 0; mixed[u] = false;
                     if (qq >= nq) continue;
@@ -669,7 +670,7 @@ __global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restri
                     if (mx || sel == 1u) b[u] = NT ? __builtin_nontemporal_load(&R1[qq]) : R1[qq];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < U; u++) {
                     const u32 qq = q + u * 64;
                     if (qq >= nq) continue;
                     const u32 sel = (sel0 ^ c[u]) & 1u;

@@ -76,6 +76,10 @@ int main(int argc, char** argv)
     double gb_sh = 0; for (size_t i = 0; i < n_sh; i++) { const u32 g = it_sh[i] % S; gb_sh += 2.0 * 16 * std::min<u32>(1u << sh, chunks - (g << sh)); } gb_sh /= 1e9;
 #define ADD(name, gb, ...) vars.push_back({name, [&]() { __VA_ARGS__; }, gb, {}})
     ADD("segments with a boundary, grid 16384", gb_sh, hipLaunchKernelGGL((k_stitch_segments<true>), dim3(16384), dim3(256), 0, 0, dws, 1, sd));
+    ADD("segments with a boundary, U8", gb_sh, hipLaunchKernelGGL((k_stitch_segments<true, 8>), dim3(16384), dim3(256), 0, 0, dws, 1, sd));
+    ADD("segments with a boundary, U4", gb_sh, hipLaunchKernelGGL((k_stitch_segments<true, 4>), dim3(16384), dim3(256), 0, 0, dws, 1, sd));
+    ADD("segments with a boundary, U1", gb_sh, hipLaunchKernelGGL((k_stitch_segments<true, 1>), dim3(16384), dim3(256), 0, 0, dws, 1, sd));
+    ADD("segments with a boundary, U2 grid 32768", gb_sh, hipLaunchKernelGGL((k_stitch_segments<true, 2>), dim3(32768), dim3(256), 0, 0, dws, 1, sd));
     ADD("segments with a boundary, grid 4096", gb_sh, hipLaunchKernelGGL((k_stitch_segments<true>), dim3(4096), dim3(256), 0, 0, dws, 1, sd));
     ADD("segments with a boundary, plain ld/st", gb_sh, hipLaunchKernelGGL((k_stitch_segments<false>), dim3(16384), dim3(256), 0, 0, dws, 1, sd));
     ADD("gamete-major rows, own segments only", gb_sh, hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)rows), dim3(256), 0, 0, dws, 1, sd));
