@@ -276,6 +276,7 @@ def main():
     # genotype rows and A/D of this one.  --no-pipeline: mate, then gev_reproduce, one after the other.
     pipeline = presample and not migrate and not args.no_pipeline
     state = {}
+    call_ms = {}                                               # host time inside each library call of the pipelined loop, summed
 
     def step_pipelined(i):
         t0 = time.perf_counter()
@@ -284,14 +285,21 @@ def main():
             state["couples"] = synthetic_random_mate(sim.sex[P], args.n_ind, rng)
             seeds[i + 1] = sim.ras_glob_seed(n_seeds)
         sd = seeds.pop(i)
+        ta = time.perf_counter()
         sex_new = ctx.presample_sex(P, args.n_ind)              # this generation's sexes: its sampling ran during the previous step
+        tb = time.perf_counter()
         ctx.reproduce_begin(P, state["couples"], int(sd[0]), sd[1:], n_people=args.n_ind)   # Simulation::reproduce, first half
+        tc = time.perf_counter()
         sim.presample(P, seeds[i + 1], args.n_ind)               # head start of the next generation, queued behind this one's lists and A/D
+        td = time.perf_counter()
         fut = seed_pool.submit(timed_draw)                       # one generation's worth of ras_glob_seed() draws per step, second host thread
         t1 = time.perf_counter()
+        for k, v in (("gev_presample_sex", tb - ta), ("gev_reproduce_begin", tc - tb), ("gev_presample", td - tc)):
+            call_ms[k] = call_ms.get(k, 0.0) + v * 1e3
         state["couples"] = synthetic_random_mate(sex_new, args.n_ind, rng, out=state["couples"])    # host mating of the NEXT generation
         t2 = time.perf_counter()
         ctx.reproduce_end(want_sex=False)                        # ... second half (the sexes are sex_new)
+        call_ms["gev_reproduce_end"] = call_ms.get("gev_reproduce_end", 0.0) + (time.perf_counter() - t2) * 1e3
         sim.sex[P] = sex_new
         sim.last_seed_reproduce = int(sd[0])
         t3 = time.perf_counter()
@@ -342,7 +350,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     del ad_ms[:], mate_ms[:], repro_ms[:], mig_ms[:], step_ms[:], seed_ms[:]
-    mig_parts.clear()
+    mig_parts.clear(); call_ms.clear()
     tot0, n0 = ctx.timing_totals()                       # (implies a sync of both library streams)
     rows0 = (0, 0, 0, 0) if args.plane_less else ctx.stitch_totals()
     barrier()
@@ -419,7 +427,8 @@ def main():
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
                          "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "host_seed_draws": float(np.mean(seed_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
                          "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None,
-                         "migration_steps": {k: v / args.steps for k, v in mig_parts.items()} if mig_parts else None},
+                         "migration_steps": {k: v / args.steps for k, v in mig_parts.items()} if mig_parts else None,
+                         "host_ms_inside_calls": {k: v / args.steps for k, v in call_ms.items()} if call_ms else None},
                "host_step_ms": [round(x, 2) for x in step_ms[:args.steps]],
             "roofline": {"bound": "hbm", "kernel": "k_stitch_segments", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
