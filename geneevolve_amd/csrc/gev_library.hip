@@ -180,7 +180,6 @@ struct gev_ctx {
     struct Scratch {
         DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, status, slow_mut, slow_rec, chrwork, cvwork;
         unsigned n_chrwork = 0; float sampling_ms_saved = -1;
-        uint8_t* h_sex = nullptr; size_t h_sex_bytes = 0;      // pinned: the head start copies the sexes back as soon as they exist (gev_presample_sex)
         hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_status = nullptr, ev_sampled = nullptr;   // the generation's status block (and A/D results) have arrived on the host
         bool timing_pending = false, stitch_pending = false;
         // gev_presample: the sampling kernels of the next gev_reproduce were already enqueued for exactly these inputs
@@ -406,7 +405,7 @@ void gev_destroy(gev_ctx* c)
     if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
-    for (auto& sc : c->sc) { if (sc.h_sex) (void)hipHostFree(sc.h_sex); if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); if (sc.ev_status) (void)hipEventDestroy(sc.ev_status); if (sc.ev_sampled) (void)hipEventDestroy(sc.ev_sampled); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
+    for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); if (sc.ev_status) (void)hipEventDestroy(sc.ev_status); if (sc.ev_sampled) (void)hipEventDestroy(sc.ev_sampled); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
     hipStream_t s = c->stream;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_seeds) (void)hipHostFree(c->h_seeds);
@@ -1279,8 +1278,9 @@ int gev_presample_sex(gev_ctx* c, int pop, uint8_t* sex_out, size_t n_people)
     gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
     if (!sc.presampled || sc.ps_pop != pop || sc.ps_n_people != n_people) return fail(GEV_ESTATE, "presample_sex: no matching gev_presample is pending");
     HIPC(hipSetDevice(c->device));
-    HIPC(hipEventSynchronize(sc.ev_sampled));              // sampling done and the sexes copied into the pinned buffer
-    memcpy(sex_out, sc.h_sex, n_people);
+    hipStream_t st = c->serialize ? c->stream : c->stream_samp;
+    HIPC(hipMemcpyAsync(sex_out, sc.sex.p, n_people, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
     return GEV_OK;
 }
 // Enqueue the sampling kernels of the NEXT gev_reproduce of `pop` now (they need the seeds and the offspring count, not the
@@ -1323,12 +1323,6 @@ int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* 
         HIPC(hipMemcpyAsync(sc.mutseeds.p, c->h_seeds, T * sizeof(u32), hipMemcpyHostToDevice, st));
     }
     GEVC(enqueue_sampling(c, sc, pop, n_people, has_mut, seed_reproduce, st));
-    if (sc.h_sex_bytes < n_people) {
-        if (sc.h_sex) { HIPC(hipStreamSynchronize(st)); (void)hipHostFree(sc.h_sex); sc.h_sex = nullptr; sc.h_sex_bytes = 0; }
-        HIPC(hipHostMalloc((void**)&sc.h_sex, n_people * 5 / 4 + 4096, hipHostMallocDefault));
-        sc.h_sex_bytes = n_people * 5 / 4 + 4096;
-    }
-    HIPC(hipMemcpyAsync(sc.h_sex, sc.sex.p, n_people, hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(sc.ev_sampled, st));
     sc.presampled = true; sc.ps_pop = pop; sc.ps_seed = seed_reproduce; sc.ps_n_people = n_people; sc.ps_has_mut = has_mut;
     return GEV_OK;
