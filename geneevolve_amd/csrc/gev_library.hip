@@ -9,7 +9,7 @@
 //   GEV_SERIALIZE=1           same as GEV_OVERLAP=0
 //   GEV_SAMPLE_BATCHED=0|1    sampling kernels: one task per wave | eight tasks per wave (default)
 //   GEV_STITCH_MODE=0|1       dense stitch kernel: k_stitch_segments (default) | k_stitch_rows (same results)
-//   GEV_SAMPLE_GRID=n         persistent workgroups of the sampling kernels (default 384 next to a stitch, 1024 alone)
+//   GEV_SAMPLE_GRID=n         persistent workgroups of the sampling kernels (default 768 next to other kernels, 1024 alone)
 //   GEV_STITCH_WG_PER_CU=n|auto stitch workgroups per CU, by dynamic LDS padding (default: unlimited; auto: measured at run time)
 //   GEV_STITCH_LDS_PAD=bytes  (experiments) that padding directly
 //   GEV_ALIAS_ROWS=0|1        write every segment of every gamete row | segments without a crossover boundary share the parental unit (default)
@@ -203,8 +203,9 @@ struct gev_ctx {
     int stitch_mode = 0;           // 0 = work-list form (production, k_stitch_segments), 1 = gamete-major (k_stitch_rows)
     bool sample_batched = true;               // K1-K3 as eight tasks per wave (gev_sample8.h); GEV_SAMPLE_BATCHED=0: one task per wave
     unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels when they have the GPU to themselves (GEV_SAMPLE_GRID)
-    unsigned sample_grid_shared = 384;        // ... and next to a running stitch: 6 waves per CU take fewer of the stitch's slots for longer, which costs
-                                              // it less than many slots briefly (config 2: +2 %, 11-chromosome shard: +5 % generations/s over 1024)
+    unsigned sample_grid_shared = 768;        // ... and next to the other streams' kernels.  Next to the 5 ms whole-row stitch of the first half of round 2, 384 was
+                                              // best (fewer of the stitch's slots taken for longer); with the 0.7 ms segment stitch and the pipelined host loop the
+                                              // sampling is what gev_presample_sex waits for: 768 finishes in 0.45 instead of 0.95 ms (config 2 +4 %, the shard unchanged)
     bool serialize = false;        // wait for every stitch (no overlap between the two streams)
     int overlap_mode = 1;          // 1 everything (default), 0 never, 2 sampling only, -1 decide after two serialised generations
     bool sparse_after_stitch = false;   // mode 2: the memory-bound sparse/CV/A-D kernels wait for the running stitch, only the ALU-bound sampling shares the GPU with it
