@@ -564,45 +564,58 @@ __global__ void __launch_bounds__(256) k_iota_u32(u32* __restrict__ a, size_t n)
 // in the stitch's work list; every other segment names the unit of the parental haplotype that is being copied there:
 // start ^ parity(#boundaries at or before the segment's first locus).  One atomic per block of 256 rows.
 #define POOL_SEG_MAX 64          // segments per row handled with a 64-bit flag word (8 KiB segments: rows up to 512 KiB = 4M loci); longer rows use larger segments
+#define POOL_RPT 4               // offspring rows per thread of k_pool_assign: one atomic per block of 1024 rows
 __global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd)
 {
     __shared__ u32 s_scan[8], s_base, s_last;
     const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
     const u32 S = pw.nseg, sh = pw.seg_shift;
-    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row0 = (size_t)blockIdx.x * (256 * POOL_RPT) + threadIdx.x;
     if (threadIdx.x == 0) s_last = 0;
-    u64 flags = 0; u32 c = 0, parent = 0, start = 0, k = 0;
-    const u32* idx = nullptr;
-    if (row < n_rows_out) {
-        const size_t i = row >> 1; const u32 s = (u32)(row & 1);
-        const size_t G = 2 * (i * nchr + w.chr) + s;
-        parent = s ? sd.mother[i] : sd.father[i];
-        start = sd.start[G]; k = sd.k[G]; idx = sd.bk_idx + sd.bk_off[G];
-        if (!pw.alias) flags = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
-        else for (u32 m = 0; m < k; m++) { const u32 g = (idx[m] >> 7) >> sh; if (g < S) flags |= 1ull << g; }
-        c = (u32)__popcll(flags);
+    u64 flags[POOL_RPT]; u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < POOL_RPT; j++) {
+        const size_t row = row0 + (size_t)j * 256;
+        flags[j] = 0;
+        if (row >= n_rows_out) continue;
+        if (!pw.alias) flags[j] = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+        else {
+            const size_t G = 2 * ((row >> 1) * nchr + w.chr) + (row & 1);
+            const u32 k = sd.k[G]; const u32* idx = sd.bk_idx + sd.bk_off[G];
+            for (u32 m = 0; m < k; m++) { const u32 g = (idx[m] >> 7) >> sh; if (g < S) flags[j] |= 1ull << g; }
+        }
+        c += (u32)__popcll(flags[j]);
     }
     u32 tot;
     const u32 ex = block_exclusive_scan_256(c, s_scan, tot);
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(&pw.pctr[1], tot) : 0u;
     __syncthreads();
-    u32 at = s_base + ex;
+    u32 at = s_base + ex, n_last = 0;
     const u32 n_free = pw.pctr[0];
-    u32* out = pw.phys_alt + row * S;
-    u32 m = 0, cnt = 0;                                       // boundaries with idx <= first locus of the segment: ascending list, one sweep
-    for (u32 g = 0; g < S && row < n_rows_out; g++) {
-        const u32 bit0 = (g << sh) << 7;
-        while (m < k && idx[m] <= bit0) { m++; cnt++; }
-        if ((flags >> g) & 1ull) {
-            if (at < n_free) { out[g] = pw.freel[at]; if (at < pw.items_cap) pw.items[at] = (u32)(row * S + g); }
-            else { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_POOL); out[g] = n_free ? pw.freel[at % n_free] : 0u; }   // reported by the host; keeps the stitch in bounds
-            if (g == S - 1) atomicAdd(&s_last, 1u);
-            at++;
-        } else {
-            const u32 sel = (start ^ cnt) & 1u;
-            out[g] = pw.phys_cur[(2 * (size_t)parent + sel) * S + g];
+#pragma unroll
+    for (int j = 0; j < POOL_RPT; j++) {
+        const size_t row = row0 + (size_t)j * 256;
+        if (row >= n_rows_out) continue;
+        const size_t i = row >> 1; const u32 s = (u32)(row & 1);
+        const size_t G = 2 * (i * nchr + w.chr) + s;
+        const u32 parent = s ? sd.mother[i] : sd.father[i];
+        const u32 start = sd.start[G], k = sd.k[G];
+        const u32* idx = sd.bk_idx + sd.bk_off[G];
+        u32* out = pw.phys_alt + row * S;
+        const u32* p0 = pw.phys_cur + (2 * (size_t)parent) * S;      // the parent's two rows of the table are adjacent
+        u32 m = 0, cnt = 0;                                   // boundaries with idx <= first locus of the segment: ascending list, one sweep
+        for (u32 g = 0; g < S; g++) {
+            const u32 bit0 = (g << sh) << 7;
+            while (m < k && idx[m] <= bit0) { m++; cnt++; }
+            if ((flags[j] >> g) & 1ull) {
+                if (at < n_free) { out[g] = pw.freel[at]; if (at < pw.items_cap) pw.items[at] = (u32)(row * S + g); }
+                else { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_POOL); out[g] = n_free ? pw.freel[at % n_free] : 0u; }   // reported by the host; keeps the stitch in bounds
+                n_last += (g == S - 1);
+                at++;
+            } else out[g] = p0[((start ^ cnt) & 1u) * S + g];
         }
     }
+    if (n_last) atomicAdd(&s_last, n_last);
     __syncthreads();
     if (threadIdx.x == 0 && s_last) atomicAdd(&pw.pctr[3], s_last);
 }

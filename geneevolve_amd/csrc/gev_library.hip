@@ -1019,7 +1019,7 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
             const unsigned pool_blocks = (unsigned)std::min<size_t>(ceil_div(4 * P.cap_people * nseg_max, 256), 1024);
             hipLaunchKernelGGL(k_pool_mark_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt, 2 * P.n_phys);
             hipLaunchKernelGGL(k_pool_collect_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt);
-            hipLaunchKernelGGL(k_pool_assign, dim3((unsigned)ceil_div(rows, 256), na), dim3(256), 0, st, Wt, rows, nchr, sd);
+            hipLaunchKernelGGL(k_pool_assign, dim3((unsigned)ceil_div(rows, 256 * POOL_RPT), na), dim3(256), 0, st, Wt, rows, nchr, sd);
         }
         // ---- sparse state: mutation lists + ancestry intervals (count -> segmented scan -> fill), CV planes
         const unsigned nseg = c->track_intervals ? 2 * na : na;            // segments [0, na): mutation lists, [na, 2 na): interval lists
