@@ -468,6 +468,7 @@ int gev_set_snps(gev_ctx* c, int pop, int chr, const u64* pos, size_t L)
     S.stride = std::max<size_t>(round_up(ceil_div(L, 8), 128), 128);
     S.seg_shift = c->seg_shift;                                    // 16 KiB segments unless the row would need more than 64 of them
     while (ceil_div(S.stride / 16, (size_t)1 << S.seg_shift) > POOL_SEG_MAX) S.seg_shift++;
+    while (S.seg_shift > 0 && ((size_t)1 << (S.seg_shift - 1)) >= S.stride / 16) S.seg_shift--;     // a row shorter than a segment: the smallest power-of-two unit that holds it
     S.nseg = (u32)ceil_div(S.stride / 16, (size_t)1 << S.seg_shift);
     HIPC(hipSetDevice(c->device));
     GEVC(h2d(c, S.d_pos, pos, L * sizeof(u64)));

@@ -214,7 +214,7 @@ def test_segments_without_a_crossover_share_the_parental_unit(gpu_lib, oracle_li
         n_shared = n_units = 0
         for c in range(cfg.nchr):
             _, unit_bytes, n_slots, tab, nseg = g.plane_ptr(0, c)
-            assert n_slots == 2 * n and unit_bytes == 16 * seg_chunks and nseg == -(-3840 // unit_bytes)      # rows of 30000 bits = 3840 bytes
+            assert n_slots == 2 * n and unit_bytes == 16 * min(seg_chunks, 256) and nseg == -(-3840 // unit_bytes)      # rows of 30000 bits = 3840 bytes = 240 chunks (a longer segment shrinks to 256 chunks)
             after = _read_device_u32(tab, n_slots * nseg)
             inherited = np.isin(after, before[c])
             fresh = after[~inherited]
@@ -262,7 +262,7 @@ def test_population_without_any_crossover(gpu_lib, oracle_lib):
         sg.couples[0] = synthetic_random_mate(sg.sex[0], cfg.n_ind, rng)
         sg.reproduce(0, gen)
     bw, bt, sw, st = g.stitch_totals()
-    assert (bw, sw) == (0, 0) and st == 3 * 2 * cfg.n_ind * cfg.nchr and bt == st * 1280          # one 1280-byte segment per row of 10000 loci
+    assert (bw, sw) == (0, 0) and st == 3 * 2 * cfg.n_ind * cfg.nchr and bt == st * 1280          # one segment per row of 10000 loci = 1280 bytes
     g.close()
 
 
