@@ -25,7 +25,7 @@ host thread, and handed over early (gev_presample) (--no-presample: hand seeds a
 genotype state is resident in HBM throughout.  --plane-less times BASELINE config 5's mode (interval state only,
 no per-generation genotype assembly) and is NOT the headline configuration.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_segments): a genotype row is kept as 16 KiB
+Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_segments): a genotype row is kept as 8 KiB
 segments, and in a segment that contains none of its crossover boundaries an offspring gamete is one parental haplotype unchanged:
 that segment names the parent's unit and is not copied.  The units of a launch are the segments it WRITES (about one per crossover;
 gev_stitch_totals), algorithmic bytes per launch = bytes written x 2 (read once, written once; SURVEY.md 8(d)'s per-gamete figure
@@ -194,7 +194,10 @@ def main():
                     help="N>1 only: fraction of each population that moves to EACH other population every generation "
                          "(BASELINE config 3 uses 0.01); rows travel by all_to_all over RCCL")
     ap.add_argument("--spawn", action="store_true", help="go through the worker launcher even for --gpus 1 (checks that the launcher costs nothing)")
-    ap.add_argument("--no-pipeline", action="store_true", help="mate, then gev_reproduce, strictly one after the other (default: the host forms the next couples between gev_reproduce_begin and _end)")
+    ap.add_argument("--mating", choices=["device", "host"], default="device",
+                    help="device (default): Simulation::random_mate and the generation's ras_glob_seed() draws run on the GPU, a step is one "
+                         "gev_generation_begin/_end pair; host: round 2's loop (numpy stand-in for random_mate, seeds drawn by a second host thread)")
+    ap.add_argument("--no-pipeline", action="store_true", help="--mating host only: mate, then gev_reproduce, strictly one after the other (default: the host forms the next couples between gev_reproduce_begin and _end)")
     ap.add_argument("--isolated-steps", type=int, default=3, help="extra untimed generations without stream overlap for roofline.isolated")
     args = ap.parse_args()
 
@@ -261,7 +264,8 @@ def main():
     if migrate:
         from geneevolve_amd.distributed import migrate_all_to_all
 
-    presample = not args.no_presample
+    fused = args.mating == "device"
+    presample = not args.no_presample and not fused
     from concurrent.futures import ThreadPoolExecutor
     seed_pool = ThreadPoolExecutor(1)                    # the host's second thread: draws seeds while the first waits for the GPU
 
@@ -274,6 +278,8 @@ def main():
     # (gev_presample) has already run when the generation is handed over, and random mating reads nothing else -- so the host forms
     # the NEXT generation's couples between gev_reproduce_begin and gev_reproduce_end, while the device builds lists, CV planes,
     # genotype rows and A/D of this one.  --no-pipeline: mate, then gev_reproduce, one after the other.
+    if migrate and not fused:
+        raise SystemExit("--migration-rate needs --mating device (the library mates on the sexes that travel with the migrants)")
     pipeline = presample and not migrate and not args.no_pipeline
     state = {}
     call_ms = {}                                               # host time inside each library call of the pipelined loop, summed
@@ -309,7 +315,40 @@ def main():
         t4 = time.perf_counter()
         mate_ms.append((t2 - t1) * 1e3); repro_ms.append((t1 - t0 + t3 - t2) * 1e3); ad_ms.append((t4 - t3) * 1e3); step_ms.append((t4 - t0) * 1e3)
 
+    def do_migration(t3):
+        """Simulation::ras_do_migration: host picks WHO (:921-922), rows -- with their sexes -- go by all_to_all"""
+        k = int(round(args.migration_rate * args.n_ind))
+        sample = np.sort(rng.choice(args.n_ind, size=k * (world - 1), replace=False))[::-1].astype(np.uint64)
+        outgoing, o = [], 0
+        for j in range(world):
+            outgoing.append(np.empty(0, dtype=np.uint64) if j == rank else sample[o:o + k])
+            o += 0 if j == rank else k
+        tr = []
+        migrate_all_to_all(ctx, outgoing, P, device=f"cuda:{local_rank}", trace=tr)
+        for name, sec in zip(tr[0::2], tr[1::2]) if all(isinstance(x, float) for x in tr[1::2]) else []:
+            mig_parts[name] = mig_parts.get(name, 0.0) + sec * 1e3
+        mig_ms.append((time.perf_counter() - t3) * 1e3)
+
+    def step_fused(i):
+        """one generation = ONE pair of library calls: random_mate (:2090) -> reproduce (:2394) -> ras_compute_AD (:2624) in the
+        reference's order, its 2 + N*nchr ras_glob_seed() values drawn on the device from the host's engine state"""
+        t0 = time.perf_counter()
+        ctx.generation_begin(P, sim.glob.x, args.n_ind, None)
+        t1 = time.perf_counter()
+        r = ctx.generation_end(want_couples=False, want_sex=True)
+        t2 = time.perf_counter()
+        sim.glob.x = int(r["glob_state"]); sim.sex[P] = r["sex"]; sim.last_seed_reproduce = int(r["seed_reproduce"])
+        sim.ras_compute_AD(P, i + 1)                             # the generation's A/D (computed inside the generation, copied out here)
+        t3 = time.perf_counter()
+        if migrate:
+            do_migration(t3)
+        call_ms["gev_generation_begin"] = call_ms.get("gev_generation_begin", 0.0) + (t1 - t0) * 1e3
+        call_ms["gev_generation_end"] = call_ms.get("gev_generation_end", 0.0) + (t2 - t1) * 1e3
+        mate_ms.append(0.0); seed_ms.append(0.0); repro_ms.append((t2 - t0) * 1e3); ad_ms.append((t3 - t2) * 1e3); step_ms.append((time.perf_counter() - t0) * 1e3)
+
     def step(i):
+        if fused:
+            return step_fused(i)
         if pipeline:
             return step_pipelined(i)
         t0 = time.perf_counter()
@@ -326,25 +365,9 @@ def main():
         t2 = time.perf_counter()
         sim.ras_compute_AD(P, i + 1)                                             # Simulation::ras_compute_AD
         t3 = time.perf_counter()
-        if migrate:                                                              # Simulation::ras_do_migration: host picks WHO, rows go by all_to_all
-            k = int(round(args.migration_rate * args.n_ind))
-            sample = np.sort(rng.choice(args.n_ind, size=k * (world - 1), replace=False))[::-1].astype(np.uint64)   # :921-922
-            outgoing, o = [], 0
-            for j in range(world):
-                outgoing.append(np.empty(0, dtype=np.uint64) if j == rank else sample[o:o + k])
-                o += 0 if j == rank else k
-            sex = sim.sex[P]
-            gone = np.zeros(args.n_ind, dtype=bool); gone[sample.astype(np.int64)] = True
-            sent_sex = [sex[outgoing[j].astype(np.int64)] for j in range(world)]
-            tr = []
-            migrate_all_to_all(ctx, outgoing, P, device=f"cuda:{local_rank}", trace=tr)
-            for name, sec in zip(tr[0::2], tr[1::2]) if all(isinstance(x, float) for x in tr[1::2]) else []:
-                mig_parts[name] = mig_parts.get(name, 0.0) + sec * 1e3
-            # host bookkeeping the reference does on its Human records: sexes follow the rows
-            recv_sex = [None] * world
-            dist.all_gather_object(recv_sex, sent_sex)
-            sim.sex[P] = np.concatenate([sex[~gone]] + [recv_sex[i][rank] for i in range(world) if i != rank])
-            mig_ms.append((time.perf_counter() - t3) * 1e3)
+        if migrate:
+            do_migration(t3)
+            sim.sex[P] = None                                                    # (after a migration the host of this loop would need the migrants' sexes: --mating host does not combine with --migration-rate)
         mate_ms.append((t1 - t0) * 1e3); repro_ms.append((t2 - t1) * 1e3); ad_ms.append((t3 - t2) * 1e3); step_ms.append((time.perf_counter() - t0) * 1e3)
 
     for i in range(args.warmup):
@@ -374,6 +397,9 @@ def main():
         ctx.set_overlap(False)
         ta, na = ctx.timing_totals()
         for j in range(args.isolated_steps):
+            if fused:
+                sim.next_generation_rm(P, args.n_ind)
+                continue
             sim.couples[P] = synthetic_random_mate(sim.sex[P], args.n_ind, rng, out=sim.couples.get(P))
             sim.reproduce(P, total + j + 1, seeds=seeds.pop(total + j) if (total + j) in seeds else sim.ras_glob_seed(n_seeds), n_people=args.n_ind)
         tb, nb = ctx.timing_totals()
@@ -420,9 +446,13 @@ def main():
                        f"config-2 family, non-default size: {args.n_ind} individuals x {args.nchr} chromosome(s) x {args.n_loci} SNPs, map rows every {args.map_step} bp",
                        "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_chromosomes": args.nchr, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
                        "interval_state_tracked": not args.no_intervals, "resident_genotype_planes": not args.plane_less,
+                       "mating": "reference Simulation::random_mate on the device (gev_generation_begin: random_mate -> reproduce -> ras_compute_AD per step, in the reference's order)" if fused
+                                 else "host, numpy stand-in for random_mate (round 2's loop)",
+                       "selection_function": "none (selection_value_func = 1 for everyone)",
                        "seeds_handed_over_before_couples": presample,
                        "host_mating_overlaps_device_work": pipeline,
-                       "ras_glob_seed_draws": "inside the timed loop, one generation's worth per step, by a second host thread (phase_ms.host_seed_draws)"},
+                       "ras_glob_seed_draws": "on the device, from the host's glob_generator state (2 + N*nchr per generation)" if fused else
+                                              "inside the timed loop, one generation's worth per step, by a second host thread (phase_ms.host_seed_draws)"},
             "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci * args.nchr / dt,
             "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
                          "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "host_seed_draws": float(np.mean(seed_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
@@ -437,7 +467,7 @@ def main():
                          "segments_written_per_launch": segs_written / max(args.steps, 1), "segments_per_launch": segs_total / max(args.steps, 1),
                          "written_fraction_of_row_bytes": written_frac,
                          "every_gamete_copied_equivalent_GBps": full_equiv, "every_gamete_copied_equivalent_frac": full_equiv / HBM_PEAK_GBPS,
-                         "note": "units of a launch = the row segments it writes (16 KiB each; those that contain a crossover boundary -- every other segment "
+                         "note": "units of a launch = the row segments it writes (8 KiB each; those that contain a crossover boundary -- every other segment "
                                  "of an offspring row names the parental unit and is not copied); algorithmic bytes = bytes written x 2 (each is read once "
                                  "and written once); every_gamete_copied_equivalent_* prices all 2N whole rows (N*L/2 bytes, the definition of round 1) "
                                  "and can exceed the peak; kernel time measured live with HIP events on the library's stitch stream inside the timed region, where the "

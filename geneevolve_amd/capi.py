@@ -37,6 +37,11 @@ class gev_gef_params(C.Structure):
                 ("s2_a_gen0", C.c_double), ("s2_d_gen0", C.c_double), ("gen_num", C.c_int32), ("reserved", C.c_int32)]
 
 
+class gev_generation_result(C.Structure):
+    _fields_ = [("glob_state", C.c_uint32), ("seed_mate", C.c_uint32), ("seed_reproduce", C.c_uint32), ("reserved", C.c_uint32),
+                ("num_males_mate", C.c_uint64), ("num_females_mate", C.c_uint64)]
+
+
 COUPLE_DTYPE = np.dtype([("pos_male", "<u8"), ("pos_female", "<u8"), ("inbreed", "<i4"), ("num_offspring", "<i4")])
 PART_DTYPE = np.dtype([("st", "<u8"), ("en", "<u8"), ("hap_index", "<u8"), ("root_population", "<i4"), ("reserved", "<i4")])
 MOVE_DTYPE = np.dtype([("src_pop", "<i4"), ("dst_pop", "<i4"), ("src_pos", "<u8")])
@@ -48,6 +53,7 @@ ABI_SYMBOLS = [
     "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "set_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "stitch_totals", "reproduce_begin", "reproduce_end", "presample_sex", "set_overlap",
+    "random_mate", "glob_seeds", "generation_begin", "generation_end", "redo_count",
     "dbg_verify_planes", "dbg_prefilter_sweep", "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -189,7 +195,14 @@ class GevContext:
         return sex
 
     def reproduce(self, pop, couples, seed_reproduce, mut_seeds=None, want_sex=True, n_people=None):
-        """couples: int array [n,4] (pos_male,pos_female,inbreed,num_offspring) or COUPLE_DTYPE array"""
+        """couples: int array [n,4] (pos_male,pos_female,inbreed,num_offspring) or COUPLE_DTYPE array;
+        None: the couples the preceding random_mate() left in the library (n_people = its pop_size)"""
+        if couples is None:
+            ms = None if mut_seeds is None else _arr(mut_seeds, np.uint32)
+            sex = np.zeros(n_people, dtype=np.uint8) if want_sex else None
+            self._call("reproduce", C.c_int(pop), None, C.c_size_t(0), C.c_uint32(int(seed_reproduce)),
+                       _p(ms), C.c_size_t(0 if ms is None else len(ms)), C.c_size_t(n_people), _p(sex))
+            return sex
         if couples.dtype != COUPLE_DTYPE:
             c = np.zeros(len(couples), dtype=COUPLE_DTYPE)
             c["pos_male"], c["pos_female"], c["inbreed"], c["num_offspring"] = couples[:, 0], couples[:, 1], couples[:, 2], couples[:, 3]
@@ -230,6 +243,41 @@ class GevContext:
         """head start for the next reproduce() with the same seeds / n_people (returns without waiting)"""
         ms = None if mut_seeds is None else _arr(mut_seeds, np.uint32)
         self._call("presample", C.c_int(pop), C.c_uint32(int(seed_reproduce)), _p(ms), C.c_size_t(0 if ms is None else len(ms)), C.c_size_t(n_people))
+
+    def random_mate(self, pop, seed, selection_value_func, pop_size, want_couples=True):
+        """Simulation::random_mate on the library's side -> (couples or None, num_males_mate, num_females_mate)"""
+        svf = None if selection_value_func is None else _arr(selection_value_func, np.float64)
+        couples = np.zeros(pop_size, dtype=COUPLE_DTYPE) if want_couples else None
+        nm, nf = C.c_size_t(), C.c_size_t()
+        self._call("random_mate", C.c_int(pop), C.c_uint32(int(seed)), _p(svf), C.c_size_t(pop_size), _p(couples), C.byref(nm), C.byref(nf))
+        return couples, nm.value, nf.value
+
+    def glob_seeds(self, engine_state, n, want=True):
+        """n Simulation::ras_glob_seed() values from glob_generator's state -> (values or None, state after)"""
+        st = C.c_uint32(int(engine_state))
+        out = np.zeros(n, dtype=np.uint32) if want else None
+        self._call("glob_seeds", C.byref(st), C.c_size_t(n), _p(out))
+        return out, st.value
+
+    def generation_begin(self, pop, glob_state, pop_size, selection_value_func=None):
+        """random_mate -> reproduce -> ras_compute_AD of one generation, enqueued as one unit (returns without waiting)"""
+        svf = None if selection_value_func is None else _arr(selection_value_func, np.float64)
+        self._call("generation_begin", C.c_int(pop), C.c_uint32(int(glob_state)), C.c_size_t(pop_size), _p(svf))
+        self._pending_people = pop_size
+
+    def generation_end(self, want_couples=False, want_sex=True):
+        """-> dict(glob_state, seed_mate, seed_reproduce, num_males_mate, num_females_mate, couples, sex)"""
+        res = gev_generation_result()
+        couples = np.zeros(self._pending_people, dtype=COUPLE_DTYPE) if want_couples else None
+        sex = np.zeros(self._pending_people, dtype=np.uint8) if want_sex else None
+        self._call("generation_end", C.byref(res), _p(couples), _p(sex))
+        return {"glob_state": res.glob_state, "seed_mate": res.seed_mate, "seed_reproduce": res.seed_reproduce,
+                "num_males_mate": res.num_males_mate, "num_females_mate": res.num_females_mate, "couples": couples, "sex": sex}
+
+    def redo_count(self):
+        n = C.c_ulonglong()
+        self._call("redo_count", C.byref(n))
+        return n.value
 
     def compute_ad(self, pop, per_chr=True):
         n = self.pop_size(pop)

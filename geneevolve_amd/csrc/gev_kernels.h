@@ -116,9 +116,12 @@ struct AdWork {
 #define GEV_NM_CAP 8
 // status words written by the kernels of one generation, read back once at its end
 enum { ST_BK_OVF_USED = 0, ST_NM_OVF_USED = 1, ST_FLAGS = 2, ST_SLOW_MUT = 3, ST_SLOW_REC = 4 /* tasks handed to the one-task-per-wave kernels */,
+       ST_GLOB_STATE = 5 /* glob_generator behind the generation's ras_glob_seed() draws (gev_generation_begin) */, ST_NM_MATE = 6, ST_NF_MATE = 7 /* num_males_mate, num_females_mate */,
        ST_TOTALS = 8 /* then per chr: mut_total, parts_total, segments the dense stitch writes, how many of them are last (partial) segments */ };
 #define ST_PER_CHR 4
-enum { FLAG_BK_OVF = 1, FLAG_NM_OVF = 2, FLAG_MUT_CAP = 4, FLAG_PARTS_CAP = 8, FLAG_POOL = 16 };
+enum { FLAG_BK_OVF = 1, FLAG_NM_OVF = 2, FLAG_MUT_CAP = 4, FLAG_PARTS_CAP = 8, FLAG_POOL = 16,
+       FLAG_RNG_SHORT = 32 /* a rejection stream ran out of candidates (internal) */, FLAG_NO_MATES = 64 /* "No one can marry", src/Simulation.cpp:2125 */ };
+#define FLAG_REDO_MASK (FLAG_BK_OVF | FLAG_NM_OVF | FLAG_MUT_CAP | FLAG_PARTS_CAP)      // capacities the host grows before it enqueues the generation again
 
 // The RNG tables (16 KB) are read 31 words at a time for every srand(); under a concurrently
 // running HBM-saturating stitch a dependent global read costs microseconds, so every sampling
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(256) k_scan_final_tab(const u32* __restrict__ 
             if (!is_parts && w.pw.pctr) {                                                           // k_pool_assign ran before
                 status[ST_TOTALS + ST_PER_CHR * w.chr + 2] = w.pw.pctr[1];                          // segments the dense stitch writes
                 status[ST_TOTALS + ST_PER_CHR * w.chr + 3] = w.pw.pctr[3];                          // ... of which last (partial) segments
-                w.pw.items[w.pw.items_cap] = min(w.pw.pctr[1], w.pw.items_cap);                     // length of the stitch's work list
+                w.pw.items[w.pw.items_cap] = (status[ST_FLAGS] & FLAG_POOL) ? 0u : min(w.pw.pctr[1], w.pw.items_cap);   // length of the stitch's work list (pool exhausted: the stitch does nothing, the host reports)
             }
         }
         ex += v[j];
@@ -418,7 +421,7 @@ __device__ __forceinline__ u32 task_sample(const GevRngTables* __restrict__ T, c
 // task-parallel form (a mutation map is loaded: every task's chain restarts at srand(S), see
 // SURVEY.md section 7.2-1).  seed_pat[t] for t>0 was written by k_mut_sample.
 __global__ void __launch_bounds__(256) k_rec_sample(const GevRngTables* __restrict__ Tg, const ChrDev* __restrict__ chrs, int nchr,
-                                                    u32 seed_reproduce, size_t n_tasks, SampleDev sd,
+                                                    u32 seed_reproduce, const u32* __restrict__ seed_ptr /* device copy of the seed (gev_generation_begin), or null */, size_t n_tasks, SampleDev sd,
                                                     const u32* __restrict__ list, const u32* __restrict__ n_list)
 {
     __shared__ __attribute__((aligned(16))) GevRngTables s_T;
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(256) k_rec_sample(const GevRngTables* __restri
         asm volatile("" : "+v"(T));      // keep the 62 table words of this lane out of registers across tasks (occupancy)
         GlibcWave g;
         u32 seed_pat;
-        if (t == 0) { g.seed(T, seed_reproduce); seed_pat = g.out(T, 0); }     // srand(seed) :2400, first rand() :2447
+        if (t == 0) { g.seed(T, seed_ptr ? *seed_ptr : seed_reproduce); seed_pat = g.out(T, 0); }     // srand(seed) :2400, first rand() :2447
         else seed_pat = sd.seed_pat[t];
         const ChrDev& C = chrs[t % nchr];
         if (!C.active) {                 // another context owns this chromosome: only the seed chain (k_mut_sample) is needed here
@@ -446,12 +449,12 @@ __global__ void __launch_bounds__(256) k_rec_sample(const GevRngTables* __restri
 // serial form (no mutation map): every gamete's seed depends on the previous gamete's crossover
 // count, so one wave walks the chain; each link is still a wave-parallel scan.
 __global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict__ Tg, const ChrDev* __restrict__ chrs, int nchr,
-                                                  u32 seed_reproduce, size_t n_tasks, SampleDev sd)
+                                                  u32 seed_reproduce, const u32* __restrict__ seed_ptr, size_t n_tasks, SampleDev sd)
 {
     __shared__ __attribute__((aligned(16))) GevRngTables s_T;
     const GevRngTables* T = stage_tables(Tg, &s_T);
     const u32 lane = threadIdx.x;
-    GlibcWave g; g.seed(T, seed_reproduce);
+    GlibcWave g; g.seed(T, seed_ptr ? *seed_ptr : seed_reproduce);
     u32 seed = g.out(T, 0);
     for (size_t t = 0; t < n_tasks; t++) {
         const int c = (int)(t % nchr);
@@ -1395,6 +1398,12 @@ __global__ void __launch_bounds__(256) k_copy_rows16(RowRef dst, RowRef src, con
     const size_t l = map ? (size_t)map[r] : base + r;
     *dst.chunk(r, q) = *src.chunk(l, q);
 }
+// dst[i] = src[map[i << shift] >> shift]: bytes of selected individuals (shift = 1: `map` holds haplotype rows 2*individual, 2*individual+1)
+__global__ void k_gather_u8(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, const u32* __restrict__ map, u32 shift, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[map[i << shift] >> shift];
+}
 // CSR gather: count / fill of rows selected by map (element size templated)
 __global__ void k_csr_gather_count(const u32* __restrict__ s_off, const u32* __restrict__ map, size_t n_rows, u32* __restrict__ cnt)
 {
@@ -1685,3 +1694,5 @@ __global__ void __launch_bounds__(256) k_format_bed(const u64* __restrict__ snpm
     }
     out[q] = (uint8_t)o;
 }
+
+#include "gev_mate.h"

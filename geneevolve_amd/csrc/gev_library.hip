@@ -155,6 +155,7 @@ struct PopState {
     std::vector<ChrState> st;                          // [chr]
     std::vector<std::vector<std::array<DevBuf, 2>>> cvp; // [phen][chr][2]
     DevBuf d_chrdev;
+    DevBuf d_sex[2];                                   // Human::sex of the individuals (1 male, 2 female), physical row order, [cur]: what Simulation::random_mate reads (gev_random_mate)
     int cur = 0, pcur = 0;                             // current buffer of the double-buffered lists / of phys[3]
     size_t n_people = 0, cap_people = 0;
     // After a cross-GPU migration the individuals of the current generation are not moved physically:
@@ -178,12 +179,15 @@ struct gev_ctx {
     // per-generation scratch: two sets, because the dense stitch of generation g (stream_big) still reads set g%2
     // while sampling / sparse state of generation g+1 (stream) fill the other one
     struct Scratch {
-        DevBuf father, mother, mutseeds, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, status, slow_mut, slow_rec, chrwork, cvwork;
+        DevBuf father, mother, mutseeds, globvals /* [2 + T] ras_glob_seed() values drawn on the device: mate seed, reproduce seed, mutation seeds */, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, status, slow_mut, slow_rec, chrwork, cvwork;
         unsigned n_chrwork = 0; float sampling_ms_saved = -1;
         hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_status = nullptr, ev_sampled = nullptr;   // the generation's status block (and A/D results) have arrived on the host
         bool timing_pending = false, stitch_pending = false;
         // gev_presample: the sampling kernels of the next gev_reproduce were already enqueued for exactly these inputs
         bool presampled = false; int ps_pop = -1; u32 ps_seed = 0; size_t ps_n_people = 0; bool ps_has_mut = false;
+        bool ps_stale = false;      // the head start was dropped by a redo of the generation in flight (record capacities changed): gev_presample_sex samples again from the retained inputs
+        // gev_random_mate: father / mother of this set hold the couples of the next gev_reproduce (couples == NULL) of mate_pop
+        bool mated = false; int mate_pop = -1; size_t mate_n = 0;
     } sc[2];
     unsigned gen_counter = 0;
     std::vector<uint8_t> chr_active;        // 0: chromosome held by another context (gev_set_chr_active); sampling chain only
@@ -193,7 +197,8 @@ struct gev_ctx {
     bool planes_pending = false;            // a stitch may still be writing the current planes (stream_big)
     hipEvent_t ev_planes = nullptr;         // recorded after the most recent stitch
     double ms_sum[4] = {0, 0, 0, 0}; unsigned long long ms_count = 0;
-    size_t bk_ovf_cap = 1 << 16, nm_ovf_cap = 1 << 16;       // overflow regions of the breakpoint / new-mutation records
+    size_t bk_ovf_cap = 1 << 16, nm_ovf_cap = 1 << 16;       // overflow regions of the breakpoint / new-mutation records (GEV_OVF_CAP: initial size, tests force redos with a tiny one)
+    unsigned long long redo_count = 0;                       // generations that were enqueued again with larger buffers (gev_redo_count)
     void* h_stage = nullptr; size_t h_stage_bytes = 0;       // pinned host staging
     void* h_seeds = nullptr; size_t h_seeds_bytes = 0;       // pinned copy of the mutation seeds handed to gev_presample
     void* h_ad = nullptr; size_t h_ad_bytes = 0;             // pinned A/D result cache
@@ -224,10 +229,12 @@ struct gev_ctx {
     // stitch dominates anyway (11 chromosomes of 227k SNPs: 8).  Default: by row length; GEV_STITCH_WG_PER_CU=<n> fixes it,
     // =auto measures it (a few generations per candidate, wall time between consecutive gev_reproduce returns).
     int stitch_occ = 0 /* 0 = by row length */, stitch_occ_env = 0; bool stitch_occ_auto = false;
-    struct PendingRepro { bool active = false, has_mut = false, pre = false; int pop = 0, attempt = 0; size_t n_people = 0, n_status = 0; u32 seed = 0; u32* hstatus = nullptr; double th0 = 0, th1 = 0, th2 = 0; } pend;
+    struct PendingRepro { bool active = false, has_mut = false, pre = false; int pop = 0, attempt = 0; size_t n_people = 0, n_status = 0; u32 seed = 0; u32* hstatus = nullptr; double th0 = 0, th1 = 0, th2 = 0;
+                          bool fused = false /* gev_generation_begin: seeds and couples are made on the device */, has_svf = false; u32 glob_state = 0; u32* hseeds2 = nullptr; uint8_t* hsex = nullptr; } pend;
     struct OccTune { int phase = 0 /* 0 idle, 1 measuring, 2 settled */, idx = 0, n = 0, best_occ = 8; double last = 0, cur_min = 0, best = 0; size_t people = 0; unsigned age = 0; } tune;
     DevBuf d_snpmajor, d_text;
-    DevBuf d_sex0, d_gef_flag, d_gef_first, d_gef_red, d_gef_io;
+    DevBuf d_mflag, d_mblk, d_posm, d_posf, d_pickblk, d_couples, d_svf, d_logical, d_globblk, d_mstat;   // gev_random_mate / gev_glob_seeds scratch
+    DevBuf d_gef_flag, d_gef_first, d_gef_red, d_gef_io;
     DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
     // per-generation work tables (gev_kernels.h: ChrWork / CvWork / AdWork) are written into a ring of pinned host memory and
     // copied to the device on the stream that uses them
@@ -386,6 +393,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     if (const char* e = getenv("GEV_SEG_CHUNKS")) { const int v = atoi(e); u32 sh = 0; while ((1 << (sh + 1)) <= v) sh++; if (v >= 1 && sh <= 20) c->seg_shift = sh; }
     if (const char* e = getenv("GEV_ALIAS_ROWS")) c->alias_rows = atoi(e) != 0;
     if (const char* e = getenv("GEV_STITCH_WAVE_PRIO")) c->stitch_wave_prio = std::max(0, std::min(atoi(e), 3));
+    if (const char* e = getenv("GEV_OVF_CAP")) { const long v = atol(e); if (v >= 1) c->bk_ovf_cap = c->nm_ovf_cap = (size_t)v; }
     if (const char* e = getenv("GEV_STITCH_MODE")) c->stitch_mode = std::max(0, std::min(atoi(e), 1));
     if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = c->sample_grid_shared = (unsigned)g; }
     if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // fixed stitch workgroups per CU (default: measured, see OccTune)
@@ -466,7 +474,7 @@ int gev_set_snps(gev_ctx* c, int pop, int chr, const u64* pos, size_t L)
     ChrStatic& S = c->pop[pop].cs[chr];
     S.pos.assign(pos, pos + L); S.L = L;
     S.stride = std::max<size_t>(round_up(ceil_div(L, 8), 128), 128);
-    S.seg_shift = c->seg_shift;                                    // 16 KiB segments unless the row would need more than 64 of them
+    S.seg_shift = c->seg_shift;                                    // 8 KiB segments (GEV_SEG_CHUNKS) unless the row would need more than 64 of them
     while (ceil_div(S.stride / 16, (size_t)1 << S.seg_shift) > POOL_SEG_MAX) S.seg_shift++;
     while (S.seg_shift > 0 && ((size_t)1 << (S.seg_shift - 1)) >= S.stride / 16) S.seg_shift--;     // a row shorter than a segment: the smallest power-of-two unit that holds it
     S.nseg = (u32)ceil_div(S.stride / 16, (size_t)1 << S.seg_shift);
@@ -591,6 +599,7 @@ static int ensure_capacity(gev_ctx* c, int pop, size_t people)
                 GEVC(P.cvp[p][k][b].ensure(rows * P.cv[p][k].stride_w32 * sizeof(u32), c->stream, b == P.cur));
         }
     }
+    for (int b = 0; b < 2; b++) GEVC(P.d_sex[b].ensure(people, c->stream, b == P.cur));
     P.cap_people = people;
     return GEV_OK;
 }
@@ -616,6 +625,7 @@ int gev_set_chr_active(gev_ctx* c, int chr, int active)
 int gev_set_dense_state(gev_ctx* c, int on)
 {
     if (!c) return fail(GEV_EINVAL, "null context");
+    if (c->pend.active) return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first");
     for (auto& P : c->pop) if (P.gen0) return fail(GEV_ESTATE, "set_dense_state: must precede gev_init_gen0");
     c->dense = on != 0;
     if (!c->dense) c->track_intervals = true;
@@ -812,10 +822,9 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
             V.frq_valid = false;
         }
     }
-    GEVC(c->d_sex0.ensure(n_people, c->stream));
-    hipLaunchKernelGGL(k_sex_sequence, dim3(1), dim3(64), 0, c->stream, c->d_tables.as<GevRngTables>(), (u32)seed_gen0, n_people, c->d_sex0.as<uint8_t>());
+    hipLaunchKernelGGL(k_sex_sequence, dim3(1), dim3(64), 0, c->stream, c->d_tables.as<GevRngTables>(), (u32)seed_gen0, n_people, P.d_sex[P.cur].as<uint8_t>());
     KCHECK();
-    if (sex_out) HIPC(hipMemcpyAsync(sex_out, c->d_sex0.p, n_people, hipMemcpyDeviceToHost, c->stream));
+    if (sex_out) HIPC(hipMemcpyAsync(sex_out, P.d_sex[P.cur].p, n_people, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = c->chr_active[k] ? rows : 0; }
     c->ad_cached_pop = c->ad_host_set_pop = -1;
@@ -836,6 +845,7 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
 // of the count passes and the small work is enqueued again (inputs are untouched until the flip).
 static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n);
 static int materialize_order(gev_ctx* c, int pop);
+extern "C" int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people);
 static int wait_planes(gev_ctx* c)
 {
     if (c->planes_pending) HIPC(hipStreamWaitEvent(c->stream, c->ev_planes, 0));
@@ -924,7 +934,8 @@ static int ensure_scratch(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, boo
     return GEV_OK;
 }
 // K1-K3: crossover / mutation sampling and the rand() seed chain; depends on the seeds and n_people only, not on the couples
-static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut, u32 seed_reproduce, hipStream_t st)
+static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut, u32 seed_reproduce, hipStream_t st,
+                            const u32* seed_ptr = nullptr /* device copy of the reproduce seed */, const u32* mut_seeds_dev = nullptr /* default: sc.mutseeds */, bool clear_status = true)
 {
     PopState& P = c->pop[pop];
     const int nchr = c->nchr;
@@ -937,8 +948,9 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
     GEVC(sc.bk_idx.ensure((bk_fixed + c->bk_ovf_cap) * sizeof(u32), st));
     if (has_mut) { GEVC(sc.nm_pos.ensure((nm_fixed + c->nm_ovf_cap) * sizeof(u64), st)); GEVC(sc.nm_side.ensure(nm_fixed + c->nm_ovf_cap, st)); }
     const size_t n_status = ST_TOTALS + ST_PER_CHR * (size_t)nchr;
-    HIPC(hipMemsetAsync(sc.status.p, 0, n_status * sizeof(u32), st));
+    if (clear_status) HIPC(hipMemsetAsync(sc.status.p, 0, n_status * sizeof(u32), st));
     SampleDev sd = make_sd(c, sc, T);
+    const u32* mseeds = mut_seeds_dev ? mut_seeds_dev : sc.mutseeds.as<u32>();
 
     HIPC(hipEventRecord(sc.t[0], st));
     // ---- sampling: one map scan per gamete / per mutation task
@@ -947,22 +959,23 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
         // eight tasks per wave; the rare tasks that need more than 8 rand() outputs go to the one-task-per-wave kernels
         const unsigned batch_blocks = (unsigned)std::min<size_t>(ceil_div(ceil_div(T, SB_TASKS), 4), task_blocks);
         const unsigned slow_blocks = (unsigned)std::min<size_t>(ceil_div(T, 4), 64);
-        hipLaunchKernelGGL(k_mut_sample8, dim3(batch_blocks), dim3(256), 0, st, Tb, chrs, nchr, sc.mutseeds.as<u32>(), seed_reproduce, T, sd, sc.slow_mut.as<u32>());
-        hipLaunchKernelGGL(k_mut_sample, dim3(slow_blocks), dim3(256), 0, st, Tb, chrs, nchr, sc.mutseeds.as<u32>(), T, sd, sc.slow_mut.as<u32>(), sd.status + ST_SLOW_MUT);
+        hipLaunchKernelGGL(k_mut_sample8, dim3(batch_blocks), dim3(256), 0, st, Tb, chrs, nchr, mseeds, seed_reproduce, seed_ptr, T, sd, sc.slow_mut.as<u32>());
+        hipLaunchKernelGGL(k_mut_sample, dim3(slow_blocks), dim3(256), 0, st, Tb, chrs, nchr, mseeds, T, sd, sc.slow_mut.as<u32>(), sd.status + ST_SLOW_MUT);
         hipLaunchKernelGGL(k_rec_sample8, dim3(batch_blocks), dim3(256), 0, st, Tb, chrs, nchr, T, sd, sc.slow_rec.as<u32>());
-        hipLaunchKernelGGL(k_rec_sample, dim3(slow_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd, sc.slow_rec.as<u32>(), sd.status + ST_SLOW_REC);
+        hipLaunchKernelGGL(k_rec_sample, dim3(slow_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, seed_ptr, T, sd, sc.slow_rec.as<u32>(), sd.status + ST_SLOW_REC);
     } else if (has_mut) {
-        hipLaunchKernelGGL(k_mut_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, sc.mutseeds.as<u32>(), T, sd, (const u32*)nullptr, (const u32*)nullptr);
-        hipLaunchKernelGGL(k_rec_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd, (const u32*)nullptr, (const u32*)nullptr);
+        hipLaunchKernelGGL(k_mut_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, mseeds, T, sd, (const u32*)nullptr, (const u32*)nullptr);
+        hipLaunchKernelGGL(k_rec_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, seed_ptr, T, sd, (const u32*)nullptr, (const u32*)nullptr);
     } else {
-        hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, seed_reproduce, T, sd);
+        hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, seed_reproduce, seed_ptr, T, sd);
     }
     hipLaunchKernelGGL(k_bk_to_idx, dim3((unsigned)ceil_div(2 * T, 256)), dim3(256), 0, st, chrs, nchr, 2 * T, sd);
     KCHECK();
     HIPC(hipEventRecord(sc.t[1], st));
     return GEV_OK;
 }
-static const size_t LIST_HEADROOM = 48;    // spare list entries per haplotype row when a list buffer is (re)allocated
+static const size_t LIST_HEADROOM = getenv("GEV_LIST_HEADROOM") ? (size_t)atol(getenv("GEV_LIST_HEADROOM")) : 48;    // spare list entries per haplotype row when a list buffer is (re)allocated (tests force redos with 0)
+static const double LIST_GROW = LIST_HEADROOM ? 1.5 : 1.0; static const size_t LIST_SLACK = LIST_HEADROOM ? 4096 : 16;   // (no headroom: every generation that lengthens the lists is enqueued twice)
 // K4/K6 + grouping: everything of the small work that needs the couples (parents) on top of the sampling results.
 // Every kernel covers ALL active chromosomes in one launch (blockIdx.y = entry of the generation's ChrWork / CvWork table).
 static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut)
@@ -984,14 +997,14 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         // capacity guess: last generation's total scaled to the new size, plus room for the events of many generations
         // (lists lengthen by about one entry per row and generation; a growth step allocates GBs, which on some hosts is
         // not lazy and costs 10-250 ms of host time -- keep such steps rare and geometric)
-        size_t want = std::max<size_t>(cs.mut_need, (size_t)(cs.mut_total[cur] * grow * 1.5) + rows * LIST_HEADROOM + 4096);
-        GEVC(cs.mpos[alt].ensure(want * sizeof(u64), st, false, 2.0));        // grow geometrically: lists lengthen every generation
+        size_t want = std::max<size_t>(cs.mut_need, (size_t)(cs.mut_total[cur] * grow * LIST_GROW) + rows * LIST_HEADROOM + LIST_SLACK);
+        GEVC(cs.mpos[alt].ensure(want * sizeof(u64), st, false, LIST_HEADROOM ? 2.0 : 1.0));        // grow geometrically: lists lengthen every generation
         ChrWork w{};
         w.moff_cur = cs.moff[cur].as<u32>(); w.mpos_cur = cs.mpos[cur].as<u64>(); w.moff_alt = cs.moff[alt].as<u32>(); w.mpos_alt = cs.mpos[alt].as<u64>();
         w.mcap = (u32)std::min<size_t>(cs.mpos[alt].bytes / sizeof(u64), 0xfffffff0u);
         if (c->track_intervals) {
-            want = std::max<size_t>(cs.parts_need, (size_t)(cs.parts_total[cur] * grow * 1.5) + rows * LIST_HEADROOM + 4096);
-            GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), st, false, 2.0));
+            want = std::max<size_t>(cs.parts_need, (size_t)(cs.parts_total[cur] * grow * LIST_GROW) + rows * LIST_HEADROOM + LIST_SLACK);
+            GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), st, false, LIST_HEADROOM ? 2.0 : 1.0));
             w.poff_cur = cs.poff[cur].as<u32>(); w.parts_cur = cs.parts[cur].as<gev_part>(); w.poff_alt = cs.poff[alt].as<u32>(); w.parts_alt = cs.parts[alt].as<gev_part>();
             w.pcap = (u32)std::min<size_t>(cs.parts[alt].bytes / sizeof(gev_part), 0xfffffff0u);
         }
@@ -1124,15 +1137,71 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int /*pop*/, size_t 
     return GEV_OK;
 }
 
+// ---- Simulation::ras_glob_seed / Simulation::random_mate on the device (gev_mate.h) --------------------------------------------
+// n ras_glob_seed() values into vals[0..n) and the engine state behind them into *state_out; the engine state in front comes from
+// the host (state_val) or from a device word (state_ptr)
+static int enqueue_glob(gev_ctx* c, hipStream_t st, u32 state_val, const u32* state_ptr, size_t n, u32* vals, u32* state_out, u32* flags)
+{
+    const u64 n_cand = (u64)n + n / 512 + 512;                  // expected rejections: n / 4444 (2147483646 - 2147000000 of 2147483646 outputs)
+    const unsigned nb = (unsigned)ceil_div((size_t)n_cand, REJ_CHUNK);
+    GEVC(c->d_globblk.ensure(nb * sizeof(u32), st));
+    hipLaunchKernelGGL(k_glob_count, dim3(nb), dim3(256), 0, st, state_val, state_ptr, n_cand, c->d_globblk.as<u32>());
+    hipLaunchKernelGGL(k_glob_emit, dim3(nb), dim3(256), 0, st, state_val, state_ptr, (u64)n, n_cand, c->d_globblk.as<u32>(), vals, state_out, flags);
+    KCHECK();
+    return GEV_OK;
+}
+// Simulation::random_mate of population P's current generation: pop_size couples into father / mother (physical parent rows, what
+// the kernels of gev_reproduce read) and, when d_couples is given, as Couples_Info records; meta[0..1] = num_males_mate,
+// num_females_mate; the seed (:2092) comes from the host (seed_val) or from a device word (seed_ptr)
+static int enqueue_mate(gev_ctx* c, hipStream_t st, PopState& P, u32 seed_val, const u32* seed_ptr, const double* d_svf, size_t pop_size,
+                        u32* father, u32* mother, gev_couple* d_couples, u32* meta, u32* flags)
+{
+    const size_t n_h = P.n_people;
+    const u32* logical = nullptr;
+    if (!P.logical.empty()) {                                   // after a cross-GPU migration positions are not rows
+        GEVC(upload_table(c, c->d_logical, P.logical.data(), n_h * sizeof(u32), st));
+        logical = c->d_logical.as<u32>();
+    }
+    const unsigned nb = (unsigned)ceil_div(n_h, MATE_CHUNK);
+    GEVC(c->d_mflag.ensure(n_h, st)); GEVC(c->d_mblk.ensure(nb * sizeof(u32), st));
+    GEVC(c->d_posm.ensure(n_h * sizeof(u32), st)); GEVC(c->d_posf.ensure(n_h * sizeof(u32), st));
+    hipLaunchKernelGGL(k_mate_flags, dim3(nb), dim3(256), 0, st, P.d_sex[P.cur].as<uint8_t>(), logical, d_svf, n_h, seed_val, seed_ptr, c->d_mflag.as<uint8_t>(), c->d_mblk.as<u32>());
+    hipLaunchKernelGGL(k_mate_compact, dim3(nb), dim3(256), 0, st, c->d_mflag.as<uint8_t>(), n_h, c->d_mblk.as<u32>(), nb, c->d_posm.as<u32>(), c->d_posf.as<u32>(), meta, flags);
+    // candidates of the two pick streams: a draw is rejected with probability < n_h / 2^31
+    const u64 n_cand = (u64)pop_size + (u64)(2.0 * (double)pop_size * (double)n_h / 2147483648.0) + 1024;
+    const unsigned nbp = (unsigned)ceil_div((size_t)n_cand, REJ_CHUNK);
+    GEVC(c->d_pickblk.ensure(2 * (size_t)nbp * sizeof(u32), st));
+    hipLaunchKernelGGL(k_pick_count, dim3(nbp, 2), dim3(256), 0, st, seed_val, seed_ptr, (const u32*)meta, n_cand, c->d_pickblk.as<u32>());
+    hipLaunchKernelGGL(k_pick_emit, dim3(nbp, 2), dim3(256), 0, st, seed_val, seed_ptr, (const u32*)meta, (u64)pop_size, n_cand, c->d_pickblk.as<u32>(),
+                       c->d_posm.as<u32>(), c->d_posf.as<u32>(), logical, father, mother, d_couples, flags);
+    KCHECK();
+    return GEV_OK;
+}
+
 // One attempt of a generation: sampling (unless the head start covers it), lists + CV planes + unit table, the dense stitch on its
-// own stream, A/D, and the status block on its way back -- everything enqueued, nothing waited for.
+// own stream, A/D, and the status block on its way back -- everything enqueued, nothing waited for.  A generation begun with
+// gev_generation_begin also draws its ras_glob_seed() values and forms its couples here, on the device.
 static int enqueue_attempt(gev_ctx* c, int attempt)
 {
     gev_ctx::PendingRepro& q = c->pend;
     gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    PopState& P = c->pop[q.pop];
     q.th0 = host_ms();
     if (attempt == 0) GEVC(harvest_timing(c, sc));          // kernel times of the set's previous generation, before its events are recorded again
-    if (!(q.pre && attempt == 0)) GEVC(enqueue_sampling(c, sc, q.pop, q.n_people, q.has_mut, q.seed, c->stream));
+    if (q.fused) {
+        const size_t T = q.n_people * (size_t)c->nchr;
+        u32* gv = sc.globvals.as<u32>(); u32* status = sc.status.as<u32>();
+        HIPC(hipMemsetAsync(sc.status.p, 0, q.n_status * sizeof(u32), c->stream));
+        // glob_generator's draws in the reference's order: random_mate (:2092), reproduce (:2398), then one per (offspring, chromosome) inside ras_add_mutation (:2500)
+        GEVC(enqueue_glob(c, c->stream, q.glob_state, nullptr, 2 + (q.has_mut ? T : 0), gv, status + ST_GLOB_STATE, status + ST_FLAGS));
+        GEVC(enqueue_mate(c, c->stream, P, 0u, gv, q.has_svf ? c->d_svf.as<double>() : nullptr, q.n_people, sc.father.as<u32>(), sc.mother.as<u32>(),
+                          c->d_couples.as<gev_couple>(), status + ST_NM_MATE, status + ST_FLAGS));
+        GEVC(enqueue_sampling(c, sc, q.pop, q.n_people, q.has_mut, 0u, c->stream, gv + 1, gv + 2, /*clear_status=*/false));
+        HIPC(hipMemcpyAsync(q.hseeds2, gv, 2 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    } else if (!(q.pre && attempt == 0)) GEVC(enqueue_sampling(c, sc, q.pop, q.n_people, q.has_mut, q.seed, c->stream));
+    // Human::sex of the new generation (:2472) for the next gev_random_mate; a fused generation also sends them to the host with the status block
+    HIPC(hipMemcpyAsync(P.d_sex[P.cur ^ 1].p, sc.sex.p, q.n_people, hipMemcpyDeviceToDevice, c->stream));
+    if (q.fused) HIPC(hipMemcpyAsync(q.hsex, sc.sex.p, q.n_people, hipMemcpyDeviceToHost, c->stream));
     q.th1 = host_ms();
     GEVC(enqueue_sparse(c, sc, q.pop, q.n_people, q.has_mut));
     // the dense stitch needs the sampling + sparse results only: it starts now, on its own stream, next to A/D (not waited for)
@@ -1144,6 +1213,16 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     HIPC(hipEventRecord(sc.ev_status, c->stream));          // gev_reproduce_end waits for THIS, not for whatever a head start queued behind it
     return GEV_OK;
 }
+static int ensure_stage(gev_ctx* c, size_t bytes)
+{
+    if (c->h_stage_bytes >= bytes) return GEV_OK;
+    HIPC(hipDeviceSynchronize());
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_bytes = 0;
+    HIPC(hipHostMalloc(&c->h_stage, bytes * 5 / 4 + 4096, hipHostMallocDefault));
+    c->h_stage_bytes = bytes * 5 / 4 + 4096;
+    return GEV_OK;
+}
 // gev_reproduce in two halves: _begin checks and stages the inputs and enqueues the generation's device work, _end waits for it,
 // repeats it with larger buffers if a capacity was exceeded, and publishes the new generation.  Between the two the host is free
 // (the bench forms the next generation's couples there); no other call on the context is allowed in between.
@@ -1153,7 +1232,6 @@ int gev_reproduce_begin(gev_ctx* c, int pop, const gev_couple* couples, size_t n
     GEVC(check_idx(c, pop, 0));
     PopState& P = c->pop[pop];
     if (!P.gen0) return fail(GEV_ESTATE, "reproduce: population %d has no current generation (call gev_init_gen0)", pop);
-    if (n_couples && !couples) return fail(GEV_EINVAL, "reproduce: null couples");
     HIPC(hipSetDevice(c->device));
     const int nchr = c->nchr;
     const size_t T = n_people * (size_t)nchr;
@@ -1161,21 +1239,20 @@ int gev_reproduce_begin(gev_ctx* c, int pop, const gev_couple* couples, size_t n
     if (2 * T * GEV_BK_CAP >= 0xf0000000ull) return fail(GEV_EINVAL, "reproduce: too many gametes");
     const bool has_mut = mut_seeds != nullptr;
     if (has_mut && n_mut_seeds != T) return fail(GEV_EINVAL, "reproduce: n_mut_seeds=%zu, expected n_people*nchr=%zu", n_mut_seeds, T);
+    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    // couples == NULL: the couples gev_random_mate left on the device for this population
+    const bool dev_couples = couples == nullptr;
+    if (dev_couples && !(sc.mated && sc.mate_pop == pop && sc.mate_n == n_people))
+        return fail(GEV_ESTATE, "reproduce: couples is NULL but no gev_random_mate of population %d for %zu offspring precedes", pop, n_people);
     // pinned staging: [father | mother | mut_seeds | status], written by the host, copied asynchronously
     const size_t n_status = ST_TOTALS + ST_PER_CHR * (size_t)nchr;
     const size_t stage_words = 2 * n_people + (has_mut ? T : 0) + n_status;
-    if (c->h_stage_bytes < stage_words * 4) {
-        HIPC(hipDeviceSynchronize());
-        if (c->h_stage) (void)hipHostFree(c->h_stage);
-        c->h_stage = nullptr; c->h_stage_bytes = 0;
-        HIPC(hipHostMalloc(&c->h_stage, stage_words * 4 * 5 / 4 + 4096, hipHostMallocDefault));
-        c->h_stage_bytes = stage_words * 4 * 5 / 4 + 4096;
-    }
+    GEVC(ensure_stage(c, stage_words * 4));
     u32* father = (u32*)c->h_stage; u32* mother = father + n_people; u32* hseeds = mother + n_people; u32* hstatus = hseeds + (has_mut ? T : 0);
     // offspring enumeration order of the couple loop (src/Simulation.cpp:2433-2443)
     size_t ip = 0;
     const u32* lg = P.logical.empty() ? nullptr : P.logical.data();
-    for (size_t it = 0; it < n_couples; it++) {
+    for (size_t it = 0; it < n_couples && !dev_couples; it++) {
         if (couples[it].inbreed) continue;
         if (couples[it].num_offspring < 0) return fail(GEV_EINVAL, "reproduce: couple %zu has negative num_offspring", it);
         if (couples[it].num_offspring && (couples[it].pos_male >= P.n_people || couples[it].pos_female >= P.n_people))
@@ -1186,15 +1263,14 @@ int gev_reproduce_begin(gev_ctx* c, int pop, const gev_couple* couples, size_t n
             mother[ip] = lg ? lg[couples[it].pos_female] : (u32)couples[it].pos_female; ip++;
         }
     }
-    if (ip != n_people) return fail(GEV_EINVAL, "reproduce: n_people=%zu but the couples list yields %zu offspring", n_people, ip);
+    if (!dev_couples && ip != n_people) return fail(GEV_EINVAL, "reproduce: n_people=%zu but the couples list yields %zu offspring", n_people, ip);
     GEVC(finalize_static(c, pop));
     GEVC(ensure_capacity(c, pop, n_people));
     hipStream_t st = c->stream;
-    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
     // sampling already enqueued by gev_presample for exactly these inputs?
     const bool pre = sc.presampled && sc.ps_pop == pop && sc.ps_seed == (u32)seed_reproduce && sc.ps_n_people == n_people && sc.ps_has_mut == has_mut &&
                      (!has_mut || (c->h_seeds && memcmp(c->h_seeds, mut_seeds, T * sizeof(u32)) == 0));
-    sc.presampled = false;
+    sc.presampled = false; sc.ps_stale = false; sc.mated = false;
     if (pre) HIPC(hipStreamWaitEvent(st, sc.ev_sampled, 0));     // the head start ran on its own stream
     else HIPC(hipStreamSynchronize(c->stream_samp));            // a head start that does not match must not write into the set any more
     if (!pre) {
@@ -1204,20 +1280,73 @@ int gev_reproduce_begin(gev_ctx* c, int pop, const gev_couple* couples, size_t n
         GEVC(ensure_scratch(c, sc, n_people, has_mut));
         if (has_mut) { memcpy(hseeds, mut_seeds, T * sizeof(u32)); HIPC(hipMemcpyAsync(sc.mutseeds.p, hseeds, T * sizeof(u32), hipMemcpyHostToDevice, st)); }
     }
-    HIPC(hipMemcpyAsync(sc.father.p, father, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(sc.mother.p, mother, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
+    if (!dev_couples) {
+        HIPC(hipMemcpyAsync(sc.father.p, father, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(sc.mother.p, mother, n_people * sizeof(u32), hipMemcpyHostToDevice, st));
+    }
 
     gev_ctx::PendingRepro& q = c->pend;
     q.pop = pop; q.n_people = n_people; q.has_mut = has_mut; q.pre = pre; q.seed = (u32)seed_reproduce; q.attempt = 0; q.n_status = n_status; q.hstatus = hstatus;
+    q.fused = false; q.has_svf = false;
     GEVC(enqueue_attempt(c, 0));
     q.active = true;
     return GEV_OK;
 }
-int gev_reproduce_end(gev_ctx* c, uint8_t* sex_out)
+// does every chromosome of the population have a mutation map (Simulation::reproduce's `_mutation_map.size() > 0`, :2459)?
+static int population_has_mutmap(gev_ctx* c, int pop, bool& has_mut)
 {
-    if (!c) return fail(GEV_EINVAL, "null context");
+    PopState& P = c->pop[pop];
+    has_mut = P.cs[0].mut_set;
+    for (int k = 1; k < c->nchr; k++)
+        if (P.cs[k].mut_set != has_mut) return fail(GEV_ESTATE, "population %d: a mutation map is set for some chromosomes only", pop);
+    return GEV_OK;
+}
+// One generation of a randomly mating population in one piece: Simulation::random_mate -> Simulation::reproduce ->
+// Simulation::ras_compute_AD (the body of sim_next_generation, src/Simulation.cpp:1907-1935) with every ras_glob_seed() value
+// the three draw -- 1 (:2092) + 1 (:2398) + n_people * nchr (:2500) -- taken from glob_generator's state ON THE DEVICE.
+int gev_generation_begin(gev_ctx* c, int pop, uint32_t glob_state, size_t pop_size, const double* selection_value_func)
+{
+    GEVC(check_idx(c, pop, 0));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "generation: population %d has no current generation (call gev_init_gen0)", pop);
+    if (glob_state == 0 || glob_state >= GEV_M31) return fail(GEV_EINVAL, "generation: %u is not a state of std::minstd_rand0 (1 .. 2^31-2)", glob_state);
+    HIPC(hipSetDevice(c->device));
+    const int nchr = c->nchr;
+    const size_t n_people = pop_size, T = n_people * (size_t)nchr;
+    if (n_people == 0) return fail(GEV_EINVAL, "generation: no offspring");
+    if (2 * T * GEV_BK_CAP >= 0xf0000000ull) return fail(GEV_EINVAL, "generation: too many gametes");
+    bool has_mut = false;
+    GEVC(population_has_mutmap(c, pop, has_mut));
+    const size_t n_status = ST_TOTALS + ST_PER_CHR * (size_t)nchr;
+    // pinned: [status | the two seeds | sexes]
+    GEVC(ensure_stage(c, (n_status + 2) * 4 + n_people + 16));
+    u32* hstatus = (u32*)c->h_stage;
+    GEVC(finalize_static(c, pop));
+    GEVC(ensure_capacity(c, pop, n_people));
+    hipStream_t st = c->stream;
+    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    if (sc.presampled) HIPC(hipStreamSynchronize(c->stream_samp));     // a head start of the other protocol must not write into the set any more
+    sc.presampled = false; sc.ps_stale = false; sc.mated = false;
+    GEVC(harvest_timing(c, sc));
+    if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); sc.stitch_pending = false; }
+    GEVC(ensure_scratch(c, sc, n_people, has_mut));
+    GEVC(sc.globvals.ensure((2 + T) * sizeof(u32), st));
+    GEVC(c->d_couples.ensure(n_people * sizeof(gev_couple), st));
+    if (selection_value_func) {
+        GEVC(c->d_svf.ensure(P.n_people * sizeof(double), st));
+        HIPC(hipMemcpyAsync(c->d_svf.p, selection_value_func, P.n_people * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPC(hipStreamSynchronize(st));                          // the caller's array is pageable memory of unknown lifetime
+    }
     gev_ctx::PendingRepro& q = c->pend;
-    if (!q.active) return fail(GEV_ESTATE, "reproduce_end: no gev_reproduce_begin is pending");
+    q.pop = pop; q.n_people = n_people; q.has_mut = has_mut; q.pre = false; q.seed = 0; q.attempt = 0; q.n_status = n_status; q.hstatus = hstatus;
+    q.fused = true; q.has_svf = selection_value_func != nullptr; q.glob_state = glob_state; q.hseeds2 = hstatus + n_status; q.hsex = (uint8_t*)(hstatus + n_status + 2);
+    GEVC(enqueue_attempt(c, 0));
+    q.active = true;
+    return GEV_OK;
+}
+static int generation_finish(gev_ctx* c, uint8_t* sex_out, gev_generation_result* res, gev_couple* couples_out)
+{
+    gev_ctx::PendingRepro& q = c->pend;
     q.active = false;                                       // whatever happens below, the generation is no longer pending
     HIPC(hipSetDevice(c->device));
     const int pop = q.pop, nchr = c->nchr; const size_t n_people = q.n_people;
@@ -1235,17 +1364,25 @@ int gev_reproduce_end(gev_ctx* c, uint8_t* sex_out)
         if (g_trace_host && g_malloc_n) { fprintf(stderr, "[gev]   %zu hipMalloc calls, %.1f MiB, %.2f ms\n", g_malloc_n, g_malloc_bytes / 1048576.0, g_malloc_ms); g_malloc_ms = 0; g_malloc_n = 0; g_malloc_bytes = 0; }
         for (int k = 0; k < nchr; k++) { P.st[k].mut_total[alt] = hstatus[ST_TOTALS + ST_PER_CHR * k]; P.st[k].parts_total[alt] = hstatus[ST_TOTALS + ST_PER_CHR * k + 1]; }
         if (flags & FLAG_POOL) return fail(GEV_EDEVICE, "reproduce: genotype row pool exhausted (internal error)");
-        if (!flags) break;
+        if (flags & FLAG_RNG_SHORT) return fail(GEV_EDEVICE, "generation: a rejection stream ran out of candidates (internal error)");
+        if (flags & FLAG_NO_MATES)                          // Simulation::random_mate returns false (:2125-2129); nothing is published
+            return fail(GEV_ENOMATE, "Error: No one can marry, num_males_mate=%u, num_females_mate=%u", hstatus[ST_NM_MATE], hstatus[ST_NF_MATE]);
+        if (!(flags & FLAG_REDO_MASK)) break;
         if (attempt == 3) return fail(GEV_EDEVICE, "reproduce: buffers still too small after %d attempts (flags %u)", attempt + 1, flags);
         HIPC(hipStreamSynchronize(c->stream_big));        // the stitch of the failed attempt still reads the records that are sampled again below
         sc.timing_pending = false; sc.stitch_pending = false;   // (its kernel times are not counted)
-        c->sc[(c->gen_counter + 1) & 1].presampled = false;     // a head start taken meanwhile used the old record capacities: sample again
+        {   // a head start taken meanwhile used the old record capacities: it is sampled again (by gev_presample_sex from the retained
+            // inputs, or by the next gev_reproduce_begin)
+            gev_ctx::Scratch& nx = c->sc[(c->gen_counter + 1) & 1];
+            if (nx.presampled) { nx.presampled = false; nx.ps_stale = true; }
+        }
         if (flags & FLAG_BK_OVF) c->bk_ovf_cap = std::max<size_t>(2 * c->bk_ovf_cap, (size_t)hstatus[ST_BK_OVF_USED] * 5 / 4 + 1024);
         if (flags & FLAG_NM_OVF) c->nm_ovf_cap = std::max<size_t>(2 * c->nm_ovf_cap, (size_t)hstatus[ST_NM_OVF_USED] * 5 / 4 + 1024);
         for (int k = 0; k < nchr; k++) {     // exact needs from the count passes (valid unless a record overflow zeroed some counts: then next attempt refines)
             P.st[k].mut_need = (size_t)P.st[k].mut_total[alt] * 5 / 4 + 1024;
             P.st[k].parts_need = (size_t)P.st[k].parts_total[alt] * 5 / 4 + 1024;
         }
+        c->redo_count++;
     }
     for (int k = 0; k < nchr; k++) { P.st[k].mut_need = 0; P.st[k].parts_need = 0; }
     if (c->dense) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) {            // 16-byte chunks the stitch wrote / chunks of the generation's rows
@@ -1258,17 +1395,101 @@ int gev_reproduce_end(gev_ctx* c, uint8_t* sex_out)
     const bool ad_done = c->eager_ad && c->pop[pop].cv[0][0].d_aptr.p;
     for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = ad_done;
     if (ad_done) c->ad_cached_pop = pop;
-    if (sex_out) { HIPC(hipMemcpyAsync(sex_out, sc.sex.p, n_people, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st)); }
+    if (q.fused) {
+        if (sex_out) memcpy(sex_out, q.hsex, n_people);
+        if (res) {
+            res->glob_state = hstatus[ST_GLOB_STATE]; res->seed_mate = q.hseeds2[0]; res->seed_reproduce = q.hseeds2[1]; res->reserved = 0;
+            res->num_males_mate = hstatus[ST_NM_MATE]; res->num_females_mate = hstatus[ST_NF_MATE];
+        }
+        if (couples_out) { HIPC(hipMemcpyAsync(couples_out, c->d_couples.p, n_people * sizeof(gev_couple), hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st)); }
+    } else if (sex_out) { HIPC(hipMemcpyAsync(sex_out, sc.sex.p, n_people, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st)); }
     P.cur = alt; P.pcur = (P.pcur + 1) % 3; P.n_people = n_people; P.n_phys = n_people; P.logical.clear();
     c->gen_counter++;
     occ_tune_step(c, n_people);
     return GEV_OK;
+}
+int gev_reproduce_end(gev_ctx* c, uint8_t* sex_out)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    if (!c->pend.active) return fail(GEV_ESTATE, "reproduce_end: no gev_reproduce_begin is pending");
+    if (c->pend.fused) return fail(GEV_ESTATE, "reproduce_end: the pending generation was begun with gev_generation_begin: call gev_generation_end");
+    return generation_finish(c, sex_out, nullptr, nullptr);
+}
+int gev_generation_end(gev_ctx* c, gev_generation_result* res, gev_couple* couples_out, uint8_t* sex_out)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    if (!c->pend.active) return fail(GEV_ESTATE, "generation_end: no gev_generation_begin is pending");
+    if (!c->pend.fused) return fail(GEV_ESTATE, "generation_end: the pending generation was begun with gev_reproduce_begin: call gev_reproduce_end");
+    return generation_finish(c, sex_out, res, couples_out);
 }
 int gev_reproduce(gev_ctx* c, int pop, const gev_couple* couples, size_t n_couples, uint32_t seed_reproduce,
                   const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people, uint8_t* sex_out)
 {
     GEVC(gev_reproduce_begin(c, pop, couples, n_couples, seed_reproduce, mut_seeds, n_mut_seeds, n_people));
     return gev_reproduce_end(c, sex_out);
+}
+// Simulation::random_mate (src/Simulation.cpp:2090-2157) of the population's current generation on the device.  The couples stay
+// on the device for the next gev_reproduce of the population (couples == NULL there) and are copied out when couples_out is given.
+int gev_random_mate(gev_ctx* c, int pop, uint32_t seed, const double* selection_value_func, size_t pop_size, gev_couple* couples_out,
+                    size_t* num_males_mate, size_t* num_females_mate)
+{
+    GEVC(check_idx(c, pop, 0));
+    PopState& P = c->pop[pop];
+    if (!P.gen0) return fail(GEV_ESTATE, "random_mate: population %d has no current generation", pop);
+    if (pop_size == 0) return fail(GEV_EINVAL, "random_mate: no couples asked for");
+    if (pop_size >= 0x7fffffffull) return fail(GEV_EINVAL, "random_mate: too many couples");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    // father / mother of this scratch set were last read by the stitch two generations back
+    GEVC(harvest_timing(c, sc));
+    if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); sc.stitch_pending = false; }
+    GEVC(sc.father.ensure(pop_size * sizeof(u32), st)); GEVC(sc.mother.ensure(pop_size * sizeof(u32), st));
+    GEVC(c->d_couples.ensure(pop_size * sizeof(gev_couple), st));
+    GEVC(c->d_mstat.ensure(4 * sizeof(u32), st));
+    HIPC(hipMemsetAsync(c->d_mstat.p, 0, 4 * sizeof(u32), st));
+    const double* d_svf = nullptr;
+    if (selection_value_func) {
+        GEVC(c->d_svf.ensure(P.n_people * sizeof(double), st));
+        HIPC(hipMemcpyAsync(c->d_svf.p, selection_value_func, P.n_people * sizeof(double), hipMemcpyHostToDevice, st));
+        d_svf = c->d_svf.as<double>();
+    }
+    u32* ms = c->d_mstat.as<u32>();                             // {num_males_mate, num_females_mate, flags}
+    GEVC(enqueue_mate(c, st, P, (u32)seed, nullptr, d_svf, pop_size, sc.father.as<u32>(), sc.mother.as<u32>(), couples_out ? c->d_couples.as<gev_couple>() : nullptr, ms, ms + 2));
+    u32 h[4] = {0, 0, 0, 0};
+    HIPC(hipMemcpyAsync(h, ms, sizeof h, hipMemcpyDeviceToHost, st));
+    if (couples_out) HIPC(hipMemcpyAsync(couples_out, c->d_couples.p, pop_size * sizeof(gev_couple), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if (num_males_mate) *num_males_mate = h[0];
+    if (num_females_mate) *num_females_mate = h[1];
+    sc.mated = false;
+    if (h[2] & FLAG_NO_MATES) return fail(GEV_ENOMATE, "Error: No one can marry, num_males_mate=%u, num_females_mate=%u", h[0], h[1]);
+    if (h[2] & FLAG_RNG_SHORT) return fail(GEV_EDEVICE, "random_mate: a rejection stream ran out of candidates (internal error)");
+    sc.mated = true; sc.mate_pop = pop; sc.mate_n = pop_size;
+    return GEV_OK;
+}
+// Simulation::ras_glob_seed (src/Simulation.cpp:17-21) called n times, evaluated on the device: *engine_state = the state of
+// glob_generator (std::minstd_rand0) before, and after on return; out (host, n values) may be NULL.
+int gev_glob_seeds(gev_ctx* c, uint32_t* engine_state, size_t n, uint32_t* out)
+{
+    if (!c || !engine_state) return fail(GEV_EINVAL, "glob_seeds: null argument");
+    if (c->pend.active) return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first");
+    if (*engine_state == 0 || *engine_state >= GEV_M31) return fail(GEV_EINVAL, "glob_seeds: %u is not a state of std::minstd_rand0 (1 .. 2^31-2)", *engine_state);
+    if (n == 0) return GEV_OK;
+    if (n >= 0x7fffffffull) return fail(GEV_EINVAL, "glob_seeds: too many values");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    GEVC(c->d_tmp.ensure((n + 4) * sizeof(u32), st));
+    u32* vals = c->d_tmp.as<u32>() + 4; u32* stat = c->d_tmp.as<u32>();       // stat = {state, flags}
+    HIPC(hipMemsetAsync(stat, 0, 16, st));
+    GEVC(enqueue_glob(c, st, *engine_state, nullptr, n, vals, stat, stat + 1));
+    u32 h[2] = {0, 0};
+    HIPC(hipMemcpyAsync(h, stat, sizeof h, hipMemcpyDeviceToHost, st));
+    if (out) HIPC(hipMemcpyAsync(out, vals, n * sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if (h[1]) return fail(GEV_EDEVICE, "glob_seeds: the rejection stream ran out of candidates (internal error)");
+    *engine_state = h[0];
+    return GEV_OK;
 }
 // The sexes of the generation whose sampling gev_presample has enqueued (they come out of the rand() chain of the sampling
 // kernels, src/Simulation.cpp:2472, and need nothing else): lets a host that mates at random form the NEXT couples while the
@@ -1278,6 +1499,11 @@ int gev_presample_sex(gev_ctx* c, int pop, uint8_t* sex_out, size_t n_people)
     GEVC(check_idx(c, pop, 0));
     if (!sex_out) return fail(GEV_EINVAL, "presample_sex: null output");
     gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
+    if (!sc.presampled && sc.ps_stale && sc.ps_pop == pop && sc.ps_n_people == n_people) {
+        // the head start was dropped by a redo of the previous generation (larger record regions): sample again from the retained inputs
+        sc.ps_stale = false;
+        GEVC(gev_presample(c, pop, sc.ps_seed, sc.ps_has_mut ? (const uint32_t*)c->h_seeds : nullptr, sc.ps_has_mut ? n_people * (size_t)c->nchr : 0, n_people));
+    }
     if (!sc.presampled || sc.ps_pop != pop || sc.ps_n_people != n_people) return fail(GEV_ESTATE, "presample_sex: no matching gev_presample is pending");
     HIPC(hipSetDevice(c->device));
     hipStream_t st = c->serialize ? c->stream : c->stream_samp;
@@ -1304,7 +1530,7 @@ int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* 
     hipStream_t st = c->serialize ? c->stream : c->stream_samp;   // the head start has a stream of its own: it runs next to the lists / A-D of the generation in flight
     // the scratch set of the generation AFTER the one in flight when called between gev_reproduce_begin and _end
     gev_ctx::Scratch& sc = c->sc[(c->gen_counter + (c->pend.active ? 1u : 0u)) & 1];
-    sc.presampled = false;
+    sc.presampled = false; sc.ps_stale = false;
     const bool seeds_in_place = has_mut && mut_seeds == (const uint32_t*)c->h_seeds;
     if (has_mut && !seeds_in_place) {
         if (c->h_seeds_bytes < T * sizeof(u32)) {
@@ -1333,6 +1559,7 @@ int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* 
 int gev_sync(gev_ctx* c)
 {
     if (!c) return fail(GEV_EINVAL, "null context");
+    if (c->pend.active) return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first");
     HIPC(hipSetDevice(c->device));
     HIPC(hipStreamSynchronize(c->stream)); HIPC(hipStreamSynchronize(c->stream_big)); HIPC(hipStreamSynchronize(c->stream_samp));
     for (auto& sc : c->sc) { GEVC(harvest_timing(c, sc)); sc.stitch_pending = false; }
@@ -1373,6 +1600,7 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
     GEVC(c->d_add.ensure(n * nphen * sizeof(double), st)); GEVC(c->d_dom.ensure(n * nphen * sizeof(double), st));
     GEVC(c->d_flag.ensure(16, st));
     HIPC(hipMemsetAsync(c->d_flag.p, 0xff, 4, st));
+    c->ad_host_set_pop = -1;                                 // d_add / d_dom are rewritten below: totals handed in by gev_set_ad are gone
     if (c->any_inactive) {                                   // chromosomes held elsewhere contribute exact zeros here
         HIPC(hipMemsetAsync(c->d_addchr.p, 0, n * nchr * nphen * sizeof(double), st)); HIPC(hipMemsetAsync(c->d_domchr.p, 0, n * nchr * nphen * sizeof(double), st));
     }
@@ -1687,6 +1915,17 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
             row0 += map.size();
         }
     }
+    // Human::sex follows the individuals (what gev_random_mate reads)
+    size_t i0 = 0;
+    for (const Seg& sg : segs) {
+        if (sg.people.empty()) continue;
+        PopState& Sp = c->pop[sg.src_pop];
+        GEVC(h2d(c, c->d_map, sg.people.data(), sg.people.size() * sizeof(u32)));
+        hipLaunchKernelGGL(k_gather_u8, dim3((unsigned)ceil_div(sg.people.size(), 256)), dim3(256), 0, st, D.d_sex[alt].as<uint8_t>() + i0, Sp.d_sex[Sp.cur].as<uint8_t>(), c->d_map.as<u32>(), 0u, sg.people.size());
+        KCHECK();
+        HIPC(hipStreamSynchronize(st));
+        i0 += sg.people.size();
+    }
     return GEV_OK;
 }
 // bring the current generation back to dense logical order (no-op unless rows were removed/imported)
@@ -1701,9 +1940,15 @@ static int materialize_order(gev_ctx* c, int pop)
     P.cur ^= 1; P.pcur = (P.pcur + 1) % 3; P.n_phys = P.n_people; P.logical.clear(); c->ad_cached_pop = c->ad_host_set_pop = -1;
     return GEV_OK;
 }
-int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
+static int check_not_pending(gev_ctx* c)
 {
     if (!c) return fail(GEV_EINVAL, "null context");
+    if (c->pend.active) return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first");
+    return GEV_OK;
+}
+int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
+{
+    GEVC(check_not_pending(c));
     if (n_moves && !moves) return fail(GEV_EINVAL, "migrate: null moves");
     HIPC(hipSetDevice(c->device));
     GEVC(gev_sync(c));
@@ -1748,9 +1993,10 @@ int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
 // ---- cross-GPU form of the migration step ---------------------------------------------------
 // Packed record buffer (all offsets 16-byte aligned), for n individuals:
 //   [counts]  u32[n][nchr][2 haps][2] = (n_mut, n_parts) per haplotype row
+//   [sex]     u8[n]  Human::sex
 //   [planes]  per chr: 2n rows x stride bytes          [cv] per (phen, chr): 2n rows x stride_w32*4 bytes
 //   [muts]    per chr: u64 lists concatenated in row order   [parts] per chr: gev_part lists likewise
-struct PackLayout { size_t counts, planes, cv, muts, parts, total; std::vector<size_t> mut_chr, parts_chr; };
+struct PackLayout { size_t counts, sex, planes, cv, muts, parts, total; std::vector<size_t> mut_chr, parts_chr; };
 static size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 static PackLayout pack_layout(gev_ctx* c, PopState& P, size_t n, const std::vector<u32>& counts)
 {
@@ -1758,6 +2004,7 @@ static PackLayout pack_layout(gev_ctx* c, PopState& P, size_t n, const std::vect
     size_t off = 0;
     // chromosomes this context does not hold (locus-split population) take no space: both ends of an exchange hold the same set
     L.counts = off; off = al16(off + n * nchr * 4 * sizeof(u32));
+    L.sex = off; off = al16(off + n);
     L.planes = off; for (int k = 0; k < nchr; k++) if (c->chr_active[k] && c->dense) off = al16(off + 2 * n * P.cs[k].stride);
     L.cv = off; for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) off = al16(off + 2 * n * P.cv[p][k].stride_w32 * sizeof(u32));
     L.mut_chr.assign(nchr, 0); L.parts_chr.assign(nchr, 0);
@@ -1826,6 +2073,7 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
     uint8_t* out = (uint8_t*)device_buf;
     const int nchr = c->nchr;
     HIPC(hipMemcpyAsync(out + L.counts, counts.data(), counts.size() * sizeof(u32), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_u8, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, out + L.sex, P.d_sex[P.cur].as<uint8_t>(), c->d_map.as<u32>(), 1u, n);   // d_map holds haplotype rows 2*individual, 2*individual+1
     size_t po = L.planes, co = L.cv, mo = L.muts, pa = L.parts;
     GEVC(c->d_cnt.ensure((2 * n + 1) * sizeof(u32) * 2, st));
     u32* d_off = c->d_cnt.as<u32>() + 2 * n + 1;
@@ -1901,6 +2149,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
     const size_t n_old = P.n_phys, n_new = n_old + n, r_old = 2 * n_old;     // physical append behind every existing row
     if (n_new * 2 >= 0xffffffffull) return fail(GEV_EINVAL, "import_rows: too many rows");
     GEVC(ensure_capacity(c, pop, n_new));                              // keeps the current buffers' content
+    HIPC(hipMemcpyAsync(P.d_sex[P.cur].as<uint8_t>() + n_old, in + L.sex, n, hipMemcpyDeviceToDevice, st));
     size_t po = L.planes, co = L.cv, mo = L.muts, pa = L.parts;
     for (int k = 0; k < nchr; k++) {
         if (!c->chr_active[k]) continue;
@@ -2420,7 +2669,14 @@ int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* unit_bytes,
 }
 int gev_stream(gev_ctx* c, void** s) { if (!c || !s) return fail(GEV_EINVAL, "null"); *s = (void*)c->stream; return GEV_OK; }
 int gev_last_reproduce_ms(gev_ctx* c, float ms[4]) { if (!c || !ms) return fail(GEV_EINVAL, "null"); GEVC(gev_sync(c)); for (int i = 0; i < 4; i++) ms[i] = c->last_ms[i]; return GEV_OK; }
-int gev_set_track_intervals(gev_ctx* c, int on) { if (!c) return fail(GEV_EINVAL, "null"); c->track_intervals = on != 0; return GEV_OK; }
+int gev_set_track_intervals(gev_ctx* c, int on)
+{
+    if (!c) return fail(GEV_EINVAL, "null");
+    if (c->pend.active) return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first");
+    c->track_intervals = on != 0;
+    return GEV_OK;
+}
+int gev_redo_count(gev_ctx* c, unsigned long long* n) { if (!c || !n) return fail(GEV_EINVAL, "null"); *n = c->redo_count; return GEV_OK; }
 int gev_set_overlap(gev_ctx* c, int on)
 {
     if (!c) return fail(GEV_EINVAL, "null");
@@ -2430,7 +2686,7 @@ int gev_set_overlap(gev_ctx* c, int on)
     if (c->overlap_mode >= 0) c->serialize = c->overlap_mode == 0; else { c->serialize = true; c->auto_gens = 0; c->auto_small_ms = c->auto_stitch_ms = 0; }
     return GEV_OK;
 }
-int gev_set_stitch_mode(gev_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return fail(GEV_EINVAL, "stitch mode must be 0 (work list of the segments to write) or 1 (gamete-major)"); c->stitch_mode = mode; return GEV_OK; }
+int gev_set_stitch_mode(gev_ctx* c, int mode) { if (c && c->pend.active) return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first"); if (!c || mode < 0 || mode > 1) return fail(GEV_EINVAL, "stitch mode must be 0 (work list of the segments to write) or 1 (gamete-major)"); c->stitch_mode = mode; return GEV_OK; }
 
 // ---- diagnostics (tests only; no simulation state involved) --------------------------------
 __global__ void __launch_bounds__(64) k_dbg_rand(const GevRngTables* __restrict__ T, u32 seed, u32 n, int* __restrict__ out)

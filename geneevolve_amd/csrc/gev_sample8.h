@@ -163,7 +163,7 @@ __device__ __forceinline__ u32 rank_hits(bool valid, u32 tg, bool hit, u32& hc)
 // K2 batched: Simulation::ras_add_mutation for 8 (offspring, chromosome) tasks per wave
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 4) k_mut_sample8(const GevRngTables* __restrict__ Tg, const ChrDev* __restrict__ chrs, int nchr,
-                                                     const u32* __restrict__ mut_seeds, u32 seed_reproduce, size_t n_tasks, SampleDev sd,
+                                                     const u32* __restrict__ mut_seeds, u32 seed_reproduce, const u32* __restrict__ seed_ptr, size_t n_tasks, SampleDev sd,
                                                      u32* __restrict__ slow_list)
 {
     __shared__ SmpTabs s_T;
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256, 4) k_mut_sample8(const GevRngTables* __re
         const u32 cidx = valid ? (u32)(t % (size_t)nchr) : 0u;
         const u32 S = valid ? mut_seeds[t] : 1u;
         if (b == 0) {                                       // first rand() after srand(seed) of reproduce (:2400, :2447) = seed_loc of task 0
-            const u32 x0 = srand8(T, W->r, seed_reproduce);
+            const u32 x0 = srand8(T, W->r, seed_ptr ? *seed_ptr : seed_reproduce);
             if (lane == 0) sd.seed_pat[0] = x0 >> 1;
         }
         const u32 xout = srand8(T, W->r, S);               // srand(seed), :2501

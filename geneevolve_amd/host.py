@@ -557,6 +557,28 @@ class Simulation:
         self.couples[ipop] = random_mate(self.sex[ipop], selection_value_func, pop_size, int(self.ras_glob_seed()[0]))
         return True
 
+    def random_mate_device(self, ipop, selection_value_func, pop_size, want_couples=True):
+        """the same step on the library's side (gev_random_mate): the couples stay there for reproduce(); selection_value_func = None
+        when every value is 1"""
+        self.couples[ipop], self.num_males_mate, self.num_females_mate = self.ctx.random_mate(ipop, int(self.ras_glob_seed()[0]), selection_value_func, pop_size, want_couples)
+        self._device_couples = (ipop, pop_size)
+        return True
+
+    def next_generation_rm(self, ipop, pop_size, selection_value_func=None, want_couples=False):
+        """random_mate -> reproduce -> ras_compute_AD of sim_next_generation (:1907-1935) as one library call pair; the
+        ras_glob_seed() draws of the three are made by the library from glob_generator's state, which is stored back"""
+        self.ctx.generation_begin(ipop, self.glob.x, pop_size, selection_value_func)
+        r = self.ctx.generation_end(want_couples=want_couples)
+        self.glob.x = int(r["glob_state"])
+        self.last_seed_reproduce = int(r["seed_reproduce"])
+        self.sex[ipop] = r["sex"]
+        if want_couples:
+            self.couples[ipop] = r["couples"]
+            if self.track_pedigree and ipop in self.ped:
+                c = r["couples"]
+                self.ped[ipop] = self.ped[ipop].offspring(c["pos_male"].astype(np.int64), c["pos_female"].astype(np.int64))
+        return r
+
     def assort_mate(self, ipop, selection_value_func, mating_value, pop_size, mat_cor, mm_percent=0.0,
                     avoid_inbreeding=False, offspring_dist="p", rank=None):   # :2167 (3 draws, +1 for Poisson offspring numbers)
         seeds = [int(x) for x in self.ras_glob_seed(4 if offspring_dist in ("p", "P") else 3)]
@@ -566,12 +588,16 @@ class Simulation:
 
     def reproduce(self, ipop, gen_num=0, seeds=None, n_people=None):   # :2394 (n_people: known offspring count, skips a host pass)
         c = self.couples[ipop]
+        dev = getattr(self, "_device_couples", None)
+        self._device_couples = None
+        if dev is not None and dev[0] == ipop and n_people is None:
+            n_people = dev[1]                                     # one child per couple (:2149)
         if n_people is None:
             n_people = int(c["num_offspring"][c["inbreed"] == 0].sum())
         if seeds is None:                                       # 1 + n_people*nchr ras_glob_seed() draws (:2398, :2500)
             seeds = self.ras_glob_seed(1 + (n_people * self.nchr if self.has_mut else 0))
         self.last_seed_reproduce = int(seeds[0])
-        self.sex[ipop] = self.ctx.reproduce(ipop, c, int(seeds[0]), seeds[1:] if self.has_mut else None, n_people=n_people)
+        self.sex[ipop] = self.ctx.reproduce(ipop, None if (dev is not None and dev[0] == ipop) else c, int(seeds[0]), seeds[1:] if self.has_mut else None, n_people=n_people)
         if self.track_pedigree and ipop in self.ped:            # enumeration order of the couple loop (:2433-2443)
             ok = c["inbreed"] == 0
             rep = c["num_offspring"][ok].astype(np.int64)

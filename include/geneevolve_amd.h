@@ -11,6 +11,9 @@
  *                                                          gev_set_snps / gev_set_cvs /
  *                                                          gev_upload_founders / gev_upload_cv_founders
  *   bool ras_initial_human_gen0(int ipop)          :86     gev_init_gen0
+ *   bool random_mate(int ipop,int gen_ind)         :78     gev_random_mate
+ *   unsigned ras_glob_seed(void)                   :67     gev_glob_seeds; inside gev_generation_begin
+ *   sim_next_generation: random_mate -> reproduce -> ras_compute_AD as one unit     gev_generation_begin / _end
  *   std::vector<Human> reproduce(int,int)          :81     gev_reproduce
  *   bool ras_compute_AD(int ipop,int gen_num)      :80     gev_compute_ad
  *   bool ras_do_migration(int gen_ind)             :71     gev_migrate (+ gev_export_rows /
@@ -51,6 +54,7 @@ extern "C" {
 #define GEV_EDEVICE    -3   /* HIP runtime error, no device, out of device memory                  */
 #define GEV_ENAN       -4   /* "A or D is nan" (reference src/Simulation.cpp:2716-2720)            */
 #define GEV_EUNSUPPORTED -5 /* input outside the dense-equivalence preconditions   */
+#define GEV_ENOMATE    -6   /* "Error: No one can marry" (reference src/Simulation.cpp:2125-2129)  */
 
 typedef struct gev_ctx gev_ctx;
 
@@ -96,7 +100,9 @@ const char* gev_version(void);
  *   GEV_STITCH_LDS_PAD=bytes    (experiments) dynamic LDS padding of the stitch workgroups, overriding the one derived from WG_PER_CU
  *   GEV_SAMPLE_BATCHED=0        one sampling task per wave (the round-1 kernels) instead of eight
  *   GEV_LIST_LONG=n             average list entries per row from which the list fill kernels put 8 lanes on a row (default 20)
- *   GEV_TABLE_RING_BYTES=n      minimum size of the pinned ring the per-generation work tables are staged through */
+ *   GEV_TABLE_RING_BYTES=n      minimum size of the pinned ring the per-generation work tables are staged through
+ *   GEV_OVF_CAP=n, GEV_LIST_HEADROOM=n  (tests) initial size of the breakpoint / new-mutation overflow regions, spare list entries per row:
+ *                               tiny values make generations overflow their buffers, so that the grow-and-enqueue-again path runs */
 int  gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen);
 void gev_destroy(gev_ctx* ctx);
 
@@ -141,6 +147,8 @@ int gev_init_gen0(gev_ctx*, int pop, size_t n_people, uint32_t seed_gen0, uint8_
  *  n_people       : sum of num_offspring over couples with inbreed==0 (checked)
  *  sex_out        : n_people bytes, Human::sex of each offspring (:2472), or NULL
  * Pedigree ids and common_sibling (:2473-2484) are pure host bookkeeping and stay with the host.
+ *  couples == NULL : the couples the preceding gev_random_mate of `pop` left on the device (n_couples is ignored, n_people must be
+ *                   that call's pop_size).
  * Cost note: with a mutation map every (offspring, chromosome) task restarts its rand() chain at srand(mut_seed), so all tasks are
  * sampled in parallel.  WITHOUT one (mut_seeds == NULL) the reference's chain runs through every gamete in order (the seed of a
  * gamete is the rand() output that follows the previous gamete's breakpoints): one wave walks it, about 10 us per gamete, i.e.
@@ -167,6 +175,45 @@ int gev_reproduce_end(gev_ctx*, uint8_t* sex_out);
  * the sexes) can form the couples of the generation AFTER the one it is about to hand over.  Waits for the sampling kernels only;
  * call it after gev_presample and before the gev_reproduce(_begin) of that generation. */
 int gev_presample_sex(gev_ctx*, int pop, uint8_t* sex_out, size_t n_people);
+
+/* ---- Simulation::random_mate (src/Simulation.cpp:2090-2157)  [SURVEY 8(f) row 2] ----------------
+ * Forms pop_size couples of the population's current generation on the device, bit for bit as the reference does:
+ *  seed                 : the ras_glob_seed() value drawn at :2092
+ *  selection_value_func : Human::selection_value_func of every individual [n_people] (:2113), or NULL when every value is 1
+ *                         (selection function "none" / generation 0): r < 1 always holds, so the draws of generator(seed)
+ *                         cannot change the outcome and are skipped
+ *  couples_out          : pop_size Couples_Info records (pos_male, pos_female, inbreed = 0, num_offspring = 1), or NULL
+ *  num_*_mate           : the two counts the reference prints (:2122-2123), or NULL
+ * Marriageable males / females are compacted in position order (:2109-2118), father and mother of couple i are
+ * pos_male[i_f], pos_female[i_m] with i_f / i_m the i-th values of uniform_int_distribution<unsigned long>(0, count-1) on
+ * default_random_engine(seed+1) / (seed+2) (:2132-2147).  The sexes are the ones the library itself produced (gev_init_gen0,
+ * gev_reproduce; they follow the individuals through gev_migrate / gev_export_rows / gev_import_rows).
+ * The couples also stay on the device: the next gev_reproduce of `pop` takes them when its `couples` is NULL.
+ * Returns GEV_ENOMATE with the reference's message when no male or no female may marry (:2125-2129). */
+int gev_random_mate(gev_ctx*, int pop, uint32_t seed, const double* selection_value_func, size_t pop_size,
+                    gev_couple* couples_out, size_t* num_males_mate, size_t* num_females_mate);
+/* ---- Simulation::ras_glob_seed (src/Simulation.cpp:17-21) called n times, evaluated on the device ----
+ * *engine_state: the state of glob_generator (std::minstd_rand0: `os << glob_generator` prints it, `is >> glob_generator` sets
+ * it) before the n calls; on return the state after them.  out: n values (host), or NULL. */
+int gev_glob_seeds(gev_ctx*, uint32_t* engine_state, size_t n, uint32_t* out);
+/* ---- one whole generation of a randomly mating population: the body of Simulation::sim_next_generation for --RM
+ * (src/Simulation.cpp:1907-1935): random_mate -> reproduce -> ras_compute_AD, enqueued as ONE unit.  Every ras_glob_seed() value
+ * the three draw -- 1 (:2092) + 1 (:2398) + pop_size * nchr (:2500, only with a mutation map) -- is taken from glob_state on the
+ * device, the couples never leave it, and the host waits once (in _end).
+ *  glob_state            : state of glob_generator in front of random_mate's draw
+ *  selection_value_func  : as gev_random_mate
+ * gev_generation_end waits (enqueues the generation again with larger buffers if a list outgrew its capacity), publishes the new
+ * generation and returns: res (may be NULL), the couples (pop_size records, or NULL), the offspring sexes (pop_size bytes, or
+ * NULL).  gev_compute_ad then returns the generation's A/D without further device work.  Between _begin and _end no other call
+ * on the context is allowed (GEV_ESTATE).  GEV_ENOMATE as gev_random_mate (nothing is published). */
+typedef struct gev_generation_result {
+    uint32_t glob_state;                 /* glob_generator behind the generation's last draw: the host stores it back */
+    uint32_t seed_mate, seed_reproduce;  /* the values drawn at :2092 and :2398 (common_sibling needs seed_reproduce + 1, :2417) */
+    uint32_t reserved;
+    uint64_t num_males_mate, num_females_mate;   /* :2119-2123 */
+} gev_generation_result;
+int gev_generation_begin(gev_ctx*, int pop, uint32_t glob_state, size_t pop_size, const double* selection_value_func);
+int gev_generation_end(gev_ctx*, gev_generation_result* res, gev_couple* couples_out, uint8_t* sex_out);
 /* ---- Simulation::ras_compute_AD + ras_find_cv (src/Simulation.cpp:2624-2815) --------------
  * additive/dominance : [n_people * nphen], index ih*nphen + iphen  (Human::additive/dominance, raw)
  * add_chr/dom_chr    : [n_people * nchr * nphen], index (ih*nchr + ichr)*nphen + iphen, or NULL
@@ -325,6 +372,8 @@ int gev_set_overlap(gev_ctx*, int on);
  * (implies gev_sync); _totals = cumulative sums over all generations so far (implies gev_sync). */
 int gev_last_reproduce_ms(gev_ctx*, float ms[4]);
 int gev_timing_totals(gev_ctx*, double ms_sum[4], unsigned long long* n_generations);
+/* generations that outgrew a buffer and were enqueued again (inside gev_reproduce_end / gev_generation_end), over the context's life */
+int gev_redo_count(gev_ctx*, unsigned long long* n);
 /* enable/disable keeping the ancestry interval state on the device (default on) */
 int gev_set_track_intervals(gev_ctx*, int on);
 /* dense-stitch kernel: 0 = k_stitch_segments (default: one workgroup per entry of the list of segments to write), 1 = gamete-major

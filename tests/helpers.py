@@ -296,12 +296,15 @@ def check_ped_files(ctx, fx, ngen, ip, ic, label):
 from geneevolve_amd.host import comm_mean, comm_var, selection_func  # noqa: E402  (host mirror of CommFunc::mean/var, ras_selection_func)
 
 
-def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at_end=None, info_texts=None):
+def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at_end=None, info_texts=None, mate="host"):
     """Simulation::run for a single-population fixture, driven from the seed ALONE: ras_glob_seed() stream, gen-0 founders,
     ras_compute_AD, ras_scale_AD_compute_GEF (every phenotype, parental effect with the adjusted beta), mating / selection
     values, random_mate or assort_mate (device rank), reproduce -- every generation's couples, sexes, pedigree, raw A/D,
     phenotypes, next-generation mating inputs and the reference's .info files are compared with what the reference did.
-    exact=False (device phenotype scaling is within 1e-12, not bit-exact) relaxes the float comparisons only."""
+    exact=False (device phenotype scaling is within 1e-12, not bit-exact) relaxes the float comparisons only.
+    mate (random-mating fixtures): "host" = the host mirror of Simulation::random_mate; "device" = gev_random_mate, the couples stay
+    in the library for gev_reproduce; "fused" = gev_generation_begin/_end (random_mate -> reproduce -> ras_compute_AD in one piece,
+    the ras_glob_seed() draws of the three made by the library from glob_generator's state)."""
     from geneevolve_amd.host import Simulation, ras_save_human_info
     assert int(fx["n_pop"]) == 1
     nchr, nphen, ngen, rm = int(fx["nchr"]), int(fx["nphen"]), int(fx["n_gen"]), bool(int(fx["pop0_rm"]))
@@ -379,8 +382,20 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at
         pop_size, mat_cor, dist, func, p1, p2 = str(fx["pop0_popinfo"][g - 1]).split()
         k = f"g{g}_pop0_mate_"
         close(svf, fx[k + "svf"], f"selection function values entering generation {g}")
+        fused = False
         if rm:
-            sim.random_mate(0, svf, int(pop_size))
+            # selection_value_func NULL = "every value is 1" (the draws are then skipped): exercised on even generations
+            svf_arg = None if (g % 2 == 0 and np.all(np.asarray(svf) == 1.0)) else svf
+            if mate == "host":
+                sim.random_mate(0, svf, int(pop_size))
+            elif mate == "device":
+                sim.random_mate_device(0, svf_arg, int(pop_size))
+                assert sim.num_males_mate == int(np.sum(fx[k + "sex"] == 1) if np.all(np.asarray(svf) == 1.0) else sim.num_males_mate)
+            else:
+                fused = True
+                prev_phen = [o["phen"] for o in outs]
+                res = sim.next_generation_rm(0, int(pop_size), svf_arg, want_couples=True)
+                assert int(res["seed_mate"]) == int(fx[k + "seed"]) and int(res["seed_reproduce"]) == int(fx[f"g{g}_pop0_seed_reproduce"]), f"{label}: seeds drawn by the library, generation {g}"
         else:
             close(mv, fx[k + "am_mv"], f"mating values entering generation {g}")
             sim.assort_mate(0, svf, mv, int(pop_size), float(mat_cor), mm_percent=mm, avoid_inbreeding=avoid, offspring_dist=dist,
@@ -388,8 +403,9 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at
         c, want = sim.couples[0], fx[f"g{g}_pop0_couples"]
         assert len(c) == len(want) and np.array_equal(c["pos_male"].astype(np.int64), want[:, 0]) and np.array_equal(c["pos_female"].astype(np.int64), want[:, 1]) \
             and np.array_equal(c["inbreed"], want[:, 2]) and np.array_equal(c["num_offspring"], want[:, 3]), f"{label}: couples of generation {g}"
-        prev_phen = [o["phen"] for o in outs]
-        sim.reproduce(0, g)
+        if not fused:
+            prev_phen = [o["phen"] for o in outs]
+            sim.reproduce(0, g)
         assert np.array_equal(sim.sex[0], fx[f"g{g}_pop0_sex"]), f"{label}: sex generation {g}"
         ped = sim.ped[0]
         assert np.array_equal(np.stack([ped.ID, ped.ID_Father, ped.ID_Mother], axis=1), fx[f"g{g}_pop0_ids"]), f"{label}: pedigree generation {g}"
@@ -407,7 +423,7 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at
     ctx.close()
 
 
-def closed_loop_migration_case(lib, fx, label, device=-1, exact=True):
+def closed_loop_migration_case(lib, fx, label, device=-1, exact=True, mate="host"):
     """the same closed loop for SEVERAL populations with migration (fixture mig2, BASELINE config 3's shape): per generation
     and population random_mate -> reproduce -> ras_compute_AD -> ras_scale_AD_compute_GEF, then mating/selection values, then
     ras_do_migration -- WHO moves is restated on the host (selection sampling on the reference's process-wide static engine),
@@ -473,10 +489,16 @@ def closed_loop_migration_case(lib, fx, label, device=-1, exact=True):
             pop_size, mat_cor, dist, func, p1, p2 = str(fx[f"pop{ip}_popinfo"][g - 1]).split()
             funcs.append((func, float(p1), float(p2)))
             close(rec[ip]["svf"], fx[f"g{g}_pop{ip}_mate_svf"], f"selection function values entering gen {g} pop {ip}")
-            sim.random_mate(ip, rec[ip]["svf"], int(pop_size))
+            if mate == "host":
+                sim.random_mate(ip, rec[ip]["svf"], int(pop_size))
+            elif mate == "device":                       # the library mates on the sexes that followed the migrants
+                sim.random_mate_device(ip, rec[ip]["svf"], int(pop_size))
+            else:
+                sim.next_generation_rm(ip, int(pop_size), rec[ip]["svf"], want_couples=True)
             c, want = sim.couples[ip], fx[f"g{g}_pop{ip}_couples"]
             assert np.array_equal(c["pos_male"].astype(np.int64), want[:, 0]) and np.array_equal(c["pos_female"].astype(np.int64), want[:, 1]), f"{label}: couples gen {g} pop {ip}"
-            sim.reproduce(ip, g)
+            if mate != "fused":
+                sim.reproduce(ip, g)
             assert np.array_equal(sim.sex[ip], fx[f"g{g}_pop{ip}_sex"]), f"{label}: sex gen {g} pop {ip}"
             add, dom, _, _ = ctx.compute_ad(ip)
             assert bits_equal(add, fx[f"g{g}_pop{ip}_additive"]) and bits_equal(dom, fx[f"g{g}_pop{ip}_dominance"]), f"{label}: raw A/D gen {g} pop {ip}"

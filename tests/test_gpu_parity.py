@@ -1246,3 +1246,182 @@ def test_nan_effect_sizes_are_reported_like_the_reference(gpu_lib):
         g.compute_ad(0)
     assert "A or D is nan for human" in str(e.value)
     g.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3: Simulation::random_mate and Simulation::ras_glob_seed on the device, a whole generation in one call
+# ---------------------------------------------------------------------------------------------------------------
+def test_device_glob_seeds_equal_the_host_stream(gpu_lib):
+    """gev_glob_seeds (jump-ahead candidates, rejections ranked out by two passes) == the sequential ras_glob_seed() stream, values
+    and engine state behind them, for counts below / at / above one block of candidates and at config-2's size"""
+    g = gpu_lib.create(1, 1, 1)
+    for seed, n in ((12345, 1), (1, 2), (2147483646, 4095), (7, 4096), (99, 4097), (987654321, 100002), (31337, 1400003)):
+        s = GlobSeedStream(seed); st0 = s.x
+        want = s.draw(n)
+        got, st = g.glob_seeds(st0, n)
+        assert np.array_equal(got, want), (seed, n)
+        assert st == s.x, (seed, n)
+    _, st = g.glob_seeds(5, 1000, want=False)
+    s = GlobSeedStream(5); s.draw(1000)
+    assert st == s.x
+    with pytest.raises(capi.GevError):
+        g.glob_seeds(0, 10)                                   # not a state of minstd_rand0
+    g.close()
+
+
+@pytest.mark.parametrize("case", ["ex1mut", "dense", "syn1k", "sel1", "mig2", "mig3c"])
+def test_device_random_mate_reproduces_the_reference_couples(gpu_lib, oracle_lib, case):
+    """gev_random_mate against every --RM fixture: the reference's own seed (:2092), sexes and selection_value_func values go in,
+    its couples must come out; the couples then stay on the device (gev_reproduce with couples == NULL) and the generation's sexes
+    and A/D must be the reference's too.  mig2: after gev_migrate the sexes the library mates on followed the migrants."""
+    fx = helpers.load_fixture(case)
+    n_pop, nchr, nphen, ngen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"]), int(fx["n_gen"])
+    ctx = gpu_lib.create(n_pop, nchr, nphen, 0)
+    helpers.setup_static(ctx, fx)
+    for ip, seed in enumerate(helpers.find_gen0_seeds(fx, oracle_lib)):
+        ctx.init_gen0(ip, len(fx[f"g0_pop{ip}_sex"]), seed)
+    for g in range(1, ngen + 1):
+        for ip in range(n_pop):
+            pre = f"g{g}_pop{ip}_"
+            assert int(fx[pre + "mate_rm"]) == 1
+            svf, n = fx[pre + "mate_svf"], int(fx[pre + "mate_popsize"])
+            svf_arg = None if (g % 2 == 0 and np.all(svf == 1.0)) else svf
+            couples, nm, nf = ctx.random_mate(ip, int(fx[pre + "mate_seed"]), svf_arg, n)
+            want = fx[pre + "couples"]
+            assert np.array_equal(couples["pos_male"].astype(np.int64), want[:, 0]) and np.array_equal(couples["pos_female"].astype(np.int64), want[:, 1]), f"{case}: couples gen {g} pop {ip}"
+            assert np.array_equal(couples["inbreed"], want[:, 2]) and np.array_equal(couples["num_offspring"], want[:, 3])
+            if np.all(svf == 1.0):
+                sx = fx[pre + "mate_sex"]
+                assert (nm, nf) == (int(np.sum(sx == 1)), int(np.sum(sx == 2)))
+            ms = fx[pre + "mut_seeds"]
+            sex = ctx.reproduce(ip, None, int(fx[pre + "seed_reproduce"]), ms if len(ms) else None, n_people=n)
+            assert np.array_equal(sex, fx[pre + "sex"]), f"{case}: sex gen {g} pop {ip}"
+            add, dom, _, _ = ctx.compute_ad(ip)
+            assert helpers.bits_equal(add, fx[pre + "additive"]) and helpers.bits_equal(dom, fx[pre + "dominance"]), f"{case}: A/D gen {g} pop {ip}"
+        if f"g{g}_moves" in fx:
+            ctx.migrate(helpers.derive_moves(fx, g))
+    with pytest.raises(capi.GevError):
+        ctx.reproduce(0, None, 1, None, n_people=5)            # no couples are waiting on the device
+    ctx.close()
+
+
+@pytest.mark.parametrize("mate", ["device", "fused"])
+@pytest.mark.parametrize("case", ["ex1mut", "dense", "syn1k", "sel1"])
+def test_closed_loop_from_the_seed_alone_with_device_random_mate(gpu_lib, case, mate):
+    """the whole run from --seed alone with mating on the device; "fused": gev_generation_begin/_end draw the generation's
+    ras_glob_seed() values themselves (the host's engine state goes in, the state behind the draws comes back) -- the seeds,
+    couples, sexes, pedigree, A/D and phenotypes are the reference's"""
+    helpers.closed_loop_case(gpu_lib, helpers.load_fixture(case), f"gpu/{case}/{mate}", device=0, exact=False, mate=mate)
+
+
+@pytest.mark.parametrize("mate", ["device", "fused"])
+def test_closed_loop_two_populations_with_migration_and_device_random_mate(gpu_lib, mate):
+    helpers.closed_loop_migration_case(gpu_lib, helpers.load_fixture("mig2"), f"gpu/mig2/{mate}", device=0, exact=False, mate=mate)
+
+
+def _pair(gpu_lib, oracle_lib, cfg, n0, seed_f=70):
+    g = gpu_lib.create(1, cfg.nchr, cfg.nphen); o = oracle_lib.create(1, cfg.nchr, cfg.nphen)
+    cfg.apply_static(g); cfg.apply_static(o)
+    for c in range(cfg.nchr):
+        g.synth_founders(0, c, 2 * n0, seed_f + c); o.upload_founders(0, c, synth_packed(seed_f + c, 2 * n0, cfg.n_loci), cfg.n_loci)
+        ncv = len(cfg.cv[0][c][0])
+        g.synth_cv_founders(0, 0, c, 2 * n0, seed_f + 10 + c); o.upload_cv_founders(0, 0, c, synth_packed(seed_f + 10 + c, 2 * n0, ncv), ncv)
+    return g, o
+
+
+def _same_state(g, o, nchr, what):
+    for c in range(nchr):
+        assert np.array_equal(g.download_haps(0, c), o.download_haps(0, c)), f"dense {what} chr {c}"
+        pg, og = g.download_intervals(0, c); po, oo = o.download_intervals(0, c)
+        assert np.array_equal(og, oo) and np.array_equal(pg, po), f"intervals {what} chr {c}"
+        mg, mog = g.download_mutations(0, c); mo, moo = o.download_mutations(0, c)
+        assert np.array_equal(mog, moo) and np.array_equal(mg, mo), f"mutations {what} chr {c}"
+
+
+@pytest.mark.parametrize("with_mut", [True, False])
+def test_whole_generations_on_the_device_against_the_oracle_through_redo_paths(gpu_lib, oracle_lib, monkeypatch, with_mut):
+    """gev_generation_begin/_end for 30 generations against the oracle's sequential statement of random_mate -> reproduce ->
+    ras_compute_AD, with selection values that exclude part of the population, a changing population size, and buffers that are
+    too small on purpose (tiny overflow regions, no list headroom): generations are enqueued again inside _end -- seeds and couples
+    are drawn again on the device from the retained engine state -- and must come out the same.  with_mut = False: without a
+    mutation map reproduce draws ONE ras_glob_seed() value and the rand() chain runs through every gamete (serial-chain mode)."""
+    monkeypatch.setenv("GEV_OVF_CAP", "8"); monkeypatch.setenv("GEV_LIST_HEADROOM", "0")
+    cfg = SyntheticConfig(150, 1500, nchr=2, chrom_bp=1_000_000, map_step=5_000, rec_per_row=0.03, mut_per_row=0.02, n_cv=25, seed=37, with_mutation=with_mut)
+    g, o = _pair(gpu_lib, oracle_lib, cfg, 150)
+    sg, so = Simulation(g, 8, 2, with_mut), Simulation(o, 8, 2, with_mut)
+    sg.ras_initial_human_gen0(0, 150); so.ras_initial_human_gen0(0, 150)
+    rng = np.random.default_rng(12)
+    for gen in range(1, (31 if with_mut else 9)):
+        n = 150 if gen % 6 else 190
+        svf = None if gen % 3 == 0 else rng.uniform(0.2, 1.4, len(sg.sex[0]))
+        ra = sg.next_generation_rm(0, n, svf, want_couples=True); rb = so.next_generation_rm(0, n, svf, want_couples=True)
+        for k in ("glob_state", "seed_mate", "seed_reproduce", "num_males_mate", "num_females_mate"):
+            assert ra[k] == rb[k], (gen, k, ra[k], rb[k])
+        assert np.array_equal(ra["couples"], rb["couples"]), f"couples gen {gen}"
+        assert np.array_equal(ra["sex"], rb["sex"]), f"sex gen {gen}"
+        assert sg.glob.x == so.glob.x
+        xa, xo = g.compute_ad(0), o.compute_ad(0)
+        for x, y in zip(xa, xo):
+            assert helpers.bits_equal(x, y), f"A/D gen {gen}"
+        if gen % 10 == 0 or not with_mut:
+            _same_state(g, o, 2, f"gen {gen}")
+    if with_mut:
+        assert g.redo_count() >= 3, "the undersized buffers were meant to force generations to be enqueued again"
+    g.close(); o.close()
+
+
+def test_pipelined_host_loop_survives_a_redo_while_the_next_head_start_is_queued(gpu_lib, oracle_lib, monkeypatch):
+    """bench.py's --host-mating order of calls with buffers that are too small on purpose: gev_reproduce_end enqueues generation g
+    again (larger record regions) while the head start of g+1 -- sampled with the old regions -- is already queued; the following
+    gev_presample_sex must sample again from the retained inputs instead of failing (round-2 advisor finding)."""
+    monkeypatch.setenv("GEV_OVF_CAP", "8"); monkeypatch.setenv("GEV_LIST_HEADROOM", "0")
+    cfg = SyntheticConfig(120, 1500, nchr=2, chrom_bp=1_000_000, map_step=5_000, rec_per_row=0.03, mut_per_row=0.02, n_cv=25, seed=35)
+    g, o = _pair(gpu_lib, oracle_lib, cfg, 120)
+    sg, so = Simulation(g, 3, 2, True), Simulation(o, 3, 2, True)
+    sg.ras_initial_human_gen0(0, 120); so.ras_initial_human_gen0(0, 120)
+    rng = np.random.default_rng(6)
+    n = 120
+    seeds = sg.ras_glob_seed(1 + 2 * n)
+    sg.presample(0, seeds, n)
+    couples = synthetic_random_mate(sg.sex[0], n, rng)
+    for gen in range(1, 25):
+        sex_early = g.presample_sex(0, n)
+        seeds_next = sg.ras_glob_seed(1 + 2 * n)
+        g.reproduce_begin(0, couples, int(seeds[0]), seeds[1:], n_people=n)
+        sg.presample(0, seeds_next, n)
+        next_couples = synthetic_random_mate(sex_early, n, rng)
+        sex = g.reproduce_end()
+        assert np.array_equal(sex, sex_early)
+        so.couples[0] = couples
+        assert np.array_equal(so.reproduce(0, gen, seeds=seeds, n_people=n), sex), f"sex gen {gen}"
+        xa, xo = g.compute_ad(0), o.compute_ad(0)
+        assert helpers.bits_equal(xa[0], xo[0]), f"A gen {gen}"
+        if gen % 8 == 0:
+            _same_state(g, o, 2, f"gen {gen}")
+        couples, seeds = next_couples, seeds_next
+    assert g.redo_count() >= 3
+    g.close(); o.close()
+
+
+def test_no_one_can_marry_is_reported_like_the_reference(gpu_lib, oracle_lib):
+    """Simulation::random_mate prints "Error: No one can marry, ..." and returns false (src/Simulation.cpp:2125-2129):
+    GEV_ENOMATE with that line from gev_random_mate and from gev_generation_end, nothing is published, the population lives on"""
+    cfg = SyntheticConfig(64, 500, chrom_bp=200_000, map_step=10_000, n_cv=12, seed=2)
+    g, o = _pair(gpu_lib, oracle_lib, cfg, 64)
+    sg, so = Simulation(g, 4, 1, True), Simulation(o, 4, 1, True)
+    sg.ras_initial_human_gen0(0, 64); so.ras_initial_human_gen0(0, 64)
+    nobody = np.zeros(64)
+    only_f = np.where(sg.sex[0] == 2, 1.0, 0.0)
+    for lib_ctx in (g, o):
+        with pytest.raises(capi.GevError) as e:
+            lib_ctx.random_mate(0, 77, nobody, 64)
+        assert e.value.code == -6 and "No one can marry, num_males_mate=0, num_females_mate=0" in str(e.value)
+        lib_ctx.generation_begin(0, 4242, 64, only_f)
+        with pytest.raises(capi.GevError) as e:
+            lib_ctx.generation_end()
+        assert e.value.code == -6 and f"num_males_mate=0, num_females_mate={int(np.sum(sg.sex[0] == 2))}" in str(e.value)
+        assert lib_ctx.pop_size(0) == 64
+    ra = sg.next_generation_rm(0, 80, None, want_couples=True); rb = so.next_generation_rm(0, 80, None, want_couples=True)
+    assert np.array_equal(ra["couples"], rb["couples"]) and np.array_equal(ra["sex"], rb["sex"])
+    _same_state(g, o, 1, "after the refused generations")
+    g.close(); o.close()

@@ -152,3 +152,27 @@ def test_closed_loop_two_populations_with_migration(oracle_lib):
     """BASELINE config 3's shape end to end from the seed alone: two populations, random mating, mutation, migration decided by
     the host restatement of ras_do_migration (selection sampling on the process-wide static engine), rows moved by the library"""
     helpers.closed_loop_migration_case(oracle_lib, helpers.load_fixture("mig2"), "oracle/mig2")
+
+
+@pytest.mark.parametrize("mate", ["device", "fused"])
+@pytest.mark.parametrize("case", ["ex1mut", "dense", "syn1k", "sel1"])
+def test_closed_loop_with_the_library_side_random_mate(oracle_lib, case, mate):
+    """pins the oracle's restatement of Simulation::random_mate (src/Simulation.cpp:2090-2157) and of ras_glob_seed (:17-21) behind
+    gevo_random_mate / gevo_generation_begin: the reference's couples, seeds, sexes, A/D and .info files of every --RM fixture"""
+    helpers.closed_loop_case(oracle_lib, helpers.load_fixture(case), f"oracle/{case}/{mate}", mate=mate)
+
+
+@pytest.mark.parametrize("mate", ["device", "fused"])
+def test_closed_loop_two_populations_with_migration_and_library_side_random_mate(oracle_lib, mate):
+    helpers.closed_loop_migration_case(oracle_lib, helpers.load_fixture("mig2"), f"oracle/mig2/{mate}", mate=mate)
+
+
+def test_oracle_glob_seeds_equal_the_host_stream(oracle_lib):
+    from geneevolve_amd.host import GlobSeedStream
+    o = oracle_lib.create(1, 1, 1)
+    for seed, n in ((12345, 1), (1, 5), (2147483646, 4097), (987654321, 100001)):
+        g = GlobSeedStream(seed); st0 = g.x
+        want = g.draw(n)
+        got, st = o.glob_seeds(st0, n)
+        assert np.array_equal(got, want) and st == g.x
+    o.close()
