@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--mating", choices=["device", "host"], default="device",
                     help="device (default): Simulation::random_mate and the generation's ras_glob_seed() draws run on the GPU, a step is one "
                          "gev_generation_begin/_end pair; host: round 2's loop (numpy stand-in for random_mate, seeds drawn by a second host thread)")
+    ap.add_argument("--no-chain", action="store_true", help="--mating device: no head start across generations (gev_set_generation_chain)")
     ap.add_argument("--no-pipeline", action="store_true", help="--mating host only: mate, then gev_reproduce, strictly one after the other (default: the host forms the next couples between gev_reproduce_begin and _end)")
     ap.add_argument("--isolated-steps", type=int, default=3, help="extra untimed generations without stream overlap for roofline.isolated")
     args = ap.parse_args()
@@ -246,6 +247,10 @@ def main():
         ctx.synth_cv_founders(P, 0, c, 2 * args.n_ind, 2000 + 100 * c + rank)
     sim = Simulation(ctx, 12345 + rank, args.nchr, True)
     sim.ras_initial_human_gen0(P, args.n_ind)
+    if args.mating == "device" and not args.no_chain:
+        # this loop makes no ras_glob_seed() draw of its own between two generations (no phenotype scaling, no migration draws): tell the
+        # library, so that it can draw the next generation's seeds and sample while this generation's rows are stitched
+        ctx.set_generation_chain(0)
     rng = np.random.default_rng(rank)
     total = args.warmup + args.steps
     # Simulation::ras_glob_seed(): 1 + N*nchr draws per generation (src/Simulation.cpp:2398, :2500), made by the host INSIDE every

@@ -9,8 +9,15 @@
 //                    the reference treats part::mutation_pos as a set (flip applied at read
 //                    time, src/Simulation.cpp:1218-1222), not as an in-place toggle.
 //   CV plane         same packing on the (sorted) CV grid, 1 + ceil(log2(n_pop)) sub-rows per
-//                    row: allele bits, then root-population id bits (a/d are looked up in the
-//                    root population, src/Simulation.cpp:2778-2779)
+//                    row: the CV alleles AS ras_find_cv RESOLVES THEM (founder allele, !founder where
+//                    the CV position is in the mutation set of the covering part, :2766-2775), then
+//                    root-population id bits (a/d are looked up in the root population, :2778-2779).
+//                    Both are inherited by the crossover pattern (recombine copies a part with its
+//                    mutation_pos, modify_part_for_mutation_pos keeps the positions inside the
+//                    trimmed part); a NEW mutation on a CV position flips the allele unless the
+//                    position already is in the covering part's set (k_cv_newmut looks it up in the
+//                    parental list).  A/D reads this plane only -- it never scans the mutation
+//                    lists, whose length grows with the age of the run
 //   mutation lists   CSR  off[2n+1] (u32), pos[] (u64, ascending per row)
 //   interval lists   CSR  off[2n+1] (u32), gev_part[] -- the reference's own state, kept for
 //                    --out_interval parity
@@ -98,14 +105,17 @@ struct ChrWork {
     int chr;
 };
 struct CvWork {
-    u32* cvp_alt; const u32* cvp_cur; const u64* pos_sorted;
+    u32* cvp_alt; const u32* cvp_cur; const u64* pos_sorted; u32* counts;      // counts: allele count per CV column (k_cv_sum_partials / k_cv_count / k_cv_newmut add, k_cv_table / k_cv_freq consume and clear)
+    uint16_t* partial;                                                        // [blocks of k_stitch_small][1024] allele counts of the block's rows per column
+    u64 bp0, bp_end;
     u32 stride_w32, sub_w32, C;
     int chr;
+    u32 cw;                                                                   // entry of the ChrWork table that holds this chromosome's lists
 };
 struct AdWork {
-    const u32* cvp; const u32* moff; const u64* mpos; const u64* pos_sorted; const u64* pos_file; const u32* col_of_icv;
+    const u32* cvp; const u64* pos_sorted; const u64* pos_file; const u32* col_of_icv;
     const double* a; const double* d; const double* const* aptr; const double* const* dptr;
-    u32* cvm; u32* counts; double* frq; double* tab; double* add_out; double* dom_out;
+    u32* counts; double* frq; double* tab; double* add_out; double* dom_out;
     u64 bp0, bp_end;
     double vd;
     u32 stride_w32, sub_w32, C;
@@ -117,7 +127,8 @@ struct AdWork {
 // status words written by the kernels of one generation, read back once at its end
 enum { ST_BK_OVF_USED = 0, ST_NM_OVF_USED = 1, ST_FLAGS = 2, ST_SLOW_MUT = 3, ST_SLOW_REC = 4 /* tasks handed to the one-task-per-wave kernels */,
        ST_GLOB_STATE = 5 /* glob_generator behind the generation's ras_glob_seed() draws (gev_generation_begin) */, ST_NM_MATE = 6, ST_NF_MATE = 7 /* num_males_mate, num_females_mate */,
-       ST_TOTALS = 8 /* then per chr: mut_total, parts_total, segments the dense stitch writes, how many of them are last (partial) segments */ };
+       ST_NEXT_STATE = 8 /* ... and behind the draws the host announced it makes before the next generation (gev_set_generation_chain) */,
+       ST_TOTALS = 16 /* then per chr: mut_total, parts_total, segments the dense stitch writes, how many of them are last (partial) segments */ };
 #define ST_PER_CHR 4
 enum { FLAG_BK_OVF = 1, FLAG_NM_OVF = 2, FLAG_MUT_CAP = 4, FLAG_PARTS_CAP = 8, FLAG_POOL = 16,
        FLAG_RNG_SHORT = 32 /* a rejection stream ran out of candidates (internal) */, FLAG_NO_MATES = 64 /* "No one can marry", src/Simulation.cpp:2125 */ };
@@ -213,11 +224,6 @@ __global__ void __launch_bounds__(256) k_scan_final_tab(const u32* __restrict__ 
         if (base + j <= n) out[base + j] = ex;
         if (base + j == n) {
             status[ST_TOTALS + ST_PER_CHR * w.chr + (is_parts ? 1 : 0)] = ex;
-            if (!is_parts && w.pw.pctr) {                                                           // k_pool_assign ran before
-                status[ST_TOTALS + ST_PER_CHR * w.chr + 2] = w.pw.pctr[1];                          // segments the dense stitch writes
-                status[ST_TOTALS + ST_PER_CHR * w.chr + 3] = w.pw.pctr[3];                          // ... of which last (partial) segments
-                w.pw.items[w.pw.items_cap] = (status[ST_FLAGS] & FLAG_POOL) ? 0u : min(w.pw.pctr[1], w.pw.items_cap);   // length of the stitch's work list (pool exhausted: the stitch does nothing, the host reports)
-            }
         }
         ex += v[j];
     }
@@ -622,6 +628,16 @@ __global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__
     __syncthreads();
     if (threadIdx.x == 0 && s_last) atomicAdd(&pw.pctr[3], s_last);
 }
+// behind k_pool_assign: the length of the stitch's work list and the segment totals of the status block, per work entry
+__global__ void __launch_bounds__(64) k_pool_publish(const ChrWork* __restrict__ Wt, u32 n_work, u32* __restrict__ status)
+{
+    for (u32 y = threadIdx.x; y < n_work; y += 64) {
+        const ChrWork& w = Wt[y];
+        status[ST_TOTALS + ST_PER_CHR * w.chr + 2] = w.pw.pctr[1];                          // segments the dense stitch writes
+        status[ST_TOTALS + ST_PER_CHR * w.chr + 3] = w.pw.pctr[3];                          // ... of which last (partial) segments
+        w.pw.items[w.pw.items_cap] = (status[ST_FLAGS] & FLAG_POOL) ? 0u : min(w.pw.pctr[1], w.pw.items_cap);   // length of the work list (pool exhausted: the stitch does nothing, the host reports)
+    }
+}
 // breakpoint (base pairs) -> first locus index >= it, for every gamete of every chromosome: one fully parallel pass,
 // so that no stitch workgroup has to walk a 20-step dependent binary search before it can start streaming
 __global__ void __launch_bounds__(256) k_bk_to_idx(const ChrDev* __restrict__ chrs, int nchr, size_t n_gametes, SampleDev sd)
@@ -771,24 +787,35 @@ __global__ void __launch_bounds__(STITCH_THREADS) k_stitch_rows(const ChrWork* _
 
 // small planes (CV grid: ~125 B rows): one HALF-WAVE (32 lanes) per output row.  The lanes first turn the row's breakpoints into
 // CV-column indices in parallel (one binary search per lane, 32 breakpoints per round) and share them with shuffles, then
-// every lane blends its own 32-bit words of the two parental rows; loads and stores are 128-byte coalesced per half-wave.
-#define SMALL_ROWS_PER_BLOCK 256         // 8 half-waves x 32 rounds: the block stages the CV position grid in LDS once
+// every lane blends its own 32-bit words of the two parental rows -- every sub-row (alleles, root-population bits) by the same
+// pattern; loads and stores are 128-byte coalesced per half-wave.  Fused into the same pass: the allele count of
+// every CV column (:2647-2655), when `count_cols` (every CV grid of the launch has <= 1024 columns): each lane adds its allele
+// word into bit-sliced counters over the block's rounds, the block adds them up in LDS and writes its 1024 partial counts with
+// plain stores (k_cv_sum_partials adds the blocks up: one global atomic per column and block was measured three times as slow
+// as the whole rest of the kernel).  The kernel is bound by the latency of the per-row descriptor chain (parent -> rows, breakpoints -> columns):
+// more threads per block = more rows in flight per block, fewer rounds (512: 16 rows, 16 rounds).
+#define SMALL_ROWS_PER_BLOCK 256         // the block stages the CV position grid in LDS once for this many rows
 #define SMALL_POS_LDS 4096               // most CV positions held in LDS (32 KiB); longer grids are searched in global memory
-__global__ void __launch_bounds__(256) k_stitch_small(const CvWork* __restrict__ Vt, u32 nsub, size_t n_rows_out, int nchr, SampleDev sd, u32 pos_lds)
+template <int SMALL_THREADS>
+__global__ void __launch_bounds__(SMALL_THREADS) k_stitch_small(const CvWork* __restrict__ Vt, u32 nsub, size_t n_rows_out, int nchr, SampleDev sd, u32 pos_lds, int count_cols)
 {
     extern __shared__ u64 s_pos[];                                        // min(largest CV grid of the launch, SMALL_POS_LDS) entries
+    __shared__ u32 s_cnt[1024];                                           // [bit][word]: column 32 * word + bit
     const CvWork& v = Vt[blockIdx.y];
     u32* __restrict__ dst = v.cvp_alt; const u32* __restrict__ src = v.cvp_cur;
     const u32 stride_w32 = v.stride_w32, sub_w32 = v.sub_w32, Cn = v.C;
     const int chr = v.chr;
     const bool in_lds = Cn <= pos_lds;
-    if (in_lds) for (u32 e = threadIdx.x; e < Cn; e += 256) s_pos[e] = v.pos_sorted[e];
+    if (in_lds) for (u32 e = threadIdx.x; e < Cn; e += SMALL_THREADS) s_pos[e] = v.pos_sorted[e];
+    if (count_cols) for (u32 e = threadIdx.x; e < 1024; e += SMALL_THREADS) s_cnt[e] = 0;
     __syncthreads();
     const u64* __restrict__ pos = in_lds ? s_pos : v.pos_sorted;
     const u32 hl = threadIdx.x & 31u, half0 = threadIdx.x & 32u;          // lane inside the half-wave / first wave lane of the half
-    for (u32 round = 0; round < SMALL_ROWS_PER_BLOCK / 8; round++) {
-    const size_t row = (size_t)blockIdx.x * SMALL_ROWS_PER_BLOCK + round * 8 + (threadIdx.x >> 5);
-    if ((size_t)blockIdx.x * SMALL_ROWS_PER_BLOCK + round * 8 >= n_rows_out) break;      // block-uniform
+    const u32 HW = SMALL_THREADS / 32;                                    // rows per round
+    u32 p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;                           // bit-sliced counters (up to 31 >= rounds) of this lane's allele word over the block's rounds
+    for (u32 round = 0; round < SMALL_ROWS_PER_BLOCK / HW; round++) {
+    const size_t row = (size_t)blockIdx.x * SMALL_ROWS_PER_BLOCK + round * HW + (threadIdx.x >> 5);
+    if ((size_t)blockIdx.x * SMALL_ROWS_PER_BLOCK + round * HW >= n_rows_out) break;      // block-uniform
     const bool live = row < n_rows_out;                                   // dead halves keep running: their lanes take part in the shuffles
     const u32 i = live ? (u32)(row >> 1) : 0u, s = (u32)(row & 1);
     const size_t G = 2 * ((size_t)i * nchr + chr) + s;
@@ -810,17 +837,99 @@ __global__ void __launch_bounds__(256) k_stitch_small(const CvWork* __restrict__
             const u32 nm = min(32u, kmax - m0);
             for (u32 m = 0; m < nm; m++) {
                 const u32 x = (u32)__shfl((int)id, (int)(half0 + m));
-                u32 t = 0;
-                if (x <= bit0) t = 0xffffffffu; else if (x < bit0 + 32u) t = 0xffffffffu << (x - bit0);
-                mask ^= t;
+                u32 tt = 0;
+                if (x <= bit0) tt = 0xffffffffu; else if (x < bit0 + 32u) tt = 0xffffffffu << (x - bit0);
+                mask ^= tt;
             }
         }
-        if (live && w < sub_w32)
+        if (live && w < sub_w32) {
+            u32 av = 0;
             for (u32 sub = 0; sub < nsub; sub++) {
                 const u32 wq = sub * sub_w32 + w;
-                D[wq] = (A[wq] & ~mask) | (B[wq] & mask);
+                const u32 val = (A[wq] & ~mask) | (B[wq] & mask);
+                D[wq] = val;
+                if (sub == 0) av = val;
             }
+            if (count_cols) {                                             // p += av, bit-sliced (ripple carry through the planes)
+                u32 c = av, t1;
+                t1 = p0 & c; p0 ^= c; c = t1; t1 = p1 & c; p1 ^= c; c = t1; t1 = p2 & c; p2 ^= c; c = t1; t1 = p3 & c; p3 ^= c; c = t1; p4 ^= c;
+            }
+        }
     }
+    }
+    if (count_cols) {                                                     // (sub_w32 <= 32: the lane's word is hl in every round)
+        if (hl < sub_w32)
+            for (u32 b = 0; b < 32; b++) {
+                const u32 n = ((p0 >> b) & 1u) | (((p1 >> b) & 1u) << 1) | (((p2 >> b) & 1u) << 2) | (((p3 >> b) & 1u) << 3) | (((p4 >> b) & 1u) << 4);
+                if (n) atomicAdd(&s_cnt[b * 32u + hl], n);
+            }
+        __syncthreads();
+        uint16_t* __restrict__ out = v.partial + (size_t)blockIdx.x * 1024;
+        for (u32 col = threadIdx.x; col < 1024; col += SMALL_THREADS) out[col] = (uint16_t)s_cnt[(col & 31u) * 32u + (col >> 5)];   // (<= 256 rows per block)
+    }
+}
+// column counts = sum of the blocks' partial counts; gridDim.y slices of the blocks, one atomic per column and slice
+__global__ void __launch_bounds__(256) k_cv_sum_partials(const CvWork* __restrict__ Vt, u32 n_blocks)
+{
+    const CvWork& v = Vt[blockIdx.z];
+    const u32 col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= v.C) return;
+    const u32 per = (n_blocks + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(b0 + per, n_blocks);
+    u32 n = 0;
+    for (u32 b = b0; b < b1; b++) n += v.partial[(size_t)b * 1024 + col];
+    if (n) atomicAdd(&v.counts[col], n);
+}
+// The generation's NEW mutations (ras_add_mutation, :2497-2552) that fall on a CV position, applied to the offspring plane behind
+// k_stitch_small: ras_find_cv reads !founder where the position is in the covering part's mutation_pos (:2770-2775), so the
+// resolved allele flips -- unless the position already was in that set (a set: a second hit changes nothing).  "Already" means:
+// in the mutation list of the parental haplotype the offspring part was cut from (start ^ parity of the breakpoints at or before
+// the position; the list the offspring inherits), or an earlier new mutation of the same task and side.  One thread per
+// (offspring, chromosome) task; a position that cannot be a CV position is dropped with one LDS read (64-Kbit hash bitmap of the
+// CV grid), so the lookups run for a handful of mutations per generation.  The column's allele count moves with the flip.
+__device__ __forceinline__ u32 cv_hash16(u64 x) { return (u32)((x * 0x9E3779B97F4A7C15ull) >> 48); }
+__global__ void __launch_bounds__(256) k_cv_newmut(const CvWork* __restrict__ Vt, const ChrWork* __restrict__ Wt, size_t n_people, int nchr, SampleDev sd, int count_cols)
+{
+    __shared__ u32 s_bits[2048];
+    const CvWork& v = Vt[blockIdx.y];
+    for (u32 q = threadIdx.x; q < 2048; q += 256) s_bits[q] = 0;
+    __syncthreads();
+    for (u32 c = threadIdx.x; c < v.C; c += 256) { const u32 h = cv_hash16(v.pos_sorted[c]); atomicOr(&s_bits[h >> 5], 1u << (h & 31)); }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_people) return;
+    const size_t t = i * nchr + v.chr;
+    const u32 n = sd.nmut[t];
+    if (!n) return;
+    const u32 off = sd.nm_off[t];
+    const ChrWork& w = Wt[v.cw];
+    for (u32 m = 0; m < n; m++) {
+        const u64 x = sd.nm_pos[off + m];
+        if (x < v.bp0 || x >= v.bp_end) continue;                         // no part contains it: ras_add_mutation appends nothing (:2526-2545)
+        const u32 h = cv_hash16(x);
+        if (!((s_bits[h >> 5] >> (h & 31)) & 1u)) continue;
+        u32 c = lower_bound_u64(v.pos_sorted, v.C, x);
+        if (c >= v.C || v.pos_sorted[c] != x) continue;
+        const u32 side = sd.nm_side[off + m];
+        bool seen = false;                                                // an earlier new mutation of this task on the same haplotype and position
+        for (u32 m2 = 0; m2 < m; m2++) seen |= sd.nm_pos[off + m2] == x && sd.nm_side[off + m2] == side;
+        if (!seen) {                                                      // inherited: in the list of the parental haplotype that covers x
+            const size_t G = 2 * t + side;
+            const u32 parent = side ? sd.mother[i] : sd.father[i];
+            const u32 k = sd.k[G]; const u64* bk = sd.bk + sd.bk_off[G];
+            u32 cnt = 0;
+            for (u32 j = 0; j < k; j++) cnt += bk[j] <= x;
+            const u32 hap = (sd.start[G] ^ cnt) & 1u;
+            const u32 l0 = w.moff_cur[2 * parent + hap], l1 = w.moff_cur[2 * parent + hap + 1];
+            const u32 at = l0 + lower_bound_u64(w.mpos_cur + l0, l1 - l0, x);
+            seen = at < l1 && w.mpos_cur[at] == x;
+        }
+        if (seen) continue;
+        u32* row = v.cvp_alt + (2 * i + side) * v.stride_w32;
+        for (; c < v.C && v.pos_sorted[c] == x; c++) {                    // every CV column at this position
+            const u32 bit = 1u << (c & 31);
+            const u32 a_old = atomicXor(&row[c >> 5], bit);
+            if (count_cols) atomicAdd(&v.counts[c], (a_old & bit) ? 0xffffffffu : 1u);
+        }
     }
 }
 
@@ -975,105 +1084,35 @@ __global__ void __launch_bounds__(256) k_parts(const ChrWork* __restrict__ Wt, u
 // ------------------------------------------------------------------------------------------
 // K6/K7: ras_find_cv + ras_compute_AD (src/Simulation.cpp:2624-2815)
 // ------------------------------------------------------------------------------------------
-// resolve CV alleles: founder allele from the stitched CV plane, flipped where the CV position is
-// in the row's mutation set (:2770-2775).  One thread per haplotype row.
-__device__ __forceinline__ void cv_apply_mut_row(
-    const u32* __restrict__ plane, u32 stride_w32, u32 sub_w32, u32* __restrict__ out /*[rows][sub_w32]*/, size_t row,
-    const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ cvpos_sorted, u32 Cn)
+// allele sub-rows of a CV plane, contiguous (gev_download_cv: the --debug .cvval dump, :2665-2683)
+__global__ void __launch_bounds__(256) k_cv_resolve(const u32* __restrict__ plane, u32 stride_w32, u32 sub_w32, u32* __restrict__ out, size_t n_rows)
 {
-    const u32* in = plane + row * stride_w32;
-    u32* o = out + row * sub_w32;
-    for (u32 w = 0; w < sub_w32; w++) o[w] = in[w];
-    for (u32 j = m_off[row]; j < m_off[row + 1]; j++) {
-        const u64 x = m_pos[j];
-        u32 c = lower_bound_u64(cvpos_sorted, Cn, x);
-        for (; c < Cn && cvpos_sorted[c] == x; c++) {               // set semantics: flipped = !founder, idempotent
-            const u32 f = (in[c >> 5] >> (c & 31)) & 1u;
-            if (f) o[c >> 5] &= ~(1u << (c & 31)); else o[c >> 5] |= (1u << (c & 31));
-        }
-    }
-}
-__global__ void __launch_bounds__(256) k_cv_apply_mut(
-    const u32* __restrict__ plane, u32 stride_w32, u32 sub_w32, u32* __restrict__ out, size_t n_rows,
-    const u32* __restrict__ m_off, const u64* __restrict__ m_pos, const u64* __restrict__ cvpos_sorted, u32 Cn)
-{
-    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row < n_rows) cv_apply_mut_row(plane, stride_w32, sub_w32, out, row, m_off, m_pos, cvpos_sorted, Cn);
-}
-// all (phenotype, chromosome) pairs of a population in one launch (blockIdx.y); also clears the column counters of the pair
-// Step 1 (coalesced): the allele sub-rows of the block's 256 haplotype rows are copied word by word (consecutive lanes =
-// consecutive words); step 2: one thread per row flips the CVs that are in the row's mutation set (few rows have any).
-// The mutation entries of the block's 256 rows are ONE contiguous range of the CSR array: the block scans it flat (coalesced,
-// independent of how the entries are spread over the rows) and drops every position that cannot be a CV position with one LDS
-// read (64-Kbit hash bitmap of the CV grid: 1000 CVs -> 1.5 % false positives); the few survivors are looked up exactly, their
-// row is found in the staged offsets, and the allele is set to !founder (idempotent: a position hit twice is still one flip).
-__device__ __forceinline__ u32 cv_hash16(u64 x) { return (u32)((x * 0x9E3779B97F4A7C15ull) >> 48); }
-__global__ void __launch_bounds__(256) k_cv_apply_mut_tab(const AdWork* __restrict__ At, size_t n_rows)
-{
-    __shared__ u32 s_bits[2048];
-    __shared__ u32 s_off[257];
-    const AdWork& a = At[blockIdx.y];
-    const size_t row0 = (size_t)blockIdx.x * 256;
-    if (blockIdx.x == 0) for (u32 c = threadIdx.x; c < a.C; c += 256) a.counts[c] = 0;     // k_cv_count (next launch) accumulates into them
-    const u32 sw = a.sub_w32;
-    const u32 n_here = (u32)min((size_t)256, n_rows - row0);
-    for (u32 q = threadIdx.x; q < 2048; q += 256) s_bits[q] = 0;
-    if (threadIdx.x <= n_here) s_off[threadIdx.x] = a.moff[row0 + threadIdx.x];
-    if (threadIdx.x == 0) s_off[n_here] = a.moff[row0 + n_here];
-    __syncthreads();
-    for (u32 c = threadIdx.x; c < a.C; c += 256) { const u32 h = cv_hash16(a.pos_sorted[c]); atomicOr(&s_bits[h >> 5], 1u << (h & 31)); }
-    for (size_t e = threadIdx.x; e < (size_t)n_here * sw; e += 256) {
-        const size_t r = e / sw; const u32 w = (u32)(e - r * sw);
-        a.cvm[(row0 + r) * sw + w] = a.cvp[(row0 + r) * a.stride_w32 + w];
-    }
-    __syncthreads();                                     // the flips below go to the rows this block has just written
-    const u32 e0 = s_off[0], e1 = s_off[n_here];
-    for (u32 eb = e0 + threadIdx.x; eb < e1; eb += 256 * 4) {
-        u64 xs[4];                                        // four independent loads in flight per lane
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const u32 e = eb + u * 256; xs[u] = e < e1 ? a.mpos[e] : 0ull; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-        const u32 e = eb + u * 256;
-        if (e >= e1) continue;
-        const u64 x = xs[u];
-        const u32 h = cv_hash16(x);
-        if (!((s_bits[h >> 5] >> (h & 31)) & 1u)) continue;
-        u32 c = lower_bound_u64(a.pos_sorted, a.C, x);
-        if (c >= a.C || a.pos_sorted[c] != x) continue;
-        u32 lo = 0, hi = n_here;                          // row of entry e: the last r with s_off[r] <= e
-        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_off[mid] <= e) lo = mid; else hi = mid - 1; }
-        const size_t row = row0 + lo;
-        const u32* in = a.cvp + row * a.stride_w32;
-        u32* o = a.cvm + row * sw;
-        for (; c < a.C && a.pos_sorted[c] == x; c++) {              // set semantics: flipped = !founder, idempotent
-            const u32 f = (in[c >> 5] >> (c & 31)) & 1u, bit = 1u << (c & 31);
-            if (f) atomicAnd(&o[c >> 5], ~bit); else atomicOr(&o[c >> 5], bit);
-        }
-        }
-    }
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_rows * sub_w32) return;
+    const size_t r = q / sub_w32; const u32 w = (u32)(q % sub_w32);
+    out[q] = plane[r * stride_w32 + w];
 }
 // allele counts per CV column (sorted order): f = sum_ih cv0+cv1 (:2647-2655), exact integers
 __global__ void __launch_bounds__(256) k_cv_count(const AdWork* __restrict__ At, size_t n_rows)
 {
     const AdWork& a = At[blockIdx.z];
-    const u32* __restrict__ cvm = a.cvm; const u32 sub_w32 = a.sub_w32, Cn = a.C; u32* __restrict__ counts = a.counts;
+    const u32 stride = a.stride_w32, Cn = a.C; u32* __restrict__ counts = a.counts;
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t rows_per = (n_rows + gridDim.y - 1) / gridDim.y;
     const size_t r0 = (size_t)blockIdx.y * rows_per, r1 = min(r0 + rows_per, n_rows);
     if (c >= Cn) return;
-    const u32* col = cvm + (c >> 5);
+    const u32* col = a.cvp + (c >> 5);
     const u32 sh = c & 31;
     u32 n = 0;
     size_t r = r0;
-    for (; r + 8 <= r1; r += 8) {                      // 8 independent loads in flight
+    for (; r + 8 <= r1; r += 8) {                      // 16 independent loads in flight
         u32 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = col[(r + j) * sub_w32];
+        for (int j = 0; j < 8; j++) v[j] = col[(r + j) * stride];
 #pragma unroll
         for (int j = 0; j < 8; j++) n += (v[j] >> sh) & 1u;
     }
-    for (; r < r1; r++) n += (col[r * sub_w32] >> sh) & 1u;
+    for (; r < r1; r++) n += (col[r * stride] >> sh) & 1u;
     if (n) atomicAdd(&counts[c], n);
 }
 // frq[icv] = f / (2*n_human) in FILE order (:2655)
@@ -1083,6 +1122,7 @@ __global__ void k_cv_freq(const AdWork* __restrict__ At, size_t n_human)
     const u32 icv = blockIdx.x * blockDim.x + threadIdx.x;
     if (icv >= a.C) return;
     const double f = (double)a.counts[a.col_of_icv[icv]];
+    a.counts[a.col_of_icv[icv]] = 0;                    // every column is read by exactly one thread: cleared for the next k_cv_count
     a.frq[icv] = f / (double)(2 * n_human);
 }
 // per individual, CVs in FILE order, sequential FP64 (no contraction: built with -ffp-contract=off):
@@ -1091,19 +1131,18 @@ __global__ void k_cv_freq(const AdWork* __restrict__ At, size_t n_human)
 __global__ void __launch_bounds__(256) k_ad_accumulate(const AdWork* __restrict__ At, u32 rp_bits, size_t n_human, size_t out_stride, u32* __restrict__ nan_flag)
 {
     const AdWork& aw = At[blockIdx.y];
-    const u32* __restrict__ cvm = aw.cvm; const u32 sub_w32 = aw.sub_w32; const u32* __restrict__ plane = aw.cvp; const u32 stride_w32 = aw.stride_w32;
+    const u32 sub_w32 = aw.sub_w32; const u32* __restrict__ plane = aw.cvp; const u32 stride_w32 = aw.stride_w32;
     const u32* __restrict__ col_of_icv = aw.col_of_icv; const double* __restrict__ frq = aw.frq;
     const double* const* __restrict__ a_of_pop = aw.aptr; const double* const* __restrict__ d_of_pop = aw.dptr; const int own_pop = aw.own_pop;
     const u64* __restrict__ cvpos_file = aw.pos_file; const u64 bp0 = aw.bp0, bp_end = aw.bp_end; const double vd = aw.vd; const u32 Cn = aw.C;
     double* __restrict__ add_out = aw.add_out; double* __restrict__ dom_out = aw.dom_out;
     const size_t ih = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ih >= n_human) return;
-    const u32* r0 = cvm + (2 * ih) * sub_w32; const u32* r1 = cvm + (2 * ih + 1) * sub_w32;
     const u32* p0 = plane + (2 * ih) * stride_w32; const u32* p1 = plane + (2 * ih + 1) * stride_w32;
     double A_chr = 0, D_chr = 0;
     for (u32 icv = 0; icv < Cn; icv++) {
         const u32 c = col_of_icv[icv];
-        const u32 t = ((r0[c >> 5] >> (c & 31)) & 1u) + ((r1[c >> 5] >> (c & 31)) & 1u);
+        const u32 t = ((p0[c >> 5] >> (c & 31)) & 1u) + ((p1[c >> 5] >> (c & 31)) & 1u);
         u32 rp0 = own_pop, rp1 = own_pop;
         if (rp_bits) {
             rp0 = 0; rp1 = 0;
@@ -1137,12 +1176,13 @@ __global__ void __launch_bounds__(256) k_ad_accumulate(const AdWork* __restrict_
 __global__ void k_cv_table(const AdWork* __restrict__ At, size_t n_human)
 {
     const AdWork& aw = At[blockIdx.y];
-    const u32* __restrict__ counts = aw.counts; const u32* __restrict__ col_of_icv = aw.col_of_icv; const u32 Cn = aw.C;
+    u32* __restrict__ counts = aw.counts; const u32* __restrict__ col_of_icv = aw.col_of_icv; const u32 Cn = aw.C;
     const double* __restrict__ a_file = aw.a; const double* __restrict__ d_file = aw.d; const u64* __restrict__ cvpos_file = aw.pos_file;
     const u64 bp0 = aw.bp0, bp_end = aw.bp_end; const double vd = aw.vd; double* __restrict__ frq = aw.frq; double* __restrict__ tab = aw.tab;
     const u32 icv = blockIdx.x * blockDim.x + threadIdx.x;
     if (icv >= Cn) return;
     const double f = (double)counts[col_of_icv[icv]];
+    counts[col_of_icv[icv]] = 0;                        // every column is read by exactly one thread: cleared for the next k_cv_count
     const double p = f / (double)(2 * n_human);
     frq[icv] = p;
     const u64 x = cvpos_file[icv];
@@ -1172,7 +1212,7 @@ __global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restr
     // 6.6 KiB table chunk sits in LDS, which lets the block run in the LDS a concurrent stitch leaves over
     extern __shared__ u32 s_rows[];                              // [2 * IPB * s1_max] rows | [AD_CHUNK] columns | [AD_CHUNK * 6] table (8-byte aligned)
     const AdWork& aw = At[blockIdx.y];
-    const u32* __restrict__ cvm = aw.cvm; const u32 sub_w32 = aw.sub_w32; const u32* __restrict__ col_of_icv = aw.col_of_icv;
+    const u32 sub_w32 = aw.sub_w32, stride = aw.stride_w32; const u32* __restrict__ col_of_icv = aw.col_of_icv;
     const double* __restrict__ tab = aw.tab; const u32 Cn = aw.C; double* __restrict__ add_out = aw.add_out; double* __restrict__ dom_out = aw.dom_out;
     u32* s_col = s_rows + (((size_t)2 * IPB * s1_max + 1) & ~(size_t)1);
     double* s_tab = (double*)(s_col + AD_CHUNK);
@@ -1180,15 +1220,16 @@ __global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restr
     const size_t ih0 = (size_t)blockIdx.x * IPB;
     const size_t n_here = min((size_t)IPB, n_human - ih0);
     const u32 words = (u32)(2 * n_here) * sub_w32;
-    const u32* src = cvm + 2 * ih0 * sub_w32;
+    const u32* src = aw.cvp + 2 * ih0 * stride;                  // the block's first CV-plane row
     if (!direct)
         for (u32 e = threadIdx.x; e < words; e += IPB) {
             const u32 row = e / sub_w32, w = e - row * sub_w32;     // row = 2*local_individual + hap
-            s_rows[((row & 1u) * IPB + (row >> 1)) * S1 + w] = src[e];
+            s_rows[((row & 1u) * IPB + (row >> 1)) * S1 + w] = src[(size_t)row * stride + w];
         }
     const bool live = threadIdx.x < n_here;
-    const u32* r0 = direct ? src + (live ? 2 * (size_t)threadIdx.x * sub_w32 : 0) : s_rows + (size_t)threadIdx.x * S1;
-    const u32* r1 = direct ? r0 + sub_w32 : s_rows + ((size_t)IPB + threadIdx.x) * S1;
+    // direct: the thread reads the allele words of its two plane rows itself; staged: they sit in LDS
+    const u32* r0 = direct ? src + (live ? 2 * (size_t)threadIdx.x * stride : 0) : s_rows + (size_t)threadIdx.x * S1;
+    const u32* r1 = direct ? r0 + stride : s_rows + ((size_t)IPB + threadIdx.x) * S1;
     // vd == 0: the reference zeroes d (:2698-2699), every D-term is (+-0) * ... = +-0 and the running sum stays +0.0
     const bool skip_d = aw.vd == 0;
     double A_chr = 0, D_chr = 0;

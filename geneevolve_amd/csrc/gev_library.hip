@@ -133,7 +133,7 @@ struct CvStatic {                        // one population x phenotype x chromos
     std::vector<u64> bp; std::vector<double> a, d; double vd = 0; bool set = false;
     std::vector<u32> col_of_icv;         // file index -> column in the sorted CV plane
     std::vector<u32> icv_of_col;
-    DevBuf d_pos_sorted, d_pos_file, d_col_of_icv, d_icv_of_col, d_a, d_d, d_frq, d_counts, d_aptr, d_dptr, d_tab;
+    DevBuf d_pos_sorted, d_pos_file, d_col_of_icv, d_icv_of_col, d_a, d_d, d_frq, d_counts, d_partial, d_aptr, d_dptr, d_tab;
     u32 C = 0, sub_w32 = 0, stride_w32 = 0;
     u32 idx_lo = 0, idx_hi = 0;
     size_t founder_rows = 0;
@@ -170,7 +170,7 @@ struct PopState {
 struct gev_ctx {
     int device = 0, n_pop = 0, nchr = 0, nphen = 0;
     u32 rp_bits = 0;
-    hipStream_t stream = nullptr, stream_samp = nullptr;
+    hipStream_t stream = nullptr, stream_samp = nullptr, stream_aux = nullptr, stream_list = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};
     bool track_intervals = true;
@@ -180,7 +180,10 @@ struct gev_ctx {
     // while sampling / sparse state of generation g+1 (stream) fill the other one
     struct Scratch {
         DevBuf father, mother, mutseeds, globvals /* [2 + T] ras_glob_seed() values drawn on the device: mate seed, reproduce seed, mutation seeds */, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, status, slow_mut, slow_rec, chrwork, cvwork;
-        unsigned n_chrwork = 0; float sampling_ms_saved = -1;
+        unsigned n_chrwork = 0, n_cvwork = 0; float sampling_ms_saved = -1;
+        size_t nseg_max = 1, cv_used_max = 0, mut_avg = 0, parts_avg = 0; u32 cv_max = 0;     // launch shapes of the generation (enqueue_tables)
+        bool cv_count_fused = false;                                                          // k_stitch_small also counts the alleles per CV column (every grid <= 1024 columns)
+        hipEvent_t ev_fork = nullptr, ev_aux = nullptr, ev_lists = nullptr, ev_forked = nullptr;   // joins of the attempt's side streams
         hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_status = nullptr, ev_sampled = nullptr;   // the generation's status block (and A/D results) have arrived on the host
         bool timing_pending = false, stitch_pending = false;
         // gev_presample: the sampling kernels of the next gev_reproduce were already enqueued for exactly these inputs
@@ -188,6 +191,9 @@ struct gev_ctx {
         bool ps_stale = false;      // the head start was dropped by a redo of the generation in flight (record capacities changed): gev_presample_sex samples again from the retained inputs
         // gev_random_mate: father / mother of this set hold the couples of the next gev_reproduce (couples == NULL) of mate_pop
         bool mated = false; int mate_pop = -1; size_t mate_n = 0;
+        // gev_set_generation_chain: seeds drawn and sampling enqueued for the NEXT gev_generation_begin (same population, size) from the predicted engine state
+        bool fused_ahead = false, fa_dropped = false, fa_has_mut = false; int fa_pop = -1; size_t fa_n = 0;
+        hipEvent_t ev_chain = nullptr, ev_tab = nullptr;
     } sc[2];
     unsigned gen_counter = 0;
     std::vector<uint8_t> chr_active;        // 0: chromosome held by another context (gev_set_chr_active); sampling chain only
@@ -198,6 +204,9 @@ struct gev_ctx {
     hipEvent_t ev_planes = nullptr;         // recorded after the most recent stitch
     double ms_sum[4] = {0, 0, 0, 0}; unsigned long long ms_count = 0;
     size_t bk_ovf_cap = 1 << 16, nm_ovf_cap = 1 << 16;       // overflow regions of the breakpoint / new-mutation records (GEV_OVF_CAP: initial size, tests force redos with a tiny one)
+    int chain_draws = -1;                                    // gev_set_generation_chain: ras_glob_seed() draws the host makes between two generations (-1: unknown, no head start)
+    bool chain_valid = false; u32 chain_state = 0;           // glob_generator state the queued head start assumed for the next gev_generation_begin
+    unsigned long long chain_hits = 0, chain_misses = 0;
     unsigned long long redo_count = 0;                       // generations that were enqueued again with larger buffers (gev_redo_count)
     void* h_stage = nullptr; size_t h_stage_bytes = 0;       // pinned host staging
     void* h_seeds = nullptr; size_t h_seeds_bytes = 0;       // pinned copy of the mutation seeds handed to gev_presample
@@ -205,6 +214,10 @@ struct gev_ctx {
     int ad_cached_pop = -1;                                  // population whose current-generation A/D sits in h_ad
     int ad_host_set_pop = -1;                                // population whose raw A/D totals on the device were supplied by gev_set_ad (locus-split: all-reduced)
     bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
+    bool ad_dom_zero = false;                                // the cached generation's dominance values are +0.0 exactly (vd == 0 everywhere): not copied
+    int stitch_start = 1;          // when the dense stitch of a generation may start: 0 behind the unit table, 1 behind the CV planes (default: measured best), 2 behind the whole small work incl. A/D (GEV_STITCH_START)
+    unsigned cv_threads = 512; bool cv_count_fused_ok = true;   // k_stitch_small: threads per block (GEV_CV_THREADS=256|512|1024), column counts in the same pass (GEV_CV_COUNT_FUSED=0: separate k_cv_count)
+    bool side_streams = true;      // mate + free list next to the sampling, lists next to CV planes + A/D (GEV_SIDE_STREAMS=0: one stream)
     int stitch_mode = 0;           // 0 = work-list form (production, k_stitch_segments), 1 = gamete-major (k_stitch_rows)
     bool sample_batched = true;               // K1-K3 as eight tasks per wave (gev_sample8.h); GEV_SAMPLE_BATCHED=0: one task per wave
     unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels when they have the GPU to themselves (GEV_SAMPLE_GRID)
@@ -364,16 +377,25 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     }
     HIPC(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
     HIPC(hipStreamCreateWithPriority(&c->stream_samp, hipStreamNonBlocking, prio_greatest));
+    HIPC(hipStreamCreateWithPriority(&c->stream_aux, hipStreamNonBlocking, prio_greatest));
+    HIPC(hipStreamCreateWithPriority(&c->stream_list, hipStreamNonBlocking, prio_greatest));
     for (auto& ev : c->ev) HIPC(hipEventCreate(&ev));
     HIPC(hipStreamCreateWithPriority(&c->stream_big, hipStreamNonBlocking, prio_least));
-    HIPC(hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming));
+    // Events that only order DEVICE work against device work carry no system-scope fence (by default recording an event makes the
+    // preceding kernel write the dirty L2 lines back to memory: tens of microseconds behind a kernel that wrote 50 MB, paid by
+    // whatever small kernel comes next).  Only the event the host waits on before it reads the results (ev_status) keeps it.
+    static const bool sysfence = getenv("GEV_EVENT_SYSFENCE") != nullptr;            // (A/B knob: the default flags everywhere)
+    const unsigned dev_only = hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence), timed = sysfence ? hipEventDefault : hipEventDisableSystemFence;
+    HIPC(hipEventCreateWithFlags(&c->ev_planes, dev_only));
     c->chr_active.assign(nchr, 1);
     for (auto& sc : c->sc) {
-        HIPC(hipEventCreateWithFlags(&sc.ev_small_done, hipEventDisableTiming));
-        HIPC(hipEventCreateWithFlags(&sc.ev_stitch_done, hipEventDisableTiming));
+        HIPC(hipEventCreateWithFlags(&sc.ev_small_done, dev_only));
+        HIPC(hipEventCreateWithFlags(&sc.ev_stitch_done, dev_only));
         HIPC(hipEventCreateWithFlags(&sc.ev_status, hipEventDisableTiming));
-        HIPC(hipEventCreateWithFlags(&sc.ev_sampled, hipEventDisableTiming));
-        for (auto& e : sc.t) HIPC(hipEventCreate(&e));
+        HIPC(hipEventCreateWithFlags(&sc.ev_sampled, dev_only));
+        HIPC(hipEventCreateWithFlags(&sc.ev_fork, dev_only)); HIPC(hipEventCreateWithFlags(&sc.ev_aux, dev_only)); HIPC(hipEventCreateWithFlags(&sc.ev_lists, dev_only));
+        HIPC(hipEventCreateWithFlags(&sc.ev_forked, dev_only)); HIPC(hipEventCreateWithFlags(&sc.ev_chain, dev_only)); HIPC(hipEventCreateWithFlags(&sc.ev_tab, dev_only));
+        for (auto& e : sc.t) HIPC(hipEventCreateWithFlags(&e, timed));
     }
     c->pop.resize(n_pop);
     for (auto& P : c->pop) {
@@ -393,6 +415,10 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     if (const char* e = getenv("GEV_SEG_CHUNKS")) { const int v = atoi(e); u32 sh = 0; while ((1 << (sh + 1)) <= v) sh++; if (v >= 1 && sh <= 20) c->seg_shift = sh; }
     if (const char* e = getenv("GEV_ALIAS_ROWS")) c->alias_rows = atoi(e) != 0;
     if (const char* e = getenv("GEV_STITCH_WAVE_PRIO")) c->stitch_wave_prio = std::max(0, std::min(atoi(e), 3));
+    if (const char* e = getenv("GEV_STITCH_START")) c->stitch_start = std::max(0, std::min(atoi(e), 2));
+    if (const char* e = getenv("GEV_SIDE_STREAMS")) c->side_streams = atoi(e) != 0;
+    if (const char* e = getenv("GEV_CV_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) c->cv_threads = (unsigned)v; }
+    if (const char* e = getenv("GEV_CV_COUNT_FUSED")) c->cv_count_fused_ok = atoi(e) != 0;
     if (const char* e = getenv("GEV_OVF_CAP")) { const long v = atol(e); if (v >= 1) c->bk_ovf_cap = c->nm_ovf_cap = (size_t)v; }
     if (const char* e = getenv("GEV_STITCH_MODE")) c->stitch_mode = std::max(0, std::min(atoi(e), 1));
     if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = c->sample_grid_shared = (unsigned)g; }
@@ -411,10 +437,12 @@ void gev_destroy(gev_ctx* c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     if (c->stream_big) { (void)hipStreamSynchronize(c->stream_big); (void)hipStreamDestroy(c->stream_big); }
     if (c->stream_samp) { (void)hipStreamSynchronize(c->stream_samp); (void)hipStreamDestroy(c->stream_samp); }
+    if (c->stream_aux) { (void)hipStreamSynchronize(c->stream_aux); (void)hipStreamDestroy(c->stream_aux); }
+    if (c->stream_list) { (void)hipStreamSynchronize(c->stream_list); (void)hipStreamDestroy(c->stream_list); }
     if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
-    for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); if (sc.ev_status) (void)hipEventDestroy(sc.ev_status); if (sc.ev_sampled) (void)hipEventDestroy(sc.ev_sampled); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
+    for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); if (sc.ev_status) (void)hipEventDestroy(sc.ev_status); if (sc.ev_sampled) (void)hipEventDestroy(sc.ev_sampled); if (sc.ev_fork) (void)hipEventDestroy(sc.ev_fork); if (sc.ev_aux) (void)hipEventDestroy(sc.ev_aux); if (sc.ev_lists) (void)hipEventDestroy(sc.ev_lists); if (sc.ev_forked) (void)hipEventDestroy(sc.ev_forked); if (sc.ev_chain) (void)hipEventDestroy(sc.ev_chain); if (sc.ev_tab) (void)hipEventDestroy(sc.ev_tab); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
     hipStream_t s = c->stream;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_seeds) (void)hipHostFree(c->h_seeds);
@@ -501,7 +529,7 @@ int gev_set_cvs(gev_ctx* c, int pop, int phen, int chr, const u64* bp, const dou
     std::vector<u64> sorted(C);
     for (u32 j = 0; j < C; j++) sorted[j] = V.bp[V.icv_of_col[j]];
     V.sub_w32 = (u32)std::max<size_t>(ceil_div(C, 32), 1);
-    V.stride_w32 = (u32)round_up((size_t)V.sub_w32 * (1 + c->rp_bits), 4);
+    V.stride_w32 = (u32)round_up((size_t)V.sub_w32 * (1 + c->rp_bits), 4);      // sub-rows: resolved alleles, root-population bits
     HIPC(hipSetDevice(c->device));
     GEVC(h2d(c, V.d_pos_sorted, sorted.data(), C * sizeof(u64)));
     GEVC(h2d(c, V.d_pos_file, V.bp.data(), C * sizeof(u64)));
@@ -511,6 +539,7 @@ int gev_set_cvs(gev_ctx* c, int pop, int phen, int chr, const u64* bp, const dou
     GEVC(h2d(c, V.d_d, d, C * sizeof(double)));
     GEVC(V.d_frq.ensure(std::max<size_t>(C, 1) * sizeof(double), c->stream));
     GEVC(V.d_counts.ensure(std::max<size_t>(C, 1) * sizeof(u32), c->stream));
+    HIPC(hipMemsetAsync(V.d_counts.p, 0, std::max<size_t>(C, 1) * sizeof(u32), c->stream));     // k_cv_count adds into them, k_cv_table / k_cv_freq consume and clear them
     V.frq_valid = false;
     c->ad_cached_pop = c->ad_host_set_pop = -1;
     c->pop[pop].finalized = false;
@@ -734,7 +763,7 @@ static int finalize_static(gev_ctx* c, int pop)
 {
     PopState& P = c->pop[pop];
     if (P.finalized) return GEV_OK;
-    for (auto& sc : c->sc) sc.presampled = false;          // maps / grids changed: a head start sampled with the old ones is void
+    for (auto& sc : c->sc) { sc.presampled = false; if (sc.fused_ahead) { sc.fused_ahead = false; sc.fa_dropped = true; } }   // maps / grids changed: a head start sampled with the old ones is void
     std::vector<ChrDev> cd(c->nchr);
     for (int k = 0; k < c->nchr; k++) {
         ChrStatic& S = P.cs[k];
@@ -843,7 +872,9 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
 // No host round trip inside a generation: variable-length outputs go to capacity-checked buffers
 // sized from the previous totals; if one was too small the buffers are grown from the exact totals
 // of the count passes and the small work is enqueued again (inputs are untouched until the flip).
-static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n);
+static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready = false);
+static int enqueue_chain_head_start(gev_ctx* c);
+static int check_not_pending(gev_ctx* c);
 static int materialize_order(gev_ctx* c, int pop);
 extern "C" int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people);
 static int wait_planes(gev_ctx* c)
@@ -978,16 +1009,13 @@ static const size_t LIST_HEADROOM = getenv("GEV_LIST_HEADROOM") ? (size_t)atol(g
 static const double LIST_GROW = LIST_HEADROOM ? 1.5 : 1.0; static const size_t LIST_SLACK = LIST_HEADROOM ? 4096 : 16;   // (no headroom: every generation that lengthens the lists is enqueued twice)
 // K4/K6 + grouping: everything of the small work that needs the couples (parents) on top of the sampling results.
 // Every kernel covers ALL active chromosomes in one launch (blockIdx.y = entry of the generation's ChrWork / CvWork table).
-static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, bool has_mut)
+// work tables of the generation (one ChrWork per active chromosome, one CvWork per (phenotype, active chromosome)): list buffers
+// sized, tables uploaded on `st`; the launch shapes the later pieces need are kept in the scratch set
+static int enqueue_tables(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, hipStream_t st)
 {
     PopState& P = c->pop[pop];
-    hipStream_t st = c->stream;
     const int nchr = c->nchr;
-    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
-    SampleDev sd = make_sd(c, sc, T);
-    if (c->sparse_after_stitch && c->planes_pending) HIPC(hipStreamWaitEvent(st, c->ev_planes, 0));
-    HIPC(hipEventRecord(sc.t[5], st));
-    // ---- work tables of this generation
+    const size_t rows = 2 * n_people;
     const int cur = P.cur, alt = P.cur ^ 1;
     const double grow = (double)rows / (double)std::max<size_t>(2 * P.n_people, 1);
     std::vector<ChrWork> cw; std::vector<CvWork> vw;
@@ -1016,57 +1044,100 @@ static int enqueue_sparse(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         cw.push_back(w);
         for (int p = 0; p < c->nphen; p++) {
             CvStatic& V = P.cv[p][k];
-            vw.push_back(CvWork{P.cvp[p][k][alt].as<u32>(), P.cvp[p][k][cur].as<u32>(), V.d_pos_sorted.as<u64>(), V.stride_w32, V.sub_w32, V.C, k});
+            GEVC(V.d_partial.ensure(ceil_div(rows, SMALL_ROWS_PER_BLOCK) * 1024 * sizeof(uint16_t), st));
+            vw.push_back(CvWork{P.cvp[p][k][alt].as<u32>(), P.cvp[p][k][cur].as<u32>(), V.d_pos_sorted.as<u64>(), V.d_counts.as<u32>(), V.d_partial.as<uint16_t>(), S.rbp.front(), S.rbp.back(), V.stride_w32, V.sub_w32, V.C, k, (u32)(cw.size() - 1)});
         }
     }
-    const unsigned na = (unsigned)cw.size();
-    sc.n_chrwork = na;
-    if (na) {
+    sc.n_chrwork = (unsigned)cw.size(); sc.n_cvwork = (unsigned)vw.size();
+    sc.nseg_max = 1; sc.cv_used_max = 0; sc.cv_max = 0;
+    for (const ChrWork& w : cw) sc.nseg_max = std::max<size_t>(sc.nseg_max, w.pw.nseg);
+    const u32 nsub = 1 + c->rp_bits;
+    sc.cv_count_fused = c->cv_count_fused_ok;
+    for (const CvWork& v : vw) { sc.cv_used_max = std::max<size_t>(sc.cv_used_max, (size_t)v.sub_w32 * nsub); sc.cv_count_fused &= v.sub_w32 <= 32; if (v.C <= SMALL_POS_LDS) sc.cv_max = std::max(sc.cv_max, v.C); }   // LDS copy of the CV grid: sized for the launch, not for the worst case (occupancy)
+    const size_t rows_cur = std::max<size_t>(2 * P.n_phys, 1);
+    sc.mut_avg = 0; sc.parts_avg = 0;
+    for (int k = 0; k < nchr; k++) if (c->chr_active[k]) { sc.mut_avg = std::max(sc.mut_avg, P.st[k].mut_total[cur] / rows_cur); sc.parts_avg = std::max(sc.parts_avg, P.st[k].parts_total[cur] / rows_cur); }
+    if (sc.n_chrwork) {
         GEVC(upload_table(c, sc.chrwork, cw.data(), cw.size() * sizeof(ChrWork), st));
         GEVC(upload_table(c, sc.cvwork, vw.data(), vw.size() * sizeof(CvWork), st));
-        const ChrWork* Wt = sc.chrwork.as<ChrWork>(); const CvWork* Vt = sc.cvwork.as<CvWork>();
-        const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
-        // ---- pool rows of the offspring: free rows = rows no parental slot points at; crossover-free gametes share the parent's row
-        if (c->dense) {
-            size_t nseg_max = 1;
-            for (const ChrWork& w : cw) nseg_max = std::max<size_t>(nseg_max, w.pw.nseg);
-            const unsigned pool_blocks = (unsigned)std::min<size_t>(ceil_div(4 * P.cap_people * nseg_max, 256), 1024);
-            hipLaunchKernelGGL(k_pool_mark_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt, 2 * P.n_phys);
-            hipLaunchKernelGGL(k_pool_collect_tab, dim3(pool_blocks, na), dim3(256), 0, st, Wt);
-            hipLaunchKernelGGL(k_pool_assign, dim3((unsigned)ceil_div(rows, 256 * POOL_RPT), na), dim3(256), 0, st, Wt, rows, nchr, sd);
-        }
-        // ---- sparse state: mutation lists + ancestry intervals (count -> segmented scan -> fill), CV planes
-        const unsigned nseg = c->track_intervals ? 2 * na : na;            // segments [0, na): mutation lists, [na, 2 na): interval lists
-        const size_t seg = rows + 1, nb = ceil_div(rows + 1, SCAN_ITEMS);
-        GEVC(c->d_cnt.ensure((size_t)nseg * seg * sizeof(u32), st)); GEVC(c->d_sums.ensure((size_t)nseg * nb * sizeof(u32), st));
-        u32* cnt = c->d_cnt.as<u32>(); u32* sums = c->d_sums.as<u32>();
-        hipLaunchKernelGGL((k_mutlist<false, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, cnt, seg, rows, nchr, (int)has_mut, sd);
-        if (c->track_intervals) hipLaunchKernelGGL((k_parts<false, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, cnt + (size_t)na * seg, seg, rows, nchr, sd);
-        hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb, nseg), dim3(256), 0, st, cnt, rows, sums, seg, nb);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1, nseg), dim3(256), 0, st, sums, nb, nb);
-        hipLaunchKernelGGL(k_scan_final_tab, dim3((unsigned)nb, nseg), dim3(256), 0, st, cnt, rows, seg, sums, nb, Wt, na, sd.status);
-        // fill: one thread per row while the lists are short; once a row inherits LIST_LONG entries or more on average (every
-        // generation adds about one), LIST_LANES lanes per row copy the inherited ranges together (at 100 entries: 2x faster)
-        const size_t rows_cur = std::max<size_t>(2 * P.n_phys, 1);
-        size_t mut_avg = 0, parts_avg = 0;
-        for (int k = 0; k < nchr; k++) if (c->chr_active[k]) { mut_avg = std::max(mut_avg, P.st[k].mut_total[cur] / rows_cur); parts_avg = std::max(parts_avg, P.st[k].parts_total[cur] / rows_cur); }
-        const unsigned fill_blocks = (unsigned)ceil_div(rows * LIST_LANES, 256);
-        if (mut_avg >= c->list_long) hipLaunchKernelGGL((k_mutlist<true, LIST_LANES>), dim3(fill_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, (int)has_mut, sd);
-        else hipLaunchKernelGGL((k_mutlist<true, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, (int)has_mut, sd);
-        if (c->track_intervals) {
-            if (parts_avg >= c->list_long) hipLaunchKernelGGL((k_parts<true, LIST_LANES>), dim3(fill_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, sd);
-            else hipLaunchKernelGGL((k_parts<true, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, sd);
-        }
-        const u32 nsub = 1 + c->rp_bits;
-        size_t max_used = 0;
-        for (const CvWork& v : vw) max_used = std::max<size_t>(max_used, (size_t)v.sub_w32 * nsub);
-        u32 cv_max = 0;
-        for (const CvWork& v : vw) if (v.C <= SMALL_POS_LDS) cv_max = std::max(cv_max, v.C);       // LDS copy of the CV grid: sized for the launch, not for the worst case (occupancy)
-        if (max_used) hipLaunchKernelGGL(k_stitch_small, dim3((unsigned)ceil_div(rows, SMALL_ROWS_PER_BLOCK), (unsigned)vw.size()), dim3(256), (size_t)cv_max * sizeof(u64), st,
-                                         Vt, nsub, rows, nchr, sd, cv_max);
-        KCHECK();
     }
-    HIPC(hipEventRecord(sc.t[2], st));
+    return GEV_OK;
+}
+// free units of the pool = units no (slot, segment) of the parents names: needs the parents' table only, not this generation's
+// sampling or couples
+static int enqueue_pool_free(gev_ctx* c, gev_ctx::Scratch& sc, int pop, hipStream_t st)
+{
+    PopState& P = c->pop[pop];
+    if (!c->dense || !sc.n_chrwork) return GEV_OK;
+    const unsigned pool_blocks = (unsigned)std::min<size_t>(ceil_div(4 * P.cap_people * sc.nseg_max, 256), 1024);
+    hipLaunchKernelGGL(k_pool_mark_tab, dim3(pool_blocks, sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), 2 * P.n_phys);
+    hipLaunchKernelGGL(k_pool_collect_tab, dim3(pool_blocks, sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>());
+    KCHECK();
+    return GEV_OK;
+}
+// units of the offspring rows (segments with a crossover boundary take a free unit and a work-list entry, the others name the
+// parental unit) + the stitch's work-list length and the segment totals of the status block
+static int enqueue_pool_assign(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, hipStream_t st)
+{
+    if (!c->dense || !sc.n_chrwork) return GEV_OK;
+    const size_t rows = 2 * n_people, T = n_people * (size_t)c->nchr;
+    SampleDev sd = make_sd(c, sc, T);
+    hipLaunchKernelGGL(k_pool_assign, dim3((unsigned)ceil_div(rows, 256 * POOL_RPT), sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, c->nchr, sd);
+    hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(64), 0, st, sc.chrwork.as<ChrWork>(), sc.n_chrwork, sd.status);
+    KCHECK();
+    return GEV_OK;
+}
+// sparse state: mutation lists + ancestry intervals (count -> segmented scan -> fill).  Needs the sampling results and the couples;
+// nothing of the generation's dense / CV / A-D work reads its output.
+static int enqueue_lists(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, bool has_mut, hipStream_t st)
+{
+    const unsigned na = sc.n_chrwork;
+    if (!na) return GEV_OK;
+    const int nchr = c->nchr;
+    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
+    SampleDev sd = make_sd(c, sc, T);
+    const ChrWork* Wt = sc.chrwork.as<ChrWork>();
+    const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
+    const unsigned nseg = c->track_intervals ? 2 * na : na;            // segments [0, na): mutation lists, [na, 2 na): interval lists
+    const size_t seg = rows + 1, nb = ceil_div(rows + 1, SCAN_ITEMS);
+    GEVC(c->d_cnt.ensure((size_t)nseg * seg * sizeof(u32), st)); GEVC(c->d_sums.ensure((size_t)nseg * nb * sizeof(u32), st));
+    u32* cnt = c->d_cnt.as<u32>(); u32* sums = c->d_sums.as<u32>();
+    hipLaunchKernelGGL((k_mutlist<false, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, cnt, seg, rows, nchr, (int)has_mut, sd);
+    if (c->track_intervals) hipLaunchKernelGGL((k_parts<false, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, cnt + (size_t)na * seg, seg, rows, nchr, sd);
+    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb, nseg), dim3(256), 0, st, cnt, rows, sums, seg, nb);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1, nseg), dim3(256), 0, st, sums, nb, nb);
+    hipLaunchKernelGGL(k_scan_final_tab, dim3((unsigned)nb, nseg), dim3(256), 0, st, cnt, rows, seg, sums, nb, Wt, na, sd.status);
+    // fill: one thread per row while the lists are short; once a row inherits LIST_LONG entries or more on average (every
+    // generation adds about one), LIST_LANES lanes per row copy the inherited ranges together (at 100 entries: 2x faster)
+    const unsigned fill_blocks = (unsigned)ceil_div(rows * LIST_LANES, 256);
+    if (sc.mut_avg >= c->list_long) hipLaunchKernelGGL((k_mutlist<true, LIST_LANES>), dim3(fill_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, (int)has_mut, sd);
+    else hipLaunchKernelGGL((k_mutlist<true, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, (int)has_mut, sd);
+    if (c->track_intervals) {
+        if (sc.parts_avg >= c->list_long) hipLaunchKernelGGL((k_parts<true, LIST_LANES>), dim3(fill_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, sd);
+        else hipLaunchKernelGGL((k_parts<true, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, sd);
+    }
+    KCHECK();
+    return GEV_OK;
+}
+// CV planes of the offspring: every sub-row (resolved alleles, root-population bits) is inherited by the gamete's crossover
+// pattern; the generation's new mutations that fall on a CV position flip the allele there (k_cv_newmut)
+static int enqueue_cv_planes(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, bool has_mut, bool count_cols, hipStream_t st)
+{
+    if (!sc.n_cvwork || !sc.cv_used_max) return GEV_OK;
+    const int nchr = c->nchr;
+    const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
+    SampleDev sd = make_sd(c, sc, T);
+    const CvWork* Vt = sc.cvwork.as<CvWork>();
+    const dim3 grid((unsigned)ceil_div(rows, SMALL_ROWS_PER_BLOCK), sc.n_cvwork); const size_t lds = (size_t)sc.cv_max * sizeof(u64); const u32 nsub = 1u + c->rp_bits;
+    if (c->cv_threads == 256) hipLaunchKernelGGL((k_stitch_small<256>), grid, dim3(256), lds, st, Vt, nsub, rows, nchr, sd, sc.cv_max, (int)count_cols);
+    else if (c->cv_threads == 1024) hipLaunchKernelGGL((k_stitch_small<1024>), grid, dim3(1024), lds, st, Vt, nsub, rows, nchr, sd, sc.cv_max, (int)count_cols);
+    else hipLaunchKernelGGL((k_stitch_small<512>), grid, dim3(512), lds, st, Vt, nsub, rows, nchr, sd, sc.cv_max, (int)count_cols);
+    if (count_cols) {
+        const unsigned nblk = (unsigned)ceil_div(rows, SMALL_ROWS_PER_BLOCK);
+        hipLaunchKernelGGL(k_cv_sum_partials, dim3(4, std::min(nblk, 32u), sc.n_cvwork), dim3(256), 0, st, Vt, nblk);
+    }
+    if (has_mut) hipLaunchKernelGGL(k_cv_newmut, dim3((unsigned)ceil_div(n_people, 256), sc.n_cvwork), dim3(256), 0, st, Vt, sc.chrwork.as<ChrWork>(), n_people, nchr, sd, (int)count_cols);
+    KCHECK();
     return GEV_OK;
 }
 // Unused dynamic LDS per stitch workgroup that limits the workgroups per CU to `occ` (160 KiB of LDS per CU; the kernels' own
@@ -1113,8 +1184,7 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int /*pop*/, size_t 
     const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
     hipStream_t sb = c->stream_big;
     SampleDev sd = make_sd(c, sc, T);
-    HIPC(hipEventRecord(sc.ev_small_done, c->stream));
-    HIPC(hipStreamWaitEvent(sb, sc.ev_small_done, 0));
+    HIPC(hipStreamWaitEvent(sb, sc.ev_small_done, 0));        // recorded behind k_pool_assign: unit table, work list, sampling results and couples are complete
     HIPC(hipEventRecord(sc.t[4], sb));
     if (c->dense && sc.n_chrwork) {
         if (rows > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
@@ -1186,31 +1256,71 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     gev_ctx::PendingRepro& q = c->pend;
     gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
     PopState& P = c->pop[q.pop];
+    // Streams of one attempt.  S carries the chain the host waits for: seeds, sampling, unit table, CV planes, A/D, results.
+    // X runs what needs neither the sampling nor (for the free list) the couples next to the sampling: Simulation::random_mate and
+    // the free list of the segment pool.  L builds the mutation / interval lists, which nothing else of the generation reads, next
+    // to the CV planes and A/D.  The dense stitch has its own stream as before.  All are joined into S before the status block
+    // leaves.  Serialised mode (kernel timings without interference): everything on S.
+    hipStream_t S = c->stream, X = (c->serialize || !c->side_streams) ? S : c->stream_aux, L = (c->serialize || !c->side_streams) ? S : c->stream_list;
+    const size_t T = q.n_people * (size_t)c->nchr;
     q.th0 = host_ms();
     if (attempt == 0) GEVC(harvest_timing(c, sc));          // kernel times of the set's previous generation, before its events are recorded again
-    if (q.fused) {
-        const size_t T = q.n_people * (size_t)c->nchr;
-        u32* gv = sc.globvals.as<u32>(); u32* status = sc.status.as<u32>();
-        HIPC(hipMemsetAsync(sc.status.p, 0, q.n_status * sizeof(u32), c->stream));
+    u32* gv = sc.globvals.as<u32>(); u32* status = sc.status.as<u32>();
+    const bool sampled = q.pre && attempt == 0;              // seeds drawn and sampling done by a head start
+    if (q.fused && !sampled) {
+        HIPC(hipMemsetAsync(sc.status.p, 0, q.n_status * sizeof(u32), S));
         // glob_generator's draws in the reference's order: random_mate (:2092), reproduce (:2398), then one per (offspring, chromosome) inside ras_add_mutation (:2500)
-        GEVC(enqueue_glob(c, c->stream, q.glob_state, nullptr, 2 + (q.has_mut ? T : 0), gv, status + ST_GLOB_STATE, status + ST_FLAGS));
-        GEVC(enqueue_mate(c, c->stream, P, 0u, gv, q.has_svf ? c->d_svf.as<double>() : nullptr, q.n_people, sc.father.as<u32>(), sc.mother.as<u32>(),
+        GEVC(enqueue_glob(c, S, q.glob_state, nullptr, 2 + (q.has_mut ? T : 0), gv, status + ST_GLOB_STATE, status + ST_FLAGS));
+    }
+    if (q.fused && c->chain_draws >= 0) {                    // where glob_generator will stand when the host comes back for the next generation
+        hipLaunchKernelGGL(k_glob_skip, dim3(1), dim3(64), 0, S, (const u32*)(status + ST_GLOB_STATE), (u32)c->chain_draws, status + ST_NEXT_STATE);
+        KCHECK();
+        HIPC(hipEventRecord(sc.ev_chain, S));
+    }
+    if (X != S) { HIPC(hipEventRecord(sc.ev_fork, S)); HIPC(hipStreamWaitEvent(X, sc.ev_fork, 0)); }
+    // overlap mode 2: only the ALU-bound sampling shares the GPU with the previous generation's stitch; everything latency-bound waits for it
+    if (c->sparse_after_stitch && c->planes_pending) HIPC(hipStreamWaitEvent(X, c->ev_planes, 0));
+    if (q.fused) {
+        GEVC(enqueue_mate(c, X, P, 0u, gv, q.has_svf ? c->d_svf.as<double>() : nullptr, q.n_people, sc.father.as<u32>(), sc.mother.as<u32>(),
                           c->d_couples.as<gev_couple>(), status + ST_NM_MATE, status + ST_FLAGS));
-        GEVC(enqueue_sampling(c, sc, q.pop, q.n_people, q.has_mut, 0u, c->stream, gv + 1, gv + 2, /*clear_status=*/false));
-        HIPC(hipMemcpyAsync(q.hseeds2, gv, 2 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-    } else if (!(q.pre && attempt == 0)) GEVC(enqueue_sampling(c, sc, q.pop, q.n_people, q.has_mut, q.seed, c->stream));
-    // Human::sex of the new generation (:2472) for the next gev_random_mate; a fused generation also sends them to the host with the status block
-    HIPC(hipMemcpyAsync(P.d_sex[P.cur ^ 1].p, sc.sex.p, q.n_people, hipMemcpyDeviceToDevice, c->stream));
-    if (q.fused) HIPC(hipMemcpyAsync(q.hsex, sc.sex.p, q.n_people, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipMemcpyAsync(q.hseeds2, gv, 2 * sizeof(u32), hipMemcpyDeviceToHost, X));
+    }
+    GEVC(enqueue_tables(c, sc, q.pop, q.n_people, S));        // (uploaded on S while X mates)
+    if (X != S) { HIPC(hipEventRecord(sc.ev_tab, S)); HIPC(hipStreamWaitEvent(X, sc.ev_tab, 0)); }
+    GEVC(enqueue_pool_free(c, sc, q.pop, X));
+    if (X != S) HIPC(hipEventRecord(sc.ev_aux, X));
+    if (q.fused && !sampled) GEVC(enqueue_sampling(c, sc, q.pop, q.n_people, q.has_mut, 0u, S, gv + 1, gv + 2, /*clear_status=*/false));
+    else if (!q.fused && !sampled) GEVC(enqueue_sampling(c, sc, q.pop, q.n_people, q.has_mut, q.seed, S));
     q.th1 = host_ms();
-    GEVC(enqueue_sparse(c, sc, q.pop, q.n_people, q.has_mut));
-    // the dense stitch needs the sampling + sparse results only: it starts now, on its own stream, next to A/D (not waited for)
-    GEVC(enqueue_stitch(c, sc, q.pop, q.n_people));
+    if (c->sparse_after_stitch && c->planes_pending && X != S) HIPC(hipStreamWaitEvent(S, c->ev_planes, 0));
+    if (X != S) HIPC(hipStreamWaitEvent(S, sc.ev_aux, 0));
+    HIPC(hipEventRecord(sc.t[5], S));
+    GEVC(enqueue_pool_assign(c, sc, q.n_people, S));
+    // The dense stitch needs the sampling results, the couples and the unit table only.  It saturates HBM, and every latency-bound
+    // kernel that runs next to it takes 2-5 times as long (and slows it down in turn): where it starts is a trade (stitch_start,
+    // measured at config 2: behind the CV planes 711, behind the unit table 691, behind A/D 617 generations/s); whatever the
+    // choice, the NEXT generation's ALU-bound sampling (head start) is what should share the GPU with it.
+    HIPC(hipEventRecord(sc.ev_forked, S));
+    if (c->stitch_start == 0) { HIPC(hipEventRecord(sc.ev_small_done, S)); GEVC(enqueue_stitch(c, sc, q.pop, q.n_people)); }
+    if (L != S) HIPC(hipStreamWaitEvent(L, sc.ev_forked, 0));
+    // Human::sex of the new generation (:2472) for the next gev_random_mate; a fused generation also sends them to the host with the status block
+    HIPC(hipMemcpyAsync(P.d_sex[P.cur ^ 1].p, sc.sex.p, q.n_people, hipMemcpyDeviceToDevice, L));
+    if (q.fused) HIPC(hipMemcpyAsync(q.hsex, sc.sex.p, q.n_people, hipMemcpyDeviceToHost, L));
+    GEVC(enqueue_lists(c, sc, q.n_people, q.has_mut, L));
+    if (L != S) HIPC(hipEventRecord(sc.ev_lists, L));
+    // the column counters are filled while the planes are written only if the A/D kernels that consume (and clear) them follow in this attempt
+    const bool ad_now = c->eager_ad && c->pop[q.pop].cv[0][0].d_aptr.p;
+    const bool count_cols = ad_now && sc.cv_count_fused && sc.n_cvwork && sc.cv_used_max;
+    GEVC(enqueue_cv_planes(c, sc, q.n_people, q.has_mut, count_cols, S));
+    HIPC(hipEventRecord(sc.t[2], S));
+    if (c->stitch_start == 1) { HIPC(hipEventRecord(sc.ev_small_done, S)); GEVC(enqueue_stitch(c, sc, q.pop, q.n_people)); }
     q.th2 = host_ms();
     c->ad_cached_pop = c->ad_host_set_pop = -1;
-    if (c->eager_ad && c->pop[q.pop].cv[0][0].d_aptr.p) GEVC(enqueue_ad(c, q.pop, c->pop[q.pop].cur ^ 1, q.n_people));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
-    HIPC(hipMemcpyAsync(q.hstatus, sc.status.p, q.n_status * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipEventRecord(sc.ev_status, c->stream));          // gev_reproduce_end waits for THIS, not for whatever a head start queued behind it
+    if (ad_now) GEVC(enqueue_ad(c, q.pop, c->pop[q.pop].cur ^ 1, q.n_people, count_cols));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
+    if (L != S) HIPC(hipStreamWaitEvent(S, sc.ev_lists, 0));
+    if (c->stitch_start >= 2) { HIPC(hipEventRecord(sc.ev_small_done, S)); GEVC(enqueue_stitch(c, sc, q.pop, q.n_people)); }
+    HIPC(hipMemcpyAsync(q.hstatus, sc.status.p, q.n_status * sizeof(u32), hipMemcpyDeviceToHost, S));
+    HIPC(hipEventRecord(sc.ev_status, S));                  // gev_reproduce_end waits for THIS, not for whatever a head start queued behind it
     return GEV_OK;
 }
 static int ensure_stage(gev_ctx* c, size_t bytes)
@@ -1270,7 +1380,7 @@ int gev_reproduce_begin(gev_ctx* c, int pop, const gev_couple* couples, size_t n
     // sampling already enqueued by gev_presample for exactly these inputs?
     const bool pre = sc.presampled && sc.ps_pop == pop && sc.ps_seed == (u32)seed_reproduce && sc.ps_n_people == n_people && sc.ps_has_mut == has_mut &&
                      (!has_mut || (c->h_seeds && memcmp(c->h_seeds, mut_seeds, T * sizeof(u32)) == 0));
-    sc.presampled = false; sc.ps_stale = false; sc.mated = false;
+    sc.presampled = false; sc.ps_stale = false; sc.mated = false; sc.fused_ahead = false; sc.fa_dropped = false; c->chain_valid = false;
     if (pre) HIPC(hipStreamWaitEvent(st, sc.ev_sampled, 0));     // the head start ran on its own stream
     else HIPC(hipStreamSynchronize(c->stream_samp));            // a head start that does not match must not write into the set any more
     if (!pre) {
@@ -1290,6 +1400,27 @@ int gev_reproduce_begin(gev_ctx* c, int pop, const gev_couple* couples, size_t n
     q.fused = false; q.has_svf = false;
     GEVC(enqueue_attempt(c, 0));
     q.active = true;
+    return GEV_OK;
+}
+static int enqueue_chain_head_start(gev_ctx* c)
+{
+    gev_ctx::PendingRepro& q = c->pend;
+    gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1]; gev_ctx::Scratch& nx = c->sc[(c->gen_counter + 1) & 1];
+    hipStream_t SS = c->serialize ? c->stream : c->stream_samp;
+    const size_t T = q.n_people * (size_t)c->nchr;
+    // the stitch that last read the other scratch set (the previous generation's) may still be running: the sampling stream waits for
+    // it, the host does not (its kernel time is collected when the set's next generation is enqueued)
+    GEVC(harvest_sampling_time(nx));
+    if (nx.stitch_pending) HIPC(hipStreamWaitEvent(SS, nx.ev_stitch_done, 0));
+    HIPC(hipStreamWaitEvent(SS, sc.ev_chain, 0));
+    GEVC(ensure_scratch(c, nx, q.n_people, q.has_mut));
+    GEVC(nx.globvals.ensure((2 + T) * sizeof(u32), SS));
+    u32* gv = nx.globvals.as<u32>(); u32* status = nx.status.as<u32>();
+    HIPC(hipMemsetAsync(nx.status.p, 0, q.n_status * sizeof(u32), SS));
+    GEVC(enqueue_glob(c, SS, 0u, sc.status.as<u32>() + ST_NEXT_STATE, 2 + (q.has_mut ? T : 0), gv, status + ST_GLOB_STATE, status + ST_FLAGS));
+    GEVC(enqueue_sampling(c, nx, q.pop, q.n_people, q.has_mut, 0u, SS, gv + 1, gv + 2, /*clear_status=*/false));
+    HIPC(hipEventRecord(nx.ev_sampled, SS));
+    nx.fused_ahead = true; nx.fa_dropped = false; nx.fa_pop = q.pop; nx.fa_n = q.n_people; nx.fa_has_mut = q.has_mut;
     return GEV_OK;
 }
 // does every chromosome of the population have a mutation map (Simulation::reproduce's `_mutation_map.size() > 0`, :2459)?
@@ -1325,12 +1456,18 @@ int gev_generation_begin(gev_ctx* c, int pop, uint32_t glob_state, size_t pop_si
     GEVC(ensure_capacity(c, pop, n_people));
     hipStream_t st = c->stream;
     gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
-    if (sc.presampled) HIPC(hipStreamSynchronize(c->stream_samp));     // a head start of the other protocol must not write into the set any more
-    sc.presampled = false; sc.ps_stale = false; sc.mated = false;
-    GEVC(harvest_timing(c, sc));
-    if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); sc.stitch_pending = false; }
-    GEVC(ensure_scratch(c, sc, n_people, has_mut));
-    GEVC(sc.globvals.ensure((2 + T) * sizeof(u32), st));
+    // seeds already drawn and sampling already enqueued for exactly this call (gev_set_generation_chain)?
+    const bool pre = sc.fused_ahead && c->chain_valid && c->chain_state == (u32)glob_state && sc.fa_pop == pop && sc.fa_n == n_people && sc.fa_has_mut == has_mut;
+    if (sc.presampled || sc.fa_dropped || (sc.fused_ahead && !pre)) HIPC(hipStreamSynchronize(c->stream_samp));     // a head start that does not match must not write into the set any more
+    if (sc.fused_ahead) { if (pre) c->chain_hits++; else c->chain_misses++; }
+    sc.presampled = false; sc.ps_stale = false; sc.mated = false; sc.fused_ahead = false; sc.fa_dropped = false; c->chain_valid = false;
+    if (pre) HIPC(hipStreamWaitEvent(st, sc.ev_sampled, 0));           // the head start ran on its own stream
+    else {
+        GEVC(harvest_timing(c, sc));
+        if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); sc.stitch_pending = false; }
+        GEVC(ensure_scratch(c, sc, n_people, has_mut));
+        GEVC(sc.globvals.ensure((2 + T) * sizeof(u32), st));
+    }
     GEVC(c->d_couples.ensure(n_people * sizeof(gev_couple), st));
     if (selection_value_func) {
         GEVC(c->d_svf.ensure(P.n_people * sizeof(double), st));
@@ -1338,10 +1475,23 @@ int gev_generation_begin(gev_ctx* c, int pop, uint32_t glob_state, size_t pop_si
         HIPC(hipStreamSynchronize(st));                          // the caller's array is pageable memory of unknown lifetime
     }
     gev_ctx::PendingRepro& q = c->pend;
-    q.pop = pop; q.n_people = n_people; q.has_mut = has_mut; q.pre = false; q.seed = 0; q.attempt = 0; q.n_status = n_status; q.hstatus = hstatus;
+    q.pop = pop; q.n_people = n_people; q.has_mut = has_mut; q.pre = pre; q.seed = 0; q.attempt = 0; q.n_status = n_status; q.hstatus = hstatus;
     q.fused = true; q.has_svf = selection_value_func != nullptr; q.glob_state = glob_state; q.hseeds2 = hstatus + n_status; q.hsex = (uint8_t*)(hstatus + n_status + 2);
     GEVC(enqueue_attempt(c, 0));
     q.active = true;
+    if (c->chain_draws >= 0) GEVC(enqueue_chain_head_start(c));
+    return GEV_OK;
+}
+// The host announced how many ras_glob_seed() values it draws itself between two generations (gev_set_generation_chain): the state
+// glob_generator will have at the next gev_generation_begin is then known on the device as soon as this generation's seeds are
+// drawn.  Draw the NEXT generation's seeds from it and run its sampling now, on the head-start stream, into the other scratch
+// set: it shares the GPU with this generation's dense stitch (ALU-bound next to HBM-bound) instead of standing in front of the
+// next generation's small work.  The next gev_generation_begin recognises it by the engine state it is handed.
+int gev_set_generation_chain(gev_ctx* c, int draws_between)
+{
+    GEVC(check_not_pending(c));
+    if (draws_between > 1000000) return fail(GEV_EINVAL, "set_generation_chain: %d draws between two generations", draws_between);
+    c->chain_draws = draws_between < 0 ? -1 : draws_between;
     return GEV_OK;
 }
 static int generation_finish(gev_ctx* c, uint8_t* sex_out, gev_generation_result* res, gev_couple* couples_out)
@@ -1375,6 +1525,7 @@ static int generation_finish(gev_ctx* c, uint8_t* sex_out, gev_generation_result
             // inputs, or by the next gev_reproduce_begin)
             gev_ctx::Scratch& nx = c->sc[(c->gen_counter + 1) & 1];
             if (nx.presampled) { nx.presampled = false; nx.ps_stale = true; }
+            if (nx.fused_ahead) { nx.fused_ahead = false; nx.fa_dropped = true; }
         }
         if (flags & FLAG_BK_OVF) c->bk_ovf_cap = std::max<size_t>(2 * c->bk_ovf_cap, (size_t)hstatus[ST_BK_OVF_USED] * 5 / 4 + 1024);
         if (flags & FLAG_NM_OVF) c->nm_ovf_cap = std::max<size_t>(2 * c->nm_ovf_cap, (size_t)hstatus[ST_NM_OVF_USED] * 5 / 4 + 1024);
@@ -1396,6 +1547,7 @@ static int generation_finish(gev_ctx* c, uint8_t* sex_out, gev_generation_result
     for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = ad_done;
     if (ad_done) c->ad_cached_pop = pop;
     if (q.fused) {
+        c->chain_valid = c->chain_draws >= 0; c->chain_state = hstatus[ST_NEXT_STATE];
         if (sex_out) memcpy(sex_out, q.hsex, n_people);
         if (res) {
             res->glob_state = hstatus[ST_GLOB_STATE]; res->seed_mate = q.hseeds2[0]; res->seed_reproduce = q.hseeds2[1]; res->reserved = 0;
@@ -1562,6 +1714,7 @@ int gev_sync(gev_ctx* c)
     if (c->pend.active) return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first");
     HIPC(hipSetDevice(c->device));
     HIPC(hipStreamSynchronize(c->stream)); HIPC(hipStreamSynchronize(c->stream_big)); HIPC(hipStreamSynchronize(c->stream_samp));
+    HIPC(hipStreamSynchronize(c->stream_aux)); HIPC(hipStreamSynchronize(c->stream_list));
     for (auto& sc : c->sc) { GEVC(harvest_timing(c, sc)); sc.stitch_pending = false; }
     c->planes_pending = false;
     if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
@@ -1590,7 +1743,8 @@ int gev_timing_totals(gev_ctx* c, double ms_sum[4], unsigned long long* n_genera
 
 // ---- Simulation::ras_compute_AD -----------------------------------------------------------
 // kernels of ras_compute_AD on buffer set `buf` (current generation, or the one being produced)
-static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
+// counts_ready: the allele counts of the CV columns were accumulated by k_stitch_small while it wrote the planes
+static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready)
 {
     PopState& P = c->pop[pop];
     hipStream_t st = c->stream;
@@ -1606,30 +1760,27 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
     }
     // one table entry per (phenotype, active chromosome); every kernel below covers all of them in one launch
     std::vector<AdWork> aw;
-    size_t cvm_words = 0; u32 c_max = 0, sub_max = 0; bool all_have_cv = true;
+    u32 c_max = 0, sub_max = 0; bool all_have_cv = true;
     for (int p = 0; p < nphen; p++)
         for (int k = 0; k < nchr; k++) {
             if (!c->chr_active[k]) continue;
             CvStatic& V = P.cv[p][k];
-            cvm_words += rows * V.sub_w32; c_max = std::max(c_max, V.C); sub_max = std::max(sub_max, V.sub_w32); all_have_cv &= V.C > 0;
+            c_max = std::max(c_max, V.C); sub_max = std::max(sub_max, V.sub_w32); all_have_cv &= V.C > 0;
         }
-    GEVC(c->d_cvm.ensure(std::max<size_t>(cvm_words * sizeof(u32), 16), st));
     // fast path: one root population and the block's rows fit LDS; else the general per-individual kernel
     const u32 S1 = sub_max | 1u;
     int ipb = 0;
     const size_t ad_tab_lds = AD_CHUNK * 4 + AD_CHUNK * 6 * 8 + 8;          // column + table chunk behind the rows
     if (c->rp_bits == 0 && all_have_cv) { for (int cand : {256, 128, 64}) if ((size_t)2 * cand * S1 * 4 + ad_tab_lds <= 64 * 1024) { ipb = cand; break; } }
-    size_t cvm_off = 0;
     for (int p = 0; p < nphen; p++)
         for (int k = 0; k < nchr; k++) {
             if (!c->chr_active[k]) continue;
-            CvStatic& V = P.cv[p][k]; ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
+            CvStatic& V = P.cv[p][k]; ChrStatic& S = P.cs[k];
             if (ipb) GEVC(V.d_tab.ensure((size_t)V.C * 6 * sizeof(double), st));
             AdWork a{};
-            a.cvp = P.cvp[p][k][buf].as<u32>(); a.moff = cs.moff[buf].as<u32>(); a.mpos = cs.mpos[buf].as<u64>();
+            a.cvp = P.cvp[p][k][buf].as<u32>();
             a.pos_sorted = V.d_pos_sorted.as<u64>(); a.pos_file = V.d_pos_file.as<u64>(); a.col_of_icv = V.d_col_of_icv.as<u32>();
             a.a = V.d_a.as<double>(); a.d = V.d_d.as<double>(); a.aptr = V.d_aptr.as<const double*>(); a.dptr = V.d_dptr.as<const double*>();
-            a.cvm = c->d_cvm.as<u32>() + cvm_off; cvm_off += rows * V.sub_w32;
             a.counts = V.d_counts.as<u32>(); a.frq = V.d_frq.as<double>(); a.tab = V.d_tab.as<double>();
             a.add_out = c->d_addchr.as<double>() + (size_t)k * nphen + p; a.dom_out = c->d_domchr.as<double>() + (size_t)k * nphen + p;
             a.bp0 = S.rbp.front(); a.bp_end = S.rbp.back(); a.vd = V.vd;
@@ -1641,8 +1792,7 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
         GEVC(upload_table(c, c->d_adwork, aw.data(), aw.size() * sizeof(AdWork), st));
         const AdWork* At = c->d_adwork.as<AdWork>();
         const size_t out_stride = (size_t)nchr * nphen;
-        hipLaunchKernelGGL(k_cv_apply_mut_tab, dim3((unsigned)ceil_div(rows, 256), nw), dim3(256), 0, st, At, rows);
-        if (c_max) {
+        if (c_max && !counts_ready) {
             const unsigned gy = (unsigned)std::min<size_t>(std::max<size_t>(rows / 512, 1), 256);
             hipLaunchKernelGGL(k_cv_count, dim3((unsigned)ceil_div(c_max, 256), gy, nw), dim3(256), 0, st, At, rows);
         }
@@ -1669,9 +1819,11 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
     hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_addchr.as<double>(), c->d_add.as<double>(), n, nchr, nphen);
     hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_domchr.as<double>(), c->d_dom.as<double>(), n, nchr, nphen);
     KCHECK();
-    // results to the pinned host cache: [flag | additive | dominance | add_chr | dom_chr]
-    const size_t nd = n * nphen, ndc = n * (size_t)nchr * nphen;
-    const size_t bytes = 16 + (2 * nd + 2 * ndc) * sizeof(double);
+    // results to the pinned host cache: [flag | additive | dominance].  The per-chromosome arrays stay on the device and are
+    // copied when gev_compute_ad is asked for them.  vd == 0 for every phenotype: the reference zeroes d (:2698-2699), every
+    // D-term is (+-0) * ... and the running sums stay +0.0 exactly -- nothing to copy, gev_compute_ad fills zeros.
+    const size_t nd = n * nphen;
+    const size_t bytes = 16 + 2 * nd * sizeof(double);
     if (c->h_ad_bytes < bytes) {
         HIPC(hipDeviceSynchronize());
         if (c->h_ad) (void)hipHostFree(c->h_ad);
@@ -1679,12 +1831,12 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n)
         HIPC(hipHostMalloc(&c->h_ad, bytes * 5 / 4 + 4096, hipHostMallocDefault));
         c->h_ad_bytes = bytes * 5 / 4 + 4096;
     }
+    c->ad_dom_zero = true;
+    for (const AdWork& a : aw) c->ad_dom_zero &= a.vd == 0;
     uint8_t* h = (uint8_t*)c->h_ad;
     HIPC(hipMemcpyAsync(h, c->d_flag.p, 4, hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(h + 16, c->d_add.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPC(hipMemcpyAsync(h + 16 + nd * 8, c->d_dom.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPC(hipMemcpyAsync(h + 16 + 2 * nd * 8, c->d_addchr.p, ndc * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPC(hipMemcpyAsync(h + 16 + (2 * nd + ndc) * 8, c->d_domchr.p, ndc * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!c->ad_dom_zero) HIPC(hipMemcpyAsync(h + 16 + nd * 8, c->d_dom.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
     return GEV_OK;
 }
 int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, double* add_chr, double* dom_chr)
@@ -1707,9 +1859,12 @@ int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, dou
     const size_t nd = n * nphen, ndc = n * (size_t)nchr * nphen;
     const u32 flag = *(const u32*)h;
     if (additive) memcpy(additive, h + 16, nd * sizeof(double));
-    if (dominance) memcpy(dominance, h + 16 + nd * 8, nd * sizeof(double));
-    if (add_chr) memcpy(add_chr, h + 16 + 2 * nd * 8, ndc * sizeof(double));
-    if (dom_chr) memcpy(dom_chr, h + 16 + (2 * nd + ndc) * 8, ndc * sizeof(double));
+    if (dominance) { if (c->ad_dom_zero) memset(dominance, 0, nd * sizeof(double)); else memcpy(dominance, h + 16 + nd * 8, nd * sizeof(double)); }
+    if (add_chr || dom_chr) {                                // (the arrays of the generation's A/D kernels are still in place: any later A/D run resets ad_cached_pop)
+        if (add_chr) HIPC(hipMemcpyAsync(add_chr, c->d_addchr.p, ndc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (dom_chr) HIPC(hipMemcpyAsync(dom_chr, c->d_domchr.p, ndc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
     if (flag != 0xffffffffu) return fail(GEV_ENAN, "Error: A or D is nan for human %u", flag);
     return GEV_OK;
 }
@@ -2585,7 +2740,7 @@ int gev_download_cv(gev_ctx* c, int pop, int phen, int chr, u64* bits, size_t ro
 {
     GEVC(check_idx(c, pop, chr, phen));
     GEVC(check_active(c, chr, "download_cv"));
-    PopState& P = c->pop[pop]; CvStatic& V = P.cv[phen][chr]; ChrState& cs = P.st[chr];
+    PopState& P = c->pop[pop]; CvStatic& V = P.cv[phen][chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_cv: population %d has no current generation", pop);
     GEVC(materialize_order(c, pop));
     if (!bits || row_stride_words * 64 < V.C) return fail(GEV_EINVAL, "download_cv: bad output buffer");
@@ -2594,9 +2749,8 @@ int gev_download_cv(gev_ctx* c, int pop, int phen, int chr, u64* bits, size_t ro
     const size_t rows = 2 * P.n_people;
     GEVC(c->d_cvm.ensure(std::max<size_t>(rows * V.sub_w32 * sizeof(u32), 16), st));
     GEVC(c->d_tmp.ensure(rows * row_stride_words * 8, st));
-    hipLaunchKernelGGL(k_cv_apply_mut, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st,
-                       P.cvp[phen][chr][P.cur].as<u32>(), V.stride_w32, V.sub_w32, c->d_cvm.as<u32>(), rows,
-                       cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), V.d_pos_sorted.as<u64>(), V.C);
+    hipLaunchKernelGGL(k_cv_resolve, dim3((unsigned)ceil_div(rows * V.sub_w32, 256)), dim3(256), 0, st,
+                       P.cvp[phen][chr][P.cur].as<u32>(), V.stride_w32, V.sub_w32, c->d_cvm.as<u32>(), rows);
     HIPC(hipMemsetAsync(c->d_tmp.p, 0, rows * row_stride_words * 8, st));
     if (V.C)
         hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)ceil_div(rows * V.sub_w32, 256)), dim3(256), 0, st,

@@ -88,6 +88,15 @@ __global__ void __launch_bounds__(256) k_glob_emit(u32 state_val, const u32* __r
                    [&](u64 i, u32 ret, u32 x) { vals[i] = ret / GLOB_SCALING + 1u; if (i == n - 1) *state_out = x; });
 }
 
+// glob_generator after n more ras_glob_seed() calls (a handful: the draws the host makes itself between two generations)
+__global__ void __launch_bounds__(64) k_glob_skip(const u32* __restrict__ state_in, u32 n, u32* __restrict__ state_out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    u32 x = *state_in;
+    for (u32 i = 0; i < n; i++) { do x = mulmod31(x, 16807u); while (x - 1u >= GLOB_PAST); }
+    *state_out = x;
+}
+
 // ---- Simulation::random_mate (src/Simulation.cpp:2090-2157) --------------------------------------------------------------------
 // :2109-2118  one uniform_real draw per individual from generator(seed) (drawn whether or not it matters), marriageable when
 // r < selection_value_func; males and females keep their order.  svf == null: every selection_value_func is 1 (selection function

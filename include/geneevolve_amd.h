@@ -214,6 +214,14 @@ typedef struct gev_generation_result {
 } gev_generation_result;
 int gev_generation_begin(gev_ctx*, int pop, uint32_t glob_state, size_t pop_size, const double* selection_value_func);
 int gev_generation_end(gev_ctx*, gev_generation_result* res, gev_couple* couples_out, uint8_t* sex_out);
+/* Head start across generations.  draws_between >= 0: the host promises that glob_generator makes exactly that many ras_glob_seed()
+ * draws of its own (ras_scale_AD_compute_GEF :3078, ras_do_migration :921, ...) between the state gev_generation_end returns and the
+ * state it passes to the next gev_generation_begin.  The state of the next call is then known on the device as soon as this
+ * generation's seeds are drawn: the library draws the next generation's seeds and runs its sampling right away, next to this
+ * generation's dense stitch, and the next gev_generation_begin (same population, same pop_size) only adds what depends on the
+ * couples.  A call that arrives with another state, population or size samples again: results never depend on the promise.
+ * draws_between < 0 (default): no head start. */
+int gev_set_generation_chain(gev_ctx*, int draws_between);
 /* ---- Simulation::ras_compute_AD + ras_find_cv (src/Simulation.cpp:2624-2815) --------------
  * additive/dominance : [n_people * nphen], index ih*nphen + iphen  (Human::additive/dominance, raw)
  * add_chr/dom_chr    : [n_people * nchr * nphen], index (ih*nchr + ichr)*nphen + iphen, or NULL
