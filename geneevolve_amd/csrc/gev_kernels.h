@@ -78,10 +78,23 @@ struct SampleDev {
 // generation names (free list, rebuilt from the parents' table at the start of every generation: mark, collect) -- and are
 // written by the dense stitch.  Units are written once and never modified (mutations are a sparse overlay of the slot).
 // Physical placement is arbitrary (atomics) and invisible: every consumer goes through the table (RowMap).
+// One entry of the dense stitch's work list = one segment of one offspring row that contains a crossover boundary, complete: the
+// stitch wave starts from ONE 32-byte uniform load (the first form read five dependent descriptor words per item).
+struct __attribute__((aligned(32))) StitchItem {
+    u32 src0, src1, dst;      // units of the parent's two haplotypes in this segment, unit to write
+    u32 meta;                 // bit 0: haplotype copied at the segment's first locus; bits 1-3: boundaries inside (0..STITCH_ITEM_B), 7 = more: b[0] = output row, the gamete's list is read; bits 8-15: segment
+    u32 b[4];                 // the boundaries inside, as bit offsets from the segment's first locus, ascending
+};
+#define STITCH_ITEM_B 4
 struct PoolWork {
     uint8_t* pool; const u32* phys_cur; u32* phys_alt;      // units; (slot, segment) -> unit of the parents / of the offspring
-    u32* live; u32* freel; u32* pctr;                       // [pool_units] marks, [pool_units] free units, {n_free, n_taken, exhausted, last segments taken}
-    u32* items;                                             // [n_taken] (slot * nseg + segment) of every unit handed out = the stitch's work list; items[items_cap] = n_taken
+    u32* live; u32* freel;                                  // [pool_units] marks, [pool_units] free units
+    // pctr: {0: length of the free list, 1: cursor = units taken from it since it was built, 2: (pool_take) exhausted, 3: last segments
+    // taken this generation, 4: cursor at the start of this generation}.  The free list is NOT rebuilt every generation: units
+    // that no table named when it was built and that were not handed out since are still unnamed, so the list stays valid and
+    // only shrinks; the host rebuilds it (mark + collect) when it runs low.
+    u32* pctr;
+    StitchItem* items;                                      // work list of the generation; ((u32*)&items[items_cap])[0] = its length
     u32 pool_units, alias, stamp, nseg, seg_shift, items_cap;
 };
 // read access to the rows of one generation
@@ -128,8 +141,8 @@ struct AdWork {
 enum { ST_BK_OVF_USED = 0, ST_NM_OVF_USED = 1, ST_FLAGS = 2, ST_SLOW_MUT = 3, ST_SLOW_REC = 4 /* tasks handed to the one-task-per-wave kernels */,
        ST_GLOB_STATE = 5 /* glob_generator behind the generation's ras_glob_seed() draws (gev_generation_begin) */, ST_NM_MATE = 6, ST_NF_MATE = 7 /* num_males_mate, num_females_mate */,
        ST_NEXT_STATE = 8 /* ... and behind the draws the host announced it makes before the next generation (gev_set_generation_chain) */,
-       ST_TOTALS = 16 /* then per chr: mut_total, parts_total, segments the dense stitch writes, how many of them are last (partial) segments */ };
-#define ST_PER_CHR 4
+       ST_TOTALS = 16 /* then per chr: mut_total, parts_total, segments the dense stitch writes, how many of them are last (partial) segments, free list length, free list cursor */ };
+#define ST_PER_CHR 6
 enum { FLAG_BK_OVF = 1, FLAG_NM_OVF = 2, FLAG_MUT_CAP = 4, FLAG_PARTS_CAP = 8, FLAG_POOL = 16,
        FLAG_RNG_SHORT = 32 /* a rejection stream ran out of candidates (internal) */, FLAG_NO_MATES = 64 /* "No one can marry", src/Simulation.cpp:2125 */ };
 #define FLAG_REDO_MASK (FLAG_BK_OVF | FLAG_NM_OVF | FLAG_MUT_CAP | FLAG_PARTS_CAP)      // capacities the host grows before it enqueues the generation again
@@ -525,7 +538,7 @@ __device__ __forceinline__ v4u blend_chunk(v4u a, v4u b, u32 sel, const u32* in,
 __device__ __forceinline__ void pool_mark(const PoolWork& pw, size_t n_entries)
 {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += (size_t)gridDim.x * blockDim.x) pw.live[pw.phys_cur[e]] = pw.stamp;
-    if (blockIdx.x == 0 && threadIdx.x < 4) pw.pctr[threadIdx.x] = 0;        // n_free, n_taken, exhausted flag, last segments taken
+    if (blockIdx.x == 0 && threadIdx.x < 8) pw.pctr[threadIdx.x] = 0;        // a new free list: length, cursor, ... (PoolWork)
 }
 // one atomic per 2048 units: the block counts its free units (8 per thread, coalesced), scans the counts, reserves a range
 __device__ __forceinline__ void pool_collect(const PoolWork& pw)
@@ -569,9 +582,11 @@ __global__ void __launch_bounds__(256) k_iota_u32(u32* __restrict__ a, size_t n)
     if (i < n) a[i] = (u32)i;
 }
 // Units of the offspring generation.  Per output row (thread): which segments contain one of the gamete's boundaries (bk_idx =
-// first locus index at or behind the breakpoint; its 16-byte chunk decides the segment)?  Those get a free unit and an entry
-// in the stitch's work list; every other segment names the unit of the parental haplotype that is being copied there:
-// start ^ parity(#boundaries at or before the segment's first locus).  One atomic per block of 256 rows.
+// first locus index at or behind the breakpoint; its 16-byte chunk decides the segment)?  Those get a unit from the free list and
+// a COMPLETE entry in the stitch's work list (StitchItem); every other segment names the unit of the parental haplotype that is
+// being copied there: start ^ parity(#boundaries at or before the segment's first locus).  One atomic per block of 1024 rows.
+// (A wave-per-row form -- lane = segment, coalesced table rows -- was measured at 333 us against 80 us for this one at 16
+// segments per row: a quarter of the lanes busy and two passes of dependent descriptor loads per row.)
 #define POOL_SEG_MAX 64          // segments per row handled with a 64-bit flag word (8 KiB segments: rows up to 512 KiB = 4M loci); longer rows use larger segments
 #define POOL_RPT 4               // offspring rows per thread of k_pool_assign: one atomic per block of 1024 rows
 __global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd)
@@ -600,7 +615,7 @@ __global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(&pw.pctr[1], tot) : 0u;
     __syncthreads();
     u32 at = s_base + ex, n_last = 0;
-    const u32 n_free = pw.pctr[0];
+    const u32 n_free = pw.pctr[0], gen_start = pw.pctr[4];
 #pragma unroll
     for (int j = 0; j < POOL_RPT; j++) {
         const size_t row = row0 + (size_t)j * 256;
@@ -617,8 +632,23 @@ __global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__
             const u32 bit0 = (g << sh) << 7;
             while (m < k && idx[m] <= bit0) { m++; cnt++; }
             if ((flags[j] >> g) & 1ull) {
-                if (at < n_free) { out[g] = pw.freel[at]; if (at < pw.items_cap) pw.items[at] = (u32)(row * S + g); }
-                else { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_POOL); out[g] = n_free ? pw.freel[at % n_free] : 0u; }   // reported by the host; keeps the stitch in bounds
+                u32 unit;
+                if (at < n_free) unit = pw.freel[at];
+                else { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_POOL); unit = n_free ? pw.freel[at % n_free] : 0u; }   // the free list ran out: the host rebuilds it and enqueues the generation again
+                out[g] = unit;
+                const u32 item = at - gen_start;
+                if (item < pw.items_cap) {
+                    // the boundaries inside the segment: behind its first locus (one exactly on it is part of cnt), in its chunks
+                    u32 b[STITCH_ITEM_B] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, nin = 0;
+                    for (u32 mm = m; mm < k && ((idx[mm] >> 7) >> sh) == g; mm++, nin++) {
+                        const u32 r = idx[mm] - bit0;
+                        if (nin == 0) b[0] = r; else if (nin == 1) b[1] = r; else if (nin == 2) b[2] = r; else if (nin == 3) b[3] = r;
+                    }
+                    const u32 meta = ((start ^ cnt) & 1u) | ((nin <= STITCH_ITEM_B ? nin : 7u) << 1) | (g << 8);
+                    uint4* o = (uint4*)&pw.items[item];
+                    o[0] = make_uint4(p0[g], p0[S + g], unit, meta);
+                    o[1] = make_uint4(nin <= STITCH_ITEM_B ? b[0] : (u32)row, b[1], b[2], b[3]);
+                }
                 n_last += (g == S - 1);
                 at++;
             } else out[g] = p0[((start ^ cnt) & 1u) * S + g];
@@ -628,14 +658,19 @@ __global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__
     __syncthreads();
     if (threadIdx.x == 0 && s_last) atomicAdd(&pw.pctr[3], s_last);
 }
-// behind k_pool_assign: the length of the stitch's work list and the segment totals of the status block, per work entry
+// behind k_pool_assign: the length of the stitch's work list and the segment totals of the status block, per work entry; the
+// counters of the next generation start here
 __global__ void __launch_bounds__(64) k_pool_publish(const ChrWork* __restrict__ Wt, u32 n_work, u32* __restrict__ status)
 {
     for (u32 y = threadIdx.x; y < n_work; y += 64) {
-        const ChrWork& w = Wt[y];
-        status[ST_TOTALS + ST_PER_CHR * w.chr + 2] = w.pw.pctr[1];                          // segments the dense stitch writes
-        status[ST_TOTALS + ST_PER_CHR * w.chr + 3] = w.pw.pctr[3];                          // ... of which last (partial) segments
-        w.pw.items[w.pw.items_cap] = (status[ST_FLAGS] & FLAG_POOL) ? 0u : min(w.pw.pctr[1], w.pw.items_cap);   // length of the work list (pool exhausted: the stitch does nothing, the host reports)
+        const ChrWork& w = Wt[y]; u32* pctr = w.pw.pctr;
+        const u32 n = pctr[1] - pctr[4];
+        u32* st = status + ST_TOTALS + ST_PER_CHR * w.chr;
+        st[2] = n;                                                                          // segments the dense stitch writes
+        st[3] = pctr[3];                                                                    // ... of which last (partial) segments
+        st[4] = pctr[0]; st[5] = pctr[1];                                                   // free list: length, cursor
+        ((u32*)&w.pw.items[w.pw.items_cap])[0] = (status[ST_FLAGS] & FLAG_POOL) ? 0u : min(n, w.pw.items_cap);   // length of the work list (free list ran out: the stitch does nothing, the host rebuilds and repeats)
+        pctr[4] = pctr[1]; pctr[3] = 0;
     }
 }
 // breakpoint (base pairs) -> first locus index >= it, for every gamete of every chromosome: one fully parallel pass,
@@ -648,43 +683,29 @@ __global__ void __launch_bounds__(256) k_bk_to_idx(const ChrDev* __restrict__ ch
     const u32 k = sd.k[G], off = sd.bk_off[G];
     for (u32 m = 0; m < k; m++) sd.bk_idx[off + m] = lower_bound_u64(C.snp_pos, C.L, sd.bk[off + m]);
 }
-// K5, production form: one WAVE per entry of the work list k_pool_assign wrote (one written segment of one gamete), persistent
-// grid.  The entry's descriptors (gamete, parent, the boundaries inside the segment -- usually one) are wave-uniform: the wave
-// index is made scalar so they come through the scalar cache, and up to eight inside boundaries sit in registers.  A chunk
-// before / behind / between them is a plain 16-byte copy from ONE parental unit, the chunk that contains one is blended by mask;
-// U chunks per lane in flight (2: 2 KiB per wave and step -- with 4 or 8 the kernel needs more registers, fewer waves fit and the
-// launch gets slower: 0.64 / 0.69 ms against 0.60 ms at config 2).  Thousands of entries are in flight per chip, which is what
-// hides the five dependent descriptor loads in front of every 8 KiB copy.
-#define SEG_KREG 8           // boundaries of one gamete inside one segment held in registers; more are read from global memory
+// K5, production form: one WAVE per entry of the work list k_pool_assign wrote (one written segment of one gamete).  The entry is
+// complete -- the two parental units, the unit to write, the haplotype copied at the segment's first locus and the (usually one)
+// boundaries inside -- so a wave starts streaming after ONE uniform 32-byte load.  A chunk before / behind / between the
+// boundaries is a plain 16-byte copy from ONE parental unit, the chunk that contains one is blended by mask; U chunks per lane in
+// flight.  Grid: sized by the host from the previous generation's list length, the loop covers whatever the list holds.
 template <bool NT, int U = 2>
 __global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restrict__ Wt, int nchr, SampleDev sd)
 {
     const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
-    const u32 S = pw.nseg, sh = pw.seg_shift, SC = 1u << sh;
-    const u32 n_items = pw.items[pw.items_cap];
+    const u32 sh = pw.seg_shift, SC = 1u << sh;
+    const u32 n_items = ((const u32*)&pw.items[pw.items_cap])[0];
     const u32 lane = threadIdx.x & 63u;
     const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
     for (u32 it = wave0; it < n_items; it += gridDim.x * 4u) {
-        const u32 e = pw.items[it];
-        const u32 row = e / S, g = e - row * S;
-        const u32 i = row >> 1, s = row & 1u;
-        const size_t G = 2 * ((size_t)i * nchr + w.chr) + s;
-        const u32 parent = s ? sd.mother[i] : sd.father[i];
-        const u32 start = sd.start[G], k = sd.k[G];
-        const u32* __restrict__ idx = sd.bk_idx + sd.bk_off[G];
+        const uint4* dp = (const uint4*)&pw.items[it];
+        const uint4 d0 = dp[0], d1 = dp[1];
+        const u32 g = (d0.w >> 8) & 0xffu, code = (d0.w >> 1) & 7u, sel0 = d0.w & 1u;
         const u32 q0 = g << sh, nq = min(SC, w.chunks - q0);
-        const u32 bit_lo = q0 << 7, bit_hi = (q0 + nq) << 7;
-        const u32 m0 = count_le_u32(idx, k, bit_lo);        // boundaries at or before the segment's first locus
-        const u32 m1 = count_le_u32(idx, k, bit_hi - 1u);
-        const u32 nin = m1 - m0;                            // boundaries inside
-        const v4u* __restrict__ R0 = (const v4u*)(pw.pool + ((size_t)pw.phys_cur[(2 * (size_t)parent) * S + g] << (sh + 4)));
-        const v4u* __restrict__ R1 = (const v4u*)(pw.pool + ((size_t)pw.phys_cur[(2 * (size_t)parent + 1) * S + g] << (sh + 4)));
-        v4u* __restrict__ D = (v4u*)(pw.pool + ((size_t)pw.phys_alt[(size_t)row * S + g] << (sh + 4)));
-        const u32 sel0 = (start ^ m0) & 1u;
-        if (nin <= SEG_KREG) {
-            u32 in[SEG_KREG];
-#pragma unroll
-            for (int m = 0; m < SEG_KREG; m++) in[m] = (u32)m < nin ? idx[m0 + m] : 0xffffffffu;
+        const v4u* __restrict__ R0 = (const v4u*)(pw.pool + ((size_t)d0.x << (sh + 4)));
+        const v4u* __restrict__ R1 = (const v4u*)(pw.pool + ((size_t)d0.y << (sh + 4)));
+        v4u* __restrict__ D = (v4u*)(pw.pool + ((size_t)d0.z << (sh + 4)));
+        if (code <= STITCH_ITEM_B) {
+            const u32 in[STITCH_ITEM_B] = {d1.x, d1.y, d1.z, d1.w};          // bit offsets inside the segment; 0xffffffff = none
             for (u32 q = lane; q < nq; q += 64 * U) {
                 v4u a[U], b[U]; u32 c[U]; bool mixed[U];
 #pragma unroll
@@ -692,10 +713,10 @@ __global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restri
                     const u32 qq = q + u * 64;
                     c[u] = 0; mixed[u] = false;
                     if (qq >= nq) continue;
-                    const u32 bit0 = bit_lo + (qq << 7);
+                    const u32 bit0 = qq << 7;
                     u32 cc = 0; bool mx = false;
 #pragma unroll
-                    for (int m = 0; m < SEG_KREG; m++) { cc += (in[m] <= bit0); mx |= (in[m] > bit0 && in[m] < bit0 + 128u); }
+                    for (int m = 0; m < STITCH_ITEM_B; m++) { cc += (in[m] <= bit0); mx |= (in[m] > bit0 && in[m] < bit0 + 128u); }
                     c[u] = cc; mixed[u] = mx;
                     const u32 sel = (sel0 ^ cc) & 1u;
                     if (mx || sel == 0u) a[u] = NT ? __builtin_nontemporal_load(&R0[qq]) : R0[qq];
@@ -709,17 +730,24 @@ __global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restri
                     v4u o;
                     if (!mixed[u]) o = sel ? b[u] : a[u];
                     else {
-                        const u32 bit0 = bit_lo + (qq << 7);
+                        const u32 bit0 = qq << 7;
                         v4u mask = sel ? (v4u)(0xffffffffu) : (v4u)(0u);       // 1 = take row 1
 #pragma unroll
-                        for (int m = 0; m < SEG_KREG; m++) if (in[m] > bit0 && in[m] < bit0 + 128u) mask ^= mask_from(in[m] - bit0);
+                        for (int m = 0; m < STITCH_ITEM_B; m++) if (in[m] > bit0 && in[m] < bit0 + 128u) mask ^= mask_from(in[m] - bit0);
                         o = (a[u] & ~mask) | (b[u] & mask);
                     }
                     if (NT) __builtin_nontemporal_store(o, &D[qq]); else D[qq] = o;
                 }
             }
         } else {
-            const u32* in = idx + m0;                       // many boundaries in one segment (hot maps): bisection on the global list
+            // many boundaries in one segment (hot maps): the gamete's own list, bisection per chunk
+            const u32 row = d1.x, i = row >> 1, s = row & 1u;
+            const size_t G = 2 * ((size_t)i * nchr + w.chr) + s;
+            const u32 k = sd.k[G];
+            const u32* __restrict__ idx = sd.bk_idx + sd.bk_off[G];
+            const u32 bit_lo = q0 << 7, bit_hi = (q0 + nq) << 7;
+            const u32 m0 = count_le_u32(idx, k, bit_lo), m1 = count_le_u32(idx, k, bit_hi - 1u);
+            const u32* in = idx + m0; const u32 nin = m1 - m0;
             for (u32 qq = lane; qq < nq; qq += 64) {
                 const u32 bit0 = bit_lo + (qq << 7);
                 const u32 c = count_le_u32(in, nin, bit0);

@@ -145,6 +145,10 @@ struct ChrState {
     // phys[pcur][s] (gev_kernels.h, PoolWork).  phys has THREE buffers: the stitch of generation g (stream_big) still reads
     // phys of g-1 and g while the small work of g+1 writes the next one.
     DevBuf pool, phys[3], live, freel, pctr, items[2]; u32 pool_stamp = 0;
+    // the free list of the pool is rebuilt (mark + collect) only when it runs low: valid = built for the current table lineage,
+    // n_free / cursor = its length and how much of it has been handed out (from the last generation's status block)
+    bool pool_list_valid = false, pool_force_rebuild = false; u32 pool_n_free = 0, pool_cursor = 0, pool_last_taken = 0;
+    unsigned long long pool_rebuilds = 0;
     DevBuf moff[2], mpos[2], poff[2], parts[2];
     size_t mut_total[2] = {0, 0}, parts_total[2] = {0, 0};   // list sizes of the two buffers (known to the host after each generation)
     size_t mut_need = 0, parts_need = 0;                     // exact capacity demand after an overflowed attempt
@@ -217,6 +221,7 @@ struct gev_ctx {
     bool ad_dom_zero = false;                                // the cached generation's dominance values are +0.0 exactly (vd == 0 everywhere): not copied
     int stitch_start = 1;          // when the dense stitch of a generation may start: 0 behind the unit table, 1 behind the CV planes (default: measured best), 2 behind the whole small work incl. A/D (GEV_STITCH_START)
     unsigned cv_threads = 512; bool cv_count_fused_ok = true;   // k_stitch_small: threads per block (GEV_CV_THREADS=256|512|1024), column counts in the same pass (GEV_CV_COUNT_FUSED=0: separate k_cv_count)
+    int stitch_u = 2;              // 16-byte chunks per lane in flight in the segment stitch (GEV_STITCH_U=1|2|4)
     bool side_streams = true;      // mate + free list next to the sampling, lists next to CV planes + A/D (GEV_SIDE_STREAMS=0: one stream)
     int stitch_mode = 0;           // 0 = work-list form (production, k_stitch_segments), 1 = gamete-major (k_stitch_rows)
     bool sample_batched = true;               // K1-K3 as eight tasks per wave (gev_sample8.h); GEV_SAMPLE_BATCHED=0: one task per wave
@@ -228,7 +233,7 @@ struct gev_ctx {
     int overlap_mode = 1;          // 1 everything (default), 0 never, 2 sampling only, -1 decide after two serialised generations
     bool sparse_after_stitch = false;   // mode 2: the memory-bound sparse/CV/A-D kernels wait for the running stitch, only the ALU-bound sampling shares the GPU with it
     int auto_gens = 0; double auto_small_ms = 0, auto_stitch_ms = 0;
-    size_t stitch_grid = 16384;    // persistent workgroups of the segment stitch per chromosome (GEV_STITCH_GRID)
+    size_t stitch_grid = 65536;    // most workgroups (4 waves = 4 work-list entries each) of the segment stitch per chromosome (GEV_STITCH_GRID)
     int stitch_wave_prio = 0;      // s_setprio level of the stitch kernel's waves (GEV_STITCH_WAVE_PRIO)
     size_t list_long = LIST_LONG;  // average list entries per row from which the list fill kernels use LIST_LANES lanes per row (GEV_LIST_LONG)
     u32 seg_shift = 9;             // log2(16-byte chunks per row segment): 8 KiB -- sweep at config 2 / the config-4 shard: 256 chunks 370 / 72, 512: 457 / 72, 1024: 450 / 58,
@@ -243,7 +248,7 @@ struct gev_ctx {
     // =auto measures it (a few generations per candidate, wall time between consecutive gev_reproduce returns).
     int stitch_occ = 0 /* 0 = by row length */, stitch_occ_env = 0; bool stitch_occ_auto = false;
     struct PendingRepro { bool active = false, has_mut = false, pre = false; int pop = 0, attempt = 0; size_t n_people = 0, n_status = 0; u32 seed = 0; u32* hstatus = nullptr; double th0 = 0, th1 = 0, th2 = 0;
-                          bool fused = false /* gev_generation_begin: seeds and couples are made on the device */, has_svf = false; u32 glob_state = 0; u32* hseeds2 = nullptr; uint8_t* hsex = nullptr; } pend;
+                          bool fused = false /* gev_generation_begin: seeds and couples are made on the device */, has_svf = false, pool_rebuilt = false; u32 glob_state = 0; u32* hseeds2 = nullptr; uint8_t* hsex = nullptr; } pend;
     struct OccTune { int phase = 0 /* 0 idle, 1 measuring, 2 settled */, idx = 0, n = 0, best_occ = 8; double last = 0, cur_min = 0, best = 0; size_t people = 0; unsigned age = 0; } tune;
     DevBuf d_snpmajor, d_text;
     DevBuf d_mflag, d_mblk, d_posm, d_posf, d_pickblk, d_couples, d_svf, d_logical, d_globblk, d_mstat;   // gev_random_mate / gev_glob_seeds scratch
@@ -417,6 +422,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     if (const char* e = getenv("GEV_STITCH_WAVE_PRIO")) c->stitch_wave_prio = std::max(0, std::min(atoi(e), 3));
     if (const char* e = getenv("GEV_STITCH_START")) c->stitch_start = std::max(0, std::min(atoi(e), 2));
     if (const char* e = getenv("GEV_SIDE_STREAMS")) c->side_streams = atoi(e) != 0;
+    if (const char* e = getenv("GEV_STITCH_U")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) c->stitch_u = v; }
     if (const char* e = getenv("GEV_CV_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) c->cv_threads = (unsigned)v; }
     if (const char* e = getenv("GEV_CV_COUNT_FUSED")) c->cv_count_fused_ok = atoi(e) != 0;
     if (const char* e = getenv("GEV_OVF_CAP")) { const long v = atol(e); if (v >= 1) c->bk_ovf_cap = c->nm_ovf_cap = (size_t)v; }
@@ -557,7 +563,7 @@ static PoolWork pool_work(const gev_ctx* c, PopState& P, int chr, int alt)
     pw.live = cs.live.as<u32>(); pw.freel = cs.freel.as<u32>(); pw.pctr = cs.pctr.as<u32>();
     pw.nseg = S.nseg; pw.seg_shift = S.seg_shift;
     pw.pool_units = (u32)(4 * P.cap_people * S.nseg); pw.alias = c->alias_rows ? 1u : 0u;
-    pw.items = cs.items[P.cur ^ 1].as<u32>(); pw.items_cap = (u32)(2 * P.cap_people * S.nseg);
+    pw.items = cs.items[P.cur ^ 1].as<StitchItem>(); pw.items_cap = (u32)(2 * P.cap_people * S.nseg);
     if (++cs.pool_stamp == 0) cs.pool_stamp = 1;          // (a stale mark of 2^32 rebuilds ago could only keep a free row out of one free list)
     pw.stamp = cs.pool_stamp;
     return pw;
@@ -613,10 +619,11 @@ static int ensure_capacity(gev_ctx* c, int pop, size_t people)
             const size_t units = rows * P.cs[k].nseg;                                          // per generation
             GEVC(cs.pool.ensure(2 * units * P.cs[k].unit_bytes(), c->stream, /*keep=*/true));   // unit numbers stay valid: the pool grows at its end
             for (int b = 0; b < 3; b++) GEVC(cs.phys[b].ensure(units * sizeof(u32), c->stream, b == P.pcur));
-            for (int b = 0; b < 2; b++) GEVC(cs.items[b].ensure((units + 1) * sizeof(u32), c->stream));
+            for (int b = 0; b < 2; b++) GEVC(cs.items[b].ensure((units + 1) * sizeof(StitchItem), c->stream));
             GEVC(cs.live.ensure(2 * units * sizeof(u32), c->stream)); GEVC(cs.freel.ensure(2 * units * sizeof(u32), c->stream));
             HIPC(hipMemsetAsync(cs.live.p, 0, cs.live.bytes, c->stream)); cs.pool_stamp = 0;   // marks are generation stamps: start from a clean buffer
-            GEVC(cs.pctr.ensure(4 * sizeof(u32), c->stream));
+            GEVC(cs.pctr.ensure(8 * sizeof(u32), c->stream));
+            cs.pool_list_valid = false;                                                         // the pool grew: its new units are in no free list yet
         }
         for (int b = 0; b < 2; b++) {
             GEVC(P.st[k].moff[b].ensure((rows + 1) * sizeof(u32), c->stream, b == P.cur));
@@ -855,7 +862,7 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     KCHECK();
     if (sex_out) HIPC(hipMemcpyAsync(sex_out, P.d_sex[P.cur].p, n_people, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = c->chr_active[k] ? rows : 0; }
+    for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = c->chr_active[k] ? rows : 0; P.st[k].pool_list_valid = false; }
     c->ad_cached_pop = c->ad_host_set_pop = -1;
     P.n_people = n_people; P.n_phys = n_people; P.logical.clear(); P.gen0 = true;
     return GEV_OK;
@@ -1065,14 +1072,29 @@ static int enqueue_tables(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
 }
 // free units of the pool = units no (slot, segment) of the parents names: needs the parents' table only, not this generation's
 // sampling or couples
-static int enqueue_pool_free(gev_ctx* c, gev_ctx::Scratch& sc, int pop, hipStream_t st)
+// The list is kept across generations (units nobody named when it was built and that were not handed out since are still
+// unnamed) and rebuilt only when what is left of it may not cover the generation: four times what the last generation took, at
+// least a quarter of a generation's segments.  Should a generation need more than is left (k_pool_assign raises FLAG_POOL), it is
+// enqueued again behind a rebuild.  GEV_POOL_REBUILD=1: every generation (the round-2 behaviour).
+static int enqueue_pool_free(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, hipStream_t st)
 {
     PopState& P = c->pop[pop];
     if (!c->dense || !sc.n_chrwork) return GEV_OK;
+    static const bool always = getenv("GEV_POOL_REBUILD") && atoi(getenv("GEV_POOL_REBUILD")) != 0;
+    bool rebuild = always;
+    for (int k = 0; k < c->nchr; k++) {
+        if (!c->chr_active[k]) continue;
+        ChrState& cs = P.st[k];
+        const size_t left = cs.pool_n_free - std::min(cs.pool_cursor, cs.pool_n_free), gen_segs = 2 * n_people * P.cs[k].nseg;
+        const size_t need = c->alias_rows ? std::max<size_t>(4 * (size_t)cs.pool_last_taken, gen_segs / 4) : gen_segs;
+        rebuild |= !cs.pool_list_valid || cs.pool_force_rebuild || left < need;
+    }
+    if (!rebuild) return GEV_OK;
     const unsigned pool_blocks = (unsigned)std::min<size_t>(ceil_div(4 * P.cap_people * sc.nseg_max, 256), 1024);
     hipLaunchKernelGGL(k_pool_mark_tab, dim3(pool_blocks, sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), 2 * P.n_phys);
     hipLaunchKernelGGL(k_pool_collect_tab, dim3(pool_blocks, sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>());
     KCHECK();
+    for (int k = 0; k < c->nchr; k++) if (c->chr_active[k]) { P.st[k].pool_list_valid = true; P.st[k].pool_force_rebuild = false; P.st[k].pool_rebuilds++; }
     return GEV_OK;
 }
 // units of the offspring rows (segments with a crossover boundary take a free unit and a work-list entry, the others name the
@@ -1178,7 +1200,7 @@ static void occ_tune_step(gev_ctx* c, size_t n_people)
     if (g_trace_host) fprintf(stderr, "[gev] stitch workgroups per CU: %d (best interval %.3f ms)\n", t.best_occ, t.best);
 }
 // the HBM-bound part, on stream_big, after the small work of the same generation: ONE launch over (parent, chromosome)
-static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int /*pop*/, size_t n_people)
+static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people)
 {
     const int nchr = c->nchr;
     const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
@@ -1190,8 +1212,14 @@ static int enqueue_stitch(gev_ctx* c, gev_ctx::Scratch& sc, int /*pop*/, size_t 
         if (rows > 0x7fffffffull) return fail(GEV_EINVAL, "reproduce: stitch grid too large");
         if (c->stitch_mode == 0) {
             // persistent grid over the work list (its length is known to the device only): enough workgroups to fill every CU
-            const unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(rows, 1), c->stitch_grid);
-            hipLaunchKernelGGL((k_stitch_segments<true>), dim3(nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : 8), sb, sc.chrwork.as<ChrWork>(), nchr, sd);
+            // one wave per entry when the list is as long as the last one; the kernel loops if it is longer
+            size_t est = 0;
+            for (int k = 0; k < nchr; k++) if (c->chr_active[k]) est = std::max<size_t>(est, c->pop[pop].st[k].pool_last_taken);
+            if (!c->alias_rows || !est) est = rows * c->pop[pop].cs[0].nseg;
+            const unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(ceil_div(est + est / 8, 4), 256), c->stitch_grid);
+            if (c->stitch_u == 4) hipLaunchKernelGGL((k_stitch_segments<true, 4>), dim3(nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : 8), sb, sc.chrwork.as<ChrWork>(), nchr, sd);
+            else if (c->stitch_u == 1) hipLaunchKernelGGL((k_stitch_segments<true, 1>), dim3(nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : 8), sb, sc.chrwork.as<ChrWork>(), nchr, sd);
+            else hipLaunchKernelGGL((k_stitch_segments<true, 2>), dim3(nblk, sc.n_chrwork), dim3(256), stitch_lds_pad(c->stitch_occ ? c->stitch_occ : 8), sb, sc.chrwork.as<ChrWork>(), nchr, sd);
         } else
             hipLaunchKernelGGL(k_stitch_rows, dim3((unsigned)rows, sc.n_chrwork), dim3(STITCH_THREADS), 0, sb, sc.chrwork.as<ChrWork>(), nchr, sd);
         KCHECK();
@@ -1287,7 +1315,7 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     }
     GEVC(enqueue_tables(c, sc, q.pop, q.n_people, S));        // (uploaded on S while X mates)
     if (X != S) { HIPC(hipEventRecord(sc.ev_tab, S)); HIPC(hipStreamWaitEvent(X, sc.ev_tab, 0)); }
-    GEVC(enqueue_pool_free(c, sc, q.pop, X));
+    GEVC(enqueue_pool_free(c, sc, q.pop, q.n_people, X));
     if (X != S) HIPC(hipEventRecord(sc.ev_aux, X));
     if (q.fused && !sampled) GEVC(enqueue_sampling(c, sc, q.pop, q.n_people, q.has_mut, 0u, S, gv + 1, gv + 2, /*clear_status=*/false));
     else if (!q.fused && !sampled) GEVC(enqueue_sampling(c, sc, q.pop, q.n_people, q.has_mut, q.seed, S));
@@ -1397,7 +1425,7 @@ int gev_reproduce_begin(gev_ctx* c, int pop, const gev_couple* couples, size_t n
 
     gev_ctx::PendingRepro& q = c->pend;
     q.pop = pop; q.n_people = n_people; q.has_mut = has_mut; q.pre = pre; q.seed = (u32)seed_reproduce; q.attempt = 0; q.n_status = n_status; q.hstatus = hstatus;
-    q.fused = false; q.has_svf = false;
+    q.fused = false; q.has_svf = false; q.pool_rebuilt = false;
     GEVC(enqueue_attempt(c, 0));
     q.active = true;
     return GEV_OK;
@@ -1476,6 +1504,7 @@ int gev_generation_begin(gev_ctx* c, int pop, uint32_t glob_state, size_t pop_si
     }
     gev_ctx::PendingRepro& q = c->pend;
     q.pop = pop; q.n_people = n_people; q.has_mut = has_mut; q.pre = pre; q.seed = 0; q.attempt = 0; q.n_status = n_status; q.hstatus = hstatus;
+    q.pool_rebuilt = false;
     q.fused = true; q.has_svf = selection_value_func != nullptr; q.glob_state = glob_state; q.hseeds2 = hstatus + n_status; q.hsex = (uint8_t*)(hstatus + n_status + 2);
     GEVC(enqueue_attempt(c, 0));
     q.active = true;
@@ -1513,11 +1542,16 @@ static int generation_finish(gev_ctx* c, uint8_t* sex_out, gev_generation_result
                                   c->gen_counter, attempt, (int)q.pre, q.th1 - q.th0, q.th2 - q.th1, host_ms() - q.th2, flags, g_graveyard.bytes / 1048576.0);
         if (g_trace_host && g_malloc_n) { fprintf(stderr, "[gev]   %zu hipMalloc calls, %.1f MiB, %.2f ms\n", g_malloc_n, g_malloc_bytes / 1048576.0, g_malloc_ms); g_malloc_ms = 0; g_malloc_n = 0; g_malloc_bytes = 0; }
         for (int k = 0; k < nchr; k++) { P.st[k].mut_total[alt] = hstatus[ST_TOTALS + ST_PER_CHR * k]; P.st[k].parts_total[alt] = hstatus[ST_TOTALS + ST_PER_CHR * k + 1]; }
-        if (flags & FLAG_POOL) return fail(GEV_EDEVICE, "reproduce: genotype row pool exhausted (internal error)");
+        if (c->dense) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) {
+            ChrState& cs = P.st[k]; const u32* stw = hstatus + ST_TOTALS + ST_PER_CHR * k;
+            cs.pool_n_free = stw[4]; cs.pool_cursor = stw[5]; cs.pool_last_taken = stw[2];
+        }
+        if ((flags & FLAG_POOL) && q.pool_rebuilt) return fail(GEV_EDEVICE, "reproduce: genotype row pool exhausted (internal error)");
         if (flags & FLAG_RNG_SHORT) return fail(GEV_EDEVICE, "generation: a rejection stream ran out of candidates (internal error)");
         if (flags & FLAG_NO_MATES)                          // Simulation::random_mate returns false (:2125-2129); nothing is published
             return fail(GEV_ENOMATE, "Error: No one can marry, num_males_mate=%u, num_females_mate=%u", hstatus[ST_NM_MATE], hstatus[ST_NF_MATE]);
-        if (!(flags & FLAG_REDO_MASK)) break;
+        if (!(flags & (FLAG_REDO_MASK | FLAG_POOL))) break;
+        if (flags & FLAG_POOL) { for (int k = 0; k < nchr; k++) P.st[k].pool_force_rebuild = true; q.pool_rebuilt = true; }   // the free list ran out: rebuild it, then the generation again
         if (attempt == 3) return fail(GEV_EDEVICE, "reproduce: buffers still too small after %d attempts (flags %u)", attempt + 1, flags);
         HIPC(hipStreamSynchronize(c->stream_big));        // the stitch of the failed attempt still reads the records that are sampled again below
         sc.timing_pending = false; sc.stitch_pending = false;   // (its kernel times are not counted)
@@ -2045,6 +2079,7 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
             dpw = pool_work(c, D, k, (D.pcur + 1) % 3);
             GEVC(pool_free_list(dpw, 2 * D.n_phys, st));
             GEVC(pool_take(dpw, 0, rows_new, st));
+            ds.pool_list_valid = false;                      // (the next generation builds its own list: the host's picture of this one is gone)
         }
         size_t row0 = 0;
         for (const Seg& sg : segs) {
@@ -2313,6 +2348,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
             const PoolWork pw = pool_work(c, P, k, P.pcur);           // new slots of the CURRENT generation
             GEVC(pool_free_list(pw, r_old, st));
             GEVC(pool_take(pw, r_old, 2 * n, st));
+            cs.pool_list_valid = false;
             const u32 chunks = (u32)(S.stride / 16);
             hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, pool_rows(P, k, pw.phys_alt + r_old * S.nseg),
                                flat_rows((void*)(in + po), S.stride), (const u32*)nullptr, (size_t)0, 2 * n, chunks);
