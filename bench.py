@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--mating", choices=["device", "host"], default="device",
                     help="device (default): Simulation::random_mate and the generation's ras_glob_seed() draws run on the GPU, a step is one "
                          "gev_generation_begin/_end pair; host: round 2's loop (numpy stand-in for random_mate, seeds drawn by a second host thread)")
+    ap.add_argument("--no-host-overlap", action="store_true", help="--mating device: read a generation's A/D before the next generation is handed over (default: hand over first)")
     ap.add_argument("--no-chain", action="store_true", help="--mating device: no head start across generations (gev_set_generation_chain)")
     ap.add_argument("--no-pipeline", action="store_true", help="--mating host only: mate, then gev_reproduce, strictly one after the other (default: the host forms the next couples between gev_reproduce_begin and _end)")
     ap.add_argument("--isolated-steps", type=int, default=3, help="extra untimed generations without stream overlap for roofline.isolated")
@@ -270,6 +271,7 @@ def main():
         from geneevolve_amd.distributed import migrate_all_to_all
 
     fused = args.mating == "device"
+    overlap_host = fused and not args.no_host_overlap
     presample = not args.no_presample and not fused
     from concurrent.futures import ThreadPoolExecutor
     seed_pool = ThreadPoolExecutor(1)                    # the host's second thread: draws seeds while the first waits for the GPU
@@ -338,17 +340,30 @@ def main():
         """one generation = ONE pair of library calls: random_mate (:2090) -> reproduce (:2394) -> ras_compute_AD (:2624) in the
         reference's order, its 2 + N*nchr ras_glob_seed() values drawn on the device from the host's engine state"""
         t0 = time.perf_counter()
-        ctx.generation_begin(P, sim.glob.x, args.n_ind, None)
+        tb = 0.0
+        if not state.get("begun"):
+            ctx.generation_begin(P, sim.glob.x, args.n_ind, None)
+            tb += time.perf_counter() - t0
         t1 = time.perf_counter()
         r = ctx.generation_end(want_couples=False, want_sex=True)
         t2 = time.perf_counter()
         sim.glob.x = int(r["glob_state"]); sim.sex[P] = r["sex"]; sim.last_seed_reproduce = int(r["seed_reproduce"])
+        state["begun"] = False
+        if overlap_host and not migrate:
+            # no selection: the next generation needs nothing the host derives from this one's A/D, so it is handed over at once and
+            # this generation's A/D (published, in the library's other pinned buffer) is read while the device already works
+            tb0 = time.perf_counter()
+            ctx.generation_begin(P, sim.glob.x, args.n_ind, None)
+            tb += time.perf_counter() - tb0
+            state["begun"] = True
+        ta = time.perf_counter()
         sim.ras_compute_AD(P, i + 1)                             # the generation's A/D (computed inside the generation, copied out here)
         t3 = time.perf_counter()
         if migrate:
             do_migration(t3)
-        call_ms["gev_generation_begin"] = call_ms.get("gev_generation_begin", 0.0) + (t1 - t0) * 1e3
+        call_ms["gev_generation_begin"] = call_ms.get("gev_generation_begin", 0.0) + tb * 1e3
         call_ms["gev_generation_end"] = call_ms.get("gev_generation_end", 0.0) + (t2 - t1) * 1e3
+        t2 = ta
         mate_ms.append(0.0); seed_ms.append(0.0); repro_ms.append((t2 - t0) * 1e3); ad_ms.append((t3 - t2) * 1e3); step_ms.append((time.perf_counter() - t0) * 1e3)
 
     def step(i):
@@ -377,6 +392,9 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if state.get("begun"):                               # (timing_totals below needs an idle context)
+        r = ctx.generation_end(want_couples=False, want_sex=True)
+        sim.glob.x = int(r["glob_state"]); sim.sex[P] = r["sex"]; state["begun"] = False
     del ad_ms[:], mate_ms[:], repro_ms[:], mig_ms[:], step_ms[:], seed_ms[:]
     mig_parts.clear(); call_ms.clear()
     tot0, n0 = ctx.timing_totals()                       # (implies a sync of both library streams)
@@ -385,12 +403,16 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
-    barrier()                                            # torch.cuda.synchronize() waits for the last dense stitch too
+    barrier()                                            # torch.cuda.synchronize() waits for the last dense stitch too (and for the generation handed over ahead, if any)
     dt = time.perf_counter() - t0
-    tot1, n1 = ctx.timing_totals()
     rows1 = (0, 0, 0, 0) if args.plane_less else ctx.stitch_totals()
-    assert n1 - n0 == args.steps
-    sample_ms = [(tot1[0] - tot0[0]) / args.steps]; stitch_ms = [(tot1[1] - tot0[1]) / args.steps]; sparse_ms = [(tot1[2] - tot0[2]) / args.steps]
+    if state.get("begun"):                               # the generation handed over in the last step: collected outside the clock (every timed step collected one)
+        r = ctx.generation_end(want_couples=False, want_sex=True)
+        sim.glob.x = int(r["glob_state"]); sim.sex[P] = r["sex"]; state["begun"] = False
+    tot1, n1 = ctx.timing_totals()
+    assert n1 - n0 in (args.steps, args.steps + 1)
+    ng = n1 - n0
+    sample_ms = [(tot1[0] - tot0[0]) / ng]; stitch_ms = [(tot1[1] - tot0[1]) / ng]; sparse_ms = [(tot1[2] - tot0[2]) / ng]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -454,6 +476,7 @@ def main():
                        "mating": "reference Simulation::random_mate on the device (gev_generation_begin: random_mate -> reproduce -> ras_compute_AD per step, in the reference's order)" if fused
                                  else "host, numpy stand-in for random_mate (round 2's loop)",
                        "selection_function": "none (selection_value_func = 1 for everyone)",
+                       "next_generation_handed_over_before_this_ones_A_D_is_read": bool(overlap_host and not migrate),
                        "seeds_handed_over_before_couples": presample,
                        "host_mating_overlaps_device_work": pipeline,
                        "ras_glob_seed_draws": "on the device, from the host's glob_generator state (2 + N*nchr per generation)" if fused else

@@ -581,82 +581,92 @@ __global__ void __launch_bounds__(256) k_iota_u32(u32* __restrict__ a, size_t n)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = (u32)i;
 }
-// Units of the offspring generation.  Per output row (thread): which segments contain one of the gamete's boundaries (bk_idx =
-// first locus index at or behind the breakpoint; its 16-byte chunk decides the segment)?  Those get a unit from the free list and
-// a COMPLETE entry in the stitch's work list (StitchItem); every other segment names the unit of the parental haplotype that is
-// being copied there: start ^ parity(#boundaries at or before the segment's first locus).  One atomic per block of 1024 rows.
-// (A wave-per-row form -- lane = segment, coalesced table rows -- was measured at 333 us against 80 us for this one at 16
-// segments per row: a quarter of the lanes busy and two passes of dependent descriptor loads per row.)
-#define POOL_SEG_MAX 64          // segments per row handled with a 64-bit flag word (8 KiB segments: rows up to 512 KiB = 4M loci); longer rows use larger segments
-#define POOL_RPT 4               // offspring rows per thread of k_pool_assign: one atomic per block of 1024 rows
-__global__ void __launch_bounds__(256) k_pool_assign(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd)
+// Units of the offspring generation, in two kernels.  Which segments of an output row contain one of the gamete's boundaries (bk_idx
+// = first locus index at or behind the breakpoint; its 16-byte chunk decides the segment)?  Those get a unit from the free list
+// and a COMPLETE entry in the stitch's work list (StitchItem); every other segment names the unit of the parental haplotype that
+// is being copied there: start ^ parity(#boundaries at or before the segment's first locus).
+//  k_pool_inherit : ONE THREAD PER TABLE ENTRY (row, segment): the segments without a boundary copy the parental entry.  The S
+//                   threads of a row read S consecutive words of one parental table row and write S consecutive words: coalesced,
+//                   nothing serial; the row's few descriptor words are the same for all of them (served by the caches).
+//  k_pool_fresh   : one thread per ROW, only for its segments WITH a boundary (about one): count them, reserve free units with
+//                   one atomic per block of 256 rows, write the table entry and the work-list entry.
+// (One thread walking all S entries of its row in global memory: 80 us at S = 16, 237 us at S = 32; the same through LDS: 197 us
+// at S = 32; one wave per row, lane = segment: 333 us at S = 16 -- the walk is a latency chain, the entries are not.)
+#define POOL_SEG_MAX 64          // segments per row handled with a 64-bit flag word (4 KiB segments: rows up to 256 KiB = 2M loci); longer rows use larger segments
+__global__ void __launch_bounds__(256) k_pool_inherit(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd, u32 lg_spad)
 {
-    __shared__ u32 s_scan[8], s_base, s_last;
     const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
     const u32 S = pw.nseg, sh = pw.seg_shift;
-    const size_t row0 = (size_t)blockIdx.x * (256 * POOL_RPT) + threadIdx.x;
-    if (threadIdx.x == 0) s_last = 0;
-    u64 flags[POOL_RPT]; u32 c = 0;
-#pragma unroll
-    for (int j = 0; j < POOL_RPT; j++) {
-        const size_t row = row0 + (size_t)j * 256;
-        flags[j] = 0;
-        if (row >= n_rows_out) continue;
-        if (!pw.alias) flags[j] = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
-        else {
-            const size_t G = 2 * ((row >> 1) * nchr + w.chr) + (row & 1);
-            const u32 k = sd.k[G]; const u32* idx = sd.bk_idx + sd.bk_off[G];
-            for (u32 m = 0; m < k; m++) { const u32 g = (idx[m] >> 7) >> sh; if (g < S) flags[j] |= 1ull << g; }
-        }
-        c += (u32)__popcll(flags[j]);
+    const u32 g = threadIdx.x & ((1u << lg_spad) - 1u);           // lg_spad = log2 of the launch's largest S rounded up to a power of two: 256 >> lg_spad rows per block
+    const size_t row = (size_t)blockIdx.x * (256u >> lg_spad) + (threadIdx.x >> lg_spad);
+    if (row >= n_rows_out || g >= S || !pw.alias) return;         // (rows are never shared: every segment is written, k_pool_fresh names them all)
+    const size_t i = row >> 1; const u32 s = (u32)(row & 1);
+    const size_t G = 2 * (i * nchr + w.chr) + s;
+    const u32 k = sd.k[G];
+    u32 cnt = 0; bool fl = false;
+    if (k) {
+        const u32* __restrict__ idx = sd.bk_idx + sd.bk_off[G];
+        const u32 bit0 = (g << sh) << 7;
+        for (u32 m = 0; m < k; m++) { const u32 id = idx[m]; cnt += id <= bit0; fl |= ((id >> 7) >> sh) == g; }
     }
+    if (fl) return;
+    const u32 parent = s ? sd.mother[i] : sd.father[i];
+    const u32 sel = (sd.start[G] ^ cnt) & 1u;
+    pw.phys_alt[row * S + g] = pw.phys_cur[(2 * (size_t)parent + sel) * S + g];
+}
+__global__ void __launch_bounds__(256) k_pool_fresh(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd)
+{
+    __shared__ u32 s_scan[8], s_base;
+    const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
+    const u32 S = pw.nseg, sh = pw.seg_shift;
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = row < n_rows_out;
+    u64 flags = 0; u32 k = 0; const u32* idx = nullptr; size_t G = 0;
+    if (live) {
+        G = 2 * ((row >> 1) * nchr + w.chr) + (row & 1);
+        k = sd.k[G]; idx = sd.bk_idx + sd.bk_off[G];
+        if (!pw.alias) flags = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+        else for (u32 m = 0; m < k; m++) { const u32 g = (idx[m] >> 7) >> sh; if (g < S) flags |= 1ull << g; }
+    }
+    const u32 c = (u32)__popcll(flags);
     u32 tot;
     const u32 ex = block_exclusive_scan_256(c, s_scan, tot);
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(&pw.pctr[1], tot) : 0u;
     __syncthreads();
+    if (!c) return;                                               // (no barrier below)
     u32 at = s_base + ex, n_last = 0;
     const u32 n_free = pw.pctr[0], gen_start = pw.pctr[4];
-#pragma unroll
-    for (int j = 0; j < POOL_RPT; j++) {
-        const size_t row = row0 + (size_t)j * 256;
-        if (row >= n_rows_out) continue;
-        const size_t i = row >> 1; const u32 s = (u32)(row & 1);
-        const size_t G = 2 * (i * nchr + w.chr) + s;
-        const u32 parent = s ? sd.mother[i] : sd.father[i];
-        const u32 start = sd.start[G], k = sd.k[G];
-        const u32* idx = sd.bk_idx + sd.bk_off[G];
-        u32* out = pw.phys_alt + row * S;
-        const u32* p0 = pw.phys_cur + (2 * (size_t)parent) * S;      // the parent's two rows of the table are adjacent
-        u32 m = 0, cnt = 0;                                   // boundaries with idx <= first locus of the segment: ascending list, one sweep
-        for (u32 g = 0; g < S; g++) {
-            const u32 bit0 = (g << sh) << 7;
-            while (m < k && idx[m] <= bit0) { m++; cnt++; }
-            if ((flags[j] >> g) & 1ull) {
-                u32 unit;
-                if (at < n_free) unit = pw.freel[at];
-                else { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_POOL); unit = n_free ? pw.freel[at % n_free] : 0u; }   // the free list ran out: the host rebuilds it and enqueues the generation again
-                out[g] = unit;
-                const u32 item = at - gen_start;
-                if (item < pw.items_cap) {
-                    // the boundaries inside the segment: behind its first locus (one exactly on it is part of cnt), in its chunks
-                    u32 b[STITCH_ITEM_B] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, nin = 0;
-                    for (u32 mm = m; mm < k && ((idx[mm] >> 7) >> sh) == g; mm++, nin++) {
-                        const u32 r = idx[mm] - bit0;
-                        if (nin == 0) b[0] = r; else if (nin == 1) b[1] = r; else if (nin == 2) b[2] = r; else if (nin == 3) b[3] = r;
-                    }
-                    const u32 meta = ((start ^ cnt) & 1u) | ((nin <= STITCH_ITEM_B ? nin : 7u) << 1) | (g << 8);
-                    uint4* o = (uint4*)&pw.items[item];
-                    o[0] = make_uint4(p0[g], p0[S + g], unit, meta);
-                    o[1] = make_uint4(nin <= STITCH_ITEM_B ? b[0] : (u32)row, b[1], b[2], b[3]);
-                }
-                n_last += (g == S - 1);
-                at++;
-            } else out[g] = p0[((start ^ cnt) & 1u) * S + g];
+    const size_t i = row >> 1;
+    const u32 parent = (row & 1) ? sd.mother[i] : sd.father[i];
+    const u32 start = sd.start[G];
+    const u32* p0 = pw.phys_cur + (2 * (size_t)parent) * S;      // the parent's two rows of the table are adjacent
+    u32 m = 0, cnt = 0;                                           // boundaries with idx <= first locus of the segment: ascending list, one sweep
+    for (u64 f = flags; f; f &= f - 1) {
+        const u32 g = (u32)__ffsll((long long)f) - 1u;
+        const u32 bit0 = (g << sh) << 7;
+        while (m < k && idx[m] <= bit0) { m++; cnt++; }
+        const u32 sel0 = (start ^ cnt) & 1u;
+        u32 unit;
+        if (at < n_free) unit = pw.freel[at];
+        else { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_POOL); unit = n_free ? pw.freel[at % n_free] : 0u; }   // the free list ran out: the host rebuilds it and enqueues the generation again
+        pw.phys_alt[row * S + g] = unit;
+        const u32 item = at - gen_start;
+        if (item < pw.items_cap) {
+            // the boundaries inside the segment: behind its first locus (one exactly on it is part of cnt), in its chunks
+            u32 b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu, nin = 0;
+            for (u32 mm = m; mm < k && ((idx[mm] >> 7) >> sh) == g; mm++, nin++) {
+                const u32 r = idx[mm] - bit0;
+                if (nin == 0) b0 = r; else if (nin == 1) b1 = r; else if (nin == 2) b2 = r; else if (nin == 3) b3 = r;
+            }
+            const u32 meta = sel0 | ((nin <= STITCH_ITEM_B ? nin : 7u) << 1) | (g << 8);
+            uint4* o = (uint4*)&pw.items[item];
+            o[0] = make_uint4(p0[g], p0[S + g], unit, meta);
+            o[1] = make_uint4(nin <= STITCH_ITEM_B ? b0 : (u32)row, b1, b2, b3);
         }
+        n_last += (g == S - 1);
+        at++;
     }
-    if (n_last) atomicAdd(&s_last, n_last);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_last) atomicAdd(&pw.pctr[3], s_last);
+    if (n_last) atomicAdd(&pw.pctr[3], n_last);
 }
 // behind k_pool_assign: the length of the stitch's work list and the segment totals of the status block, per work entry; the
 // counters of the next generation start here

@@ -16,7 +16,7 @@
 //   GEV_LIST_LONG=n           average list entries per row from which the list fill kernels put eight lanes on a row (default 20)
 //   GEV_STITCH_PRIORITY=1|2   stitch stream high / all streams equal (default: small streams high, stitch low)
 //   GEV_STITCH_GRID=n         persistent workgroups of the segment stitch per chromosome (default 16384)
-//   GEV_SEG_CHUNKS=2^k        16-byte chunks per row segment (default 512 = 8 KiB)
+//   GEV_SEG_CHUNKS=2^k        16-byte chunks per row segment (default 128 = 2 KiB)
 //   GEV_STITCH_WAVE_PRIO=0..3 s_setprio level of the stitch kernel's waves (default 0; measured: no effect next to the sampling kernels)
 //   GEV_TABLE_RING_BYTES=n    minimum size of the pinned ring the per-generation work tables are staged in (default 256 KiB)
 //   GEV_TRACE_HOST=1          stderr: host time per phase of gev_reproduce, allocations, deferred frees
@@ -214,14 +214,16 @@ struct gev_ctx {
     unsigned long long redo_count = 0;                       // generations that were enqueued again with larger buffers (gev_redo_count)
     void* h_stage = nullptr; size_t h_stage_bytes = 0;       // pinned host staging
     void* h_seeds = nullptr; size_t h_seeds_bytes = 0;       // pinned copy of the mutation seeds handed to gev_presample
-    void* h_ad = nullptr; size_t h_ad_bytes = 0;             // pinned A/D result cache
+    // pinned A/D result cache, two buffers: [(gen_counter + 1) & 1] holds the PUBLISHED generation's values, the generation in flight
+    // fills the other one -- gev_compute_ad may therefore be served between gev_generation_begin and _end (the host hands the next
+    // generation over first and reads the last one's A/D while the device works)
+    void* h_ad2[2] = {nullptr, nullptr}; size_t h_ad2_bytes[2] = {0, 0}; bool ad_dom_zero2[2] = {false, false};
     int ad_cached_pop = -1;                                  // population whose current-generation A/D sits in h_ad
     int ad_host_set_pop = -1;                                // population whose raw A/D totals on the device were supplied by gev_set_ad (locus-split: all-reduced)
     bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
-    bool ad_dom_zero = false;                                // the cached generation's dominance values are +0.0 exactly (vd == 0 everywhere): not copied
     int stitch_start = 1;          // when the dense stitch of a generation may start: 0 behind the unit table, 1 behind the CV planes (default: measured best), 2 behind the whole small work incl. A/D (GEV_STITCH_START)
     unsigned cv_threads = 512; bool cv_count_fused_ok = true;   // k_stitch_small: threads per block (GEV_CV_THREADS=256|512|1024), column counts in the same pass (GEV_CV_COUNT_FUSED=0: separate k_cv_count)
-    int stitch_u = 2;              // 16-byte chunks per lane in flight in the segment stitch (GEV_STITCH_U=1|2|4)
+    int stitch_u = 2;              // 16-byte chunks per lane in flight in the segment stitch: a 2 KiB segment is one step of a wave (GEV_STITCH_U=1|2|4; 8 KiB segments: 2: 722, 4: 778 generations/s)
     bool side_streams = true;      // mate + free list next to the sampling, lists next to CV planes + A/D (GEV_SIDE_STREAMS=0: one stream)
     int stitch_mode = 0;           // 0 = work-list form (production, k_stitch_segments), 1 = gamete-major (k_stitch_rows)
     bool sample_batched = true;               // K1-K3 as eight tasks per wave (gev_sample8.h); GEV_SAMPLE_BATCHED=0: one task per wave
@@ -236,8 +238,10 @@ struct gev_ctx {
     size_t stitch_grid = 65536;    // most workgroups (4 waves = 4 work-list entries each) of the segment stitch per chromosome (GEV_STITCH_GRID)
     int stitch_wave_prio = 0;      // s_setprio level of the stitch kernel's waves (GEV_STITCH_WAVE_PRIO)
     size_t list_long = LIST_LONG;  // average list entries per row from which the list fill kernels use LIST_LANES lanes per row (GEV_LIST_LONG)
-    u32 seg_shift = 9;             // log2(16-byte chunks per row segment): 8 KiB -- sweep at config 2 / the config-4 shard: 256 chunks 370 / 72, 512: 457 / 72, 1024: 450 / 58,
-                                   // 2048: 375 generations/s (smaller: more table entries to manage; larger: more bytes copied per crossover); GEV_SEG_CHUNKS=<power of two>
+    u32 seg_shift = 7;             // log2(16-byte chunks per row segment): 2 KiB.  Smaller: more table entries to manage per generation; larger: more bytes copied per
+                                   // crossover.  Round 3 (free list kept across generations, one thread per table entry), config 2: 128 chunks 906, 256: 845, 512: 745
+                                   // generations/s; round 2 (list rebuilt and every row's entries walked by one thread every generation): 256: 370, 512: 457, 1024: 450.
+                                   // A row has at most 64 segments: longer rows get larger segments (gev_set_snps).  GEV_SEG_CHUNKS=<power of two>
     bool alias_rows = true;        // crossover-free gametes share their parent's pool row instead of copying it (GEV_ALIAS_ROWS=0: copy every row)
     unsigned long long chunks_written_sum = 0, chunks_total_sum = 0, segments_written_sum = 0, segments_total_sum = 0;   // over all generations and active chromosomes (gev_stitch_totals)
     // Stitch workgroups per CU (8 = every wave slot).  The hardware queue priority does not let the small kernels of the next
@@ -452,7 +456,7 @@ void gev_destroy(gev_ctx* c)
     hipStream_t s = c->stream;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_seeds) (void)hipHostFree(c->h_seeds);
-    if (c->h_ad) (void)hipHostFree(c->h_ad);
+    for (void* h : c->h_ad2) if (h) (void)hipHostFree(h);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
     delete c;
     if (s) (void)hipStreamDestroy(s);
@@ -508,7 +512,7 @@ int gev_set_snps(gev_ctx* c, int pop, int chr, const u64* pos, size_t L)
     ChrStatic& S = c->pop[pop].cs[chr];
     S.pos.assign(pos, pos + L); S.L = L;
     S.stride = std::max<size_t>(round_up(ceil_div(L, 8), 128), 128);
-    S.seg_shift = c->seg_shift;                                    // 8 KiB segments (GEV_SEG_CHUNKS) unless the row would need more than 64 of them
+    S.seg_shift = c->seg_shift;                                    // 2 KiB segments (GEV_SEG_CHUNKS) unless the row would need more than 64 of them
     while (ceil_div(S.stride / 16, (size_t)1 << S.seg_shift) > POOL_SEG_MAX) S.seg_shift++;
     while (S.seg_shift > 0 && ((size_t)1 << (S.seg_shift - 1)) >= S.stride / 16) S.seg_shift--;     // a row shorter than a segment: the smallest power-of-two unit that holds it
     S.nseg = (u32)ceil_div(S.stride / 16, (size_t)1 << S.seg_shift);
@@ -879,8 +883,9 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
 // No host round trip inside a generation: variable-length outputs go to capacity-checked buffers
 // sized from the previous totals; if one was too small the buffers are grown from the exact totals
 // of the count passes and the small work is enqueued again (inputs are untouched until the flip).
-static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready = false);
+static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready = false, int hbuf = -1);
 static int enqueue_chain_head_start(gev_ctx* c);
+static int prepare_eager_ad(gev_ctx* c, int pop);
 static int check_not_pending(gev_ctx* c);
 static int materialize_order(gev_ctx* c, int pop);
 extern "C" int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people);
@@ -1104,7 +1109,9 @@ static int enqueue_pool_assign(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people
     if (!c->dense || !sc.n_chrwork) return GEV_OK;
     const size_t rows = 2 * n_people, T = n_people * (size_t)c->nchr;
     SampleDev sd = make_sd(c, sc, T);
-    hipLaunchKernelGGL(k_pool_assign, dim3((unsigned)ceil_div(rows, 256 * POOL_RPT), sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, c->nchr, sd);
+    u32 lg = 0; while ((1u << lg) < sc.nseg_max) lg++;               // rows per block of k_pool_inherit: 256 >> lg
+    hipLaunchKernelGGL(k_pool_inherit, dim3((unsigned)ceil_div(rows, (size_t)(256u >> lg)), sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, c->nchr, sd, lg);
+    hipLaunchKernelGGL(k_pool_fresh, dim3((unsigned)ceil_div(rows, 256), sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, c->nchr, sd);
     hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(64), 0, st, sc.chrwork.as<ChrWork>(), sc.n_chrwork, sd.status);
     KCHECK();
     return GEV_OK;
@@ -1343,8 +1350,9 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     HIPC(hipEventRecord(sc.t[2], S));
     if (c->stitch_start == 1) { HIPC(hipEventRecord(sc.ev_small_done, S)); GEVC(enqueue_stitch(c, sc, q.pop, q.n_people)); }
     q.th2 = host_ms();
-    c->ad_cached_pop = c->ad_host_set_pop = -1;
-    if (ad_now) GEVC(enqueue_ad(c, q.pop, c->pop[q.pop].cur ^ 1, q.n_people, count_cols));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
+    if (c->ad_cached_pop != q.pop) c->ad_cached_pop = -1;    // (the device-side arrays are about to be rewritten; the published values of q.pop stay readable in their pinned buffer)
+    c->ad_host_set_pop = -1;
+    if (ad_now) GEVC(enqueue_ad(c, q.pop, c->pop[q.pop].cur ^ 1, q.n_people, count_cols, (int)(c->gen_counter & 1)));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
     if (L != S) HIPC(hipStreamWaitEvent(S, sc.ev_lists, 0));
     if (c->stitch_start >= 2) { HIPC(hipEventRecord(sc.ev_small_done, S)); GEVC(enqueue_stitch(c, sc, q.pop, q.n_people)); }
     HIPC(hipMemcpyAsync(q.hstatus, sc.status.p, q.n_status * sizeof(u32), hipMemcpyDeviceToHost, S));
@@ -1403,6 +1411,7 @@ int gev_reproduce_begin(gev_ctx* c, int pop, const gev_couple* couples, size_t n
     }
     if (!dev_couples && ip != n_people) return fail(GEV_EINVAL, "reproduce: n_people=%zu but the couples list yields %zu offspring", n_people, ip);
     GEVC(finalize_static(c, pop));
+    GEVC(prepare_eager_ad(c, pop));
     GEVC(ensure_capacity(c, pop, n_people));
     hipStream_t st = c->stream;
     // sampling already enqueued by gev_presample for exactly these inputs?
@@ -1451,6 +1460,18 @@ static int enqueue_chain_head_start(gev_ctx* c)
     nx.fused_ahead = true; nx.fa_dropped = false; nx.fa_pop = q.pop; nx.fa_n = q.n_people; nx.fa_has_mut = q.has_mut;
     return GEV_OK;
 }
+// A/D is computed with the generation (same enqueue, same wait) once the per-population a/d tables exist; they are set up by the
+// first gev_compute_ad, or here as soon as every population of the context has its static inputs
+static int prepare_eager_ad(gev_ctx* c, int pop)
+{
+    if (c->pop[pop].cv[0][0].d_aptr.p) return GEV_OK;
+    for (const PopState& Q : c->pop)
+        for (int k = 0; k < c->nchr; k++) {
+            if (Q.cs[k].rbp.empty() || (c->chr_active[k] && Q.cs[k].pos.empty() && Q.cs[k].L)) return GEV_OK;
+            for (int p = 0; p < c->nphen; p++) if (c->chr_active[k] && !Q.cv[p][k].set) return GEV_OK;
+        }
+    return check_multipop(c);
+}
 // does every chromosome of the population have a mutation map (Simulation::reproduce's `_mutation_map.size() > 0`, :2459)?
 static int population_has_mutmap(gev_ctx* c, int pop, bool& has_mut)
 {
@@ -1481,6 +1502,7 @@ int gev_generation_begin(gev_ctx* c, int pop, uint32_t glob_state, size_t pop_si
     GEVC(ensure_stage(c, (n_status + 2) * 4 + n_people + 16));
     u32* hstatus = (u32*)c->h_stage;
     GEVC(finalize_static(c, pop));
+    GEVC(prepare_eager_ad(c, pop));
     GEVC(ensure_capacity(c, pop, n_people));
     hipStream_t st = c->stream;
     gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
@@ -1523,7 +1545,14 @@ int gev_set_generation_chain(gev_ctx* c, int draws_between)
     c->chain_draws = draws_between < 0 ? -1 : draws_between;
     return GEV_OK;
 }
+static int generation_finish_inner(gev_ctx* c, uint8_t* sex_out, gev_generation_result* res, gev_couple* couples_out);
 static int generation_finish(gev_ctx* c, uint8_t* sex_out, gev_generation_result* res, gev_couple* couples_out)
+{
+    const int rc = generation_finish_inner(c, sex_out, res, couples_out);
+    if (rc != GEV_OK) c->ad_cached_pop = -1;                 // the device-side A/D arrays hold a generation that was not published
+    return rc;
+}
+static int generation_finish_inner(gev_ctx* c, uint8_t* sex_out, gev_generation_result* res, gev_couple* couples_out)
 {
     gev_ctx::PendingRepro& q = c->pend;
     q.active = false;                                       // whatever happens below, the generation is no longer pending
@@ -1579,7 +1608,7 @@ static int generation_finish(gev_ctx* c, uint8_t* sex_out, gev_generation_result
     }
     const bool ad_done = c->eager_ad && c->pop[pop].cv[0][0].d_aptr.p;
     for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = ad_done;
-    if (ad_done) c->ad_cached_pop = pop;
+    c->ad_cached_pop = ad_done ? pop : -1;
     if (q.fused) {
         c->chain_valid = c->chain_draws >= 0; c->chain_state = hstatus[ST_NEXT_STATE];
         if (sex_out) memcpy(sex_out, q.hsex, n_people);
@@ -1778,8 +1807,10 @@ int gev_timing_totals(gev_ctx* c, double ms_sum[4], unsigned long long* n_genera
 // ---- Simulation::ras_compute_AD -----------------------------------------------------------
 // kernels of ras_compute_AD on buffer set `buf` (current generation, or the one being produced)
 // counts_ready: the allele counts of the CV columns were accumulated by k_stitch_small while it wrote the planes
-static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready)
+// hbuf: the pinned result buffer (default: the published generation's)
+static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready, int hbuf)
 {
+    if (hbuf < 0) hbuf = (int)((c->gen_counter + 1) & 1);
     PopState& P = c->pop[pop];
     hipStream_t st = c->stream;
     const size_t rows = 2 * n;
@@ -1858,42 +1889,53 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready)
     // D-term is (+-0) * ... and the running sums stay +0.0 exactly -- nothing to copy, gev_compute_ad fills zeros.
     const size_t nd = n * nphen;
     const size_t bytes = 16 + 2 * nd * sizeof(double);
-    if (c->h_ad_bytes < bytes) {
-        HIPC(hipDeviceSynchronize());
-        if (c->h_ad) (void)hipHostFree(c->h_ad);
-        c->h_ad = nullptr; c->h_ad_bytes = 0;
-        HIPC(hipHostMalloc(&c->h_ad, bytes * 5 / 4 + 4096, hipHostMallocDefault));
-        c->h_ad_bytes = bytes * 5 / 4 + 4096;
+    if (c->h_ad2_bytes[hbuf] < bytes) {
+        HIPC(hipStreamSynchronize(st));                      // (copies into the old buffer may be in flight on this stream)
+        void* old = c->h_ad2[hbuf];
+        c->h_ad2[hbuf] = nullptr; c->h_ad2_bytes[hbuf] = 0;
+        HIPC(hipHostMalloc(&c->h_ad2[hbuf], bytes * 5 / 4 + 4096, hipHostMallocDefault));
+        c->h_ad2_bytes[hbuf] = bytes * 5 / 4 + 4096;
+        if (old) (void)hipHostFree(old);
     }
-    c->ad_dom_zero = true;
-    for (const AdWork& a : aw) c->ad_dom_zero &= a.vd == 0;
-    uint8_t* h = (uint8_t*)c->h_ad;
+    bool dom_zero = true;
+    for (const AdWork& a : aw) dom_zero &= a.vd == 0;
+    c->ad_dom_zero2[hbuf] = dom_zero;
+    uint8_t* h = (uint8_t*)c->h_ad2[hbuf];
     HIPC(hipMemcpyAsync(h, c->d_flag.p, 4, hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(h + 16, c->d_add.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (!c->ad_dom_zero) HIPC(hipMemcpyAsync(h + 16 + nd * 8, c->d_dom.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!dom_zero) HIPC(hipMemcpyAsync(h + 16 + nd * 8, c->d_dom.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
     return GEV_OK;
 }
 int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, double* add_chr, double* dom_chr)
 {
-    GEVC(check_idx(c, pop, 0));
+    if (!c) return fail(GEV_EINVAL, "null context");
+    if (pop < 0 || pop >= c->n_pop) return fail(GEV_EINVAL, "population index %d out of range", pop);
     PopState& P = c->pop[pop];
     if (!P.gen0) return fail(GEV_ESTATE, "compute_ad: population %d has no current generation", pop);
-    HIPC(hipSetDevice(c->device));
-    if (!c->pop[pop].cv[0][0].d_aptr.p) GEVC(check_multipop(c));
-    GEVC(materialize_order(c, pop));
-    const size_t n = P.n_people;
     const int nchr = c->nchr, nphen = c->nphen;
-    if (c->ad_cached_pop != pop) {          // not computed eagerly by the last gev_reproduce of this population
-        GEVC(enqueue_ad(c, pop, P.cur, n));
-        HIPC(hipStreamSynchronize(c->stream));
-        c->ad_cached_pop = pop;
-        for (int p = 0; p < nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = true;
+    const int hb = (int)((c->gen_counter + 1) & 1);          // the published generation's result buffer
+    if (c->pend.active) {
+        // a generation is in flight: the CURRENT generation's values can still be handed out if they were computed with it (they
+        // sit in the other pinned buffer); anything that needs device work has to wait for gev_reproduce_end / gev_generation_end
+        if (c->ad_cached_pop != pop || add_chr || dom_chr)
+            return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first");
+    } else {
+        HIPC(hipSetDevice(c->device));
+        if (!c->pop[pop].cv[0][0].d_aptr.p) GEVC(check_multipop(c));
+        GEVC(materialize_order(c, pop));
+        if (c->ad_cached_pop != pop) {          // not computed eagerly by the last gev_reproduce of this population
+            GEVC(enqueue_ad(c, pop, P.cur, P.n_people));
+            HIPC(hipStreamSynchronize(c->stream));
+            c->ad_cached_pop = pop;
+            for (int p = 0; p < nphen; p++) for (int k = 0; k < nchr; k++) P.cv[p][k].frq_valid = true;
+        }
     }
-    const uint8_t* h = (const uint8_t*)c->h_ad;
+    const size_t n = P.n_people;
+    const uint8_t* h = (const uint8_t*)c->h_ad2[hb];
     const size_t nd = n * nphen, ndc = n * (size_t)nchr * nphen;
     const u32 flag = *(const u32*)h;
     if (additive) memcpy(additive, h + 16, nd * sizeof(double));
-    if (dominance) { if (c->ad_dom_zero) memset(dominance, 0, nd * sizeof(double)); else memcpy(dominance, h + 16 + nd * 8, nd * sizeof(double)); }
+    if (dominance) { if (c->ad_dom_zero2[hb]) memset(dominance, 0, nd * sizeof(double)); else memcpy(dominance, h + 16 + nd * 8, nd * sizeof(double)); }
     if (add_chr || dom_chr) {                                // (the arrays of the generation's A/D kernels are still in place: any later A/D run resets ad_cached_pop)
         if (add_chr) HIPC(hipMemcpyAsync(add_chr, c->d_addchr.p, ndc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         if (dom_chr) HIPC(hipMemcpyAsync(dom_chr, c->d_domchr.p, ndc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -2841,7 +2883,13 @@ int gev_download_mutations(gev_ctx* c, int pop, int chr, u64* out, u64* hap_offs
 }
 
 // ---- introspection ------------------------------------------------------------------------
-int gev_pop_size(gev_ctx* c, int pop, size_t* n) { GEVC(check_idx(c, pop, 0)); if (!n) return fail(GEV_EINVAL, "null"); *n = c->pop[pop].n_people; return GEV_OK; }
+int gev_pop_size(gev_ctx* c, int pop, size_t* n)          // (the published generation's size; allowed while a generation is in flight)
+{
+    if (!c || !n) return fail(GEV_EINVAL, "null");
+    if (pop < 0 || pop >= c->n_pop) return fail(GEV_EINVAL, "population index %d out of range", pop);
+    *n = c->pop[pop].n_people;
+    return GEV_OK;
+}
 int gev_plane_ptr(gev_ctx* c, int pop, int chr, void** dptr, size_t* unit_bytes, size_t* n_slots, const uint32_t** unit_of, uint32_t* segments_per_row)
 {
     if (c) GEVC(check_dense(c, "plane_ptr"));

@@ -95,7 +95,7 @@ const char* gev_version(void);
  *   GEV_OVERLAP=0|1|2|-1        stream overlap mode (gev_set_overlap)
  *   GEV_ALIAS_ROWS=0            write every segment of every gamete row (default 1: a segment without a crossover boundary shares the parental unit)
  *   GEV_STITCH_WG_PER_CU=n|auto dense-stitch workgroups per CU (default: unlimited; auto = measured at run time)
- *   GEV_SEG_CHUNKS=2^k          16-byte chunks per row segment (default 512 = 8 KiB; small values exercise many segments on small rows)
+ *   GEV_SEG_CHUNKS=2^k          16-byte chunks per row segment (default 128 = 2 KiB; a row has at most 64 segments, longer rows get larger ones)
  *   GEV_STITCH_MODE=0|1         stitch kernel (gev_set_stitch_mode)
  *   GEV_STITCH_LDS_PAD=bytes    (experiments) dynamic LDS padding of the stitch workgroups, overriding the one derived from WG_PER_CU
  *   GEV_SAMPLE_BATCHED=0        one sampling task per wave (the round-1 kernels) instead of eight
@@ -228,6 +228,10 @@ int gev_set_generation_chain(gev_ctx*, int draws_between);
  * bv = additive + dominance is left to the host (:2715, :2744). */
 int gev_compute_ad(gev_ctx*, int pop, double* additive, double* dominance,
                    double* add_chr, double* dom_chr);
+/* (gev_reproduce / gev_generation_end compute the new generation's A/D with the generation, so the call after them only copies.
+ * The totals of the PUBLISHED generation can also be read while the next one is in flight -- between gev_generation_begin and _end:
+ * a host without selection hands the next generation over first and reads this one's values while the device works; the
+ * per-chromosome arrays need the device and are refused there.) */
 /* ---- Simulation::ras_scale_AD_compute_GEF (src/Simulation.cpp:3075-3206)  [SURVEY 8(f) row 1] ----
  * Scales the raw A/D of the last gev_compute_ad to the generation-0 variances, draws the noise term
  * e ~ N(0,1) from std::normal_distribution on minstd_rand0(seed) (seed = the ras_glob_seed() value

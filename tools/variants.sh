@@ -9,12 +9,10 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d['roofline']
 print(round(d['value'],1), 'gen/s', round(d['ms_per_step'],3), 'ms  stitch', round(d['phase_ms']['dense_stitch'],3), 'iso', round(r['isolated_kernel_ms'] or 0,3), 'segs', int(r['segments_written_per_launch']), 'frac', round(r['frac'],3), 'isofrac', round(r['isolated_frac'] or 0,3), 'sampling', round(d['phase_ms']['sampling'],3), 'sparse', round(d['phase_ms']['sparse_lists_and_cv_planes'],3), d['phase_ms']['host_ms_inside_calls'])" >> $out; }
-run GEV_STITCH_START=1
-run GEV_STITCH_START=0
-run GEV_STITCH_START=1 GEV_STITCH_U=4
-run GEV_STITCH_START=1 GEV_STITCH_U=1
-run GEV_STITCH_START=1 GEV_SEG_CHUNKS=256
-run GEV_STITCH_START=1 GEV_SEG_CHUNKS=128
-run GEV_STITCH_START=0 GEV_SEG_CHUNKS=256
-run GEV_STITCH_START=1 GEV_POOL_REBUILD=1
+run A=1
+run GEV_LIST_LONG=4
+run GEV_LIST_LONG=8
+run GEV_STITCH_START=2
+run GEV_OVERLAP=2
+run A=1 --no-host-overlap
 cat $out
