@@ -42,7 +42,20 @@ struct ChrDev {
     u32 r_amax, m_amax;   // largest a_hi of the recombination / mutation thresholds (scan prefilter)
     const u64* snp_pos;   // [L] Legend.pos of the genotype plane
     u32 L, active;        // active == 0: this context holds no genotype / CV state of the chromosome (locus-split populations)
+    // coarse index over snp_pos: coarse[j] = first locus at or behind position coarse_base + (j << coarse_shift), j = 0 .. coarse_n:
+    // a breakpoint becomes a locus index with one table read and a search over the few loci of its bucket (snp_lower_bound)
+    const u32* coarse; u64 coarse_base; u32 coarse_shift, coarse_n;
 };
+// first locus index whose position is >= x (== lower_bound over the chromosome's SNP positions)
+__device__ __forceinline__ u32 snp_lower_bound(const ChrDev& C, u64 x)
+{
+    if (!C.L || x <= C.coarse_base) return 0u;                    // coarse_base = position of the first locus
+    const u64 j = (x - C.coarse_base) >> C.coarse_shift;
+    if (j >= C.coarse_n) return C.L;                              // behind the last locus
+    u32 lo = C.coarse[j], hi = C.coarse[j + 1];                   // the answer lies in [lo, hi]
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (C.snp_pos[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
 
 // per-generation sampling results (all chromosomes; task t = offspring*nchr + chr, gamete G = 2t+s)
 struct SampleDev {
@@ -129,6 +142,8 @@ struct AdWork {
     const u32* cvp; const u64* pos_sorted; const u64* pos_file; const u32* col_of_icv;
     const double* a; const double* d; const double* const* aptr; const double* const* dptr;
     u32* counts; double* frq; double* tab; double* add_out; double* dom_out;
+    double* add_tot; double* dom_tot;   // one chromosome: Human::additive / dominance of this phenotype written with the per-chromosome values (0 + x, the sum over chromosomes of :2729-2746); else null
+    const uint16_t* partial;            // k_stitch_small's per-block allele counts of this CV grid, or null
     u64 bp0, bp_end;
     double vd;
     u32 stride_w32, sub_w32, C;
@@ -386,14 +401,14 @@ __global__ void __launch_bounds__(256) k_mut_sample(const GevRngTables* __restri
 // Simulation::reproduce (:2447-2455)
 // ------------------------------------------------------------------------------------------
 // one scan of the recombination map for one gamete; the first `cap` breakpoints bp[j] + rand()%dist (:2990) go to `out`
-__device__ __forceinline__ u32 rec_scan_write(const GevRngTables* __restrict__ T, const ChrDev& C, u32 seed, GlibcWave& g, u64* __restrict__ out, u32 cap)
+__device__ __forceinline__ u32 rec_scan_write(const GevRngTables* __restrict__ T, const ChrDev& C, u32 seed, GlibcWave& g, u64* __restrict__ out, u32* __restrict__ out_idx, u32 cap)
 {
     const u32 lane = threadIdx.x & 63;
     u32 h = 0;
     wave_scan_hits(T, seed + 1u, C.rthr, C.r_amax, 0, C.R, [&](u32 row) {
         if (h < cap) {
             const u64 v = C.rbp[row] + (u64)g.out(T, h) % C.bp_dist;
-            if (lane == 0) out[h] = v;
+            if (lane == 0) { out[h] = v; out_idx[h] = snp_lower_bound(C, v); }     // the breakpoint and the first locus at or behind it
         }
         h++;
     });
@@ -406,7 +421,7 @@ __device__ __forceinline__ u32 gamete_sample(const GevRngTables* __restrict__ T,
     const u32 lane = threadIdx.x & 63;
     g.seed(T, seed);
     u32 off = (u32)G * GEV_BK_CAP;
-    const u32 k = rec_scan_write(T, C, seed, g, sd.bk + off, GEV_BK_CAP);
+    const u32 k = rec_scan_write(T, C, seed, g, sd.bk + off, sd.bk_idx + off, GEV_BK_CAP);
     u32 k_store = k;
     if (k > GEV_BK_CAP) {
         u32 o = 0;
@@ -415,7 +430,7 @@ __device__ __forceinline__ u32 gamete_sample(const GevRngTables* __restrict__ T,
         if (o + k <= sd.bk_ovf_cap) {
             off = sd.bk_ovf_base + o;
             g.seed(T, seed);
-            rec_scan_write(T, C, seed, g, sd.bk + off, k);
+            rec_scan_write(T, C, seed, g, sd.bk + off, sd.bk_idx + off, k);
         } else { if (lane == 0) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_BK_OVF); k_store = 0; }
     }
     if (lane == 0) { sd.k[G] = k_store; sd.bk_off[G] = off; }
@@ -593,26 +608,35 @@ __global__ void __launch_bounds__(256) k_iota_u32(u32* __restrict__ a, size_t n)
 // (One thread walking all S entries of its row in global memory: 80 us at S = 16, 237 us at S = 32; the same through LDS: 197 us
 // at S = 32; one wave per row, lane = segment: 333 us at S = 16 -- the walk is a latency chain, the entries are not.)
 #define POOL_SEG_MAX 64          // segments per row handled with a 64-bit flag word (4 KiB segments: rows up to 256 KiB = 2M loci); longer rows use larger segments
-__global__ void __launch_bounds__(256) k_pool_inherit(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd, u32 lg_spad)
+#define POOL_INH 4              // table entries (consecutive segments of one row) per thread of k_pool_inherit: the row's descriptor words are read once for them
+__global__ void __launch_bounds__(256) k_pool_inherit(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd, u32 lg_tpr)
 {
     const ChrWork& w = Wt[blockIdx.y]; const PoolWork& pw = w.pw;
     const u32 S = pw.nseg, sh = pw.seg_shift;
-    const u32 g = threadIdx.x & ((1u << lg_spad) - 1u);           // lg_spad = log2 of the launch's largest S rounded up to a power of two: 256 >> lg_spad rows per block
-    const size_t row = (size_t)blockIdx.x * (256u >> lg_spad) + (threadIdx.x >> lg_spad);
-    if (row >= n_rows_out || g >= S || !pw.alias) return;         // (rows are never shared: every segment is written, k_pool_fresh names them all)
+    const u32 g0 = (threadIdx.x & ((1u << lg_tpr) - 1u)) * POOL_INH;   // 2^lg_tpr threads per row (the launch's largest S / POOL_INH rounded up to a power of two): 256 >> lg_tpr rows per block
+    const size_t row = (size_t)blockIdx.x * (256u >> lg_tpr) + (threadIdx.x >> lg_tpr);
+    if (row >= n_rows_out || g0 >= S || !pw.alias) return;        // (rows are never shared: every segment is written, k_pool_fresh names them all)
     const size_t i = row >> 1; const u32 s = (u32)(row & 1);
     const size_t G = 2 * (i * nchr + w.chr) + s;
     const u32 k = sd.k[G];
-    u32 cnt = 0; bool fl = false;
+    u32 cnt[POOL_INH] = {0, 0, 0, 0}; bool fl[POOL_INH] = {false, false, false, false};
     if (k) {
         const u32* __restrict__ idx = sd.bk_idx + sd.bk_off[G];
-        const u32 bit0 = (g << sh) << 7;
-        for (u32 m = 0; m < k; m++) { const u32 id = idx[m]; cnt += id <= bit0; fl |= ((id >> 7) >> sh) == g; }
+        for (u32 m = 0; m < k; m++) {
+            const u32 id = idx[m], gs = (id >> 7) >> sh;
+#pragma unroll
+            for (int j = 0; j < POOL_INH; j++) { cnt[j] += id <= (((g0 + j) << sh) << 7); fl[j] |= gs == g0 + j; }
+        }
     }
-    if (fl) return;
     const u32 parent = s ? sd.mother[i] : sd.father[i];
-    const u32 sel = (sd.start[G] ^ cnt) & 1u;
-    pw.phys_alt[row * S + g] = pw.phys_cur[(2 * (size_t)parent + sel) * S + g];
+    const u32 start = sd.start[G];
+    const u32* __restrict__ p0 = pw.phys_cur + (2 * (size_t)parent) * S;
+    u32* __restrict__ out = pw.phys_alt + row * S;
+    u32 v[POOL_INH];
+#pragma unroll
+    for (int j = 0; j < POOL_INH; j++) if (g0 + j < S && !fl[j]) v[j] = p0[((start ^ cnt[j]) & 1u) * S + g0 + j];
+#pragma unroll
+    for (int j = 0; j < POOL_INH; j++) if (g0 + j < S && !fl[j]) out[g0 + j] = v[j];
 }
 __global__ void __launch_bounds__(256) k_pool_fresh(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, SampleDev sd)
 {
@@ -682,16 +706,6 @@ __global__ void __launch_bounds__(64) k_pool_publish(const ChrWork* __restrict__
         ((u32*)&w.pw.items[w.pw.items_cap])[0] = (status[ST_FLAGS] & FLAG_POOL) ? 0u : min(n, w.pw.items_cap);   // length of the work list (free list ran out: the stitch does nothing, the host rebuilds and repeats)
         pctr[4] = pctr[1]; pctr[3] = 0;
     }
-}
-// breakpoint (base pairs) -> first locus index >= it, for every gamete of every chromosome: one fully parallel pass,
-// so that no stitch workgroup has to walk a 20-step dependent binary search before it can start streaming
-__global__ void __launch_bounds__(256) k_bk_to_idx(const ChrDev* __restrict__ chrs, int nchr, size_t n_gametes, SampleDev sd)
-{
-    const size_t G = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (G >= n_gametes) return;
-    const ChrDev& C = chrs[(G >> 1) % nchr];
-    const u32 k = sd.k[G], off = sd.bk_off[G];
-    for (u32 m = 0; m < k; m++) sd.bk_idx[off + m] = lower_bound_u64(C.snp_pos, C.L, sd.bk[off + m]);
 }
 // K5, production form: one WAVE per entry of the work list k_pool_assign wrote (one written segment of one gamete).  The entry is
 // complete -- the two parental units, the unit to write, the haplotype copied at the segment's first locus and the (usually one)
@@ -905,17 +919,6 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_stitch_small(const CvWork* __
         uint16_t* __restrict__ out = v.partial + (size_t)blockIdx.x * 1024;
         for (u32 col = threadIdx.x; col < 1024; col += SMALL_THREADS) out[col] = (uint16_t)s_cnt[(col & 31u) * 32u + (col >> 5)];   // (<= 256 rows per block)
     }
-}
-// column counts = sum of the blocks' partial counts; gridDim.y slices of the blocks, one atomic per column and slice
-__global__ void __launch_bounds__(256) k_cv_sum_partials(const CvWork* __restrict__ Vt, u32 n_blocks)
-{
-    const CvWork& v = Vt[blockIdx.z];
-    const u32 col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= v.C) return;
-    const u32 per = (n_blocks + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(b0 + per, n_blocks);
-    u32 n = 0;
-    for (u32 b = b0; b < b1; b++) n += v.partial[(size_t)b * 1024 + col];
-    if (n) atomicAdd(&v.counts[col], n);
 }
 // The generation's NEW mutations (ras_add_mutation, :2497-2552) that fall on a CV position, applied to the offspring plane behind
 // k_stitch_small: ras_find_cv reads !founder where the position is in the covering part's mutation_pos (:2770-2775), so the
@@ -1153,20 +1156,58 @@ __global__ void __launch_bounds__(256) k_cv_count(const AdWork* __restrict__ At,
     for (; r < r1; r++) n += (col[r * stride] >> sh) & 1u;
     if (n) atomicAdd(&counts[c], n);
 }
-// frq[icv] = f / (2*n_human) in FILE order (:2655)
-__global__ void k_cv_freq(const AdWork* __restrict__ At, size_t n_human)
+// Column counts complete -> allele frequencies and the per-CV term table, in ONE launch: every block first adds its slice of
+// k_stitch_small's per-block partial counts to the column counters (n_blocks == 0: k_cv_count has filled them); the block that
+// finishes last (a counter per work entry) then turns the counters into frq[] and the table of the three possible A- and D-terms
+// per CV, computed with EXACTLY the expressions of the reference's per-individual loop (:2686-2712: same operations, same order,
+// so the sums stay bit-identical): tab[icv] = { (0-2p)alpha, (1-2p)alpha, (2-2p)alpha, -2pp*d, 2pq*d, -2qq*d }, and clears the
+// counters for the next generation.  (As separate launches behind one another these were two to three kernels of a few
+// microseconds each -- 75 us each next to the dense stitch.)
+__global__ void __launch_bounds__(256) k_cv_finish(const AdWork* __restrict__ At, u32 n_blocks, size_t n_human, u32* __restrict__ done, u32* __restrict__ nan_flag)
 {
-    const AdWork& a = At[blockIdx.y];
-    const u32 icv = blockIdx.x * blockDim.x + threadIdx.x;
-    if (icv >= a.C) return;
-    const double f = (double)a.counts[a.col_of_icv[icv]];
-    a.counts[a.col_of_icv[icv]] = 0;                    // every column is read by exactly one thread: cleared for the next k_cv_count
-    a.frq[icv] = f / (double)(2 * n_human);
+    __shared__ bool s_last;
+    const AdWork& aw = At[blockIdx.z];
+    const u32 col = blockIdx.x * 256 + threadIdx.x;
+    if (n_blocks && col < aw.C) {
+        const u32 per = (n_blocks + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(b0 + per, n_blocks);
+        u32 n = 0;
+        for (u32 b = b0; b < b1; b++) n += aw.partial[(size_t)b * 1024 + col];
+        if (n) atomicAdd(&aw.counts[col], n);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&done[blockIdx.z], 1u) == gridDim.x * gridDim.y - 1u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) { done[blockIdx.z] = 0; if (blockIdx.z == 0) *nan_flag = 0xffffffffu; }     // (the A/D kernels of this launch sequence report the first NaN individual with atomicMin)
+    for (u32 icv = threadIdx.x; icv < aw.C; icv += 256) {
+        const u32 c = aw.col_of_icv[icv];
+        const double f = (double)atomicExch(&aw.counts[c], 0u);     // every column is read by exactly one thread; read at the L2, where the atomics landed
+        const double p = f / (double)(2 * n_human);
+        aw.frq[icv] = p;
+        if (!aw.tab) continue;                                      // (several root populations: k_ad_accumulate looks a and d up per haplotype)
+        const u64 x = aw.pos_file[icv];
+        const bool covered = (x >= aw.bp0 && x < aw.bp_end);
+        const double a0 = covered ? aw.a[icv] : 0.0, d0 = covered ? aw.d[icv] : 0.0;
+        const double a = (a0 + a0) / 2;
+        double d = (d0 + d0) / 2;
+        if (aw.vd == 0) d = 0;
+        const double q = 1 - p;
+        const double alpha = a + d * (q - p);
+        double* t = aw.tab + 6 * (size_t)icv;
+        t[0] = ((double)0u - 2 * p) * alpha;
+        t[1] = ((double)1u - 2 * p) * alpha;
+        t[2] = ((double)2u - 2 * p) * alpha;
+        t[3] = (-2 * p * p) * d;
+        t[4] = (2 * p * q) * d;
+        t[5] = (-2 * q * q) * d;
+    }
 }
 // per individual, CVs in FILE order, sequential FP64 (no contraction: built with -ffp-contract=off):
 //   A += (t - 2p)(a + d(q-p));  D += {-2pp, 2pq, -2qq}[t] * d      (:2686-2712)
 // a, d are the mean of the two haplotypes' root-population values (:2695-2696)
-__global__ void __launch_bounds__(256) k_ad_accumulate(const AdWork* __restrict__ At, u32 rp_bits, size_t n_human, size_t out_stride, u32* __restrict__ nan_flag)
+__global__ void __launch_bounds__(256) k_ad_accumulate(const AdWork* __restrict__ At, u32 rp_bits, size_t n_human, size_t out_stride, size_t tot_stride, u32* __restrict__ nan_flag)
 {
     const AdWork& aw = At[blockIdx.y];
     const u32 sub_w32 = aw.sub_w32; const u32* __restrict__ plane = aw.cvp; const u32 stride_w32 = aw.stride_w32;
@@ -1206,44 +1247,15 @@ __global__ void __launch_bounds__(256) k_ad_accumulate(const AdWork* __restrict_
     }
     add_out[ih * out_stride] = A_chr;
     dom_out[ih * out_stride] = D_chr;
+    if (aw.add_tot) { aw.add_tot[ih * tot_stride] = 0.0 + A_chr; aw.dom_tot[ih * tot_stride] = 0.0 + D_chr; }   // one chromosome: the sum over chromosomes (:2729-2746) is 0 + x
     if (A_chr != A_chr || D_chr != D_chr) atomicMin(nan_flag, (u32)(ih < 0xffffffffull ? ih : 0xfffffffeull));
-}
-// Single-root-population fast path.  Per CV the three possible contributions are computed once
-// with EXACTLY the expressions of the per-individual loop (same operations, same order, so the
-// sums stay bit-identical):  tab[icv] = { (0-2p)alpha, (1-2p)alpha, (2-2p)alpha, -2pp*d, 2pq*d, -2qq*d }.
-__global__ void k_cv_table(const AdWork* __restrict__ At, size_t n_human)
-{
-    const AdWork& aw = At[blockIdx.y];
-    u32* __restrict__ counts = aw.counts; const u32* __restrict__ col_of_icv = aw.col_of_icv; const u32 Cn = aw.C;
-    const double* __restrict__ a_file = aw.a; const double* __restrict__ d_file = aw.d; const u64* __restrict__ cvpos_file = aw.pos_file;
-    const u64 bp0 = aw.bp0, bp_end = aw.bp_end; const double vd = aw.vd; double* __restrict__ frq = aw.frq; double* __restrict__ tab = aw.tab;
-    const u32 icv = blockIdx.x * blockDim.x + threadIdx.x;
-    if (icv >= Cn) return;
-    const double f = (double)counts[col_of_icv[icv]];
-    counts[col_of_icv[icv]] = 0;                        // every column is read by exactly one thread: cleared for the next k_cv_count
-    const double p = f / (double)(2 * n_human);
-    frq[icv] = p;
-    const u64 x = cvpos_file[icv];
-    const bool covered = (x >= bp0 && x < bp_end);
-    const double a0 = covered ? a_file[icv] : 0.0, d0 = covered ? d_file[icv] : 0.0;
-    const double a = (a0 + a0) / 2;
-    double d = (d0 + d0) / 2;
-    if (vd == 0) d = 0;
-    const double q = 1 - p;
-    const double alpha = a + d * (q - p);
-    tab[6 * icv + 0] = ((double)0u - 2 * p) * alpha;
-    tab[6 * icv + 1] = ((double)1u - 2 * p) * alpha;
-    tab[6 * icv + 2] = ((double)2u - 2 * p) * alpha;
-    tab[6 * icv + 3] = (-2 * p * p) * d;
-    tab[6 * icv + 4] = (2 * p * q) * d;
-    tab[6 * icv + 5] = (-2 * q * q) * d;
 }
 // One thread per individual; the block's 2*IPB haplotype rows are staged through LDS with a
 // coalesced read ([hap][individual][S+1] layout: row stride S+1 words is odd -> conflict-free
 // column reads).  col_of_icv / tab are wave-uniform (scalar loads); t selects per lane.
 #define AD_CHUNK 128          // CVs whose table entries sit in LDS at a time
 template <int IPB>
-__global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restrict__ At, u32 s1_max, size_t n_human, size_t out_stride, u32* __restrict__ nan_flag, int direct)
+__global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restrict__ At, u32 s1_max, size_t n_human, size_t out_stride, size_t tot_stride, u32* __restrict__ nan_flag, int direct)
 {
     // direct (every CV file of the launch is in position order): a thread walks its two rows word by word, 32 CVs per word, so
     // it reads them straight from global memory (256 contiguous bytes per individual) and the launch passes s1_max = 0: only the
@@ -1326,17 +1338,18 @@ __global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restr
     const size_t ih = ih0 + threadIdx.x;
     add_out[ih * out_stride] = A_chr;
     dom_out[ih * out_stride] = D_chr;
+    if (aw.add_tot) { aw.add_tot[ih * tot_stride] = 0.0 + A_chr; aw.dom_tot[ih * tot_stride] = 0.0 + D_chr; }   // one chromosome: the sum over chromosomes (:2729-2746) is 0 + x
     if (A_chr != A_chr || D_chr != D_chr) atomicMin(nan_flag, (u32)(ih < 0xffffffffull ? ih : 0xfffffffeull));
 }
-// sum over chromosomes in order (:2729-2746)
-__global__ void k_ad_sum_chr(const double* __restrict__ chr_vals /*[n][nchr][nphen]*/, double* __restrict__ tot /*[n][nphen]*/, size_t n, int nchr, int nphen)
+// sum over chromosomes in order (:2729-2746), additive and dominance values in one launch
+__global__ void k_ad_sum_chr(const double* __restrict__ add_chr /*[n][nchr][nphen]*/, const double* __restrict__ dom_chr, double* __restrict__ add /*[n][nphen]*/, double* __restrict__ dom, size_t n, int nchr, int nphen)
 {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n * nphen) return;
     const size_t ih = q / nphen; const int p = (int)(q % nphen);
-    double s = 0;
-    for (int c = 0; c < nchr; c++) s += chr_vals[(ih * nchr + c) * nphen + p];
-    tot[q] = s;
+    double sa = 0, sd = 0;
+    for (int c = 0; c < nchr; c++) { sa += add_chr[(ih * nchr + c) * nphen + p]; sd += dom_chr[(ih * nchr + c) * nphen + p]; }
+    add[q] = sa; dom[q] = sd;
 }
 
 // ------------------------------------------------------------------------------------------

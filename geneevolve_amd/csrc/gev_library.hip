@@ -120,7 +120,7 @@ struct ChrStatic {                       // one population x one chromosome
     std::vector<u64> rbp; std::vector<double> rprob; u64 bp_dist = 0;
     std::vector<u64> mbp; std::vector<double> mrate; bool mut_set = false;
     std::vector<u64> pos;                // Legend.pos
-    DevBuf d_rthr, d_rbp, d_mthr, d_mbp, d_pos;
+    DevBuf d_rthr, d_rbp, d_mthr, d_mbp, d_pos, d_coarse;
     size_t L = 0, stride = 0;            // bytes of a whole genotype row in flat (host-side / staging) layouts, multiple of 128
     u32 nseg = 1, seg_shift = 9;         // the device keeps a row as nseg segments of 2^seg_shift 16-byte chunks (gev_kernels.h, PoolWork)
     size_t unit_bytes() const { return (size_t)16 << seg_shift; }
@@ -257,6 +257,7 @@ struct gev_ctx {
     DevBuf d_snpmajor, d_text;
     DevBuf d_mflag, d_mblk, d_posm, d_posf, d_pickblk, d_couples, d_svf, d_logical, d_globblk, d_mstat;   // gev_random_mate / gev_glob_seeds scratch
     DevBuf d_gef_flag, d_gef_first, d_gef_red, d_gef_io;
+    DevBuf d_cvdone;
     DevBuf d_cnt, d_sums, d_map, d_cvm, d_addchr, d_domchr, d_add, d_dom, d_flag, d_stage, d_thr32, d_tmp;
     // per-generation work tables (gev_kernels.h: ChrWork / CvWork / AdWork) are written into a ring of pinned host memory and
     // copied to the device on the stream that uses them
@@ -782,8 +783,25 @@ static int finalize_static(gev_ctx* c, int pop)
         const u64 bp0 = S.rbp.front(), bpe = S.rbp.back();
         S.idx_lo = (u32)(std::lower_bound(S.pos.begin(), S.pos.end(), bp0) - S.pos.begin());
         S.idx_hi = (u32)(std::lower_bound(S.pos.begin(), S.pos.end(), bpe) - S.pos.begin());
+        // coarse index over the SNP positions: buckets of 2^shift base pairs holding about eight loci each (at most 2^21 buckets)
+        u64 cbase = 0; u32 cshift = 0, cn = 0;
+        if (S.L) {
+            cbase = S.pos.front();
+            const u64 span = S.pos.back() - cbase + 1;
+            while (cshift < 63 && ((span >> cshift) > std::max<u64>(S.L / 8, 1) || (span >> cshift) > (1ull << 21))) cshift++;
+            cn = (u32)((span >> cshift) + 1);
+            std::vector<u32> coarse(cn + 1);
+            size_t at = 0;
+            for (u32 j = 0; j <= cn; j++) {                      // coarse[j] = lower_bound(pos, cbase + (j << cshift)): one sweep
+                const u64 x = cbase + ((u64)j << cshift);
+                while (at < S.L && S.pos[at] < x) at++;
+                coarse[j] = (u32)at;
+            }
+            GEVC(h2d(c, S.d_coarse, coarse.data(), coarse.size() * sizeof(u32)));
+        }
         cd[k] = ChrDev{S.d_rthr.as<GevThr>(), S.d_rbp.as<u64>(), S.d_mthr.as<GevThr>(), S.d_mbp.as<u64>(), S.bp_dist, bp0, bpe,
-                       (u32)S.rbp.size(), (u32)S.mbp.size(), S.r_amax, S.m_amax, S.d_pos.as<u64>(), (u32)S.L, (u32)c->chr_active[k]};
+                       (u32)S.rbp.size(), (u32)S.mbp.size(), S.r_amax, S.m_amax, S.d_pos.as<u64>(), (u32)S.L, (u32)c->chr_active[k],
+                       S.d_coarse.as<u32>(), cbase, cshift, cn};
         for (int p = 0; p < c->nphen; p++) {
             CvStatic& V = P.cv[p][k];
             if (!V.set) continue;
@@ -1012,7 +1030,6 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
     } else {
         hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, seed_reproduce, seed_ptr, T, sd);
     }
-    hipLaunchKernelGGL(k_bk_to_idx, dim3((unsigned)ceil_div(2 * T, 256)), dim3(256), 0, st, chrs, nchr, 2 * T, sd);
     KCHECK();
     HIPC(hipEventRecord(sc.t[1], st));
     return GEV_OK;
@@ -1109,7 +1126,7 @@ static int enqueue_pool_assign(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people
     if (!c->dense || !sc.n_chrwork) return GEV_OK;
     const size_t rows = 2 * n_people, T = n_people * (size_t)c->nchr;
     SampleDev sd = make_sd(c, sc, T);
-    u32 lg = 0; while ((1u << lg) < sc.nseg_max) lg++;               // rows per block of k_pool_inherit: 256 >> lg
+    u32 lg = 0; while ((1u << lg) * POOL_INH < sc.nseg_max) lg++;    // threads per row of k_pool_inherit: 2^lg, rows per block: 256 >> lg
     hipLaunchKernelGGL(k_pool_inherit, dim3((unsigned)ceil_div(rows, (size_t)(256u >> lg)), sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, c->nchr, sd, lg);
     hipLaunchKernelGGL(k_pool_fresh, dim3((unsigned)ceil_div(rows, 256), sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, c->nchr, sd);
     hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(64), 0, st, sc.chrwork.as<ChrWork>(), sc.n_chrwork, sd.status);
@@ -1161,10 +1178,6 @@ static int enqueue_cv_planes(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, 
     if (c->cv_threads == 256) hipLaunchKernelGGL((k_stitch_small<256>), grid, dim3(256), lds, st, Vt, nsub, rows, nchr, sd, sc.cv_max, (int)count_cols);
     else if (c->cv_threads == 1024) hipLaunchKernelGGL((k_stitch_small<1024>), grid, dim3(1024), lds, st, Vt, nsub, rows, nchr, sd, sc.cv_max, (int)count_cols);
     else hipLaunchKernelGGL((k_stitch_small<512>), grid, dim3(512), lds, st, Vt, nsub, rows, nchr, sd, sc.cv_max, (int)count_cols);
-    if (count_cols) {
-        const unsigned nblk = (unsigned)ceil_div(rows, SMALL_ROWS_PER_BLOCK);
-        hipLaunchKernelGGL(k_cv_sum_partials, dim3(4, std::min(nblk, 32u), sc.n_cvwork), dim3(256), 0, st, Vt, nblk);
-    }
     if (has_mut) hipLaunchKernelGGL(k_cv_newmut, dim3((unsigned)ceil_div(n_people, 256), sc.n_cvwork), dim3(256), 0, st, Vt, sc.chrwork.as<ChrWork>(), n_people, nchr, sd, (int)count_cols);
     KCHECK();
     return GEV_OK;
@@ -1818,7 +1831,7 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready,
     GEVC(c->d_addchr.ensure(n * nchr * nphen * sizeof(double), st)); GEVC(c->d_domchr.ensure(n * nchr * nphen * sizeof(double), st));
     GEVC(c->d_add.ensure(n * nphen * sizeof(double), st)); GEVC(c->d_dom.ensure(n * nphen * sizeof(double), st));
     GEVC(c->d_flag.ensure(16, st));
-    HIPC(hipMemsetAsync(c->d_flag.p, 0xff, 4, st));
+    if (!c->d_cvdone.p) { GEVC(c->d_cvdone.ensure((size_t)nchr * nphen * sizeof(u32), st)); HIPC(hipMemsetAsync(c->d_cvdone.p, 0, (size_t)nchr * nphen * sizeof(u32), st)); }   // k_cv_finish's block counters (they re-zero themselves)
     c->ad_host_set_pop = -1;                                 // d_add / d_dom are rewritten below: totals handed in by gev_set_ad are gone
     if (c->any_inactive) {                                   // chromosomes held elsewhere contribute exact zeros here
         HIPC(hipMemsetAsync(c->d_addchr.p, 0, n * nchr * nphen * sizeof(double), st)); HIPC(hipMemsetAsync(c->d_domchr.p, 0, n * nchr * nphen * sizeof(double), st));
@@ -1846,8 +1859,11 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready,
             a.cvp = P.cvp[p][k][buf].as<u32>();
             a.pos_sorted = V.d_pos_sorted.as<u64>(); a.pos_file = V.d_pos_file.as<u64>(); a.col_of_icv = V.d_col_of_icv.as<u32>();
             a.a = V.d_a.as<double>(); a.d = V.d_d.as<double>(); a.aptr = V.d_aptr.as<const double*>(); a.dptr = V.d_dptr.as<const double*>();
-            a.counts = V.d_counts.as<u32>(); a.frq = V.d_frq.as<double>(); a.tab = V.d_tab.as<double>();
+            a.counts = V.d_counts.as<u32>(); a.frq = V.d_frq.as<double>(); a.tab = ipb ? V.d_tab.as<double>() : nullptr;
             a.add_out = c->d_addchr.as<double>() + (size_t)k * nphen + p; a.dom_out = c->d_domchr.as<double>() + (size_t)k * nphen + p;
+            const bool one_chr = nchr == 1;                                     // the sum over chromosomes is 0 + x: written with the per-chromosome value
+            a.add_tot = one_chr ? c->d_add.as<double>() + p : nullptr; a.dom_tot = one_chr ? c->d_dom.as<double>() + p : nullptr;
+            a.partial = counts_ready ? V.d_partial.as<uint16_t>() : nullptr;
             a.bp0 = S.rbp.front(); a.bp_end = S.rbp.back(); a.vd = V.vd;
             a.stride_w32 = V.stride_w32; a.sub_w32 = V.sub_w32; a.C = V.C; a.own_pop = pop; a.cols_sorted = V.cols_sorted ? 1u : 0u;
             aw.push_back(a);
@@ -1856,34 +1872,35 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready,
     if (nw) {
         GEVC(upload_table(c, c->d_adwork, aw.data(), aw.size() * sizeof(AdWork), st));
         const AdWork* At = c->d_adwork.as<AdWork>();
-        const size_t out_stride = (size_t)nchr * nphen;
+        const size_t out_stride = (size_t)nchr * nphen, tot_stride = (size_t)nphen;
+        u32* flag = c->d_flag.as<u32>();
         if (c_max && !counts_ready) {
             const unsigned gy = (unsigned)std::min<size_t>(std::max<size_t>(rows / 512, 1), 256);
             hipLaunchKernelGGL(k_cv_count, dim3((unsigned)ceil_div(c_max, 256), gy, nw), dim3(256), 0, st, At, rows);
         }
+        // counts -> frequencies (+ the term table of the fast path), NaN flag reset: one launch
+        const unsigned nblk = counts_ready ? (unsigned)ceil_div(rows, SMALL_ROWS_PER_BLOCK) : 0u;
+        hipLaunchKernelGGL(k_cv_finish, dim3((unsigned)std::max<size_t>(ceil_div(c_max, 256), 1), nblk ? std::min(nblk, 32u) : 1u, nw), dim3(256), 0, st, At, nblk, n, c->d_cvdone.as<u32>(), flag);
         if (ipb) {
-            hipLaunchKernelGGL(k_cv_table, dim3((unsigned)ceil_div(c_max, 256), nw), dim3(256), 0, st, At, n);
             bool direct = true;                                  // every CV file in position order: rows are read from global memory, no row staging
             for (const AdWork& a : aw) direct &= a.cols_sorted != 0;
             if (direct) {
                 const unsigned nb = (unsigned)ceil_div(n, 256);
-                hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), ad_tab_lds, st, At, 0u, n, out_stride, c->d_flag.as<u32>(), 1);
+                hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), ad_tab_lds, st, At, 0u, n, out_stride, tot_stride, flag, 1);
             } else {
                 const size_t lds = (size_t)2 * ipb * S1 * 4 + ad_tab_lds;
                 const unsigned nb = (unsigned)ceil_div(n, ipb);
-                if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>(), 0);
-                else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb, nw), dim3(128), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>(), 0);
-                else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb, nw), dim3(64), lds, st, At, S1, n, out_stride, c->d_flag.as<u32>(), 0);
+                if (ipb == 256) hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), lds, st, At, S1, n, out_stride, tot_stride, flag, 0);
+                else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb, nw), dim3(128), lds, st, At, S1, n, out_stride, tot_stride, flag, 0);
+                else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb, nw), dim3(64), lds, st, At, S1, n, out_stride, tot_stride, flag, 0);
             }
-        } else {
-            if (c_max) hipLaunchKernelGGL(k_cv_freq, dim3((unsigned)ceil_div(c_max, 256), nw), dim3(256), 0, st, At, n);
-            hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256), nw), dim3(256), 0, st, At, c->rp_bits, n, out_stride, c->d_flag.as<u32>());
-        }
+        } else hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256), nw), dim3(256), 0, st, At, c->rp_bits, n, out_stride, tot_stride, flag);
+        KCHECK();
+    } else HIPC(hipMemsetAsync(c->d_flag.p, 0xff, 4, st));
+    if (nchr > 1 || !nw) {                                   // one chromosome: the A/D kernels wrote the totals themselves
+        hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_addchr.as<double>(), c->d_domchr.as<double>(), c->d_add.as<double>(), c->d_dom.as<double>(), n, nchr, nphen);
         KCHECK();
     }
-    hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_addchr.as<double>(), c->d_add.as<double>(), n, nchr, nphen);
-    hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_domchr.as<double>(), c->d_dom.as<double>(), n, nchr, nphen);
-    KCHECK();
     // results to the pinned host cache: [flag | additive | dominance].  The per-chromosome arrays stay on the device and are
     // copied when gev_compute_ad is asked for them.  vd == 0 for every phenotype: the reference zeroes d (:2698-2699), every
     // D-term is (+-0) * ... and the running sums stay +0.0 exactly -- nothing to copy, gev_compute_ad fills zeros.

@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(256, 4) k_rec_sample8(const GevRngTables* __re
                     const u64 v = C.rbp[row] + (dist > 0x7fffffffull ? (u64)rv : (u64)(rv % (u32)dist));
                     const size_t G = 2 * (b * SB_TASKS + tg) + side;
                     sd.bk[G * GEV_BK_CAP + h] = v;
+                    sd.bk_idx[G * GEV_BK_CAP + h] = snp_lower_bound(C, v);     // first locus at or behind the breakpoint (what the dense stitch and the unit table work with)
                 }
             }
             count = 0;

@@ -22,6 +22,7 @@ function signatures / the one marker comment, not by line numbers):
                   ras_init_generation0 / sim_next_generation   population[ipop].ras_save_human_info(gen_num) -> gevglue_save_human_info
                                             (the same .info bytes, written once instead of flushed per individual)
                   ras_scale_AD_compute_GEF  + first statement: with GEV_GEF_DEVICE=1 return gevglue_scale_gef (gev_scale_ad_compute_gef)
+                  random_mate               + first statement: return gevglue_random_mate (gev_random_mate) unless GEV_MATE_HOST=1
 """
 import os
 import re
@@ -86,7 +87,8 @@ def build(out_name, backend_link, extra_sources=()):
             "bool gevglue_write_interval(Simulation&, int);\n"
             "bool gevglue_save_human_info(Simulation&, int, int);\n"
             "bool gevglue_presample(Simulation&, int, int);\nstd::vector<unsigned long int> gevglue_rank(std::vector<double>&);\n"
-            "bool gevglue_use_device_gef();\nbool gevglue_scale_gef(Simulation&, int, int, int, double, double);\n")
+            "bool gevglue_use_device_gef();\nbool gevglue_scale_gef(Simulation&, int, int, int, double, double);\n"
+            "bool gevglue_use_device_mate();\nbool gevglue_random_mate(Simulation&, int, int);\n")
     inc = re.search(r'#include\s+"Simulation.h"', cpp)
     cpp = cpp[:inc.end()] + decl + cpp[inc.end():]
     cpp = insert_before_last_return_true(cpp, r"^bool\s+Simulation::ras_init_parameters\s*\(", "if (!gevglue_init_static(*this)) return false;")
@@ -110,6 +112,9 @@ def build(out_name, backend_link, extra_sources=()):
     # ras_scale_AD_compute_GEF (:3075): optional device version (GEV_GEF_DEVICE=1), else the function's own body
     i, j = body_span(cpp, r"^bool\s+Simulation::ras_scale_AD_compute_GEF\s*\(")
     cpp = cpp[:i + 1] + "\n    if (gevglue_use_device_gef()) return gevglue_scale_gef(*this, gen_num, ipop, iphen, s2_a_gen0, s2_d_gen0);\n" + cpp[i + 1:]
+    # random_mate (:2090): the library forms the couples (gev_random_mate); the function's own body stays behind GEV_MATE_HOST=1
+    i, j = body_span(cpp, r"^bool\s+Simulation::random_mate\s*\(\s*int\s+ipop\s*,\s*int\s+gen_ind\s*\)")
+    cpp = cpp[:i + 1] + "\n    if (gevglue_use_device_mate()) return gevglue_random_mate(*this, ipop, gen_ind);\n" + cpp[i + 1:]
     # Population::ras_save_human_info call sites (:610, :2018): same bytes, one write instead of one flush per individual
     n_calls = cpp.count("population[ipop].ras_save_human_info(gen_num);")
     if n_calls != 2:

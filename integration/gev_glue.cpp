@@ -205,6 +205,39 @@ struct GevGlue {
         return true;
     }
 
+    // Simulation::random_mate (:2090-2157) in the library: the same ras_glob_seed() draw, the same stdout lines, the couples
+    // filled into _couples_info from what gev_random_mate returns.  GEV_MATE_HOST=1 keeps the reference's own function.
+    static bool use_device_mate() { static const bool off = getenv("GEV_MATE_HOST") && atoi(getenv("GEV_MATE_HOST")) != 0; return !off; }
+    static bool random_mate(Simulation& S, int ipop, int gen_ind)
+    {
+        Population& P = S.population[ipop];
+        const unsigned seed = S.ras_glob_seed();                                        // :2092
+        const unsigned long n_h = P.h.size(), pop_size = P._pop_size[gen_ind];
+        if (S._debug) {
+            std::cout << "Debug: Simulation::random_mate; seed=" << seed << std::endl;
+            std::cout << "Debug: Simulation::random_mate; n_h=" << n_h << std::endl;
+        }
+        std::vector<double> svf(n_h);
+        bool all_one = true;
+        for (unsigned long i = 0; i < n_h; i++) { svf[i] = P.h[i].selection_value_func; all_one &= svf[i] == 1.0; }
+        std::vector<gev_couple> cpl(pop_size);
+        size_t nm = 0, nf = 0;
+        const int rc = gev_random_mate(ctx(), ipop, seed, all_one ? NULL : svf.data(), pop_size, cpl.data(), &nm, &nf);
+        if (rc == GEV_OK || rc == GEV_ENOMATE) {
+            std::cout << "        num_males_mate    = " << nm << std::endl;              // :2122-2123
+            std::cout << "        num_females_mate  = " << nf << std::endl;
+        }
+        if (rc == GEV_ENOMATE) { std::cout << gev_last_error() << std::endl; return false; }   // the reference's own line (:2127)
+        if (rc) return fail("gev_random_mate");
+        std::vector<Couples_Info> couples_info(pop_size);
+        for (unsigned long i = 0; i < pop_size; i++) {
+            couples_info[i].pos_male = cpl[i].pos_male; couples_info[i].pos_female = cpl[i].pos_female;
+            couples_info[i].inbreed = false; couples_info[i].num_offspring = 1;          // :2148-2149
+        }
+        P._couples_info = couples_info;
+        return true;
+    }
+
     // CommFunc::ras_rank (src/CommFunc.cpp:152-161) for assort_mate (:2278-2279): O(n^2) on the host, a stable sort on the device
     static std::vector<unsigned long int> rank(std::vector<double>& x)
     {
@@ -406,4 +439,6 @@ bool gevglue_presample(Simulation& S, int ipop, int gen_num) { return GevGlue::p
 bool gevglue_save_human_info(Simulation& S, int ipop, int gen_num) { return GevGlue::save_human_info(S, ipop, gen_num); }
 std::vector<unsigned long int> gevglue_rank(std::vector<double>& x) { return GevGlue::rank(x); }
 bool gevglue_use_device_gef() { return GevGlue::use_device_gef(); }
+bool gevglue_use_device_mate() { return GevGlue::use_device_mate(); }
+bool gevglue_random_mate(Simulation& S, int ipop, int gen_ind) { return GevGlue::random_mate(S, ipop, gen_ind); }
 bool gevglue_scale_gef(Simulation& S, int gen_num, int ipop, int iphen, double s2_a_gen0, double s2_d_gen0) { return GevGlue::scale_gef(S, gen_num, ipop, iphen, s2_a_gen0, s2_d_gen0); }

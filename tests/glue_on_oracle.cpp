@@ -23,11 +23,13 @@ int gevo_download_plink_matrix(Ctx*, int, int, size_t, size_t, uint64_t*, size_t
 int gevo_download_intervals(Ctx*, int, int, gev_part*, uint64_t*, size_t*);
 
 int gevo_rank_f64(Ctx*, const double*, size_t, unsigned long long*);
+int gevo_random_mate(Ctx*, int, uint32_t, const double*, size_t, gev_couple*, size_t*, size_t*);
 int gevo_scale_ad_compute_gef(Ctx*, int, int, const gev_gef_params*, uint32_t, const double*, const double*, const double*, double*, double*, double*, double*, double*, double*);
 
 const char* gev_last_error(void) { return gevo_last_error(); }
 int gev_presample(gev_ctx*, int, uint32_t, const uint32_t*, size_t, size_t) { return 0; }      // a head start only: the oracle samples inside reproduce
 int gev_rank_f64(gev_ctx* c, const double* x, size_t n, unsigned long long* r) { return gevo_rank_f64((Ctx*)c, x, n, r); }
+int gev_random_mate(gev_ctx* c, int p, uint32_t seed, const double* svf, size_t n, gev_couple* out, size_t* nm, size_t* nf) { return gevo_random_mate((Ctx*)c, p, seed, svf, n, out, nm, nf); }
 int gev_scale_ad_compute_gef(gev_ctx* c, int p, int ph, const gev_gef_params* par, uint32_t seed, const double* cs, const double* ff, const double* fm,
                              double* a, double* d, double* bv, double* e, double* pe, double* phen)
 { return gevo_scale_ad_compute_gef((Ctx*)c, p, ph, par, seed, cs, ff, fm, a, d, bv, e, pe, phen); }
