@@ -184,8 +184,10 @@ struct gev_ctx {
     // while sampling / sparse state of generation g+1 (stream) fill the other one
     struct Scratch {
         DevBuf father, mother, mutseeds, globvals /* [2 + T] ras_glob_seed() values drawn on the device: mate seed, reproduce seed, mutation seeds */, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, status, slow_mut, slow_rec, chrwork, cvwork;
+        std::vector<uint8_t> chrwork_shadow, cvwork_shadow;     // what the device copies of the tables hold (upload_table_cached)
         unsigned n_chrwork = 0, n_cvwork = 0; float sampling_ms_saved = -1;
         size_t nseg_max = 1, cv_used_max = 0, mut_avg = 0, parts_avg = 0; u32 cv_max = 0;     // launch shapes of the generation (enqueue_tables)
+        bool pool_rebuild = false;                                                            // this attempt rebuilds the free list of the segment pool
         bool cv_count_fused = false;                                                          // k_stitch_small also counts the alleles per CV column (every grid <= 1024 columns)
         hipEvent_t ev_fork = nullptr, ev_aux = nullptr, ev_lists = nullptr, ev_forked = nullptr;   // joins of the attempt's side streams
         hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_status = nullptr, ev_sampled = nullptr;   // the generation's status block (and A/D results) have arrived on the host
@@ -262,7 +264,7 @@ struct gev_ctx {
     // per-generation work tables (gev_kernels.h: ChrWork / CvWork / AdWork) are written into a ring of pinned host memory and
     // copied to the device on the stream that uses them
     uint8_t* h_ring = nullptr; size_t h_ring_bytes = 0, h_ring_off = 0;
-    DevBuf d_adwork;
+    DevBuf d_adwork2[2]; std::vector<uint8_t> adwork_shadow[2];
     std::map<double, GevThr> thr_cache;
 };
 
@@ -569,10 +571,10 @@ static PoolWork pool_work(const gev_ctx* c, PopState& P, int chr, int alt)
     pw.nseg = S.nseg; pw.seg_shift = S.seg_shift;
     pw.pool_units = (u32)(4 * P.cap_people * S.nseg); pw.alias = c->alias_rows ? 1u : 0u;
     pw.items = cs.items[P.cur ^ 1].as<StitchItem>(); pw.items_cap = (u32)(2 * P.cap_people * S.nseg);
-    if (++cs.pool_stamp == 0) cs.pool_stamp = 1;          // (a stale mark of 2^32 rebuilds ago could only keep a free row out of one free list)
-    pw.stamp = cs.pool_stamp;
+    pw.stamp = cs.pool_stamp;                             // (pool_new_stamp before a rebuild of the free list)
     return pw;
 }
+static void pool_new_stamp(ChrState& cs) { if (++cs.pool_stamp == 0) cs.pool_stamp = 1; }   // (a stale mark of 2^32 rebuilds ago could only keep a free unit out of one free list)
 // read access to the current generation's rows / a flat buffer of whole rows, for the kernels that move or read rows
 static RowMap row_map(const PopState& P, int chr)
 {
@@ -945,6 +947,9 @@ static int harvest_timing(gev_ctx* c, gev_ctx::Scratch& sc)
 }
 // host table -> device buffer `dst` on stream `st`, staged through the pinned ring (the host copy must stay valid until the
 // asynchronous copy has run: a slot is reused only after a wrap, which waits for the stream)
+// ... unless the device copy already holds exactly these bytes (the tables of a scratch set repeat from generation to generation
+// as long as no buffer moved): `shadow` = host copy of what was uploaded last
+static int upload_table_cached(gev_ctx* c, DevBuf& dst, std::vector<uint8_t>& shadow, const void* src, size_t bytes, hipStream_t st);
 static int upload_table(gev_ctx* c, DevBuf& dst, const void* src, size_t bytes, hipStream_t st)
 {
     GEVC(dst.ensure(std::max<size_t>(bytes, 16), st));
@@ -963,6 +968,15 @@ static int upload_table(gev_ctx* c, DevBuf& dst, const void* src, size_t bytes, 
     memcpy(c->h_ring + c->h_ring_off, src, bytes);
     HIPC(hipMemcpyAsync(dst.p, c->h_ring + c->h_ring_off, bytes, hipMemcpyHostToDevice, st));
     c->h_ring_off += need;
+    return GEV_OK;
+}
+static int upload_table_cached(gev_ctx* c, DevBuf& dst, std::vector<uint8_t>& shadow, const void* src, size_t bytes, hipStream_t st)
+{
+    if (dst.p && shadow.size() == bytes && bytes && memcmp(shadow.data(), src, bytes) == 0) return GEV_OK;
+    const void* before = dst.p;
+    GEVC(upload_table(c, dst, src, bytes, st));
+    (void)before;
+    shadow.assign((const uint8_t*)src, (const uint8_t*)src + bytes);
     return GEV_OK;
 }
 static SampleDev make_sd(gev_ctx* c, gev_ctx::Scratch& sc, size_t T)
@@ -1048,6 +1062,20 @@ static int enqueue_tables(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     const int cur = P.cur, alt = P.cur ^ 1;
     const double grow = (double)rows / (double)std::max<size_t>(2 * P.n_people, 1);
     std::vector<ChrWork> cw; std::vector<CvWork> vw;
+    // The free list of the segment pool is kept across generations (units nobody named when it was built and that were not handed
+    // out since are still unnamed) and rebuilt only when what is left of it may not cover the generation: four times what the last
+    // generation took, at least a quarter of a generation's segments.  Should a generation need more than is left (k_pool_fresh
+    // raises FLAG_POOL), it is enqueued again behind a rebuild.  GEV_POOL_REBUILD=1: every generation (the round-2 behaviour).
+    static const bool always = getenv("GEV_POOL_REBUILD") && atoi(getenv("GEV_POOL_REBUILD")) != 0;
+    sc.pool_rebuild = always;
+    if (c->dense) for (int k = 0; k < nchr; k++) {
+        if (!c->chr_active[k]) continue;
+        ChrState& cs = P.st[k];
+        const size_t left = cs.pool_n_free - std::min(cs.pool_cursor, cs.pool_n_free), gen_segs = 2 * n_people * P.cs[k].nseg;
+        const size_t need = c->alias_rows ? std::max<size_t>(4 * (size_t)cs.pool_last_taken, gen_segs / 4) : gen_segs;
+        sc.pool_rebuild |= !cs.pool_list_valid || cs.pool_force_rebuild || left < need;
+    }
+    if (sc.pool_rebuild) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) pool_new_stamp(P.st[k]);     // the marks of the rebuild
     for (int k = 0; k < nchr; k++) {
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
@@ -1087,31 +1115,17 @@ static int enqueue_tables(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     sc.mut_avg = 0; sc.parts_avg = 0;
     for (int k = 0; k < nchr; k++) if (c->chr_active[k]) { sc.mut_avg = std::max(sc.mut_avg, P.st[k].mut_total[cur] / rows_cur); sc.parts_avg = std::max(sc.parts_avg, P.st[k].parts_total[cur] / rows_cur); }
     if (sc.n_chrwork) {
-        GEVC(upload_table(c, sc.chrwork, cw.data(), cw.size() * sizeof(ChrWork), st));
-        GEVC(upload_table(c, sc.cvwork, vw.data(), vw.size() * sizeof(CvWork), st));
+        GEVC(upload_table_cached(c, sc.chrwork, sc.chrwork_shadow, cw.data(), cw.size() * sizeof(ChrWork), st));
+        GEVC(upload_table_cached(c, sc.cvwork, sc.cvwork_shadow, vw.data(), vw.size() * sizeof(CvWork), st));
     }
     return GEV_OK;
 }
 // free units of the pool = units no (slot, segment) of the parents names: needs the parents' table only, not this generation's
 // sampling or couples
-// The list is kept across generations (units nobody named when it was built and that were not handed out since are still
-// unnamed) and rebuilt only when what is left of it may not cover the generation: four times what the last generation took, at
-// least a quarter of a generation's segments.  Should a generation need more than is left (k_pool_assign raises FLAG_POOL), it is
-// enqueued again behind a rebuild.  GEV_POOL_REBUILD=1: every generation (the round-2 behaviour).
-static int enqueue_pool_free(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_people, hipStream_t st)
+static int enqueue_pool_free(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t /*n_people*/, hipStream_t st)
 {
     PopState& P = c->pop[pop];
-    if (!c->dense || !sc.n_chrwork) return GEV_OK;
-    static const bool always = getenv("GEV_POOL_REBUILD") && atoi(getenv("GEV_POOL_REBUILD")) != 0;
-    bool rebuild = always;
-    for (int k = 0; k < c->nchr; k++) {
-        if (!c->chr_active[k]) continue;
-        ChrState& cs = P.st[k];
-        const size_t left = cs.pool_n_free - std::min(cs.pool_cursor, cs.pool_n_free), gen_segs = 2 * n_people * P.cs[k].nseg;
-        const size_t need = c->alias_rows ? std::max<size_t>(4 * (size_t)cs.pool_last_taken, gen_segs / 4) : gen_segs;
-        rebuild |= !cs.pool_list_valid || cs.pool_force_rebuild || left < need;
-    }
-    if (!rebuild) return GEV_OK;
+    if (!c->dense || !sc.n_chrwork || !sc.pool_rebuild) return GEV_OK;      // (decided by enqueue_tables)
     const unsigned pool_blocks = (unsigned)std::min<size_t>(ceil_div(4 * P.cap_people * sc.nseg_max, 256), 1024);
     hipLaunchKernelGGL(k_pool_mark_tab, dim3(pool_blocks, sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), 2 * P.n_phys);
     hipLaunchKernelGGL(k_pool_collect_tab, dim3(pool_blocks, sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>());
@@ -1350,12 +1364,8 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     // choice, the NEXT generation's ALU-bound sampling (head start) is what should share the GPU with it.
     HIPC(hipEventRecord(sc.ev_forked, S));
     if (c->stitch_start == 0) { HIPC(hipEventRecord(sc.ev_small_done, S)); GEVC(enqueue_stitch(c, sc, q.pop, q.n_people)); }
-    if (L != S) HIPC(hipStreamWaitEvent(L, sc.ev_forked, 0));
-    // Human::sex of the new generation (:2472) for the next gev_random_mate; a fused generation also sends them to the host with the status block
-    HIPC(hipMemcpyAsync(P.d_sex[P.cur ^ 1].p, sc.sex.p, q.n_people, hipMemcpyDeviceToDevice, L));
-    if (q.fused) HIPC(hipMemcpyAsync(q.hsex, sc.sex.p, q.n_people, hipMemcpyDeviceToHost, L));
-    GEVC(enqueue_lists(c, sc, q.n_people, q.has_mut, L));
-    if (L != S) HIPC(hipEventRecord(sc.ev_lists, L));
+    // (the host enqueues slower than the device runs the first kernels of a generation: what the host waits for goes first, the
+    // list kernels, which nothing of the generation reads, last)
     // the column counters are filled while the planes are written only if the A/D kernels that consume (and clear) them follow in this attempt
     const bool ad_now = c->eager_ad && c->pop[q.pop].cv[0][0].d_aptr.p;
     const bool count_cols = ad_now && sc.cv_count_fused && sc.n_cvwork && sc.cv_used_max;
@@ -1366,6 +1376,12 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     if (c->ad_cached_pop != q.pop) c->ad_cached_pop = -1;    // (the device-side arrays are about to be rewritten; the published values of q.pop stay readable in their pinned buffer)
     c->ad_host_set_pop = -1;
     if (ad_now) GEVC(enqueue_ad(c, q.pop, c->pop[q.pop].cur ^ 1, q.n_people, count_cols, (int)(c->gen_counter & 1)));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
+    if (L != S) HIPC(hipStreamWaitEvent(L, sc.ev_forked, 0));
+    // Human::sex of the new generation (:2472) for the next gev_random_mate; a fused generation also sends them to the host with the status block
+    HIPC(hipMemcpyAsync(P.d_sex[P.cur ^ 1].p, sc.sex.p, q.n_people, hipMemcpyDeviceToDevice, L));
+    if (q.fused) HIPC(hipMemcpyAsync(q.hsex, sc.sex.p, q.n_people, hipMemcpyDeviceToHost, L));
+    GEVC(enqueue_lists(c, sc, q.n_people, q.has_mut, L));
+    if (L != S) HIPC(hipEventRecord(sc.ev_lists, L));
     if (L != S) HIPC(hipStreamWaitEvent(S, sc.ev_lists, 0));
     if (c->stitch_start >= 2) { HIPC(hipEventRecord(sc.ev_small_done, S)); GEVC(enqueue_stitch(c, sc, q.pop, q.n_people)); }
     HIPC(hipMemcpyAsync(q.hstatus, sc.status.p, q.n_status * sizeof(u32), hipMemcpyDeviceToHost, S));
@@ -1870,8 +1886,9 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready,
         }
     const unsigned nw = (unsigned)aw.size();
     if (nw) {
-        GEVC(upload_table(c, c->d_adwork, aw.data(), aw.size() * sizeof(AdWork), st));
-        const AdWork* At = c->d_adwork.as<AdWork>();
+        DevBuf& adw = c->d_adwork2[hbuf]; std::vector<uint8_t>& adw_shadow = c->adwork_shadow[hbuf];      // (one table per result buffer: they alternate with the generations)
+        GEVC(upload_table_cached(c, adw, adw_shadow, aw.data(), aw.size() * sizeof(AdWork), st));
+        const AdWork* At = adw.as<AdWork>();
         const size_t out_stride = (size_t)nchr * nphen, tot_stride = (size_t)nphen;
         u32* flag = c->d_flag.as<u32>();
         if (c_max && !counts_ready) {
@@ -2135,6 +2152,7 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
         // genotype rows: fresh pool rows of the destination, filled from the sources' pools
         PoolWork dpw{};
         if (c->dense) {
+            pool_new_stamp(ds);
             dpw = pool_work(c, D, k, (D.pcur + 1) % 3);
             GEVC(pool_free_list(dpw, 2 * D.n_phys, st));
             GEVC(pool_take(dpw, 0, rows_new, st));
@@ -2404,6 +2422,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         if (c->dense) {
+            pool_new_stamp(cs);
             const PoolWork pw = pool_work(c, P, k, P.pcur);           // new slots of the CURRENT generation
             GEVC(pool_free_list(pw, r_old, st));
             GEVC(pool_take(pw, r_old, 2 * n, st));

@@ -11,7 +11,6 @@ r=d['roofline']
 print(round(d['value'],1), 'gen/s', round(d['ms_per_step'],3), 'ms  stitch', round(d['phase_ms']['dense_stitch'],3), 'iso', round(r['isolated_kernel_ms'] or 0,3), 'segs', int(r['segments_written_per_launch']), 'frac', round(r['frac'],3), 'isofrac', round(r['isolated_frac'] or 0,3), 'sampling', round(d['phase_ms']['sampling'],3), 'sparse', round(d['phase_ms']['sparse_lists_and_cv_planes'],3), d['phase_ms']['host_ms_inside_calls'])" >> $out; }
 run A=1
 run A=1 --no-host-overlap
-run GEV_STITCH_START=2
+run GEV_STITCH_START=0
 run A=1 --no-intervals
-run A=1 --nchr 11 --n-ind 125000 --n-loci 227000 --steps 10 --warmup 4
 cat $out
