@@ -554,7 +554,10 @@ def extra_cases(which):
       mig3c   two populations x THREE chromosomes, mutation map, migration every generation, parental effect (vf > 0): the
               fixture of the locus-split + migration test (2 populations x 2 chromosome shards = 4 ranks)
       c4mini  BASELINE config 4 in miniature: two populations x the 22 autosomes of Recom.Map.b37.50KbDiff (the reference's
-              own map file), assortative mating (mat_cor 0.4, Poisson family sizes), mutation map, migration"""
+              own map file), assortative mating (mat_cor 0.4, Poisson family sizes), mutation map, migration
+      vt2     --vt_type 2: the parental effect of a child is beta * (the parents' PARENTAL EFFECTS, not their phenotypes)
+              (src/Simulation.cpp:3128-3131), beta adjusted on var(F) after generation 0 (:653-657); two phenotypes (vf > 0 and
+              vf = 0), random mating with a logit selection function, mutation map"""
     if "mig3c" in which:
         rs = np.random.RandomState(555)
         R = 151
@@ -575,6 +578,24 @@ def extra_cases(which):
                 f.write("0.9 0.1 0.15 0.85\n")
         c.args_extra = ["--file_migration", os.path.join(WORK, "mig3c.txt")]
         run_case(c, 60606, dense_gens={2, 4})
+    if "vt2" in which:
+        rs = np.random.RandomState(222)
+        R = 121
+        rbp = (1000 + 500 * np.arange(R)).astype(np.uint64)
+        rcM = np.cumsum(np.r_[0.0, np.full(R - 1, 0.9)])
+        snp = np.arange(1200, 61000, 130).astype(np.uint64)
+        nf = 260
+        founders = (rs.rand(nf, len(snp)) < rs.uniform(0.05, 0.5, len(snp))).astype(np.uint8)
+        cvbp = np.sort(rs.choice(np.arange(1100, 60900, 20), size=70, replace=False)).astype(np.uint64)
+        phens = [{"bp": [cvbp], "a": [rs.randn(70)], "d": [rs.randn(70) * 0.2], "val": [(rs.rand(nf, 70) < 0.35).astype(np.uint8)],
+                  "va": 0.45, "vd": 0.05, "ve": 0.3, "vf": 0.2},
+                 {"bp": [cvbp], "a": [rs.randn(70)], "d": [np.zeros(70)], "val": [(rs.rand(nf, 70) < 0.35).astype(np.uint8)],
+                  "va": 0.6, "vd": 0.0, "ve": 0.4, "vf": 0.0}]
+        c = Case("vt2")
+        c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=phens, RM=True,
+                  mut_bp=[rbp], mut_rate=[np.full(R, 0.01)], popinfo=["130 0 p logit 1 1", "125 0 p thr 1 1", "120 0 p logit 0.5 1", "126 0 p logit 1 1", "118 0 p thr 1 1"])
+        c.args_extra = ["--vt_type", "2"]
+        run_case(c, 20202, dense_gens={5})
     if "c4mini" in which:
         rs = np.random.RandomState(444)
         d = os.path.join(WORK, "rmap")

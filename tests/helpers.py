@@ -318,6 +318,8 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at
     extra = [str(x) for x in fx["args_extra"]]
     mm = float(extra[extra.index("--MM") + 1]) if "--MM" in extra else 0.0
     avoid = "--avoid_inbreeding" in extra
+    vt_type = int(extra[extra.index("--vt_type") + 1]) if "--vt_type" in extra else 1     # parameters.cpp default 1
+    handed_down = "phen" if vt_type == 1 else "parental_effect"                           # what _Pop_info_prev_gen hands to the children's F (:3123-3132)
     has_mut = bool(int(fx["pop0_has_mut"]))
     sim = Simulation(ctx, int(fx["seed"]), nchr, has_mut, track_pedigree=True)
 
@@ -336,9 +338,11 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at
             seed = int(sim.ras_glob_seed()[0])
             if g > 0:
                 assert seed == int(fx[f"g{g}_pop0_ph{p}_gef_seed"]), f"{label}: the ras_glob_seed() stream is out of step at generation {g}"
-            ff = prev_phen[p][sim.ped[0].ID_Father] if g > 0 else np.zeros(n)
-            fm = prev_phen[p][sim.ped[0].ID_Mother] if g > 0 else np.zeros(n)
+            ff = prev_phen[p][sim.ped[0].ID_Father] if g > 0 else np.zeros(n)       # vt_type 1: the parents' phenotypes (:3123-3127);
+            fm = prev_phen[p][sim.ped[0].ID_Mother] if g > 0 else np.zeros(n)       # vt_type 2: their parental effects (:3128-3132)
             if g > 0:
+                assert int(fx[f"g{g}_pop0_ph{p}_gef_vt"]) == vt_type
+                assert bits_equal(np.stack([ff, fm], axis=1), fx[f"g{g}_pop0_ph{p}_gef_in"][:, 1:3]) or not exact, f"{label}: parental inputs, phenotype {p} generation {g}"
                 assert bits_equal(common[p], fx[f"g{g}_pop0_ph{p}_gef_in"][:, 0]), f"{label}: common sibling effect, phenotype {p} generation {g}"
             o = ctx.scale_ad_compute_gef(0, p, g, seed, va, vd, ve, vf, beta[p], s2[p][0], s2[p][1], common_sibling=common[p], f_father=ff, f_mother=fm)
             o["common_sibling"] = common[p]
@@ -376,8 +380,11 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at
     z = (sv - sv_mean) / np.sqrt(sv_var) if sv_var > 0 else sv - sv_mean
     svf = np.ones(len(mv))                                                      # generation 0: everybody may marry (:3388)
     check_info_file(0, outs, mv, z, svf)
-    for p in range(nphen):                                                      # "adjust beta", vt_type 1 (:650-653)
-        beta[p] = float(np.sqrt(var[p][3] / (2 * comm_var(outs[p]["phen"]))))
+    for p in range(nphen):                                                      # "adjust beta" (:648-657): on var(P), or (vt_type 2) on var(F) when that is > 0
+        if vt_type == 1:
+            beta[p] = float(np.sqrt(var[p][3] / (2 * comm_var(outs[p]["phen"]))))
+        elif vt_type == 2 and comm_var(outs[p]["parental_effect"]) > 0:
+            beta[p] = float(np.sqrt(var[p][3] / (2 * comm_var(outs[p]["parental_effect"]))))
     for g in range(1, ngen + 1):
         pop_size, mat_cor, dist, func, p1, p2 = str(fx["pop0_popinfo"][g - 1]).split()
         k = f"g{g}_pop0_mate_"
@@ -393,7 +400,7 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at
                 assert sim.num_males_mate == int(np.sum(fx[k + "sex"] == 1) if np.all(np.asarray(svf) == 1.0) else sim.num_males_mate)
             else:
                 fused = True
-                prev_phen = [o["phen"] for o in outs]
+                prev_phen = [o[handed_down] for o in outs]
                 res = sim.next_generation_rm(0, int(pop_size), svf_arg, want_couples=True)
                 assert int(res["seed_mate"]) == int(fx[k + "seed"]) and int(res["seed_reproduce"]) == int(fx[f"g{g}_pop0_seed_reproduce"]), f"{label}: seeds drawn by the library, generation {g}"
         else:
@@ -404,7 +411,7 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at
         assert len(c) == len(want) and np.array_equal(c["pos_male"].astype(np.int64), want[:, 0]) and np.array_equal(c["pos_female"].astype(np.int64), want[:, 1]) \
             and np.array_equal(c["inbreed"], want[:, 2]) and np.array_equal(c["num_offspring"], want[:, 3]), f"{label}: couples of generation {g}"
         if not fused:
-            prev_phen = [o["phen"] for o in outs]
+            prev_phen = [o[handed_down] for o in outs]
             sim.reproduce(0, g)
         assert np.array_equal(sim.sex[0], fx[f"g{g}_pop0_sex"]), f"{label}: sex generation {g}"
         ped = sim.ped[0]

@@ -83,7 +83,7 @@ def test_synth_founders_match_specification(gpu_lib):
     ctx.close()
 
 
-@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini"])
+@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini", "vt2"])
 def test_gpu_replays_reference_generations_bit_exact(gpu_lib, oracle_lib, case):
     fx = helpers.load_fixture(case)
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
@@ -712,7 +712,7 @@ def test_unsupported_inputs_are_refused_not_miscomputed(gpu_lib):
     g.close()
 
 
-@pytest.mark.parametrize("case", ["dense", "ex1sub"])
+@pytest.mark.parametrize("case", ["dense", "ex1sub", "vt2"])
 def test_gpu_scale_ad_compute_gef_matches_reference(gpu_lib, oracle_lib, case):
     """SURVEY 8(f) row 1 on the device: phenotype floats within 1e-12 relative of the reference's hex-dumped values
     (north star: 1e-6); e comes from the parallel polar-method normal stream, var(e) from parallel sums."""
@@ -1156,7 +1156,7 @@ def test_pipelined_host_loop_through_list_growth_and_redo_paths(gpu_lib, oracle_
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1", "ex1full"])
+@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1", "ex1full", "vt2"])
 def test_closed_loop_from_the_seed_alone_on_gpu(gpu_lib, case):
     """the same closed loop on the HIP library (A/D, intervals, genotypes, couples, sexes bit-exact; scaled phenotypes and what
     derives from them within 1e-9 relative: the device's parallel variance / log are not bit-identical to libm's)"""
@@ -1306,7 +1306,7 @@ def test_device_random_mate_reproduces_the_reference_couples(gpu_lib, oracle_lib
 
 
 @pytest.mark.parametrize("mate", ["device", "fused"])
-@pytest.mark.parametrize("case", ["ex1mut", "dense", "syn1k", "sel1"])
+@pytest.mark.parametrize("case", ["ex1mut", "dense", "syn1k", "sel1", "vt2"])
 def test_closed_loop_from_the_seed_alone_with_device_random_mate(gpu_lib, case, mate):
     """the whole run from --seed alone with mating on the device; "fused": gev_generation_begin/_end draw the generation's
     ras_glob_seed() values themselves (the host's engine state goes in, the state behind the draws comes back) -- the seeds,

@@ -111,7 +111,7 @@ def test_recombine_direct_calls(oracle_lib):
         assert list(om) == wm, f"trial {k}: mutation_pos"
 
 
-@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini"])
+@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini", "vt2"])
 def test_oracle_replays_reference_generations(oracle_lib, case):
     fx = helpers.load_fixture(case)
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
@@ -119,7 +119,7 @@ def test_oracle_replays_reference_generations(oracle_lib, case):
     assert n_dense >= 1
 
 
-@pytest.mark.parametrize("case", ["dense", "ex1sub", "mig2", "mig3c", "c4mini"])
+@pytest.mark.parametrize("case", ["dense", "ex1sub", "mig2", "mig3c", "c4mini", "vt2"])
 def test_oracle_scale_ad_compute_gef_matches_reference(oracle_lib, case):
     """ras_scale_AD_compute_GEF (src/Simulation.cpp:3075-3206) incl. libstdc++ normal_distribution."""
     fx = helpers.load_fixture(case)
@@ -141,7 +141,7 @@ def test_rank_matches_reference_vectors(oracle_lib):
     o.close()
 
 
-@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1", "ex1full"])
+@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1", "ex1full", "vt2"])
 def test_closed_loop_from_the_seed_alone(oracle_lib, case):
     """the reference's whole generation loop (assortative mating, inbreeding avoidance, Poisson / fixed families, logit
     selection) re-driven from --seed by the host mirror on top of the C-ABI (oracle build): bit-identical at every step"""
@@ -155,7 +155,7 @@ def test_closed_loop_two_populations_with_migration(oracle_lib):
 
 
 @pytest.mark.parametrize("mate", ["device", "fused"])
-@pytest.mark.parametrize("case", ["ex1mut", "dense", "syn1k", "sel1"])
+@pytest.mark.parametrize("case", ["ex1mut", "dense", "syn1k", "sel1", "vt2"])
 def test_closed_loop_with_the_library_side_random_mate(oracle_lib, case, mate):
     """pins the oracle's restatement of Simulation::random_mate (src/Simulation.cpp:2090-2157) and of ras_glob_seed (:17-21) behind
     gevo_random_mate / gevo_generation_begin: the reference's couples, seeds, sexes, A/D and .info files of every --RM fixture"""
