@@ -17,6 +17,9 @@ function signatures / the one marker comment, not by line numbers):
                   ras_convert_interval_to_hap_matrix     body -> gevglue_hap_matrix      (--out_hap)
                   ras_convert_interval_to_format_plink   body -> gevglue_plink_matrix    (--out_plink, --out_plink01)
                   ras_write_hap_to_interval_format       body -> gevglue_write_interval  (--out_interval)
+                  ras_convert_interval_from_vcf_to_hap_matrix      body -> gevglue_vcf_hap_matrix    (VCF panel: --out_hap)
+                  ras_convert_interval_from_vcf_to_vcf_structure   body -> gevglue_vcf_structure     (VCF panel: --out_vcf)
+                  ras_convert_interval_from_vcf_to_plink           body -> gevglue_vcf_plink_matrix  (VCF panel: --out_plink, --out_plink01)
                   assort_mate               the two CommFunc::ras_rank calls -> gevglue_rank (gev_rank_f64: stable sort on the device)
                   sim_next_generation       + gevglue_presample before the mating of each population (gev_presample; random mating)
                   ras_init_generation0 / sim_next_generation   population[ipop].ras_save_human_info(gen_num) -> gevglue_save_human_info
@@ -70,7 +73,8 @@ def build(out_name, backend_link, extra_sources=()):
     """edit + compile + link; backend_link = linker arguments of the C-ABI implementation; extra_sources = more C++ files"""
     if not os.path.isdir(REF):
         print("build_gpu_cli: no reference tree, skipped"); return None
-    need = [os.path.join(OUT, "ge", f"{n}.o") for n in ("Main", "Population", "CommFunc", "RasRandomNumber", "RasMatrix", "format_hap", "format_plink", "format_vcf", "parameters")]
+    need = [os.path.join(OUT, "ge", f"{n}.o") for n in ("Main", "Population", "CommFunc", "RasRandomNumber", "RasMatrix", "format_hap", "format_plink", "format_vcf_return", "parameters")]   # format_vcf_return: format_vcf.cpp with
+    # the `return` its read_vcf_header_sample lacks (oracle/ref_vcf_return.cpp); without it every --file_ref_vcf run crashes at start-up
     need.append(os.path.join(OUT, "libStatGen.a"))
     for f in need:
         if not os.path.exists(f):
@@ -85,6 +89,9 @@ def build(out_name, backend_link, extra_sources=()):
             "bool gevglue_hap_matrix(Simulation&, int, std::vector<Legend>&, int, Hap_SNP&);\n"
             "bool gevglue_plink_matrix(Simulation&, int, std::vector<Legend>&, int, std::vector<std::vector<bool> >&, plink_PED_ids&, plink_MAP&);\n"
             "bool gevglue_write_interval(Simulation&, int);\n"
+            "bool gevglue_vcf_hap_matrix(Simulation&, std::vector<vcf_structure>&, int, int, Hap_SNP&);\n"
+            "bool gevglue_vcf_structure(Simulation&, vcf_structure&, int, int, int, std::vector<vcf_structure>&);\n"
+            "bool gevglue_vcf_plink_matrix(Simulation&, std::vector<std::vector<bool> >&, plink_PED_ids&, plink_MAP&, int, int, std::vector<vcf_structure>&);\n"
             "bool gevglue_save_human_info(Simulation&, int, int);\n"
             "bool gevglue_presample(Simulation&, int, int);\nstd::vector<unsigned long int> gevglue_rank(std::vector<double>&);\n"
             "bool gevglue_use_device_gef();\nbool gevglue_scale_gef(Simulation&, int, int, int, double, double);\n"
@@ -98,6 +105,10 @@ def build(out_name, backend_link, extra_sources=()):
     cpp = replace_body(cpp, r"^bool\s+Simulation::ras_convert_interval_to_hap_matrix\s*\(", "    return gevglue_hap_matrix(*this, ipop, pops_legend, ichr, hap_snp);")
     cpp = replace_body(cpp, r"^bool\s+Simulation::ras_convert_interval_to_format_plink\s*\(", "    return gevglue_plink_matrix(*this, ipop, pops_legend, ichr, matrix_plink_ped, plink_ped_ids, plink_map);")
     cpp = replace_body(cpp, r"^bool\s+Simulation::ras_write_hap_to_interval_format\s*\(\s*int\s+gen_num\s*\)", "    return gevglue_write_interval(*this, gen_num);")
+    # the VCF-panel siblings (:1477, :1690, :1838)
+    cpp = replace_body(cpp, r"^bool\s+Simulation::ras_convert_interval_from_vcf_to_hap_matrix\s*\(", "    return gevglue_vcf_hap_matrix(*this, vcf_structure_allpops_chr, ipop, ichr, hap_snp);")
+    cpp = replace_body(cpp, r"^bool\s+Simulation::ras_convert_interval_from_vcf_to_vcf_structure\s*\(", "    return gevglue_vcf_structure(*this, vcf_out, gen_num, ipop, ichr, vcf_structure_allpops_chr);")
+    cpp = replace_body(cpp, r"^bool\s+Simulation::ras_convert_interval_from_vcf_to_plink\s*$", "    return gevglue_vcf_plink_matrix(*this, matrix_plink_ped, plink_ped_ids, plink_map, ipop, ichr, vcf_structure_allpops_chr);")
     # assort_mate (:2278-2279): the two O(n^2) CommFunc::ras_rank calls on the bivariate-normal template -> device sort
     i, j = body_span(cpp, r"^bool\s+Simulation::assort_mate\s*\(")
     body = cpp[i:j]

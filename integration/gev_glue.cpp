@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <iostream>
 #include <random>
@@ -42,7 +43,6 @@ struct GevGlue {
     static bool init_static(Simulation& S)
     {
         const int n_pop = S._n_pop, nchr = S.population[0]._nchr, nphen = (int)S.population[0]._pheno_scheme.size();
-        if (S._ref_is_vcf) { std::cout << "Error: the GPU build reads hap/legend panels only." << std::endl; return false; }
         if (gev_create(&ctx(), -1, n_pop, nchr, nphen)) return fail("gev_create");
         for (int ipop = 0; ipop < n_pop; ipop++) {
             Population& P = S.population[ipop];
@@ -50,14 +50,25 @@ struct GevGlue {
                 if (gev_set_rmap(ctx(), ipop, c, P._rmap[c].bp.data(), P._recom_prob[c].data(), P._rmap[c].bp.size(), P._rmap[c].bp_dist_in_rmap)) return fail("gev_set_rmap");
                 if (P._mutation_map.size() > 0 &&
                     gev_set_mutmap(ctx(), ipop, c, P._mutation_map[c].bp.data(), P._mutation_map[c].mutation_rate.data(), P._mutation_map[c].bp.size())) return fail("gev_set_mutmap");
-                // the founder panel the reference itself only reads at output time (ras_read_hap_legend_sample_chr, :1105)
-                Legend legend; Hap_SNP hs;
-                const long nind = CommFunc::ras_FileLineNumber(P._hap_legend_sample_name[c][2]);
-                const long nsnp = format_hap::read_legend(legend, P._hap_legend_sample_name[c][1]);
-                if (!format_hap::read_hap(hs, P._hap_legend_sample_name[c][0], nind, nsnp, false)) return false;
-                if (gev_set_snps(ctx(), ipop, c, legend.pos.data(), legend.pos.size())) return fail("gev_set_snps");
-                size_t w; std::vector<uint64_t> bits = pack(hs.hap, legend.pos.size(), w);
-                if (gev_upload_founders(ctx(), ipop, c, bits.data(), w, hs.hap.size(), legend.pos.size())) return fail("gev_upload_founders");
+                // the founder panel the reference itself only reads at output time (ras_read_hap_legend_sample_chr, :1105;
+                // VCF panel: ras_read_vcf_pops_chr, :1764)
+                size_t w; std::vector<uint64_t> bits;
+                if (S._ref_is_vcf) {
+                    vcf_structure vs;
+                    if (!format_vcf::read_vcf_file(P._ref_vcf_address[c], vs)) { std::cout << "Error in reading vcf file." << std::endl; return false; }
+                    std::vector<unsigned long int> pos(vs.POS.begin(), vs.POS.end());
+                    if (gev_set_snps(ctx(), ipop, c, pos.data(), pos.size())) return fail("gev_set_snps");
+                    bits = pack(vs.data, pos.size(), w);
+                    if (gev_upload_founders(ctx(), ipop, c, bits.data(), w, vs.data.size(), pos.size())) return fail("gev_upload_founders");
+                } else {
+                    Legend legend; Hap_SNP hs;
+                    const long nind = CommFunc::ras_FileLineNumber(P._hap_legend_sample_name[c][2]);
+                    const long nsnp = format_hap::read_legend(legend, P._hap_legend_sample_name[c][1]);
+                    if (!format_hap::read_hap(hs, P._hap_legend_sample_name[c][0], nind, nsnp, false)) return false;
+                    if (gev_set_snps(ctx(), ipop, c, legend.pos.data(), legend.pos.size())) return fail("gev_set_snps");
+                    bits = pack(hs.hap, legend.pos.size(), w);
+                    if (gev_upload_founders(ctx(), ipop, c, bits.data(), w, hs.hap.size(), legend.pos.size())) return fail("gev_upload_founders");
+                }
                 for (int p = 0; p < nphen; p++) {
                     CV_INFO& I = P._pheno_scheme[p]._cv_info[c];
                     if (gev_set_cvs(ctx(), ipop, p, c, I.bp.data(), I.genetic_value_a.data(), I.genetic_value_d.data(), I.bp.size(), P._pheno_scheme[p]._vd)) return fail("gev_set_cvs");
@@ -373,6 +384,67 @@ struct GevGlue {
         return true;
     }
 
+    // rows x nsnp genotype bits of a population from the library into the reference's vector<vector<bool>> (2 rows per individual)
+    static bool fetch_haps(int ipop, int ichr, size_t n_human, size_t nsnp, std::vector<std::vector<bool> >& rows)
+    {
+        const size_t w = (nsnp + 63) / 64;
+        std::vector<uint64_t> bits(2 * n_human * std::max<size_t>(w, 1));
+        if (gev_download_haps(ctx(), ipop, ichr, 0, 2 * n_human, bits.data(), w)) return fail("gev_download_haps");
+        rows.assign(2 * n_human, std::vector<bool>(nsnp, false));
+        for (size_t r = 0; r < 2 * n_human; r++)
+            for (size_t ii = 0; ii < nsnp; ii++) rows[r][ii] = (bits[r * w + (ii >> 6)] >> (ii & 63)) & 1;
+        return true;
+    }
+    // the VCF-panel siblings: the panel was handed to the library at start-up (init_static), the genotype rows are resident
+    // Simulation::ras_convert_interval_from_vcf_to_hap_matrix (:1838-1881)
+    static bool vcf_hap_matrix(Simulation& S, std::vector<vcf_structure>& vcf_all, int ipop, int ichr, Hap_SNP& hap_snp)
+    {
+        const size_t n_human = S.population[ipop].h.size(), nsnp = vcf_all[ipop].ID.size();
+        std::cout << "      n_human=" << n_human << std::endl;
+        return fetch_haps(ipop, ichr, n_human, nsnp, hap_snp.hap);
+    }
+    // Simulation::ras_convert_interval_from_vcf_to_vcf_structure (:1690-1758): columns, meta lines and sample names as :1701-1733
+    static bool vcf_structure_out(Simulation& S, vcf_structure& vcf_out, int gen_num, int ipop, int ichr, std::vector<vcf_structure>& vcf_all)
+    {
+        Population& P = S.population[ipop];
+        const size_t n_human = P.h.size(), nsnp = vcf_all[ipop].ID.size();
+        std::cout << "      n_human=" << n_human << std::endl;
+        vcf_out.SAMPLES.resize(n_human);
+        vcf_out.CHROM = vcf_all[ipop].CHROM; vcf_out.POS = vcf_all[ipop].POS; vcf_out.ID = vcf_all[ipop].ID; vcf_out.REF = vcf_all[ipop].REF;
+        vcf_out.ALT = vcf_all[ipop].ALT; vcf_out.QUAL = vcf_all[ipop].QUAL; vcf_out.FILTER = vcf_all[ipop].FILTER;
+        vcf_out.INFO = std::vector<std::string>(nsnp, "."); vcf_out.FORMAT = std::vector<std::string>(nsnp, "GT");
+        std::time_t t = std::time(NULL);
+        char day[100];
+        std::strftime(day, sizeof(day), "%Y%m%d", std::localtime(&t));
+        vcf_out.meta_lines = {"##fileformat=VCFv4.1", "##Phasing=phased", "##CreatedBy=GeneEvolve", "##fileDate=" + std::string(day),
+                              "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">"};
+        for (size_t ih = 0; ih < n_human; ih++) vcf_out.SAMPLES[ih] = "g" + std::to_string(gen_num) + "_" + std::to_string(P.h[ih].ID + 1);
+        return fetch_haps(ipop, ichr, n_human, nsnp, vcf_out.data);
+    }
+    // Simulation::ras_convert_interval_from_vcf_to_plink (:1477-1571): matrix from the device, ids and map exactly as :1546-1568
+    static bool vcf_plink_matrix(Simulation& S, std::vector<std::vector<bool> >& matrix_plink_ped, plink_PED_ids& plink_ped_ids, plink_MAP& plink_map,
+                                 int ipop, int ichr, std::vector<vcf_structure>& vcf_all)
+    {
+        Population& P = S.population[ipop];
+        const size_t n_human = P.h.size(), nsnp = vcf_all[ipop].ID.size(), w = (2 * nsnp + 63) / 64;
+        std::cout << "      n_human=" << n_human << std::endl;
+        std::vector<uint64_t> bits(n_human * std::max<size_t>(w, 1));
+        if (gev_download_plink_matrix(ctx(), ipop, ichr, 0, n_human, bits.data(), w)) return fail("gev_download_plink_matrix");
+        matrix_plink_ped.assign(n_human, std::vector<bool>(nsnp * 2, false));
+        plink_ped_ids.alloc(n_human); plink_map.alloc(nsnp);
+        for (size_t ih = 0; ih < n_human; ih++) {
+            for (size_t b = 0; b < 2 * nsnp; b++) matrix_plink_ped[ih][b] = (bits[ih * w + (b >> 6)] >> (b & 63)) & 1;
+            plink_ped_ids.FID[ih] = std::to_string(P.h[ih].ID_Father + 1); plink_ped_ids.IID[ih] = std::to_string(P.h[ih].ID + 1);
+            plink_ped_ids.PID[ih] = std::to_string(P.h[ih].ID_Father + 1); plink_ped_ids.MID[ih] = std::to_string(P.h[ih].ID_Mother + 1);
+            plink_ped_ids.sex[ih] = P.h[ih].sex; plink_ped_ids.phen[ih] = -9;
+        }
+        for (size_t i = 0; i < nsnp; i++) {
+            plink_map.chr[i] = std::to_string(S._all_active_chrs[ichr]); plink_map.rs[i] = vcf_all[ipop].ID[i]; plink_map.cM[i] = 0;
+            plink_map.pos[i] = vcf_all[ipop].POS[i]; plink_map.al0[i] = vcf_all[ipop].REF[i]; plink_map.al1[i] = vcf_all[ipop].ALT[i];
+        }
+        return true;
+    }
+
     // Simulation::ras_convert_interval_to_format_plink (:1308-1416): matrix from the device, ids and map exactly as :1391-1413
     static bool plink_matrix(Simulation& S, int ipop, std::vector<Legend>& pops_legend, int ichr, std::vector<std::vector<bool> >& matrix_plink_ped,
                              plink_PED_ids& plink_ped_ids, plink_MAP& plink_map)
@@ -429,6 +501,9 @@ struct GevGlue {
 // free functions the edited Simulation.cpp calls
 bool gevglue_plink_matrix(Simulation& S, int ipop, std::vector<Legend>& pops_legend, int ichr, std::vector<std::vector<bool> >& m, plink_PED_ids& ids, plink_MAP& map) { return GevGlue::plink_matrix(S, ipop, pops_legend, ichr, m, ids, map); }
 bool gevglue_write_interval(Simulation& S, int gen_num) { return GevGlue::write_interval(S, gen_num); }
+bool gevglue_vcf_hap_matrix(Simulation& S, std::vector<vcf_structure>& v, int ipop, int ichr, Hap_SNP& hap_snp) { return GevGlue::vcf_hap_matrix(S, v, ipop, ichr, hap_snp); }
+bool gevglue_vcf_structure(Simulation& S, vcf_structure& out, int gen_num, int ipop, int ichr, std::vector<vcf_structure>& v) { return GevGlue::vcf_structure_out(S, out, gen_num, ipop, ichr, v); }
+bool gevglue_vcf_plink_matrix(Simulation& S, std::vector<std::vector<bool> >& m, plink_PED_ids& ids, plink_MAP& map, int ipop, int ichr, std::vector<vcf_structure>& v) { return GevGlue::vcf_plink_matrix(S, m, ids, map, ipop, ichr, v); }
 bool gevglue_init_static(Simulation& S) { return GevGlue::init_static(S); }
 bool gevglue_after_gen0(Simulation& S, int ipop, unsigned seed) { return GevGlue::after_gen0(S, ipop, seed); }
 std::vector<Human> gevglue_reproduce(Simulation& S, int ipop, int gen_num) { return GevGlue::reproduce(S, ipop, gen_num); }

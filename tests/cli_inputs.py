@@ -21,7 +21,21 @@ def _write_hap(path, bits):                      # [nhap][L] -> SNP-major text
             f.write(" ".join("1" if b else "0" for b in bits[:, i]) + "\n")
 
 
-def write_inputs_from_fixture(fx, wd, prefix="out"):
+def _write_vcf(path, chrom, bits, pos, prefix):
+    """phased biallelic VCF of a founder panel [nhap][L]: the file tests/golden/make_golden.py:write_vcf gave the reference"""
+    al0, al1 = _legend_alleles(len(pos))
+    n = bits.shape[0] // 2
+    F = np.asarray(bits, dtype=np.uint8)
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"{prefix}{i+1}" for i in range(n)) + "\n")
+        for j, p in enumerate(pos):
+            gts = "\t".join(f"{F[2*i, j]}|{F[2*i+1, j]}" for i in range(n))
+            f.write(f"{chrom}\t{int(p)}\trs{j+1}\t{chr(al0[j])}\t{chr(al1[j])}\t.\tPASS\t.\tGT\t{gts}\n")
+
+
+def write_inputs_from_fixture(fx, wd, prefix="out", vcf_panel=False):
+    """vcf_panel: the founder panels as phased VCF files behind --file_ref_vcf instead of hap/legend/indv behind --file_hap_name"""
     os.makedirs(wd, exist_ok=True)
     n_pop, nchr, nphen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"])
     args = []
@@ -48,6 +62,13 @@ def write_inputs_from_fixture(fx, wd, prefix="out"):
                     for i in range(nh // 2):
                         g.write(f"p{ip}i{i+1}\n")
                 f.write(f"{c} {base}.hap {base}.legend {base}.indv\n")
+                if vcf_panel:
+                    _write_vcf(base + ".vcf", c, bits, pos, f"p{ip}i")
+        if vcf_panel:
+            with open(os.path.join(wd, f"p{ip}.vcfaddr.txt"), "w") as f:
+                f.write("chr vcf\n")
+                for c in labels:
+                    f.write(f"{c} {os.path.join(wd, f'p{ip}.chr{c}')}.vcf\n")
         with open(os.path.join(wd, f"p{ip}.rmap.txt"), "w") as f:
             f.write("chr bp cM\n")
             for ic, c in enumerate(labels):
@@ -57,8 +78,9 @@ def write_inputs_from_fixture(fx, wd, prefix="out"):
             f.write("pop_size mat_cor offspring_dist selection_func selection_func_par1 selection_func_par2\n")
             for r in fx[pre + "popinfo"]:
                 f.write(str(r) + "\n")
-        a = ["--file_gen_info", os.path.join(wd, f"p{ip}.popinfo.txt"), "--file_hap_name", os.path.join(wd, f"p{ip}.hapaddr.txt"),
-             "--file_recom_map", os.path.join(wd, f"p{ip}.rmap.txt")]
+        a = ["--file_gen_info", os.path.join(wd, f"p{ip}.popinfo.txt")] + \
+            (["--file_ref_vcf", os.path.join(wd, f"p{ip}.vcfaddr.txt")] if vcf_panel else ["--file_hap_name", os.path.join(wd, f"p{ip}.hapaddr.txt")]) + \
+            ["--file_recom_map", os.path.join(wd, f"p{ip}.rmap.txt")]
         if int(fx[pre + "has_mut"]):
             with open(os.path.join(wd, f"p{ip}.mmap.txt"), "w") as f:
                 f.write("chr bp mutation_rate\n")

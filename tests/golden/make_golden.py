@@ -385,7 +385,8 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
     # return supplied (oracle/ref_vcf_return.cpp); it is used here and nowhere else.
     if vcf:
         wd4 = os.path.join(wd, "cli_vcf"); os.makedirs(wd4)
-        args4 = [x if x != os.path.join(wd, "out") else os.path.join(wd4, "out") for x in args] + ["--out_vcf"]
+        # vcf == "full": the VCF-panel siblings of the output paths as well (ras_write_vcf_to_hap_legend_sample, ras_write_vcf_to_plink_format)
+        args4 = [x if x != os.path.join(wd, "out") else os.path.join(wd4, "out") for x in args] + ["--out_vcf"] + (["--out_hap", "--out_plink", "--out_interval"] if vcf == "full" else [])
         for ip, P in enumerate(case.pops):
             addr = os.path.join(wd4, f"p{ip}.vcfaddr.txt")
             with open(addr, "w") as f:
@@ -414,6 +415,10 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
                         continue
                     tok = line.split(b"\t", 9)
                     gt.update(b"\t" + tok[9] + b"\n"); body.update(line + b"\n")
+                if vcf == "full":
+                    for ext in ("hap", "ped", "map", "int"):
+                        rawx = open(os.path.join(wd4, f"out.pop{ip+1}.gen{ngen}.chr{c}.{ext}"), "rb").read()
+                        arrs[f"vcfrun_{ext}file_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(rawx).digest(), dtype=np.uint8)
                 k = f"vcffile_pop{ip}_chr{ic}_"
                 arrs[k + "gt_sha"] = np.frombuffer(gt.digest(), dtype=np.uint8)
                 arrs[k + "body_sha"] = np.frombuffer(body.digest(), dtype=np.uint8)
@@ -555,6 +560,8 @@ def extra_cases(which):
               fixture of the locus-split + migration test (2 populations x 2 chromosome shards = 4 ranks)
       c4mini  BASELINE config 4 in miniature: two populations x the 22 autosomes of Recom.Map.b37.50KbDiff (the reference's
               own map file), assortative mating (mat_cor 0.4, Poisson family sizes), mutation map, migration
+      vcf1    VCF reference panels, two populations with migration and mutation: .vcf, .hap, .ped/.map and .int files of the
+              VCF-panel run (GeneEvolve_ref_vcf)
       vt2     --vt_type 2: the parental effect of a child is beta * (the parents' PARENTAL EFFECTS, not their phenotypes)
               (src/Simulation.cpp:3128-3131), beta adjusted on var(F) after generation 0 (:653-657); two phenotypes (vf > 0 and
               vf = 0), random mating with a logit selection function, mutation map"""
@@ -596,6 +603,30 @@ def extra_cases(which):
                   mut_bp=[rbp], mut_rate=[np.full(R, 0.01)], popinfo=["130 0 p logit 1 1", "125 0 p thr 1 1", "120 0 p logit 0.5 1", "126 0 p logit 1 1", "118 0 p thr 1 1"])
         c.args_extra = ["--vt_type", "2"]
         run_case(c, 20202, dense_gens={5})
+    if "vcf1" in which:
+        # VCF reference panels (--file_ref_vcf) for two populations that exchange migrants: every output format the VCF-panel run
+        # can write (--out_vcf --out_hap --out_plink --out_interval), from oracle/_ref/GeneEvolve_ref_vcf (the reference with the one
+        # missing `return` of format_vcf::read_vcf_header_sample supplied, oracle/ref_vcf_return.cpp)
+        rs = np.random.RandomState(808)
+        R = 161
+        rbp = (1000 + 100 * np.arange(R)).astype(np.uint64)
+        rcM = np.cumsum(np.r_[0.0, np.full(R - 1, 0.9)])
+        snp = np.arange(950, 17100, 9).astype(np.uint64)                       # some SNPs outside [bp0, bpEnd)
+        cvbp = np.sort(rs.choice(np.arange(1000, 17000), size=50, replace=False)).astype(np.uint64)
+        cvbp[:15] = np.sort(rs.choice(snp, 15, replace=False))
+        cvbp = np.sort(cvbp)
+        c = Case("vcf1")
+        for ip, n0 in enumerate((90, 80)):
+            nf = 200
+            f2 = (rs.rand(nf, len(snp)) < rs.uniform(0.05, 0.5, len(snp))).astype(np.uint8)
+            ph = {"bp": [cvbp], "a": [rs.randn(50)], "d": [rs.randn(50) * 0.2], "val": [(rs.rand(nf, 50) < 0.4).astype(np.uint8)], "va": 0.5, "vd": 0.1, "ve": 0.4}
+            c.add_pop(chrs=[1], founders=[f2], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph], RM=True,
+                      mut_bp=[rbp], mut_rate=[np.full(R, 0.02)], popinfo=[f"{n0} 0 p thr 1 1"] * 4)
+        with open(os.path.join(WORK, "vcf1.txt"), "w") as f:
+            for g in range(4):
+                f.write("0.85 0.15 0.2 0.8\n")
+        c.args_extra = ["--file_migration", os.path.join(WORK, "vcf1.txt")]
+        run_case(c, 31415, dense_gens={4}, vcf="full")
     if "c4mini" in which:
         rs = np.random.RandomState(444)
         d = os.path.join(WORK, "rmap")

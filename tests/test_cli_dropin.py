@@ -59,6 +59,60 @@ def run_cli(exe, case, tmp_path):
                 f"{case}: .hap file of population {ip+1} chromosome {lab} differs from the unmodified reference's"
 
 
+def run_cli_vcf_panel(exe, case, tmp_path):
+    """VCF reference panels (--file_ref_vcf): ras_write_vcf_to_vcf_format / _to_hap_legend_sample / _to_plink_format and their
+    converters ras_convert_interval_from_vcf_to_{vcf_structure, hap_matrix, plink} (src/Simulation.cpp:1477-1571, 1690-1758,
+    1838-1881) bound to the library: .vcf data lines, .hap, .ped, .map, .int and every .info file equal GeneEvolve_ref_vcf's
+    (the reference with the `return` its format_vcf::read_vcf_header_sample lacks supplied -- the unmodified build crashes on every
+    VCF panel, tests/golden/make_golden.py).  The ##fileDate line of the .vcf header is today's date and is not compared."""
+    fx = helpers.load_fixture(case)
+    wd = str(tmp_path / case)
+    full = f"vcfrun_hapfile_pop0_chr0_sha" in fx
+    args = write_inputs_from_fixture(fx, wd, vcf_panel=True)
+    r = subprocess.run([exe] + args + ["--out_vcf"] + (["--out_hap", "--out_plink", "--out_interval"] if full else []), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"{case}: exit {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
+    ngen = int(fx["n_gen"])
+    digest = lambda raw: np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
+    for g in range(ngen + 1):
+        for ip in range(int(fx["n_pop"])):
+            raw = open(os.path.join(wd, f"out.info.pop{ip+1}.gen{g}.txt"), "rb").read()
+            assert np.array_equal(digest(raw), fx[f"infofile_pop{ip}_gen{g}_sha"]), f"{case}: .info file of generation {g} population {ip+1} differs"
+    for ip in range(int(fx["n_pop"])):
+        for ic in range(int(fx["nchr"])):
+            base = os.path.join(wd, f"out.pop{ip+1}.gen{ngen}.chr{int(fx[f'pop{ip}_chr{ic}_label'])}")
+            body, samples = hashlib.sha256(), None
+            for line in open(base + ".vcf", "rb").read().split(b"\n")[:-1]:
+                if line.startswith(b"##"):
+                    continue
+                if line.startswith(b"#"):
+                    samples = line.split(b"\t")[9:]
+                    continue
+                body.update(line + b"\n")
+            k = f"vcffile_pop{ip}_chr{ic}_"
+            assert len(samples) == int(fx[k + "n_samples"]) and samples[0] == fx[k + "first_sample"].tobytes(), f"{case}: .vcf sample columns (pop {ip+1})"
+            assert np.array_equal(np.frombuffer(body.digest(), dtype=np.uint8), fx[k + "body_sha"]), f"{case}: .vcf data lines differ (pop {ip+1} chr index {ic})"
+            if full:
+                for ext in ("hap", "ped", "map", "int"):
+                    assert np.array_equal(digest(open(base + "." + ext, "rb").read()), fx[f"vcfrun_{ext}file_pop{ip}_chr{ic}_sha"]), f"{case}: .{ext} file of the VCF-panel run differs (pop {ip+1} chr index {ic})"
+
+
+@pytest.mark.parametrize("case", ["vcf1", "dense"])
+def test_reference_cli_with_vcf_panels_on_the_c_abi_oracle_backend(case, tmp_path):
+    exe = os.path.join(REFDIR, "GeneEvolve_glue_on_oracle")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/GeneEvolve_glue_on_oracle not built (needs the reference tree)")
+    run_cli_vcf_panel(exe, case, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["vcf1", "dense"])
+def test_reference_cli_with_vcf_panels_on_the_hip_library(case, tmp_path):
+    exe = os.path.join(REFDIR, "GeneEvolve_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/GeneEvolve_gpu not built (needs the reference tree at build time)")
+    run_cli_vcf_panel(exe, case, tmp_path)
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_reference_cli_on_the_c_abi_oracle_backend(case, tmp_path):
     exe = os.path.join(REFDIR, "GeneEvolve_glue_on_oracle")
