@@ -121,13 +121,13 @@ struct RowMap {
     __device__ __forceinline__ u32 word32(size_t slot, u32 w) const { return ((const u32*)chunk(slot, w >> 2))[w & 3u]; }
     __device__ __forceinline__ u64 word64(size_t slot, u32 w) const { return ((const u64*)chunk(slot, w >> 1))[w & 1u]; }
 };
+#include "gev_lists.h"
 struct ChrWork {
-    const u32* moff_cur; const u64* mpos_cur; u32* moff_alt; u64* mpos_alt;                 // mutation lists (CSR), parents / offspring
-    const u32* poff_cur; const gev_part* parts_cur; u32* poff_alt; gev_part* parts_alt;     // ancestry intervals
+    LpWork lp;                                                                              // mutation lists and ancestry intervals: shared pieces (gev_lists.h)
     PoolWork pw; const u64* snp_pos;                                                        // genotype rows
     size_t stride;                                                                          // bytes of a whole row (host-side layouts)
     u64 bp0, bp_end;
-    u32 mcap, pcap, chunks, bpr, L;
+    u32 chunks, bpr, L;
     int chr;
 };
 struct CvWork {
@@ -229,32 +229,6 @@ __global__ void __launch_bounds__(256) k_scan_final(const u32* __restrict__ in, 
     u32 tot; u32 ex = block_exclusive_scan_256(s, lds, tot) + sums[blockIdx.x];
 #pragma unroll
     for (int j = 0; j < 4; j++) { if (base + j <= n) out[base + j] = ex; ex += v[j]; }
-}
-
-// segmented form for the per-chromosome list offsets of one generation: segment y < n_work scans the mutation counts of work
-// entry y into its moff_alt, segment n_work + y the interval counts into poff_alt; the totals go to the status block
-__global__ void __launch_bounds__(256) k_scan_final_tab(const u32* __restrict__ in, size_t n, size_t in_stride, const u32* __restrict__ sums, size_t sums_stride,
-                                                        const ChrWork* __restrict__ W, u32 n_work, u32* __restrict__ status)
-{
-    __shared__ u32 lds[8];
-    const u32 y = blockIdx.y;
-    const bool is_parts = y >= n_work;
-    const ChrWork& w = W[is_parts ? y - n_work : y];
-    u32* __restrict__ out = is_parts ? w.poff_alt : w.moff_alt;
-    in += (size_t)y * in_stride; sums += (size_t)y * sums_stride;
-    const size_t base = (size_t)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
-    u32 v[4], sv = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) { v[j] = base + j < n ? in[base + j] : 0; sv += v[j]; }
-    u32 tot; u32 ex = block_exclusive_scan_256(sv, lds, tot) + sums[blockIdx.x];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (base + j <= n) out[base + j] = ex;
-        if (base + j == n) {
-            status[ST_TOTALS + ST_PER_CHR * w.chr + (is_parts ? 1 : 0)] = ex;
-        }
-        ex += v[j];
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -960,9 +934,7 @@ __global__ void __launch_bounds__(256) k_cv_newmut(const CvWork* __restrict__ Vt
             u32 cnt = 0;
             for (u32 j = 0; j < k; j++) cnt += bk[j] <= x;
             const u32 hap = (sd.start[G] ^ cnt) & 1u;
-            const u32 l0 = w.moff_cur[2 * parent + hap], l1 = w.moff_cur[2 * parent + hap + 1];
-            const u32 at = l0 + lower_bound_u64(w.mpos_cur + l0, l1 - l0, x);
-            seen = at < l1 && w.mpos_cur[at] == x;
+            seen = lp_has_mutation(w.lp, (size_t)2 * parent + hap, x, w.bp0);
         }
         if (seen) continue;
         u32* row = v.cvp_alt + (2 * i + side) * v.stride_w32;
@@ -973,154 +945,6 @@ __global__ void __launch_bounds__(256) k_cv_newmut(const CvWork* __restrict__ Vt
         }
     }
 }
-
-// ------------------------------------------------------------------------------------------
-// sparse overlay: mutation lists.  Offspring row = { x in parent hap h : start^parity(x) == h }
-// (recombine + modify_part_for_mutation_pos, :2903-2970) + new mutations of its side that fall
-// inside [bp0, bp_end) (ras_add_mutation only appends to a part that contains bp_mut, :2526-2545)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 upper_bound_u64(const u64* __restrict__ a, u32 n, u64 v)   // #{a[i] <= v}
-{
-    u32 lo = 0, hi = n;
-    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-// G lanes work on one output row: all of them walk the (short) control flow, the copies of inherited ranges are shared out
-// (G = 1 for the count pass, which only needs the range lengths; G = 8 for the fill pass: 64 contiguous bytes per step)
-template <bool FILL, int G>
-__global__ void __launch_bounds__(256) k_mutlist(const ChrWork* __restrict__ Wt, u32* __restrict__ cnt, size_t cnt_stride,
-                                                 size_t n_rows_out, int nchr, int has_mut, SampleDev sd)
-{
-    const ChrWork& w = Wt[blockIdx.y];
-    const u32* __restrict__ p_off = w.moff_cur; const u64* __restrict__ p_pos = w.mpos_cur;    // parent generation CSR
-    u32* __restrict__ o_cnt = cnt + (size_t)blockIdx.y * cnt_stride;
-    const u32* __restrict__ o_off = w.moff_alt; u64* __restrict__ o_pos = w.mpos_alt;
-    const int chr = w.chr; const u64 bp0 = w.bp0, bp_end = w.bp_end; const u32 cap = w.mcap;
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t row = tid / G; const u32 sub = (u32)(tid % G);
-    if (row >= n_rows_out) return;
-    if (FILL && o_off[row + 1] > cap) { if (o_off[row] <= cap && sub == 0) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_MUT_CAP); return; }   // host grows and redoes
-    const u32 i = (u32)(row >> 1), s = (u32)(row & 1);
-    const size_t t = (size_t)i * nchr + chr, G_ = 2 * t + s;
-    const u32 parent = s ? sd.mother[i] : sd.father[i];
-    const u32 start = sd.start[G_], k = sd.k[G_];
-    const u64* bk = sd.bk + sd.bk_off[G_];
-    const u32 a0 = p_off[2 * parent], a1 = p_off[2 * parent + 1], b1 = p_off[2 * parent + 2];   // hap0 = [a0,a1), hap1 = [a1,b1)
-    u32 in = 0, nn = 0;
-    const u64* npos = nullptr; const uint8_t* nside = nullptr;
-    if (has_mut) { in = sd.nm_off[t]; nn = in + sd.nmut[t]; npos = sd.nm_pos; nside = sd.nm_side; }
-    u32 n = 0;
-    u64* out = FILL ? o_pos + o_off[row] : nullptr;
-    // The breakpoints cut the positions into k+1 intervals [bk[j-1], bk[j]) that take hap start, start^1, start, ...: the inherited
-    // entries are k+1 contiguous ranges of the two sorted parental lists (two binary searches each), concatenated.  The new
-    // mutations of this side are merged in as a stream: a new position goes in front of the first inherited entry that is larger
-    // (the reference's insertion keeps an equal old entry in front).
-#define NEXT_NEW() while (in < nn && !(nside[in] == s && npos[in] >= bp0 && npos[in] < bp_end)) in++
-#define COPY_OLD(from, to) do { for (u32 q_ = (from) + sub; q_ < (to); q_ += G) out[n + (q_ - (from))] = p_pos[q_]; n += (to) - (from); } while (0)
-    NEXT_NEW();
-    for (u32 j = 0; j <= k; j++) {
-        const u32 h = (start ^ j) & 1u;
-        const u32 L0 = h ? a1 : a0, L1 = h ? b1 : a1;
-        const u32 lo = j == 0 ? L0 : L0 + lower_bound_u64(p_pos + L0, L1 - L0, bk[j - 1]);
-        const u32 hi = j == k ? L1 : L0 + lower_bound_u64(p_pos + L0, L1 - L0, bk[j]);
-        if (hi <= lo) continue;
-        if (!FILL) { n += hi - lo; continue; }
-        u32 cur = lo;
-        while (in < nn) {
-            const u64 vn = npos[in];
-            const u32 split = cur + upper_bound_u64(p_pos + cur, hi - cur, vn);      // first inherited entry > vn
-            if (split >= hi) break;                                                   // none in this interval: vn stays pending
-            COPY_OLD(cur, split);
-            if (sub == 0) out[n] = vn;
-            n++; in++; NEXT_NEW(); cur = split;
-        }
-        COPY_OLD(cur, hi);
-    }
-    while (in < nn) { if (FILL && sub == 0) out[n] = npos[in]; n++; in++; NEXT_NEW(); }
-#undef COPY_OLD
-#undef NEXT_NEW
-    if (!FILL) o_cnt[row] = n;
-}
-
-// ------------------------------------------------------------------------------------------
-// K4: ancestry interval lists == Simulation::recombine (:2903-2958), statement by statement on CSR
-// ------------------------------------------------------------------------------------------
-// one part, optionally clipped, as two 16-byte register moves (a struct temporary would be placed in LDS: 14 KiB per block)
-__device__ __forceinline__ void put_part(gev_part* dst, const gev_part* src, bool set_st, u64 st, bool set_en, u64 en)
-{
-    uint4 a = ((const uint4*)src)[0]; const uint4 b = ((const uint4*)src)[1];        // a = {st, en}, b = {hap_index, root_population, reserved}
-    if (set_st) { a.x = (u32)st; a.y = (u32)(st >> 32); }
-    if (set_en) { a.z = (u32)en; a.w = (u32)(en >> 32); }
-    ((uint4*)dst)[0] = a; ((uint4*)dst)[1] = b;
-}
-// Simulation::recombine (:2903-2958) on the CSR interval lists.  The parts of a haplotype tile [bp0, bp_end) (st ascending,
-// en[i] = st[i+1]), so inside one interval [Lc, Rc) of the crossover pattern the reference's loop emits: at most one part clipped
-// at Lc (:2922 / :2931), then a RUN of whole parts -- everything up to the first part that ends behind Rc -- and at most one part
-// clipped at Rc (:2947).  The run is a contiguous range of the parent's list: found by bisection, counted by subtraction
-// (count pass, G = 1) or copied by G lanes together (fill pass, G = 8: 128 contiguous bytes per step).
-template <bool FILL, int G>
-__global__ void __launch_bounds__(256) k_parts(const ChrWork* __restrict__ Wt, u32* __restrict__ cnt, size_t cnt_stride,
-                                               size_t n_rows_out, int nchr, SampleDev sd)
-{
-    const ChrWork& w = Wt[blockIdx.y];
-    const u32* __restrict__ p_off = w.poff_cur; const gev_part* __restrict__ p_parts = w.parts_cur;
-    u32* __restrict__ o_cnt = cnt + (size_t)blockIdx.y * cnt_stride;
-    const u32* __restrict__ o_off = w.poff_alt; gev_part* __restrict__ o_parts = w.parts_alt;
-    const int chr = w.chr; const u64 bp0 = w.bp0, bp_end = w.bp_end; const u32 cap = w.pcap;
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t row = tid / G; const u32 sub = (u32)(tid % G);
-    if (row >= n_rows_out) return;
-    if (FILL && o_off[row + 1] > cap) { if (o_off[row] <= cap && sub == 0) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_PARTS_CAP); return; }
-    const u32 i = (u32)(row >> 1), s = (u32)(row & 1);
-    const size_t G_ = 2 * ((size_t)i * nchr + chr) + s;
-    const u32 parent = s ? sd.mother[i] : sd.father[i];
-    u32 hap = sd.start[G_];
-    const u32 k = sd.k[G_];
-    const u64* bk = sd.bk + sd.bk_off[G_];
-    gev_part* out = FILL ? o_parts + o_off[row] : nullptr;
-    u32 n = 0;
-    // whole parts [from, to) of the parent's list -> out[n ...], 16 bytes per lane and step
-#define COPY_RUN(from, to) do { if (FILL) { const uint4* s_ = (const uint4*)(p_parts + (from)); uint4* d_ = (uint4*)(out + n); \
-                                            for (u32 u_ = sub; u_ < 2u * ((to) - (from)); u_ += G) d_[u_] = s_[u_]; } n += (to) - (from); } while (0)
-#define FIRST_EN_GT(x, from, res) do { u32 lo_ = (from), hi_ = h1; while (lo_ < hi_) { const u32 mid_ = (lo_ + hi_) >> 1; if (p_parts[mid_].en <= (x)) lo_ = mid_ + 1; else hi_ = mid_; } res = lo_; } while (0)
-    if (k == 0) {                                                       // locs.size() < 3, :2910
-        const u32 h0 = p_off[2 * parent + hap], h1 = p_off[2 * parent + hap + 1];
-        COPY_RUN(h0, h1);
-        if (!FILL) o_cnt[row] = n;
-        return;
-    }
-    for (u32 i1 = 1; i1 <= k + 1; i1++) {                               // locs = [bp0, bk..., bp_end]
-        const u64 Lc = (i1 == 1) ? bp0 : bk[i1 - 2];
-        const u64 Rc = (i1 == k + 1) ? bp_end : bk[i1 - 1];
-        const u32 h0 = p_off[2 * parent + hap], h1 = p_off[2 * parent + hap + 1];
-        u32 i2;
-        FIRST_EN_GT(Lc, h0, i2);                                                                    // :2918
-        if (i2 < h1 && p_parts[i2].st < Lc && Lc < p_parts[i2].en && Rc < p_parts[i2].en) {         // :2922
-            if (FILL && sub == 0) put_part(out + n, p_parts + i2, true, Lc, true, Rc); n++; i2++;
-        }
-        if (i2 < h1 && p_parts[i2].st < Lc && Lc < p_parts[i2].en && Rc >= p_parts[i2].en) {        // :2931
-            if (FILL && sub == 0) put_part(out + n, p_parts + i2, true, Lc, false, 0); n++; i2++;
-        }
-        // :2939 -- while (en <= Rc && Lc <= st): from here on every part starts at or behind Lc (the one that did not is handled
-        // above), so the loop runs up to the first part that ends behind Rc
-        if (FILL && G == 1) {                                       // short lists (one thread per row): copy while walking, as the reference does
-            while (i2 < h1 && p_parts[i2].en <= Rc && Lc <= p_parts[i2].st) { put_part(out + n, p_parts + i2, false, 0, false, 0); n++; i2++; }
-        } else if (i2 < h1 && Lc <= p_parts[i2].st) {
-            u32 iR;
-            FIRST_EN_GT(Rc, i2, iR);
-            COPY_RUN(i2, iR);
-            i2 = iR;
-        }
-        if (i2 < h1 && p_parts[i2].st < Rc && Rc < p_parts[i2].en) {                                 // :2947
-            if (FILL && sub == 0) put_part(out + n, p_parts + i2, false, 0, true, Rc); n++;
-        }
-        hap ^= 1u;                                                                                   // :2955
-    }
-#undef COPY_RUN
-#undef FIRST_EN_GT
-    if (!FILL) o_cnt[row] = n;
-}
-
 
 // ------------------------------------------------------------------------------------------
 // K6/K7: ras_find_cv + ras_compute_AD (src/Simulation.cpp:2624-2815)
@@ -1787,4 +1611,6 @@ __global__ void __launch_bounds__(256) k_format_bed(const u64* __restrict__ snpm
     out[q] = (uint8_t)o;
 }
 
+#define GEV_LISTS_KERNELS
+#include "gev_lists.h"
 #include "gev_mate.h"

@@ -149,9 +149,21 @@ struct ChrState {
     // n_free / cursor = its length and how much of it has been handed out (from the last generation's status block)
     bool pool_list_valid = false, pool_force_rebuild = false; u32 pool_n_free = 0, pool_cursor = 0, pool_last_taken = 0;
     unsigned long long pool_rebuilds = 0;
+    // Sparse state (mutation lists, ancestry interval lists) in TWO forms, each derived from the other on demand:
+    //   pieces (gev_lists.h): what Simulation::reproduce reads and writes -- per-range pieces shared between parent and offspring
+    //   CSR (moff/mpos, poff/parts of buffer P.cur): what everything else reads (downloads, output, migration, plane-less assembly)
+    // csr_valid / lp.valid say which of them describe the current generation (at least one does).
     DevBuf moff[2], mpos[2], poff[2], parts[2];
-    size_t mut_total[2] = {0, 0}, parts_total[2] = {0, 0};   // list sizes of the two buffers (known to the host after each generation)
-    size_t mut_need = 0, parts_need = 0;                     // exact capacity demand after an overflowed attempt
+    size_t mut_total[2] = {0, 0}, parts_total[2] = {0, 0};   // list sizes of the two CSR buffers
+    bool csr_valid = true;
+    struct LpState {
+        DevBuf ptab[2], mtab[2], parena, marena, ctr;        // tables [P.cur] = current generation; ctr: {interval entries, mutation entries appended by an import, overflow flags}
+        u32 p_used = 0, m_used = 0;                          // arena cursors (entries)
+        u32 p_last = 0, m_last = 0;                          // what the last generation appended
+        u32 nseg = 0, lgw = 0;
+        bool valid = false, grow_p = false, grow_m = false;
+        unsigned long long imports = 0;                      // full imports (first use, after a CSR-side change, compactions)
+    } lp;
 };
 struct PopState {
     std::vector<ChrStatic> cs;                         // [chr]
@@ -186,7 +198,7 @@ struct gev_ctx {
         DevBuf father, mother, mutseeds, globvals /* [2 + T] ras_glob_seed() values drawn on the device: mate seed, reproduce seed, mutation seeds */, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, status, slow_mut, slow_rec, chrwork, cvwork;
         std::vector<uint8_t> chrwork_shadow, cvwork_shadow;     // what the device copies of the tables hold (upload_table_cached)
         unsigned n_chrwork = 0, n_cvwork = 0; float sampling_ms_saved = -1;
-        size_t nseg_max = 1, cv_used_max = 0, mut_avg = 0, parts_avg = 0; u32 cv_max = 0;     // launch shapes of the generation (enqueue_tables)
+        size_t nseg_max = 1, cv_used_max = 0; u32 cv_max = 0;     // launch shapes of the generation (enqueue_tables)
         bool pool_rebuild = false;                                                            // this attempt rebuilds the free list of the segment pool
         bool cv_count_fused = false;                                                          // k_stitch_small also counts the alleles per CV column (every grid <= 1024 columns)
         hipEvent_t ev_fork = nullptr, ev_aux = nullptr, ev_lists = nullptr, ev_forked = nullptr;   // joins of the attempt's side streams
@@ -886,7 +898,7 @@ int gev_init_gen0(gev_ctx* c, int pop, size_t n_people, uint32_t seed_gen0, uint
     KCHECK();
     if (sex_out) HIPC(hipMemcpyAsync(sex_out, P.d_sex[P.cur].p, n_people, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = c->chr_active[k] ? rows : 0; P.st[k].pool_list_valid = false; }
+    for (int k = 0; k < c->nchr; k++) { P.st[k].mut_total[P.cur] = 0; P.st[k].parts_total[P.cur] = c->chr_active[k] ? rows : 0; P.st[k].pool_list_valid = false; P.st[k].csr_valid = true; P.st[k].lp.valid = false; }
     c->ad_cached_pop = c->ad_host_set_pop = -1;
     P.n_people = n_people; P.n_phys = n_people; P.logical.clear(); P.gen0 = true;
     return GEV_OK;
@@ -908,6 +920,7 @@ static int enqueue_chain_head_start(gev_ctx* c);
 static int prepare_eager_ad(gev_ctx* c, int pop);
 static int check_not_pending(gev_ctx* c);
 static int materialize_order(gev_ctx* c, int pop);
+static int ensure_csr(gev_ctx* c, int pop);
 extern "C" int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people);
 static int wait_planes(gev_ctx* c)
 {
@@ -1048,6 +1061,95 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
     HIPC(hipEventRecord(sc.t[1], st));
     return GEV_OK;
 }
+// ---- sparse state as shared pieces (gev_lists.h) -------------------------------------------------------------------------
+// ranges of 2^lgw bp, at most LP_MAXSEG of them (GEV_LIST_SEGS: fewer; 1 = one piece per row and list)
+static void lp_geometry(const ChrStatic& S, u32& nseg, u32& lgw)
+{
+    static const u32 max_seg = getenv("GEV_LIST_SEGS") ? (u32)std::min(std::max(atoi(getenv("GEV_LIST_SEGS")), 1), LP_MAXSEG) : (u32)LP_MAXSEG;
+    const u64 span = S.rbp.back() - S.rbp.front();
+    lgw = 0;
+    while ((span >> lgw) + 1 > max_seg) lgw++;
+    nseg = (u32)(span >> lgw) + 1;
+}
+static size_t lp_arena_entries(size_t rows, size_t live)
+{
+    // arena = room for the pieces of many generations (each appends a few entries per row); GEV_LIST_HEADROOM=0: just what is live
+    // (tests: every generation then overflows, grows and is enqueued again)
+    static const size_t per_row = getenv("GEV_LIST_ARENA") ? (size_t)atol(getenv("GEV_LIST_ARENA")) : 512;
+    static const bool tight = getenv("GEV_LIST_HEADROOM") && atol(getenv("GEV_LIST_HEADROOM")) == 0;
+    if (tight) return live + 16;
+    return std::min<size_t>(std::max<size_t>(2 * live + 4096, rows * per_row), 0xfffffff0u);
+}
+// CSR of buffer P.cur -> pieces (tables of buffer P.cur, arenas restarted): first use, after a CSR-side change, compaction
+static int lp_import_all(gev_ctx* c, PopState& P, int k, hipStream_t st)
+{
+    ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k]; ChrState::LpState& lp = cs.lp;
+    const size_t rows = 2 * P.n_phys;
+    lp_geometry(S, lp.nseg, lp.lgw);
+    const bool track = c->track_intervals;
+    const size_t live_p = track ? cs.parts_total[P.cur] + rows * lp.nseg : 0, live_m = cs.mut_total[P.cur];
+    if (live_p >= 0xfffffff0u || live_m >= 0xfffffff0u) return fail(GEV_EDEVICE, "list pieces: more than 2^32 list entries on one chromosome");
+    const size_t tab_rows = std::max<size_t>(rows, 2 * P.cap_people);
+    for (int b = 0; b < 2; b++) {
+        if (track) GEVC(lp.ptab[b].ensure(tab_rows * lp.nseg * sizeof(uint2), st));
+        GEVC(lp.mtab[b].ensure(tab_rows * lp.nseg * sizeof(uint2), st));
+    }
+    if (track) GEVC(lp.parena.ensure(lp_arena_entries(rows, live_p) * sizeof(LpPart), st));
+    GEVC(lp.marena.ensure(std::max<size_t>(lp_arena_entries(rows, live_m), 16) * sizeof(u64), st));
+    GEVC(lp.ctr.ensure(4 * sizeof(u32), st));
+    HIPC(hipMemsetAsync(lp.ctr.p, 0, 4 * sizeof(u32), st));
+    if (rows)
+        hipLaunchKernelGGL(k_lp_import, dim3((unsigned)ceil_div(rows * LP_MAXSEG, 256)), dim3(256), 0, st,
+                           track ? cs.poff[P.cur].as<u32>() : (const u32*)nullptr, track ? cs.parts[P.cur].as<gev_part>() : (const gev_part*)nullptr,
+                           cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>(), (size_t)0, rows,
+                           track ? lp.ptab[P.cur].as<uint2>() : (uint2*)nullptr, lp.mtab[P.cur].as<uint2>(), lp.parena.as<LpPart>(), lp.marena.as<u64>(),
+                           0u, 0u, (u32)(lp.parena.bytes / sizeof(LpPart)), (u32)(lp.marena.bytes / sizeof(u64)), lp.nseg, lp.lgw, (u64)S.rbp.front(),
+                           lp.ctr.as<u32>(), lp.ctr.as<u32>() + 2);
+    KCHECK();
+    u32 h[4] = {0, 0, 0, 0};
+    HIPC(hipMemcpyAsync(h, lp.ctr.p, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if (h[2]) return fail(GEV_EDEVICE, "list pieces: import overflowed its arena (internal error: %u of %zu interval, %u of %zu mutation entries)", h[0], lp.parena.bytes / sizeof(LpPart), h[1], lp.marena.bytes / sizeof(u64));
+    lp.p_used = h[0]; lp.m_used = h[1]; lp.p_last = 0; lp.m_last = 0; lp.valid = true; lp.grow_p = lp.grow_m = false; lp.imports++;
+    return GEV_OK;
+}
+// the CSR form of the current generation (buffer P.cur), materialised from the pieces when it is not there
+static int ensure_csr(gev_ctx* c, int pop)
+{
+    PopState& P = c->pop[pop];
+    hipStream_t st = c->stream;
+    const size_t rows = 2 * P.n_phys;
+    for (int k = 0; k < c->nchr; k++) {
+        ChrState& cs = P.st[k]; ChrState::LpState& lp = cs.lp;
+        if (!c->chr_active[k] || cs.csr_valid) continue;
+        if (!lp.valid) return fail(GEV_ESTATE, "internal error: neither form of the sparse state is valid (pop %d chr %d)", pop, k);
+        const bool track = c->track_intervals;
+        GEVC(cs.moff[P.cur].ensure((rows + 1) * sizeof(u32), st)); GEVC(cs.poff[P.cur].ensure((rows + 1) * sizeof(u32), st));
+        GEVC(c->d_cnt.ensure(2 * (rows + 1) * sizeof(u32), st));
+        u32* pcnt = c->d_cnt.as<u32>(); u32* mcnt = pcnt + rows + 1;
+        const unsigned blocks = (unsigned)ceil_div(std::max<size_t>(rows, 1) * LP_MAXSEG, 256);
+        hipLaunchKernelGGL(k_lp_count, dim3(blocks), dim3(256), 0, st, track ? lp.ptab[P.cur].as<uint2>() : (const uint2*)nullptr, lp.mtab[P.cur].as<uint2>(), lp.nseg,
+                           (const u32*)nullptr, rows, track ? pcnt : (u32*)nullptr, mcnt);
+        KCHECK();
+        u32 tot_m = 0, tot_p = 0;
+        GEVC(scan_u32(c, mcnt, rows, cs.moff[P.cur].as<u32>(), &tot_m));
+        if (track) GEVC(scan_u32(c, pcnt, rows, cs.poff[P.cur].as<u32>(), &tot_p));
+        GEVC(cs.mpos[P.cur].ensure(std::max<size_t>(tot_m, 2) * sizeof(u64), st, false, 1.25));
+        if (track) GEVC(cs.parts[P.cur].ensure(std::max<size_t>(tot_p, 1) * sizeof(gev_part), st, false, 1.25));
+        hipLaunchKernelGGL(k_lp_fill, dim3(blocks), dim3(256), 0, st, track ? lp.ptab[P.cur].as<uint2>() : (const uint2*)nullptr, lp.mtab[P.cur].as<uint2>(),
+                           lp.parena.as<LpPart>(), lp.marena.as<u64>(), lp.nseg, (const u32*)nullptr, rows, (u64)P.cs[k].rbp.back(),
+                           cs.poff[P.cur].as<u32>(), cs.parts[P.cur].as<gev_part>(), cs.moff[P.cur].as<u32>(), cs.mpos[P.cur].as<u64>());
+        KCHECK();
+        HIPC(hipStreamSynchronize(st));
+        cs.mut_total[P.cur] = tot_m; cs.parts_total[P.cur] = track ? tot_p : 0; cs.csr_valid = true;
+    }
+    return GEV_OK;
+}
+// a CSR-side change of the current generation (generation 0, migration, import, order restoring): the pieces no longer describe it
+static void lists_changed_in_csr(gev_ctx* c, PopState& P)
+{
+    for (int k = 0; k < c->nchr; k++) { P.st[k].csr_valid = true; P.st[k].lp.valid = false; }
+}
 static const size_t LIST_HEADROOM = getenv("GEV_LIST_HEADROOM") ? (size_t)atol(getenv("GEV_LIST_HEADROOM")) : 48;    // spare list entries per haplotype row when a list buffer is (re)allocated (tests force redos with 0)
 static const double LIST_GROW = LIST_HEADROOM ? 1.5 : 1.0; static const size_t LIST_SLACK = LIST_HEADROOM ? 4096 : 16;   // (no headroom: every generation that lengthens the lists is enqueued twice)
 // K4/K6 + grouping: everything of the small work that needs the couples (parents) on top of the sampling results.
@@ -1060,7 +1162,6 @@ static int enqueue_tables(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     const int nchr = c->nchr;
     const size_t rows = 2 * n_people;
     const int cur = P.cur, alt = P.cur ^ 1;
-    const double grow = (double)rows / (double)std::max<size_t>(2 * P.n_people, 1);
     std::vector<ChrWork> cw; std::vector<CvWork> vw;
     // The free list of the segment pool is kept across generations (units nobody named when it was built and that were not handed
     // out since are still unnamed) and rebuilt only when what is left of it may not cover the generation: four times what the last
@@ -1079,20 +1180,37 @@ static int enqueue_tables(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     for (int k = 0; k < nchr; k++) {
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
-        // capacity guess: last generation's total scaled to the new size, plus room for the events of many generations
-        // (lists lengthen by about one entry per row and generation; a growth step allocates GBs, which on some hosts is
-        // not lazy and costs 10-250 ms of host time -- keep such steps rare and geometric)
-        size_t want = std::max<size_t>(cs.mut_need, (size_t)(cs.mut_total[cur] * grow * LIST_GROW) + rows * LIST_HEADROOM + LIST_SLACK);
-        GEVC(cs.mpos[alt].ensure(want * sizeof(u64), st, false, LIST_HEADROOM ? 2.0 : 1.0));        // grow geometrically: lists lengthen every generation
-        ChrWork w{};
-        w.moff_cur = cs.moff[cur].as<u32>(); w.mpos_cur = cs.mpos[cur].as<u64>(); w.moff_alt = cs.moff[alt].as<u32>(); w.mpos_alt = cs.mpos[alt].as<u64>();
-        w.mcap = (u32)std::min<size_t>(cs.mpos[alt].bytes / sizeof(u64), 0xfffffff0u);
-        if (c->track_intervals) {
-            want = std::max<size_t>(cs.parts_need, (size_t)(cs.parts_total[cur] * grow * LIST_GROW) + rows * LIST_HEADROOM + LIST_SLACK);
-            GEVC(cs.parts[alt].ensure(want * sizeof(gev_part), st, false, LIST_HEADROOM ? 2.0 : 1.0));
-            w.poff_cur = cs.poff[cur].as<u32>(); w.parts_cur = cs.parts[cur].as<gev_part>(); w.poff_alt = cs.poff[alt].as<u32>(); w.parts_alt = cs.parts[alt].as<gev_part>();
-            w.pcap = (u32)std::min<size_t>(cs.parts[alt].bytes / sizeof(gev_part), 0xfffffff0u);
+        // the parents' pieces: imported from the CSR form when that is what describes them; an arena that may not hold this
+        // generation's pieces is compacted first (pieces -> CSR -> pieces: what no table names any more is dropped)
+        ChrState::LpState& lp = cs.lp;
+        const size_t rows_cur = 2 * P.n_phys;
+        const size_t guess_p = std::max<size_t>(4 * (size_t)lp.p_last, 8 * rows), guess_m = std::max<size_t>(4 * (size_t)lp.m_last, 4 * rows);
+        const bool tight = LIST_HEADROOM == 0;
+        if (lp.valid && !lp.grow_p && !lp.grow_m && !tight) {
+            const bool full_p = c->track_intervals && lp.p_used + guess_p > lp.parena.bytes / sizeof(LpPart);
+            const bool full_m = lp.m_used + guess_m > lp.marena.bytes / sizeof(u64);
+            if (full_p || full_m) { GEVC(ensure_csr(c, pop)); lp.valid = false; }
         }
+        // room the arenas must have on top of what is used: an attempt overflowed (its status block holds what it wanted to append) ...
+        size_t need_p = lp.grow_p ? (size_t)lp.p_last * 5 / 4 + 1024 : 0, need_m = lp.grow_m ? (size_t)lp.m_last * 5 / 4 + 1024 : 0;
+        if (!lp.valid) {
+            GEVC(lp_import_all(c, P, k, st));
+            if (!tight) { need_p = c->track_intervals ? guess_p : 0; need_m = guess_m; }     // ... or a fresh import has to leave room for this generation
+        }
+        if (need_p && lp.p_used + need_p > lp.parena.bytes / sizeof(LpPart))
+            GEVC(lp.parena.ensure(std::min<size_t>(lp.p_used + need_p, 0xfffffff0u) * sizeof(LpPart), st, /*keep=*/true, tight ? 1.0 : 1.5));
+        if (need_m && lp.m_used + need_m > lp.marena.bytes / sizeof(u64))
+            GEVC(lp.marena.ensure(std::min<size_t>(lp.m_used + need_m, 0xfffffff0u) * sizeof(u64), st, /*keep=*/true, tight ? 1.0 : 1.5));
+        lp.grow_p = lp.grow_m = false;
+        const size_t tab_bytes = std::max<size_t>(rows, rows_cur) * lp.nseg * sizeof(uint2);
+        if (c->track_intervals) { GEVC(lp.ptab[alt].ensure(tab_bytes, st)); }
+        GEVC(lp.mtab[alt].ensure(tab_bytes, st));
+        ChrWork w{};
+        w.lp.ptab_cur = lp.ptab[cur].as<uint2>(); w.lp.ptab_alt = lp.ptab[alt].as<uint2>(); w.lp.mtab_cur = lp.mtab[cur].as<uint2>(); w.lp.mtab_alt = lp.mtab[alt].as<uint2>();
+        w.lp.parena = lp.parena.as<LpPart>(); w.lp.marena = lp.marena.as<u64>();
+        w.lp.pbase = lp.p_used; w.lp.mbase = lp.m_used;
+        w.lp.pcap = (u32)std::min<size_t>(lp.parena.bytes / sizeof(LpPart), 0xfffffff0u); w.lp.mcap = (u32)std::min<size_t>(lp.marena.bytes / sizeof(u64), 0xfffffff0u);
+        w.lp.nseg = lp.nseg; w.lp.lgw = lp.lgw; w.lp.track = c->track_intervals ? 1u : 0u;
         w.bp0 = S.rbp.front(); w.bp_end = S.rbp.back(); w.chr = k;
         if (c->dense) {
             w.pw = pool_work(c, P, k, (P.pcur + 1) % 3); w.snp_pos = S.d_pos.as<u64>();
@@ -1111,9 +1229,6 @@ static int enqueue_tables(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
     const u32 nsub = 1 + c->rp_bits;
     sc.cv_count_fused = c->cv_count_fused_ok;
     for (const CvWork& v : vw) { sc.cv_used_max = std::max<size_t>(sc.cv_used_max, (size_t)v.sub_w32 * nsub); sc.cv_count_fused &= v.sub_w32 <= 32; if (v.C <= SMALL_POS_LDS) sc.cv_max = std::max(sc.cv_max, v.C); }   // LDS copy of the CV grid: sized for the launch, not for the worst case (occupancy)
-    const size_t rows_cur = std::max<size_t>(2 * P.n_phys, 1);
-    sc.mut_avg = 0; sc.parts_avg = 0;
-    for (int k = 0; k < nchr; k++) if (c->chr_active[k]) { sc.mut_avg = std::max(sc.mut_avg, P.st[k].mut_total[cur] / rows_cur); sc.parts_avg = std::max(sc.parts_avg, P.st[k].parts_total[cur] / rows_cur); }
     if (sc.n_chrwork) {
         GEVC(upload_table_cached(c, sc.chrwork, sc.chrwork_shadow, cw.data(), cw.size() * sizeof(ChrWork), st));
         GEVC(upload_table_cached(c, sc.cvwork, sc.cvwork_shadow, vw.data(), vw.size() * sizeof(CvWork), st));
@@ -1156,26 +1271,8 @@ static int enqueue_lists(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, bool
     const int nchr = c->nchr;
     const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
     SampleDev sd = make_sd(c, sc, T);
-    const ChrWork* Wt = sc.chrwork.as<ChrWork>();
-    const unsigned row_blocks = (unsigned)ceil_div(rows, 256);
-    const unsigned nseg = c->track_intervals ? 2 * na : na;            // segments [0, na): mutation lists, [na, 2 na): interval lists
-    const size_t seg = rows + 1, nb = ceil_div(rows + 1, SCAN_ITEMS);
-    GEVC(c->d_cnt.ensure((size_t)nseg * seg * sizeof(u32), st)); GEVC(c->d_sums.ensure((size_t)nseg * nb * sizeof(u32), st));
-    u32* cnt = c->d_cnt.as<u32>(); u32* sums = c->d_sums.as<u32>();
-    hipLaunchKernelGGL((k_mutlist<false, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, cnt, seg, rows, nchr, (int)has_mut, sd);
-    if (c->track_intervals) hipLaunchKernelGGL((k_parts<false, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, cnt + (size_t)na * seg, seg, rows, nchr, sd);
-    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb, nseg), dim3(256), 0, st, cnt, rows, sums, seg, nb);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1, nseg), dim3(256), 0, st, sums, nb, nb);
-    hipLaunchKernelGGL(k_scan_final_tab, dim3((unsigned)nb, nseg), dim3(256), 0, st, cnt, rows, seg, sums, nb, Wt, na, sd.status);
-    // fill: one thread per row while the lists are short; once a row inherits LIST_LONG entries or more on average (every
-    // generation adds about one), LIST_LANES lanes per row copy the inherited ranges together (at 100 entries: 2x faster)
-    const unsigned fill_blocks = (unsigned)ceil_div(rows * LIST_LANES, 256);
-    if (sc.mut_avg >= c->list_long) hipLaunchKernelGGL((k_mutlist<true, LIST_LANES>), dim3(fill_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, (int)has_mut, sd);
-    else hipLaunchKernelGGL((k_mutlist<true, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, (int)has_mut, sd);
-    if (c->track_intervals) {
-        if (sc.parts_avg >= c->list_long) hipLaunchKernelGGL((k_parts<true, LIST_LANES>), dim3(fill_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, sd);
-        else hipLaunchKernelGGL((k_parts<true, 1>), dim3(row_blocks, na), dim3(256), 0, st, Wt, (u32*)nullptr, (size_t)0, rows, nchr, sd);
-    }
+    // one launch: every (offspring row, position range) either names the parent's pieces or builds its own (gev_lists.h)
+    hipLaunchKernelGGL(k_lp_generation, dim3((unsigned)ceil_div(rows * LP_MAXSEG, 256), na), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, nchr, (int)has_mut, sd);
     KCHECK();
     return GEV_OK;
 }
@@ -1599,7 +1696,7 @@ static int generation_finish_inner(gev_ctx* c, uint8_t* sex_out, gev_generation_
         if (g_trace_host) fprintf(stderr, "[gev] gen %u attempt %d pre %d: enqueue sampling %.2f ms, sparse %.2f ms, A/D + wait %.2f ms, flags %u, graveyard %.1f MiB\n",
                                   c->gen_counter, attempt, (int)q.pre, q.th1 - q.th0, q.th2 - q.th1, host_ms() - q.th2, flags, g_graveyard.bytes / 1048576.0);
         if (g_trace_host && g_malloc_n) { fprintf(stderr, "[gev]   %zu hipMalloc calls, %.1f MiB, %.2f ms\n", g_malloc_n, g_malloc_bytes / 1048576.0, g_malloc_ms); g_malloc_ms = 0; g_malloc_n = 0; g_malloc_bytes = 0; }
-        for (int k = 0; k < nchr; k++) { P.st[k].mut_total[alt] = hstatus[ST_TOTALS + ST_PER_CHR * k]; P.st[k].parts_total[alt] = hstatus[ST_TOTALS + ST_PER_CHR * k + 1]; }
+        for (int k = 0; k < nchr; k++) { P.st[k].lp.m_last = hstatus[ST_TOTALS + ST_PER_CHR * k]; P.st[k].lp.p_last = hstatus[ST_TOTALS + ST_PER_CHR * k + 1]; }   // entries appended to the arenas
         if (c->dense) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) {
             ChrState& cs = P.st[k]; const u32* stw = hstatus + ST_TOTALS + ST_PER_CHR * k;
             cs.pool_n_free = stw[4]; cs.pool_cursor = stw[5]; cs.pool_last_taken = stw[2];
@@ -1621,13 +1718,14 @@ static int generation_finish_inner(gev_ctx* c, uint8_t* sex_out, gev_generation_
         }
         if (flags & FLAG_BK_OVF) c->bk_ovf_cap = std::max<size_t>(2 * c->bk_ovf_cap, (size_t)hstatus[ST_BK_OVF_USED] * 5 / 4 + 1024);
         if (flags & FLAG_NM_OVF) c->nm_ovf_cap = std::max<size_t>(2 * c->nm_ovf_cap, (size_t)hstatus[ST_NM_OVF_USED] * 5 / 4 + 1024);
-        for (int k = 0; k < nchr; k++) {     // exact needs from the count passes (valid unless a record overflow zeroed some counts: then next attempt refines)
-            P.st[k].mut_need = (size_t)P.st[k].mut_total[alt] * 5 / 4 + 1024;
-            P.st[k].parts_need = (size_t)P.st[k].parts_total[alt] * 5 / 4 + 1024;
-        }
+        if (flags & FLAG_PARTS_CAP) for (int k = 0; k < nchr; k++) P.st[k].lp.grow_p = c->chr_active[k] && c->track_intervals;   // an arena was full: doubled before the next attempt
+        if (flags & FLAG_MUT_CAP) for (int k = 0; k < nchr; k++) P.st[k].lp.grow_m = c->chr_active[k];
         c->redo_count++;
     }
-    for (int k = 0; k < nchr; k++) { P.st[k].mut_need = 0; P.st[k].parts_need = 0; }
+    for (int k = 0; k < nchr; k++) if (c->chr_active[k]) {      // the offspring's pieces are the state now; the CSR form is made when somebody asks for it
+        ChrState::LpState& lp = P.st[k].lp;
+        lp.p_used += lp.p_last; lp.m_used += lp.m_last; P.st[k].csr_valid = false;
+    }
     if (c->dense) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) {            // 16-byte chunks the stitch wrote / chunks of the generation's rows
         const ChrStatic& S = P.cs[k];
         const unsigned long long units = hstatus[ST_TOTALS + ST_PER_CHR * k + 2], last = hstatus[ST_TOTALS + ST_PER_CHR * k + 3];
@@ -2105,6 +2203,7 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
     hipStream_t st = c->stream;
     const int alt = D.cur ^ 1;
     const size_t rows_new = 2 * n_new;
+    for (const Seg& sg : segs) if (!sg.people.empty()) GEVC(ensure_csr(c, sg.src_pop));      // whole lists of the sources are read
     // capacity of the alternate buffers (the current ones keep their content)
     if (n_new > D.cap_people) GEVC(ensure_capacity(c, dst, n_new));
     GEVC(c->d_cnt.ensure((rows_new + 1) * sizeof(u32), st));
@@ -2193,12 +2292,14 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
         HIPC(hipStreamSynchronize(st));
         i0 += sg.people.size();
     }
+    for (int k = 0; k < c->nchr; k++) { D.st[k].csr_valid = true; D.st[k].lp.valid = false; }     // (the caller flips to the buffers written here: CSR form, no pieces yet)
     return GEV_OK;
 }
 // bring the current generation back to dense logical order (no-op unless rows were removed/imported)
 static int materialize_order(gev_ctx* c, int pop)
 {
     PopState& P = c->pop[pop];
+    GEVC(ensure_csr(c, pop));                     // every caller reads whole lists next
     if (P.logical.empty()) return GEV_OK;
     GEVC(gev_sync(c));
     Seg all; all.src_pop = pop; all.people = P.logical;
@@ -2252,6 +2353,7 @@ int gev_migrate(gev_ctx* c, const gev_move* moves, size_t n_moves)
     }
     // grow every destination first (capacity growth copies the current buffers), then gather
     for (int p = 0; p < c->n_pop; p++) if (n_new[p] > c->pop[p].cap_people) GEVC(ensure_capacity(c, p, n_new[p]));
+    for (int p = 0; p < c->n_pop; p++) GEVC(ensure_csr(c, p));          // whole lists of every population are read (before any flag of a destination changes)
     for (int p = 0; p < c->n_pop; p++) GEVC(gather_population(c, p, plan[p], n_new[p]));
     for (int p = 0; p < c->n_pop; p++) { c->pop[p].cur ^= 1; c->pop[p].pcur = (c->pop[p].pcur + 1) % 3; c->pop[p].n_people = n_new[p]; c->pop[p].n_phys = n_new[p]; }
     c->ad_cached_pop = c->ad_host_set_pop = -1;
@@ -2296,6 +2398,7 @@ static int export_counts(gev_ctx* c, int pop, const uint64_t* positions, size_t 
     }
     counts.assign(n * nchr * 4, 0);
     if (!n) return GEV_OK;
+    GEVC(ensure_csr(c, pop));
     GEVC(h2d(c, c->d_map, map.data(), map.size() * sizeof(u32)));
     GEVC(c->d_cnt.ensure(2 * n * sizeof(u32) * 2 + 16, c->stream));
     std::vector<u32> tmp(2 * n);
@@ -2404,6 +2507,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
     if (!device_buf) return fail(GEV_EINVAL, "import_rows: null buffer");
     HIPC(hipSetDevice(c->device));
     GEVC(gev_sync(c));
+    GEVC(ensure_csr(c, pop));                     // the immigrants' lists are appended to the CSR form; the pieces are made from it again
     hipStream_t st = c->stream;
     const int nchr = c->nchr;
     const uint8_t* in = (const uint8_t*)device_buf;
@@ -2466,6 +2570,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
     if (P.logical.empty()) { P.logical.resize(P.n_people); for (size_t i = 0; i < P.n_people; i++) P.logical[i] = (u32)i; }
     for (size_t i = 0; i < n; i++) P.logical.push_back((u32)(n_old + i));
     P.n_phys = n_new; P.n_people = P.logical.size(); c->ad_cached_pop = c->ad_host_set_pop = -1;
+    lists_changed_in_csr(c, P);
     return GEV_OK;
 }
 
@@ -2517,6 +2622,7 @@ static int snp_major_device(gev_ctx* c, int pop, int chr, size_t s0, size_t ns, 
 {
     PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
     hipStream_t st = c->stream;
+    GEVC(ensure_csr(c, pop));
     const size_t rows = 2 * P.n_people;
     stride_w64 = ceil_div(rows, 64);
     GEVC(c->d_snpmajor.ensure(std::max<size_t>(ns * stride_w64 * 8, 16), st));
@@ -2591,6 +2697,7 @@ static int stage_individuals(gev_ctx* c, int pop, int chr, size_t ind0, size_t n
     hipStream_t st = c->stream;
     GEVC(c->d_stage.ensure(std::max<size_t>(2 * n * S.stride, 16), st));
     if (!n) return GEV_OK;
+    GEVC(ensure_csr(c, pop));
     GEVC(stage_rows(c, P, chr, 2 * ind0, 2 * n));
     hipLaunchKernelGGL(k_snp_apply_mut, dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, st,
                        row_map(P, chr), c->d_stage.as<u32>(), S.stride / 4, 2 * ind0, 2 * n,
@@ -2734,6 +2841,7 @@ static int materialize_rows(gev_ctx* c, int pop, int chr, size_t row0, size_t nr
     PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
     hipStream_t st = c->stream;
     const size_t w64 = ceil_div(n_snps, 64), w32 = 2 * w64;
+    GEVC(ensure_csr(c, pop));
     HIPC(hipMemsetAsync(plain, 0, nr * w64 * 8, st));                                     // pad bits of the last word stay 0
     hipLaunchKernelGGL(k_materialize_tile, dim3((unsigned)ceil_div(nr * ceil_div(n_snps, 32), 256)), dim3(256), 0, st,
                        cs.poff[P.cur].as<u32>(), cs.parts[P.cur].as<gev_part>(), row0, nr, S.d_pos.as<u64>(), (u32)snp_begin, (u32)n_snps,
@@ -2947,6 +3055,8 @@ int gev_set_track_intervals(gev_ctx* c, int on)
 {
     if (!c) return fail(GEV_EINVAL, "null");
     if (c->pend.active) return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first");
+    if (c->track_intervals == (on != 0)) return GEV_OK;
+    for (int p = 0; p < c->n_pop; p++) if (c->pop[p].gen0) { GEVC(ensure_csr(c, p)); lists_changed_in_csr(c, c->pop[p]); }   // the pieces are rebuilt with / without the interval tables
     c->track_intervals = on != 0;
     return GEV_OK;
 }

@@ -1,0 +1,315 @@
+// gev_lists.h -- the sparse per-haplotype state (ancestry interval lists, mutation lists) as SHARED PIECES.
+//
+// Simulation::recombine (src/Simulation.cpp:2903-2958) copies the parent's parts unchanged between two crossovers, and
+// ras_add_mutation (:2497-2552) appends to one part: per generation a haplotype's lists change around its ~1 crossover and its
+// ~0.5 new mutations and nowhere else.  Rewriting the whole lists every generation (the CSR form of rounds 1-2) costs bytes
+// proportional to the AGE of the run (lists lengthen by about one entry per generation).  Here the chromosome is cut into
+// nseg <= LP_MAXSEG position ranges of 2^lgw bp, and the list of a haplotype row is the concatenation of one PIECE per range:
+//
+//   interval piece  (row, t) -> {offset, n}: n+1 LpPart entries in the arena: entry 0 = the part that covers the range's first
+//                   position (carry-in, owned by an earlier range), entries 1..n = the parts whose st lies in the range.
+//                   The parts of a haplotype tile [bp0, bp_end) (st ascending, en[i] = st[i+1]: recombine keeps that), so en is
+//                   not stored: it is the next st of the row (bp_end for the last part).
+//   mutation piece  (row, t) -> {offset, n}: the n positions of the row's (ascending) mutation list that lie in the range.
+//
+// A range that contains no crossover boundary of the gamete (and, for the mutation piece, no new mutation) NAMES the parent's
+// piece -- one 8-byte table entry, nothing copied; only the ranges with an event get a new piece, appended to the arena with one
+// atomic per workgroup.  Pieces are immutable.  Everything else that wants whole lists (downloads, output, migration, the
+// plane-less genotype assembly) reads the CSR form, which is materialised from the pieces on demand (k_lp_count / k_lp_fill)
+// and turned back into pieces by k_lp_import_*; when an arena fills up, that round trip is also its compaction.
+// (included twice by gev_kernels.h: the types in front of ChrWork, the kernels -- GEV_LISTS_KERNELS -- behind the scan helpers)
+#ifndef GEV_LISTS_TYPES
+#define GEV_LISTS_TYPES
+
+#define LP_MAXSEG 32
+struct __attribute__((aligned(16))) LpPart { u64 st; u32 hap_index; u32 root_population; };
+struct LpWork {
+    const uint2* ptab_cur; uint2* ptab_alt;      // [rows][nseg] interval pieces of the parents / of the offspring
+    const uint2* mtab_cur; uint2* mtab_alt;      // [rows][nseg] mutation pieces
+    LpPart* parena; u64* marena;
+    u32 pbase, mbase, pcap, mcap;                // arena cursors at the start of the attempt, capacities (entries)
+    u32 nseg, lgw;
+    u32 track;                                   // interval pieces are kept (gev_set_track_intervals)
+};
+#define LP_INF (~0ull)
+__device__ __forceinline__ u32 lp_seg(u64 x, u64 bp0, u32 lgw, u32 nseg)
+{
+    if (x <= bp0) return 0u;
+    const u64 t = (x - bp0) >> lgw;
+    return t >= nseg ? nseg - 1u : (u32)t;
+}
+// first position of range t (0 for the first range: positions in front of bp0 count to it), first position behind it (none: last)
+__device__ __forceinline__ u64 lp_lo(u32 t, u64 bp0, u32 lgw) { return t == 0 ? 0ull : bp0 + ((u64)t << lgw); }
+__device__ __forceinline__ u64 lp_hi(u32 t, u64 bp0, u32 lgw, u32 nseg) { return t + 1 >= nseg ? LP_INF : bp0 + ((u64)(t + 1) << lgw); }
+
+// is position x in the mutation list of haplotype row `row` (parents' table)?  (k_cv_newmut: the set semantics of a new mutation)
+__device__ __forceinline__ bool lp_has_mutation(const LpWork& lp, size_t row, u64 x, u64 bp0)
+{
+    const uint2 me = lp.mtab_cur[row * lp.nseg + lp_seg(x, bp0, lp.lgw, lp.nseg)];
+    const u64* a = lp.marena + me.x;
+    u32 l = 0, r = me.y;
+    while (l < r) { const u32 m = (l + r) >> 1; if (a[m] < x) l = m + 1; else r = m; }
+    return l < me.y && a[l] == x;
+}
+
+#endif   // GEV_LISTS_TYPES
+#ifdef GEV_LISTS_KERNELS
+// One interval [Lc, Rc) of the crossover pattern on ONE piece of the source haplotype: Simulation::recombine's statements
+// (:2918-2950) with en derived from the next entry.  e[0..n] = carry-in + owned entries, en_last = what the last entry's en is
+// known to be (bp_end in the last range, otherwise "behind this range").  head: Lc lies in this range (the interval starts
+// here); otherwise the interval began in an earlier range and only the whole-part run / the clip at Rc concern this piece.
+template <bool FILL>
+__device__ __forceinline__ u32 lp_interval(const LpPart* __restrict__ e, u32 n, u64 en_last, bool head, u64 Lc, u64 Rc, LpPart* __restrict__ out, u32 at)
+{
+#define LP_EN(i) ((i) < n ? e[(i) + 1].st : en_last)
+    u32 i2 = head ? 0u : 1u, emitted = 0;
+    if (head) {
+        while (i2 <= n && LP_EN(i2) <= Lc) i2++;                                                     // :2918
+        if (i2 <= n && e[i2].st < Lc && Lc < LP_EN(i2) && Rc < LP_EN(i2)) {                          // :2922
+            if (FILL) { LpPart p = e[i2]; p.st = Lc; out[at + emitted] = p; } emitted++; i2++;
+        }
+        if (i2 <= n && e[i2].st < Lc && Lc < LP_EN(i2) && Rc >= LP_EN(i2)) {                         // :2931
+            if (FILL) { LpPart p = e[i2]; p.st = Lc; out[at + emitted] = p; } emitted++; i2++;
+        }
+        if (i2 == 0) i2 = 1;                                                                         // the carry-in is owned (and was emitted) by an earlier range
+    }
+    while (i2 <= n && LP_EN(i2) <= Rc && Lc <= e[i2].st) { if (FILL) out[at + emitted] = e[i2]; emitted++; i2++; }   // :2939
+    if (i2 <= n && i2 >= 1 && e[i2].st < Rc && Rc < LP_EN(i2)) { if (FILL) out[at + emitted] = e[i2]; emitted++; }    // :2947 (en = Rc is implicit)
+#undef LP_EN
+    return emitted;
+}
+
+// ------------------------------------------------------------------------------------------
+// one generation: thread (offspring row, range t).  Ranges without an event copy two table entries; the others build their
+// pieces in two passes over the (short) source pieces -- count, one atomic per workgroup and arena, fill.
+// ------------------------------------------------------------------------------------------
+template <bool FILL>
+__device__ __forceinline__ u32 lp_build_parts(const LpWork& lp, const u32 parent, const u32 start, const u64* __restrict__ bk, const u32 j0, const u32 j1,
+                                              const u32 t, const u64 bp0, const u64 bp_end, LpPart* __restrict__ out)
+{
+    const bool last = t + 1 >= lp.nseg;
+    const u64 en_last = last ? bp_end : LP_INF;
+    u32 n = 0;
+    for (u32 q = j0; q <= j1; q++) {                               // interval q: behind breakpoint q-1, in front of breakpoint q
+        const u32 h = (start ^ q) & 1u;
+        const uint2 pe = lp.ptab_cur[((size_t)2 * parent + h) * lp.nseg + t];
+        const LpPart* e = lp.parena + pe.x;
+        const bool head = q > j0 || t == 0;                        // the interval starts in this range (the very first one starts at bp0)
+        const u64 Lc = q > j0 ? bk[q - 1] : bp0;
+        const u64 Rc = q < j1 ? bk[q] : (last ? bp_end : LP_INF);
+        if (FILL && q == j0) out[0] = e[0];                        // carry-in: the part that covers the range's first position
+        n += lp_interval<FILL>(e, pe.y, en_last, head, Lc, Rc, out, 1 + n);
+    }
+    return n;
+}
+// mutation piece of a range with events: the inherited entries are, per interval, a contiguous run of the source piece; the new
+// mutations of this side that lie in the range are merged in (a new position goes behind every inherited entry that is not larger)
+template <bool FILL>
+__device__ __forceinline__ u32 lp_build_muts(const LpWork& lp, const u32 parent, const u32 start, const u64* __restrict__ bk, const u32 j0, const u32 j1,
+                                             const u32 t, const u64* __restrict__ npos, const uint8_t* __restrict__ nside, u32 in, const u32 nn, const u32 s,
+                                             const u64 bp0, const u64 bp_end, u64* __restrict__ out)
+{
+#define LP_NEXT_NEW() while (in < nn && !(nside[in] == s && npos[in] >= bp0 && npos[in] < bp_end && lp_seg(npos[in], bp0, lp.lgw, lp.nseg) == t)) in++
+    u32 n = 0;
+    LP_NEXT_NEW();
+    for (u32 q = j0; q <= j1; q++) {
+        const u32 h = (start ^ q) & 1u;
+        const uint2 me = lp.mtab_cur[((size_t)2 * parent + h) * lp.nseg + t];
+        const u64* a = lp.marena + me.x;
+        u32 lo = 0, hi = me.y;
+        if (q > j0) { const u64 v = bk[q - 1]; u32 l = 0, r = me.y; while (l < r) { const u32 m = (l + r) >> 1; if (a[m] < v) l = m + 1; else r = m; } lo = l; }
+        if (q < j1) { const u64 v = bk[q]; u32 l = lo, r = me.y; while (l < r) { const u32 m = (l + r) >> 1; if (a[m] < v) l = m + 1; else r = m; } hi = l; }
+        for (u32 x = lo; x < hi; x++) {
+            const u64 v = a[x];
+            while (in < nn && npos[in] < v) { if (FILL) out[n] = npos[in]; n++; in++; LP_NEXT_NEW(); }
+            if (FILL) out[n] = v; n++;
+        }
+    }
+    while (in < nn) { if (FILL) out[n] = npos[in]; n++; in++; LP_NEXT_NEW(); }
+#undef LP_NEXT_NEW
+    return n;
+}
+__global__ void __launch_bounds__(256) k_lp_generation(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, int has_mut, SampleDev sd)
+{
+    __shared__ u32 lds[8];
+    __shared__ u32 s_base[2];
+    const ChrWork& w = Wt[blockIdx.y];
+    const LpWork& lp = w.lp;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = tid / LP_MAXSEG; const u32 t = (u32)(tid % LP_MAXSEG);
+    const bool live = row < n_rows_out && t < lp.nseg;
+    const u64 bp0 = w.bp0, bp_end = w.bp_end;
+    u32 parent = 0, start = 0, j0 = 0, j1 = 0, s = 0, in = 0, nn = 0;
+    const u64* bk = nullptr;
+    bool fresh_p = false, fresh_m = false;
+    u32 np = 0, nm = 0;
+    if (live) {
+        const u32 i = (u32)(row >> 1); s = (u32)(row & 1);
+        const size_t task = (size_t)i * nchr + w.chr, G_ = 2 * task + s;
+        parent = s ? sd.mother[i] : sd.father[i];
+        start = sd.start[G_];
+        const u32 k = sd.k[G_];
+        bk = sd.bk + sd.bk_off[G_];
+        const u64 lo_b = lp_lo(t, bp0, lp.lgw), hi_b = lp_hi(t, bp0, lp.lgw, lp.nseg);
+        for (u32 j = 0; j < k; j++) { const u64 v = bk[j]; j0 += v < lo_b; j1 += v < hi_b; }
+        bool new_here = false;
+        if (has_mut) {
+            in = sd.nm_off[task]; nn = in + sd.nmut[task];
+            for (u32 m = in; m < nn; m++) { const u64 x = sd.nm_pos[m]; new_here |= sd.nm_side[m] == s && x >= bp0 && x < bp_end && lp_seg(x, bp0, lp.lgw, lp.nseg) == t; }
+        }
+        fresh_p = lp.track && j1 > j0;
+        fresh_m = j1 > j0 || new_here;
+        const size_t src = ((size_t)2 * parent + ((start ^ j0) & 1u)) * lp.nseg + t, dst = row * lp.nseg + t;
+        if (lp.track && !fresh_p) lp.ptab_alt[dst] = lp.ptab_cur[src];
+        if (!fresh_m) lp.mtab_alt[dst] = lp.mtab_cur[src];
+        if (fresh_p) np = 1 + lp_build_parts<false>(lp, parent, start, bk, j0, j1, t, bp0, bp_end, nullptr);
+        if (fresh_m) nm = lp_build_muts<false>(lp, parent, start, bk, j0, j1, t, sd.nm_pos, sd.nm_side, in, nn, s, bp0, bp_end, nullptr);
+    }
+    // arena space: one atomic per workgroup and arena (placement is arbitrary and invisible: everything goes through the tables)
+    u32 tot_p, tot_m;
+    const u32 ex_p = block_exclusive_scan_256(np, lds, tot_p);
+    const u32 ex_m = block_exclusive_scan_256(nm, lds, tot_m);
+    if (threadIdx.x == 0) {
+        s_base[0] = tot_p ? atomicAdd(&sd.status[ST_TOTALS + ST_PER_CHR * w.chr + 1], tot_p) : 0u;
+        s_base[1] = tot_m ? atomicAdd(&sd.status[ST_TOTALS + ST_PER_CHR * w.chr + 0], tot_m) : 0u;
+    }
+    __syncthreads();
+    if (!live) return;
+    const size_t dst = row * lp.nseg + t;
+    if (fresh_p) {
+        const u64 off = (u64)lp.pbase + s_base[0] + ex_p;
+        if (off + np > lp.pcap) { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_PARTS_CAP); lp.ptab_alt[dst] = make_uint2(0u, 0u); }
+        else { lp_build_parts<true>(lp, parent, start, bk, j0, j1, t, bp0, bp_end, lp.parena + off); lp.ptab_alt[dst] = make_uint2((u32)off, np - 1u); }
+    }
+    if (fresh_m) {
+        const u64 off = (u64)lp.mbase + s_base[1] + ex_m;
+        if (off + nm > lp.mcap) { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_MUT_CAP); lp.mtab_alt[dst] = make_uint2(0u, 0u); }
+        else { lp_build_muts<true>(lp, parent, start, bk, j0, j1, t, sd.nm_pos, sd.nm_side, in, nn, s, bp0, bp_end, lp.marena + off); lp.mtab_alt[dst] = make_uint2((u32)off, nm); }
+    }
+}
+// ------------------------------------------------------------------------------------------
+// pieces -> CSR (downloads, output, migration, plane-less assembly, compaction).  Row r of the output is table row
+// (map ? map[r] : r).  Half a wave per row (LP_MAXSEG = 32 lanes): counts by a butterfly sum, offsets by a 32-lane scan.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lp_count(const uint2* __restrict__ ptab, const uint2* __restrict__ mtab, u32 nseg, const u32* __restrict__ map, size_t n_rows,
+                                                  u32* __restrict__ pcnt, u32* __restrict__ mcnt)
+{
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t r = tid / LP_MAXSEG; const u32 t = (u32)(tid % LP_MAXSEG);
+    u32 np = 0, nm = 0;
+    if (r < n_rows && t < nseg) {
+        const size_t row = map ? (size_t)map[r] : r;
+        if (ptab) np = ptab[row * nseg + t].y;
+        nm = mtab[row * nseg + t].y;
+    }
+#pragma unroll
+    for (int d = 1; d < LP_MAXSEG; d <<= 1) { np += __shfl_xor(np, d, LP_MAXSEG); nm += __shfl_xor(nm, d, LP_MAXSEG); }
+    if (r < n_rows && t == 0) { if (pcnt) pcnt[r] = np; mcnt[r] = nm; }
+}
+__global__ void __launch_bounds__(256) k_lp_fill(const uint2* __restrict__ ptab, const uint2* __restrict__ mtab, const LpPart* __restrict__ parena, const u64* __restrict__ marena,
+                                                 u32 nseg, const u32* __restrict__ map, size_t n_rows, u64 bp_end,
+                                                 const u32* __restrict__ poff, gev_part* __restrict__ parts, const u32* __restrict__ moff, u64* __restrict__ mpos)
+{
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t r = tid / LP_MAXSEG; const u32 t = (u32)(tid % LP_MAXSEG);
+    const bool live = r < n_rows && t < nseg;
+    const size_t row = live ? (map ? (size_t)map[r] : r) : 0;
+    uint2 pe = make_uint2(0u, 0u), me = make_uint2(0u, 0u);
+    if (live) { if (ptab) pe = ptab[row * nseg + t]; me = mtab[row * nseg + t]; }
+    u32 ip = pe.y, im = me.y;                                          // inclusive scans over the row's ranges
+#pragma unroll
+    for (int d = 1; d < LP_MAXSEG; d <<= 1) { const u32 a = __shfl_up(ip, d, LP_MAXSEG), b = __shfl_up(im, d, LP_MAXSEG); if (t >= (u32)d) { ip += a; im += b; } }
+    // en of a range's last part = st of the row's next part = first owned st of the next non-empty range (bp_end behind the last)
+    u64 nxt = (live && pe.y) ? parena[pe.x + 1].st : LP_INF;           // this range's first owned st
+    u64 after = LP_INF;                                                // min over the ranges behind this one
+    {
+        u64 run = nxt;                                                 // suffix minimum, exclusive: shift down by one first
+        u64 v = __shfl_down(run, 1, LP_MAXSEG); if (t + 1 >= LP_MAXSEG) v = LP_INF;
+        run = v;
+#pragma unroll
+        for (int d = 1; d < LP_MAXSEG; d <<= 1) { u64 o = __shfl_down(run, d, LP_MAXSEG); if (t + d >= LP_MAXSEG) o = LP_INF; run = run < o ? run : o; }
+        after = run;
+    }
+    if (!live) return;
+    if (ptab && pe.y) {
+        gev_part* out = parts + poff[r] + (ip - pe.y);
+        const LpPart* e = parena + pe.x + 1;
+        for (u32 j = 0; j < pe.y; j++) {
+            gev_part p; p.st = e[j].st; p.en = j + 1 < pe.y ? e[j + 1].st : (after == LP_INF ? bp_end : after);
+            p.hap_index = e[j].hap_index; p.root_population = (int32_t)e[j].root_population; p.reserved = 0;
+            out[j] = p;
+        }
+    }
+    if (me.y) {
+        u64* out = mpos + moff[r] + (im - me.y);
+        const u64* a = marena + me.x;
+        for (u32 j = 0; j < me.y; j++) out[j] = a[j];
+    }
+}
+// CSR -> pieces for table rows [row0, row0 + n_rows) (generation 0, uploads, immigrants, compaction): CSR row r -> table row row0 + r.
+// ctr[0], ctr[1]: entries appended to the interval / mutation arena by this launch (on top of pbase / mbase); flag: an arena is full
+__global__ void __launch_bounds__(256) k_lp_import(const u32* __restrict__ poff, const gev_part* __restrict__ parts, const u32* __restrict__ moff, const u64* __restrict__ mpos,
+                                                   size_t row0, size_t n_rows, uint2* __restrict__ ptab, uint2* __restrict__ mtab, LpPart* __restrict__ parena, u64* __restrict__ marena,
+                                                   u32 pbase, u32 mbase, u32 pcap, u32 mcap, u32 nseg, u32 lgw, u64 bp0, u32* __restrict__ ctr, u32* __restrict__ flag)
+{
+    __shared__ u32 lds[8];
+    __shared__ u32 s_base[2];
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t r = tid / LP_MAXSEG; const u32 t = (u32)(tid % LP_MAXSEG);
+    const bool live = r < n_rows && t < nseg;
+    u32 p_lo = 0, p_hi = 0, p_first = 0, m_lo = 0, m_hi = 0, np = 0, nm = 0;
+    if (live) {
+        const u64 lo_b = lp_lo(t, bp0, lgw), hi_b = lp_hi(t, bp0, lgw, nseg);
+        if (ptab) {
+            const u32 a = poff[r], b = poff[r + 1];
+            p_first = a;
+            u32 l = a, h = b; while (l < h) { const u32 m = (l + h) >> 1; if (parts[m].st < lo_b) l = m + 1; else h = m; } p_lo = l;
+            if (hi_b == LP_INF) p_hi = b; else { l = p_lo; h = b; while (l < h) { const u32 m = (l + h) >> 1; if (parts[m].st < hi_b) l = m + 1; else h = m; } p_hi = l; }
+            np = 1 + (p_hi - p_lo);
+        }
+        const u32 a = moff[r], b = moff[r + 1];
+        u32 l = a, h = b; while (l < h) { const u32 m = (l + h) >> 1; if (mpos[m] < lo_b) l = m + 1; else h = m; } m_lo = l;
+        if (hi_b == LP_INF) m_hi = b; else { l = m_lo; h = b; while (l < h) { const u32 m = (l + h) >> 1; if (mpos[m] < hi_b) l = m + 1; else h = m; } m_hi = l; }
+        nm = m_hi - m_lo;
+    }
+    u32 tot_p, tot_m;
+    const u32 ex_p = block_exclusive_scan_256(np, lds, tot_p);
+    const u32 ex_m = block_exclusive_scan_256(nm, lds, tot_m);
+    if (threadIdx.x == 0) { s_base[0] = tot_p ? atomicAdd(&ctr[0], tot_p) : 0u; s_base[1] = tot_m ? atomicAdd(&ctr[1], tot_m) : 0u; }
+    __syncthreads();
+    if (!live) return;
+    const size_t dst = (row0 + r) * nseg + t;
+    if (ptab) {
+        const u64 off = (u64)pbase + s_base[0] + ex_p;
+        if (off + np > pcap) { atomicOr(flag, 1u); ptab[dst] = make_uint2(0u, 0u); }
+        else {
+            LpPart* o = parena + off;
+            const u32 have = poff[r + 1] - p_first;
+            const u32 c = p_lo > p_first ? p_lo - 1 : p_lo;              // the part in front of the range's first owned one (first range: a copy of it)
+            for (u32 j = 0; j < np; j++) {
+                const u32 q = j == 0 ? c : p_lo + j - 1;
+                LpPart e; e.st = 0; e.hap_index = 0; e.root_population = 0;
+                if (have && q < poff[r + 1]) { e.st = parts[q].st; e.hap_index = (u32)parts[q].hap_index; e.root_population = (u32)parts[q].root_population; }
+                o[j] = e;
+            }
+            ptab[dst] = make_uint2((u32)off, np - 1u);
+        }
+    }
+    {
+        const u64 off = (u64)mbase + s_base[1] + ex_m;
+        if (off + nm > mcap) { atomicOr(flag, 2u); mtab[dst] = make_uint2(0u, 0u); }
+        else { u64* o = marena + off; for (u32 j = 0; j < nm; j++) o[j] = mpos[m_lo + j]; mtab[dst] = make_uint2((u32)off, nm); }
+    }
+}
+// table rows of selected individuals: dst row r <- src row map[r] (both tables; pieces are shared, nothing else moves)
+__global__ void __launch_bounds__(256) k_lp_gather_rows(const uint2* __restrict__ sp, const uint2* __restrict__ sm, uint2* __restrict__ dp, uint2* __restrict__ dm,
+                                                        const u32* __restrict__ map, size_t n_rows, u32 nseg)
+{
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t r = tid / nseg; const u32 t = (u32)(tid % nseg);
+    if (r >= n_rows) return;
+    const size_t s = (size_t)map[r] * nseg + t, d = r * nseg + t;
+    if (sp) dp[d] = sp[s];
+    dm[d] = sm[s];
+}
+#endif   // GEV_LISTS_KERNELS
