@@ -157,7 +157,7 @@ struct ChrState {
     size_t mut_total[2] = {0, 0}, parts_total[2] = {0, 0};   // list sizes of the two CSR buffers
     bool csr_valid = true;
     struct LpState {
-        DevBuf ptab[2], mtab[2], parena, marena, ctr;        // tables [P.cur] = current generation; ctr: {interval entries, mutation entries appended by an import, overflow flags}
+        DevBuf ptab[2], mtab[2], parena, marena, ctr, items;        // tables [P.cur] = current generation; ctr: {interval entries, mutation entries appended by an import, overflow flags}
         u32 p_used = 0, m_used = 0;                          // arena cursors (entries)
         u32 p_last = 0, m_last = 0;                          // what the last generation appended
         u32 nseg = 0, lgw = 0;
@@ -277,6 +277,7 @@ struct gev_ctx {
     // copied to the device on the stream that uses them
     uint8_t* h_ring = nullptr; size_t h_ring_bytes = 0, h_ring_off = 0;
     DevBuf d_adwork2[2]; std::vector<uint8_t> adwork_shadow[2];
+    DevBuf d_lp_nitems;                                 // [nchr] length of each chromosome's work list of list pieces to build
     std::map<double, GevThr> thr_cache;
 };
 
@@ -1211,6 +1212,9 @@ static int enqueue_tables(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         w.lp.pbase = lp.p_used; w.lp.mbase = lp.m_used;
         w.lp.pcap = (u32)std::min<size_t>(lp.parena.bytes / sizeof(LpPart), 0xfffffff0u); w.lp.mcap = (u32)std::min<size_t>(lp.marena.bytes / sizeof(u64), 0xfffffff0u);
         w.lp.nseg = lp.nseg; w.lp.lgw = lp.lgw; w.lp.track = c->track_intervals ? 1u : 0u;
+        GEVC(lp.items.ensure(rows * LP_MAXSEG * sizeof(u32), st));
+        GEVC(c->d_lp_nitems.ensure((size_t)nchr * sizeof(u32), st));
+        w.lp.items = lp.items.as<u32>(); w.lp.n_items = c->d_lp_nitems.as<u32>() + k;
         w.bp0 = S.rbp.front(); w.bp_end = S.rbp.back(); w.chr = k;
         if (c->dense) {
             w.pw = pool_work(c, P, k, (P.pcur + 1) % 3); w.snp_pos = S.d_pos.as<u64>();
@@ -1272,7 +1276,9 @@ static int enqueue_lists(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, bool
     const size_t T = n_people * (size_t)nchr, rows = 2 * n_people;
     SampleDev sd = make_sd(c, sc, T);
     // one launch: every (offspring row, position range) either names the parent's pieces or builds its own (gev_lists.h)
-    hipLaunchKernelGGL(k_lp_generation, dim3((unsigned)ceil_div(rows * LP_MAXSEG, 256), na), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, nchr, (int)has_mut, sd);
+    HIPC(hipMemsetAsync(c->d_lp_nitems.p, 0, c->d_lp_nitems.bytes, st));
+    hipLaunchKernelGGL(k_lp_inherit, dim3((unsigned)ceil_div(rows, 256), na), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, nchr, (int)has_mut, sd);
+    hipLaunchKernelGGL(k_lp_build, dim3((unsigned)std::min<size_t>(ceil_div(rows * 4, 256), 2048), na), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), nchr, (int)has_mut, sd);
     KCHECK();
     return GEV_OK;
 }

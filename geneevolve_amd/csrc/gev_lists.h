@@ -30,6 +30,7 @@ struct LpWork {
     u32 pbase, mbase, pcap, mcap;                // arena cursors at the start of the attempt, capacities (entries)
     u32 nseg, lgw;
     u32 track;                                   // interval pieces are kept (gev_set_track_intervals)
+    u32* items; u32* n_items;                    // work list of the generation: the (row, range) pairs with an event
 };
 #define LP_INF (~0ull)
 __device__ __forceinline__ u32 lp_seg(u64 x, u64 bp0, u32 lgw, u32 nseg)
@@ -129,62 +130,124 @@ __device__ __forceinline__ u32 lp_build_muts(const LpWork& lp, const u32 parent,
 #undef LP_NEXT_NEW
     return n;
 }
-__global__ void __launch_bounds__(256) k_lp_generation(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, int has_mut, SampleDev sd)
+// events of (row, t): crossover boundaries in front of / up to the end of the range, a new mutation of the row's side inside it
+struct LpEvents { u32 parent, start, s, j0, j1, in, nn; const u64* bk; bool fresh_p, fresh_m; };
+__device__ __forceinline__ LpEvents lp_events(const ChrWork& w, size_t row, u32 t, int nchr, int has_mut, const SampleDev& sd)
+{
+    const LpWork& lp = w.lp;
+    LpEvents ev;
+    const u32 i = (u32)(row >> 1); ev.s = (u32)(row & 1);
+    const size_t task = (size_t)i * nchr + w.chr, G_ = 2 * task + ev.s;
+    ev.parent = ev.s ? sd.mother[i] : sd.father[i];
+    ev.start = sd.start[G_];
+    const u32 k = sd.k[G_];
+    ev.bk = sd.bk + sd.bk_off[G_];
+    const u64 lo_b = lp_lo(t, w.bp0, lp.lgw), hi_b = lp_hi(t, w.bp0, lp.lgw, lp.nseg);
+    ev.j0 = 0; ev.j1 = 0;
+    for (u32 j = 0; j < k; j++) { const u64 v = ev.bk[j]; ev.j0 += v < lo_b; ev.j1 += v < hi_b; }
+    bool new_here = false;
+    ev.in = 0; ev.nn = 0;
+    if (has_mut) {
+        ev.in = sd.nm_off[task]; ev.nn = ev.in + sd.nmut[task];
+        for (u32 m = ev.in; m < ev.nn; m++) { const u64 x = sd.nm_pos[m]; new_here |= sd.nm_side[m] == ev.s && x >= w.bp0 && x < w.bp_end && lp_seg(x, w.bp0, lp.lgw, lp.nseg) == t; }
+    }
+    ev.fresh_p = lp.track && ev.j1 > ev.j0;
+    ev.fresh_m = ev.j1 > ev.j0 || new_here;
+    return ev;
+}
+// pass 1.  A workgroup takes 256 offspring rows.  First one thread per row turns the row's crossover boundaries and new mutations
+// into three bit masks over the ranges (source haplotype at the range's start, ranges with a boundary, ranges with a new
+// mutation) and puts the ranges with an event on the work list of pass 2 (items = row * LP_MAXSEG + t; one atomic per
+// workgroup); then all threads stream the table entries of the 256 rows: a range without an event names the parent's pieces.
+__global__ void __launch_bounds__(256) k_lp_inherit(const ChrWork* __restrict__ Wt, size_t n_rows_out, int nchr, int has_mut, SampleDev sd)
+{
+    __shared__ u32 lds[8];
+    __shared__ u32 s_base;
+    __shared__ u32 s_parent[256], s_hap[256], s_fp[256], s_fm[256];
+    const ChrWork& w = Wt[blockIdx.y];
+    const LpWork& lp = w.lp;
+    const size_t row0 = (size_t)blockIdx.x * 256;
+    const size_t row = row0 + threadIdx.x;
+    u32 fresh = 0;
+    if (row < n_rows_out) {
+        const u32 i = (u32)(row >> 1), s = (u32)(row & 1);
+        const size_t task = (size_t)i * nchr + w.chr, G_ = 2 * task + s;
+        const u32 start = sd.start[G_], k = sd.k[G_];
+        const u64* bk = sd.bk + sd.bk_off[G_];
+        u32 cross = 0, flip = 0, mut = 0;                                  // flip bit t: an odd number of boundaries lies in front of range t
+        for (u32 j = 0; j < k; j++) {
+            const u32 g = lp_seg(bk[j], w.bp0, lp.lgw, lp.nseg);
+            cross |= 1u << g;
+            flip ^= g + 1 >= 32 ? 0u : ~0u << (g + 1);
+        }
+        if (has_mut) {
+            const u32 in = sd.nm_off[task], nn = in + sd.nmut[task];
+            for (u32 m = in; m < nn; m++) { const u64 x = sd.nm_pos[m]; if (sd.nm_side[m] == s && x >= w.bp0 && x < w.bp_end) mut |= 1u << lp_seg(x, w.bp0, lp.lgw, lp.nseg); }
+        }
+        s_parent[threadIdx.x] = s ? sd.mother[i] : sd.father[i];
+        s_hap[threadIdx.x] = start ? ~flip : flip;
+        s_fp[threadIdx.x] = lp.track ? cross : 0u;
+        s_fm[threadIdx.x] = cross | mut;
+        fresh = cross | mut;
+    }
+    u32 tot;
+    const u32 ex = block_exclusive_scan_256((u32)__popc(fresh), lds, tot);
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(lp.n_items, tot) : 0u;
+    __syncthreads();
+    for (u32 at = s_base + ex; fresh; fresh &= fresh - 1u) lp.items[at++] = (u32)(row * LP_MAXSEG) + (u32)__builtin_ctz(fresh);
+    const u32 nseg = lp.nseg;
+    const u32 n_here = (u32)(n_rows_out - row0 < 256 ? n_rows_out - row0 : 256);
+    for (u32 e = threadIdx.x; e < n_here * nseg; e += 256) {
+        const u32 r = e / nseg, t = e - r * nseg;
+        const size_t src = ((size_t)2 * s_parent[r] + ((s_hap[r] >> t) & 1u)) * nseg + t, dst = (row0 + r) * nseg + t;
+        if (lp.track && !((s_fp[r] >> t) & 1u)) lp.ptab_alt[dst] = lp.ptab_cur[src];
+        if (!((s_fm[r] >> t) & 1u)) lp.mtab_alt[dst] = lp.mtab_cur[src];
+    }
+}
+// pass 2, thread per item (persistent grid): the pieces of a range with an event, in two walks over the (short) source pieces --
+// count, one atomic per workgroup and arena, fill
+__global__ void __launch_bounds__(256) k_lp_build(const ChrWork* __restrict__ Wt, int nchr, int has_mut, SampleDev sd)
 {
     __shared__ u32 lds[8];
     __shared__ u32 s_base[2];
     const ChrWork& w = Wt[blockIdx.y];
     const LpWork& lp = w.lp;
-    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t row = tid / LP_MAXSEG; const u32 t = (u32)(tid % LP_MAXSEG);
-    const bool live = row < n_rows_out && t < lp.nseg;
+    const u32 n_items = *lp.n_items;
     const u64 bp0 = w.bp0, bp_end = w.bp_end;
-    u32 parent = 0, start = 0, j0 = 0, j1 = 0, s = 0, in = 0, nn = 0;
-    const u64* bk = nullptr;
-    bool fresh_p = false, fresh_m = false;
-    u32 np = 0, nm = 0;
-    if (live) {
-        const u32 i = (u32)(row >> 1); s = (u32)(row & 1);
-        const size_t task = (size_t)i * nchr + w.chr, G_ = 2 * task + s;
-        parent = s ? sd.mother[i] : sd.father[i];
-        start = sd.start[G_];
-        const u32 k = sd.k[G_];
-        bk = sd.bk + sd.bk_off[G_];
-        const u64 lo_b = lp_lo(t, bp0, lp.lgw), hi_b = lp_hi(t, bp0, lp.lgw, lp.nseg);
-        for (u32 j = 0; j < k; j++) { const u64 v = bk[j]; j0 += v < lo_b; j1 += v < hi_b; }
-        bool new_here = false;
-        if (has_mut) {
-            in = sd.nm_off[task]; nn = in + sd.nmut[task];
-            for (u32 m = in; m < nn; m++) { const u64 x = sd.nm_pos[m]; new_here |= sd.nm_side[m] == s && x >= bp0 && x < bp_end && lp_seg(x, bp0, lp.lgw, lp.nseg) == t; }
+    for (u32 base = blockIdx.x * 256u; base < n_items; base += gridDim.x * 256u) {       // (uniform per workgroup)
+        const u32 q = base + threadIdx.x;
+        const bool live = q < n_items;
+        size_t row = 0; u32 t = 0, np = 0, nm = 0;
+        LpEvents ev{};
+        if (live) {
+            const u32 it = lp.items[q];
+            row = it / LP_MAXSEG; t = it % LP_MAXSEG;
+            ev = lp_events(w, row, t, nchr, has_mut, sd);
+            if (ev.fresh_p) np = 1 + lp_build_parts<false>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, bp0, bp_end, nullptr);
+            if (ev.fresh_m) nm = lp_build_muts<false>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, sd.nm_pos, sd.nm_side, ev.in, ev.nn, ev.s, bp0, bp_end, nullptr);
         }
-        fresh_p = lp.track && j1 > j0;
-        fresh_m = j1 > j0 || new_here;
-        const size_t src = ((size_t)2 * parent + ((start ^ j0) & 1u)) * lp.nseg + t, dst = row * lp.nseg + t;
-        if (lp.track && !fresh_p) lp.ptab_alt[dst] = lp.ptab_cur[src];
-        if (!fresh_m) lp.mtab_alt[dst] = lp.mtab_cur[src];
-        if (fresh_p) np = 1 + lp_build_parts<false>(lp, parent, start, bk, j0, j1, t, bp0, bp_end, nullptr);
-        if (fresh_m) nm = lp_build_muts<false>(lp, parent, start, bk, j0, j1, t, sd.nm_pos, sd.nm_side, in, nn, s, bp0, bp_end, nullptr);
-    }
-    // arena space: one atomic per workgroup and arena (placement is arbitrary and invisible: everything goes through the tables)
-    u32 tot_p, tot_m;
-    const u32 ex_p = block_exclusive_scan_256(np, lds, tot_p);
-    const u32 ex_m = block_exclusive_scan_256(nm, lds, tot_m);
-    if (threadIdx.x == 0) {
-        s_base[0] = tot_p ? atomicAdd(&sd.status[ST_TOTALS + ST_PER_CHR * w.chr + 1], tot_p) : 0u;
-        s_base[1] = tot_m ? atomicAdd(&sd.status[ST_TOTALS + ST_PER_CHR * w.chr + 0], tot_m) : 0u;
-    }
-    __syncthreads();
-    if (!live) return;
-    const size_t dst = row * lp.nseg + t;
-    if (fresh_p) {
-        const u64 off = (u64)lp.pbase + s_base[0] + ex_p;
-        if (off + np > lp.pcap) { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_PARTS_CAP); lp.ptab_alt[dst] = make_uint2(0u, 0u); }
-        else { lp_build_parts<true>(lp, parent, start, bk, j0, j1, t, bp0, bp_end, lp.parena + off); lp.ptab_alt[dst] = make_uint2((u32)off, np - 1u); }
-    }
-    if (fresh_m) {
-        const u64 off = (u64)lp.mbase + s_base[1] + ex_m;
-        if (off + nm > lp.mcap) { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_MUT_CAP); lp.mtab_alt[dst] = make_uint2(0u, 0u); }
-        else { lp_build_muts<true>(lp, parent, start, bk, j0, j1, t, sd.nm_pos, sd.nm_side, in, nn, s, bp0, bp_end, lp.marena + off); lp.mtab_alt[dst] = make_uint2((u32)off, nm); }
+        u32 tot_p, tot_m;
+        const u32 ex_p = block_exclusive_scan_256(np, lds, tot_p);
+        const u32 ex_m = block_exclusive_scan_256(nm, lds, tot_m);
+        if (threadIdx.x == 0) {
+            s_base[0] = tot_p ? atomicAdd(&sd.status[ST_TOTALS + ST_PER_CHR * w.chr + 1], tot_p) : 0u;
+            s_base[1] = tot_m ? atomicAdd(&sd.status[ST_TOTALS + ST_PER_CHR * w.chr + 0], tot_m) : 0u;
+        }
+        __syncthreads();
+        if (live) {
+            const size_t dst = row * lp.nseg + t;
+            if (ev.fresh_p) {
+                const u64 off = (u64)lp.pbase + s_base[0] + ex_p;
+                if (off + np > lp.pcap) { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_PARTS_CAP); lp.ptab_alt[dst] = make_uint2(0u, 0u); }
+                else { lp_build_parts<true>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, bp0, bp_end, lp.parena + off); lp.ptab_alt[dst] = make_uint2((u32)off, np - 1u); }
+            }
+            if (ev.fresh_m) {
+                const u64 off = (u64)lp.mbase + s_base[1] + ex_m;
+                if (off + nm > lp.mcap) { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_MUT_CAP); lp.mtab_alt[dst] = make_uint2(0u, 0u); }
+                else { lp_build_muts<true>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, sd.nm_pos, sd.nm_side, ev.in, ev.nn, ev.s, bp0, bp_end, lp.marena + off); lp.mtab_alt[dst] = make_uint2((u32)off, nm); }
+            }
+        }
+        __syncthreads();                                  // s_base is written again in the next round
     }
 }
 // ------------------------------------------------------------------------------------------
