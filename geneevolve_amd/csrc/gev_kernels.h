@@ -995,7 +995,15 @@ __global__ void __launch_bounds__(256) k_cv_finish(const AdWork* __restrict__ At
     if (n_blocks && col < aw.C) {
         const u32 per = (n_blocks + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(b0 + per, n_blocks);
         u32 n = 0;
-        for (u32 b = b0; b < b1; b++) n += aw.partial[(size_t)b * 1024 + col];
+        u32 b = b0;
+        for (; b + 8 <= b1; b += 8) {                       // eight independent loads in flight (next to the dense stitch a dependent load costs microseconds)
+            u32 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = aw.partial[(size_t)(b + j) * 1024 + col];
+#pragma unroll
+            for (int j = 0; j < 8; j++) n += v[j];
+        }
+        for (; b < b1; b++) n += aw.partial[(size_t)b * 1024 + col];
         if (n) atomicAdd(&aw.counts[col], n);
     }
     __threadfence();
@@ -1005,27 +1013,43 @@ __global__ void __launch_bounds__(256) k_cv_finish(const AdWork* __restrict__ At
     if (!s_last) return;
     __threadfence();
     if (threadIdx.x == 0) { done[blockIdx.z] = 0; if (blockIdx.z == 0) *nan_flag = 0xffffffffu; }     // (the A/D kernels of this launch sequence report the first NaN individual with atomicMin)
-    for (u32 icv = threadIdx.x; icv < aw.C; icv += 256) {
-        const u32 c = aw.col_of_icv[icv];
-        const double f = (double)atomicExch(&aw.counts[c], 0u);     // every column is read by exactly one thread; read at the L2, where the atomics landed
-        const double p = f / (double)(2 * n_human);
-        aw.frq[icv] = p;
-        if (!aw.tab) continue;                                      // (several root populations: k_ad_accumulate looks a and d up per haplotype)
-        const u64 x = aw.pos_file[icv];
-        const bool covered = (x >= aw.bp0 && x < aw.bp_end);
-        const double a0 = covered ? aw.a[icv] : 0.0, d0 = covered ? aw.d[icv] : 0.0;
-        const double a = (a0 + a0) / 2;
-        double d = (d0 + d0) / 2;
-        if (aw.vd == 0) d = 0;
-        const double q = 1 - p;
-        const double alpha = a + d * (q - p);
-        double* t = aw.tab + 6 * (size_t)icv;
-        t[0] = ((double)0u - 2 * p) * alpha;
-        t[1] = ((double)1u - 2 * p) * alpha;
-        t[2] = ((double)2u - 2 * p) * alpha;
-        t[3] = (-2 * p * p) * d;
-        t[4] = (2 * p * q) * d;
-        t[5] = (-2 * q * q) * d;
+    // four CVs per thread and round: the loads of a round are issued together (a dependent global access costs microseconds next
+    // to the dense stitch, and this block is alone on the generation's critical path)
+    for (u32 icv0 = threadIdx.x; icv0 < aw.C; icv0 += 1024) {
+        u32 cc[4]; u32 cnt[4]; u64 xs[4]; double as_[4], ds_[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const u32 icv = icv0 + 256u * u; cc[u] = icv < aw.C ? aw.col_of_icv[icv] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u32 icv = icv0 + 256u * u;
+            cnt[u] = icv < aw.C ? atomicExch(&aw.counts[cc[u]], 0u) : 0u;   // every column is read by exactly one thread; read at the L2, where the atomics landed
+            xs[u] = icv < aw.C ? aw.pos_file[icv] : 0ull;
+            as_[u] = icv < aw.C ? aw.a[icv] : 0.0; ds_[u] = icv < aw.C ? aw.d[icv] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u32 icv = icv0 + 256u * u;
+            if (icv >= aw.C) continue;
+            const double f = (double)cnt[u];
+            const double p = f / (double)(2 * n_human);
+            aw.frq[icv] = p;
+            if (!aw.tab) continue;                                      // (several root populations: k_ad_accumulate looks a and d up per haplotype)
+            const u64 x = xs[u];
+            const bool covered = (x >= aw.bp0 && x < aw.bp_end);
+            const double a0 = covered ? as_[u] : 0.0, d0 = covered ? ds_[u] : 0.0;
+            const double a = (a0 + a0) / 2;
+            double d = (d0 + d0) / 2;
+            if (aw.vd == 0) d = 0;
+            const double q = 1 - p;
+            const double alpha = a + d * (q - p);
+            double* t = aw.tab + 6 * (size_t)icv;
+            t[0] = ((double)0u - 2 * p) * alpha;
+            t[1] = ((double)1u - 2 * p) * alpha;
+            t[2] = ((double)2u - 2 * p) * alpha;
+            t[3] = (-2 * p * p) * d;
+            t[4] = (2 * p * q) * d;
+            t[5] = (-2 * q * q) * d;
+        }
     }
 }
 // per individual, CVs in FILE order, sequential FP64 (no contraction: built with -ffp-contract=off):
@@ -1162,6 +1186,60 @@ __global__ void __launch_bounds__(IPB) k_ad_accumulate_tab(const AdWork* __restr
     const size_t ih = ih0 + threadIdx.x;
     add_out[ih * out_stride] = A_chr;
     dom_out[ih * out_stride] = D_chr;
+    if (aw.add_tot) { aw.add_tot[ih * tot_stride] = 0.0 + A_chr; aw.dom_tot[ih * tot_stride] = 0.0 + D_chr; }   // one chromosome: the sum over chromosomes (:2729-2746) is 0 + x
+    if (A_chr != A_chr || D_chr != D_chr) atomicMin(nan_flag, (u32)(ih < 0xffffffffull ? ih : 0xfffffffeull));
+}
+// The same sums when every CV file of the launch is in position order and the allele sub-row is a whole number of 16-byte
+// chunks: the term table goes through LDS in FEW large pieces (12 KiB: 512 CVs when only the A-terms are needed -- vd == 0, the
+// D-sum stays +0.0 -- else 256 CVs), and a thread reads the piece's words of its two plane rows (up to 4 x 16 bytes each) in one
+// go before the barrier: two to four global round trips per individual instead of eight (next to the dense stitch every one of
+// them costs microseconds).  Same operations in the same order per individual as k_ad_accumulate_tab.
+template <bool SKIP_D>
+__global__ void __launch_bounds__(256) k_ad_accumulate_wide(const AdWork* __restrict__ At, size_t n_human, size_t out_stride, size_t tot_stride, u32* __restrict__ nan_flag)
+{
+    constexpr u32 PIECE = SKIP_D ? 512u : 256u, TERMS = SKIP_D ? 3u : 6u, WORDS = PIECE / 32u;
+    __shared__ double s_tab[PIECE * TERMS];                           // 12 KiB
+    const AdWork& aw = At[blockIdx.y];
+    const double* __restrict__ tab = aw.tab;
+    const u32 Cn = aw.C, stride = aw.stride_w32;
+    const size_t ih = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = ih < n_human;
+    const u32* r0 = aw.cvp + (live ? 2 * ih * stride : 0);
+    const u32* r1 = r0 + stride;
+    double A_chr = 0, D_chr = 0;
+    for (u32 base = 0; base < Cn; base += PIECE) {
+        const u32 nj = min(PIECE, Cn - base);
+        u32 w0[WORDS], w1[WORDS];
+#pragma unroll
+        for (u32 q = 0; q < WORDS / 4; q++) {
+            uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
+            if (q * 128 < nj) { a = *(const uint4*)(r0 + (base >> 5) + 4 * q); b = *(const uint4*)(r1 + (base >> 5) + 4 * q); }
+            w0[4 * q] = a.x; w0[4 * q + 1] = a.y; w0[4 * q + 2] = a.z; w0[4 * q + 3] = a.w;
+            w1[4 * q] = b.x; w1[4 * q + 1] = b.y; w1[4 * q + 2] = b.z; w1[4 * q + 3] = b.w;
+        }
+        __syncthreads();                                              // the previous piece is consumed
+        for (u32 e = threadIdx.x; e < nj * TERMS; e += 256) {
+            const u32 cv = e / TERMS, k = e - cv * TERMS;
+            s_tab[e] = tab[6 * (size_t)(base + cv) + k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 q = 0; q < WORDS; q++) {
+            if (q * 32 >= nj) break;
+            u32 a = w0[q], b = w1[q];
+            const u32 m = min(32u, nj - q * 32);
+            const double* tj = s_tab + TERMS * (q * 32);
+#pragma unroll 4
+            for (u32 j = 0; j < m; j++) {
+                const u32 t = (a & 1u) + (b & 1u); a >>= 1; b >>= 1;
+                A_chr += tj[TERMS * j + t];
+                if (!SKIP_D) D_chr += tj[TERMS * j + 3 + t];
+            }
+        }
+    }
+    if (!live) return;
+    aw.add_out[ih * out_stride] = A_chr;
+    aw.dom_out[ih * out_stride] = D_chr;
     if (aw.add_tot) { aw.add_tot[ih * tot_stride] = 0.0 + A_chr; aw.dom_tot[ih * tot_stride] = 0.0 + D_chr; }   // one chromosome: the sum over chromosomes (:2729-2746) is 0 + x
     if (A_chr != A_chr || D_chr != D_chr) atomicMin(nan_flag, (u32)(ih < 0xffffffffull ? ih : 0xfffffffeull));
 }

@@ -2001,11 +2001,18 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready,
         }
         // counts -> frequencies (+ the term table of the fast path), NaN flag reset: one launch
         const unsigned nblk = counts_ready ? (unsigned)ceil_div(rows, SMALL_ROWS_PER_BLOCK) : 0u;
-        hipLaunchKernelGGL(k_cv_finish, dim3((unsigned)std::max<size_t>(ceil_div(c_max, 256), 1), nblk ? std::min(nblk, 32u) : 1u, nw), dim3(256), 0, st, At, nblk, n, c->d_cvdone.as<u32>(), flag);
+        hipLaunchKernelGGL(k_cv_finish, dim3((unsigned)std::max<size_t>(ceil_div(c_max, 256), 1), nblk ? std::min((nblk + 7u) / 8u, 128u) : 1u, nw), dim3(256), 0, st, At, nblk, n, c->d_cvdone.as<u32>(), flag);
         if (ipb) {
             bool direct = true;                                  // every CV file in position order: rows are read from global memory, no row staging
             for (const AdWork& a : aw) direct &= a.cols_sorted != 0;
-            if (direct) {
+            bool chunked = direct, skip_d = true;                 // ... in whole 16-byte chunks: the term table in few large pieces (k_ad_accumulate_wide)
+            for (const AdWork& a : aw) { chunked &= (a.sub_w32 & 3u) == 0 && (a.stride_w32 & 3u) == 0 && a.C > 0 && (size_t)a.sub_w32 * 32 >= (((size_t)a.C + 127) & ~(size_t)127); skip_d &= a.vd == 0; }
+            static const bool no_dir = getenv("GEV_AD_DIR") && atoi(getenv("GEV_AD_DIR")) == 0;
+            if (chunked && !no_dir) {
+                const unsigned nb = (unsigned)ceil_div(n, 256);
+                if (skip_d) hipLaunchKernelGGL((k_ad_accumulate_wide<true>), dim3(nb, nw), dim3(256), 0, st, At, n, out_stride, tot_stride, flag);
+                else hipLaunchKernelGGL((k_ad_accumulate_wide<false>), dim3(nb, nw), dim3(256), 0, st, At, n, out_stride, tot_stride, flag);
+            } else if (direct) {
                 const unsigned nb = (unsigned)ceil_div(n, 256);
                 hipLaunchKernelGGL((k_ad_accumulate_tab<256>), dim3(nb, nw), dim3(256), ad_tab_lds, st, At, 0u, n, out_stride, tot_stride, flag, 1);
             } else {
