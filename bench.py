@@ -1,39 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- generations/sec of the reproduction hot path (gev_reproduce + gev_compute_ad)
-on BASELINE.json's config 2: 100k individuals x 1M biallelic SNPs, 1 chromosome of 100 Mb,
-uniform recombination map (2001 rows, 5e-4/row), mutation 1e-8/bp (5e-4/row), 1000 CVs.
+"""bench.py -- generations/sec of the reproduction hot path on BASELINE.json's config 2: 100k individuals x 1M biallelic
+SNPs, 1 chromosome of 100 Mb, uniform recombination map (2001 rows, 5e-4/row), mutation 1e-8/bp (5e-4/row), 1000 CVs.
 
     python bench.py [--gpus N --steps K --warmup W]             (N > 1: starts its own N rank processes, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --gpus 2 --migration-rate 0.01              (BASELINE config 3: two populations exchanging 1 % per generation)
 
-One process per GPU; each rank advances its OWN population of the full config-2 size (weak
-scaling: populations shard across GPUs); no data-path collective is
-needed without migration.  A step = one generation: the host makes the couples list from the
-sexes (mating is outside the hot path), Simulation::reproduce and Simulation::ras_compute_AD run
-on the GPU through the C-ABI.  The host loop is software-pipelined (default; --no-pipeline: mate, then
-gev_reproduce, strictly one after the other): the sexes of a generation come out of the sampling
-kernels' rand() chain, which the head start (gev_presample) has run before the generation is handed over,
-and random mating reads nothing but the sexes -- so every step hands generation g over with
-gev_reproduce_begin, issues the head start of g+1, forms the couples of g+1 on the host from
-gev_presample_sex's result while the device builds g, and collects g with gev_reproduce_end.  The dense stitch
-runs on the library's own stream and overlaps all of that (every generation's stitch is complete before the
-timed region ends: the closing barrier synchronises the device).
-The ras_glob_seed() values of the next generation (1 + N*nchr draws, src/Simulation.cpp:2398, :2500) are pure draws of the
-host's stream, known before its couples are: they are drawn INSIDE the timed loop, one generation's worth per step, by a second
-host thread, and handed over early (gev_presample) (--no-presample: hand seeds and couples over together, no pipelining).  The founder panel is generated on the device before the timed region, so
-genotype state is resident in HBM throughout.  --plane-less times BASELINE config 5's mode (interval state only,
-no per-generation genotype assembly) and is NOT the headline configuration.
+One process per GPU; each rank advances its OWN population of the full config-2 size (weak scaling: populations shard across
+GPUs); no data-path collective is needed without migration.  A step = one generation in the reference's
+order -- Simulation::random_mate (src/Simulation.cpp:2090), Simulation::reproduce (:2394), Simulation::ras_compute_AD (:2624) --
+all of it on the GPU behind ONE pair of C-ABI calls (gev_generation_begin / gev_generation_end): the generation's 2 + N*nchr
+ras_glob_seed() values are drawn on the device from the host's glob_generator state, the couples are formed there, the state
+behind the draws comes back with the sexes and A/D.  With selection "none" (this workload) the next generation needs nothing the
+host derives from this one's A/D, so the loop hands generation g+1 over before it reads generation g's A/D (published in the
+library's second pinned buffer); --no-host-overlap reads first.  gev_set_generation_chain(0) tells the library that the host
+draws nothing from glob_generator between two generations: it then samples generation g+1 while generation g's rows are
+stitched.  --mating host is round 2's loop (numpy stand-in for random_mate, seeds drawn by a second host thread).  The founder
+panel is generated on the device before the timed region, so genotype state is resident in HBM throughout.  --plane-less times
+BASELINE config 5's mode (interval state only) and is NOT the headline configuration.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dense stitch kernel (k_stitch_segments): a genotype row is kept as 8 KiB
-segments, and in a segment that contains none of its crossover boundaries an offspring gamete is one parental haplotype unchanged:
-that segment names the parent's unit and is not copied.  The units of a launch are the segments it WRITES (about one per crossover;
-gev_stitch_totals), algorithmic bytes per launch = bytes written x 2 (read once, written once; SURVEY.md 8(d)'s per-gamete figure
-restricted to the bytes that change hands), divided by the kernel's duration measured with HIP events on the library's own stream.
-`every_gamete_copied_equivalent_*` prices all 2N whole rows (N*L/2 bytes, the definition of round 1).  `traffic` holds the measured HBM bytes (newest committed rocprofv3
-PMC passes) and `hbm_actual_GBps` = traffic / kernel time, the rate the memory system really sustained.  `cpu_baseline` times the
-unmodified reference (oracle/_ref/ref_harness, kind "reference"; when it is absent the bit-exact CPU oracle, kind
-"port") on a bounded sample of the same workload on this box's host cores (1 thread: the reference is single threaded).
+Prints ONE JSON line (rank 0).
+  roofline      prices the dense stitch (k_stitch_segments).  A genotype row is kept as segments (2 KiB by default, GEV_SEG_CHUNKS);
+                in a segment that contains none of its crossover boundaries an offspring gamete is one parental haplotype unchanged:
+                that segment names the parent's unit and is not copied.  The units of a launch are the segments it WRITES (about one
+                per crossover; gev_stitch_totals); algorithmic bytes per launch = bytes written x 2 (read once, written once;
+                SURVEY.md 8(d)'s per-gamete figure restricted to the bytes that change hands), divided by the kernel's duration
+                measured with HIP events on the library's own stream.  frac / kernel_ms = live, inside the timed region, where the
+                kernel shares the GPU with the next generation's sampling and this generation's A/D chain; isolated_* = the same
+                kernel alone (extra untimed generations with the streams serialised).  `traffic` = measured HBM bytes (newest
+                committed rocprofv3 PMC passes of the same launch) or null.
+  sampling_kernels   the Bernoulli-draw kernels (k_rec_sample8, k_mut_sample8 + the slow-task kernels): draws/s live and alone, and
+                the share of the VALU issue peak (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave instruction, MI355X_MICROARCH.md)
+                their measured VALU instruction count (committed PMC pass) amounts to.
+  sustained_300 the same loop for 300 more generations after the timed region (lists and pools age): generations/s over them and
+                the step time of the first and last 20.
+  cli_dropin    the newest committed timing of the reference's own program bound to the library (tools/cli_timing.py; not run here).
+  cpu_baseline  the unmodified reference (oracle/_ref/ref_harness, kind "reference"; when the binary is absent the bit-exact CPU
+                oracle, kind "port", and `reference_binary_present` false) on a bounded sample of the same workload, 1 host thread.
 """
 import argparse
 import json
@@ -201,6 +204,7 @@ def main():
     ap.add_argument("--no-chain", action="store_true", help="--mating device: no head start across generations (gev_set_generation_chain)")
     ap.add_argument("--no-pipeline", action="store_true", help="--mating host only: mate, then gev_reproduce, strictly one after the other (default: the host forms the next couples between gev_reproduce_begin and _end)")
     ap.add_argument("--isolated-steps", type=int, default=3, help="extra untimed generations without stream overlap for roofline.isolated")
+    ap.add_argument("--sustained-steps", type=int, default=300, help="generations run after the timed region for the sustained_300 block (0: none; default config and one GPU only)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` as typed: no rendezvous environment yet -> this process becomes the launcher.  It starts one
@@ -418,8 +422,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # host-side means of the timed region (the sustained run below appends to the same lists)
+    host_means = {"host_mating": float(np.mean(mate_ms)), "host_seed_draws": float(np.mean(seed_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
+                  "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None,
+                  "migration_steps": {k: v / args.steps for k, v in mig_parts.items()} if mig_parts else None,
+                  "host_ms_inside_calls": {k: v / args.steps for k, v in call_ms.items()} if call_ms else None}
+    main_step_ms = [round(x, 2) for x in step_ms[:args.steps]]
+    # the same loop for a few hundred generations more: lists lengthen, pools and arenas age (not part of `value`)
+    sustained = None
+    if args.sustained_steps > 0 and world == 1 and fused and not args.plane_less:
+        del step_ms[:]
+        barrier()
+        ts = time.perf_counter()
+        for i in range(total, total + args.sustained_steps):
+            step(i)
+        barrier()
+        dts = time.perf_counter() - ts
+        if state.get("begun"):
+            r = ctx.generation_end(want_couples=False, want_sex=True)
+            sim.glob.x = int(r["glob_state"]); sim.sex[P] = r["sex"]; state["begun"] = False
+        med = float(np.median(step_ms)); slow = [(total + 1 + i, round(v, 2)) for i, v in enumerate(step_ms) if v > 2 * med]
+        k20 = min(20, len(step_ms))
+        first, last = float(np.mean(step_ms[:k20])), float(np.mean(step_ms[-k20:]))
+        sustained = {"generations": args.sustained_steps, "from_generation": total + 1, "generations_per_s": args.sustained_steps / dts, "ms_per_step": dts / args.sustained_steps * 1e3,
+                     "host_step_ms_first_20": first, "host_step_ms_last_20": last, "last_over_first": last / first if first > 0 else None,
+                     "host_step_ms_median": med, "steps_over_twice_the_median": slow[:32], "ms_in_those_steps": float(sum(v for _, v in slow)),
+                     "redone_generations": int(ctx.redo_count()), "list_pieces": ctx.list_stats(P, 0)}
+        total += args.sustained_steps
+        tot1s, n1s = ctx.timing_totals()
+
     # a few extra, untimed generations with the two library streams serialised: the stitch kernel alone on the GPU
-    iso = None
+    iso = None; iso_sampling = None
     if args.isolated_steps > 0 and not migrate and not args.plane_less:
         ctx.set_overlap(False)
         ta, na = ctx.timing_totals()
@@ -431,6 +464,7 @@ def main():
             sim.reproduce(P, total + j + 1, seeds=seeds.pop(total + j) if (total + j) in seeds else sim.ras_glob_seed(n_seeds), n_people=args.n_ind)
         tb, nb = ctx.timing_totals()
         iso = (tb[1] - ta[1]) / max(nb - na, 1)
+        iso_sampling = (tb[0] - ta[0]) / max(nb - na, 1)
         ctx.set_overlap(True)
 
     if rank == 0:
@@ -482,12 +516,10 @@ def main():
                        "ras_glob_seed_draws": "on the device, from the host's glob_generator state (2 + N*nchr per generation)" if fused else
                                               "inside the timed loop, one generation's worth per step, by a second host thread (phase_ms.host_seed_draws)"},
             "loci_individuals_per_sec": world * args.steps * args.n_ind * args.n_loci * args.nchr / dt,
-            "phase_ms": {"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)),
-                         "dense_stitch": stitch, "host_mating": float(np.mean(mate_ms)), "host_seed_draws": float(np.mean(seed_ms)), "gev_reproduce_wall": float(np.mean(repro_ms)),
-                         "gev_compute_ad_wall": float(np.mean(ad_ms)), "migration_wall": float(np.mean(mig_ms)) if mig_ms else None,
-                         "migration_steps": {k: v / args.steps for k, v in mig_parts.items()} if mig_parts else None,
-                         "host_ms_inside_calls": {k: v / args.steps for k, v in call_ms.items()} if call_ms else None},
-               "host_step_ms": [round(x, 2) for x in step_ms[:args.steps]],
+            "phase_ms": dict({"sampling": float(np.mean(sample_ms)), "sparse_lists_and_cv_planes": float(np.mean(sparse_ms)), "dense_stitch": stitch}, **host_means),
+            "host_step_ms": main_step_ms,
+            "sustained_300": sustained,
+            "list_pieces": ctx.list_stats(P, 0) if lib.exports("list_stats") else None,
             "roofline": {"bound": "hbm", "kernel": "k_stitch_segments", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "hbm_actual_GBps": hbm_actual, "hbm_actual_frac": hbm_actual / HBM_PEAK_GBPS if hbm_actual else None,
@@ -495,7 +527,8 @@ def main():
                          "segments_written_per_launch": segs_written / max(args.steps, 1), "segments_per_launch": segs_total / max(args.steps, 1),
                          "written_fraction_of_row_bytes": written_frac,
                          "every_gamete_copied_equivalent_GBps": full_equiv, "every_gamete_copied_equivalent_frac": full_equiv / HBM_PEAK_GBPS,
-                         "note": "units of a launch = the row segments it writes (8 KiB each; those that contain a crossover boundary -- every other segment "
+                         "segment_bytes": (bytes_total / segs_total) if segs_total else None,
+                         "note": "units of a launch = the row segments it writes (segment_bytes each on average; those that contain a crossover boundary -- every other segment "
                                  "of an offspring row names the parental unit and is not copied); algorithmic bytes = bytes written x 2 (each is read once "
                                  "and written once); every_gamete_copied_equivalent_* prices all 2N whole rows (N*L/2 bytes, the definition of round 1) "
                                  "and can exceed the peak; kernel time measured live with HIP events on the library's stitch stream inside the timed region, where the "
@@ -505,10 +538,47 @@ def main():
                          "isolated_frac": (alg_bytes / (iso * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso else None,
                          "isolated_hbm_actual_GBps": (traffic / (iso * 1e-3) / 1e9) if (iso and traffic) else None},
         }
+        # K1/K2: the sampling kernels are ALU-bound integer work (one minstd step + one threshold compare per map row and gamete)
+        rows_rec = (100_000_000 // args.map_step) + 1
+        draws = float(args.n_ind) * args.nchr * (2.0 * rows_rec + (rows_rec - 1))      # 2N gametes x recombination rows + N tasks x mutation rows
+        samp_live = float(np.mean(sample_ms))
+        VALU_PEAK = 256 * 4 * 2.4e9 / 2.0                        # wave instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per wave every 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
+        valu, valu_src = None, None
+        for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sampling_pmc_instructions.json")))):
+            try:
+                pm = json.load(open(f))
+                valu = sum(v["SQ_INSTS_VALU"] for k, v in pm.items() if isinstance(v, dict) and "SQ_INSTS_VALU" in v)
+                valu_src = os.path.relpath(f, ROOT)
+                break
+            except Exception:  # noqa: BLE001
+                continue
+        default_shape = (args.n_ind, args.n_loci, args.nchr, args.map_step) == (100_000, 1_000_000, 1, 50_000)
+        out["sampling_kernels"] = {
+            "kernels": "k_mut_sample8 + k_mut_sample + k_rec_sample8 + k_rec_sample (+ the ras_glob_seed draws of the generation)",
+            "bernoulli_draws_per_generation": draws, "live_ms": samp_live, "isolated_ms": iso_sampling,
+            "draws_per_s_live": draws / (samp_live * 1e-3) if samp_live > 0 else None,
+            "draws_per_s_isolated": draws / (iso_sampling * 1e-3) if iso_sampling else None,
+            "valu_wave_instructions_per_generation": valu if default_shape else None, "valu_source": valu_src if default_shape else None,
+            "valu_issue_peak_wave_instructions_per_s": VALU_PEAK,
+            "frac_of_valu_issue_peak_isolated": (valu / (iso_sampling * 1e-3) / VALU_PEAK) if (valu and iso_sampling and default_shape) else None,
+            "frac_of_valu_issue_peak_live": (valu / (samp_live * 1e-3) / VALU_PEAK) if (valu and samp_live > 0 and default_shape) else None,
+            "note": "bound: integer VALU issue (no HBM traffic to speak of: the map thresholds sit in LDS); live = next to the dense stitch and the A/D chain, where the "
+                    "kernels get a share of the SIMDs; instruction count from the committed PMC pass (SQ_INSTS_VALU summed over the sampling kernels of one generation)"}
+        clis = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cli_dropin.json")))
+        if clis:
+            try:
+                out["cli_dropin"] = dict(json.load(open(clis[-1])), source=os.path.relpath(clis[-1], ROOT),
+                                         note="the reference's own command-line program with its hot path bound to the library (integration/), timed by tools/cli_timing.py on one MI355X box; not measured by this run")
+            except Exception:  # noqa: BLE001
+                out["cli_dropin"] = None
+        else:
+            out["cli_dropin"] = None
         if not args.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N=1 only
             port = cpu_baseline(args, args.n_loci)
             ref = cpu_baseline_reference(args)
-            out["cpu_baseline"] = ref if ref is not None else port
+            out["cpu_baseline"] = dict(ref if ref is not None else port, reference_binary_present=ref is not None)
+            if ref is None:
+                print("bench.py: oracle/_ref/ref_harness is absent or failed: cpu_baseline is the CPU oracle (kind \"port\"), not the reference itself", file=sys.stderr)
             out["cpu_baseline_port"] = port
             out["gpu_over_cpu"] = (gens_per_s / world) / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "set_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "stitch_totals", "reproduce_begin", "reproduce_end", "presample_sex", "set_overlap",
-    "random_mate", "glob_seeds", "generation_begin", "generation_end", "set_generation_chain", "redo_count",
+    "random_mate", "glob_seeds", "generation_begin", "generation_end", "set_generation_chain", "redo_count", "list_stats",
     "dbg_verify_planes", "dbg_prefilter_sweep", "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -277,6 +277,13 @@ class GevContext:
     def set_generation_chain(self, draws_between):
         """ras_glob_seed() draws the host makes itself between two generation_begin() calls (None: unknown, no head start)"""
         self._call("set_generation_chain", C.c_int(-1 if draws_between is None else int(draws_between)))
+
+    def list_stats(self, pop=0, chrom=0):
+        """gev_list_stats as a dict"""
+        out = (C.c_ulonglong * 10)()
+        self._call("list_stats", C.c_int(pop), C.c_int(chrom), out)
+        keys = ("rebuilds", "interval_entries_used", "mutation_entries_used", "interval_capacity", "mutation_capacity", "ranges_per_row", "interval_entries_last_generation", "mutation_entries_last_generation", "compactions", "reserved")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def redo_count(self):
         n = C.c_ulonglong()

@@ -162,7 +162,7 @@ struct ChrState {
         u32 p_last = 0, m_last = 0;                          // what the last generation appended
         u32 nseg = 0, lgw = 0;
         bool valid = false, grow_p = false, grow_m = false;
-        unsigned long long imports = 0;                      // full imports (first use, after a CSR-side change, compactions)
+        unsigned long long imports = 0, compactions = 0;     // rebuilds from whole lists (first use, after a CSR-side change); arena compactions
     } lp;
 };
 struct PopState {
@@ -277,6 +277,7 @@ struct gev_ctx {
     // copied to the device on the stream that uses them
     uint8_t* h_ring = nullptr; size_t h_ring_bytes = 0, h_ring_off = 0;
     DevBuf d_adwork2[2]; std::vector<uint8_t> adwork_shadow[2];
+    DevBuf d_lpc_bits, d_lpc_cnt, d_lpc_wpre, d_lpc_len, d_lpc_old, d_lpc_new, d_lpc_tmp;     // scratch of an arena compaction (lp_compact)
     DevBuf d_lp_nitems;                                 // [nchr] length of each chromosome's work list of list pieces to build
     std::map<double, GevThr> thr_cache;
 };
@@ -1066,20 +1067,29 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
 // ranges of 2^lgw bp, at most LP_MAXSEG of them (GEV_LIST_SEGS: fewer; 1 = one piece per row and list)
 static void lp_geometry(const ChrStatic& S, u32& nseg, u32& lgw)
 {
-    static const u32 max_seg = getenv("GEV_LIST_SEGS") ? (u32)std::min(std::max(atoi(getenv("GEV_LIST_SEGS")), 1), LP_MAXSEG) : (u32)LP_MAXSEG;
+    const u32 max_seg = getenv("GEV_LIST_SEGS") ? (u32)std::min(std::max(atoi(getenv("GEV_LIST_SEGS")), 1), LP_MAXSEG) : (u32)LP_MAXSEG;
     const u64 span = S.rbp.back() - S.rbp.front();
     lgw = 0;
     while ((span >> lgw) + 1 > max_seg) lgw++;
     nseg = (u32)(span >> lgw) + 1;
 }
-static size_t lp_arena_entries(size_t rows, size_t live)
+static size_t lp_arena_entries(size_t rows, size_t live, int n_active_chr)
 {
-    // arena = room for the pieces of many generations (each appends a few entries per row); GEV_LIST_HEADROOM=0: just what is live
-    // (tests: every generation then overflows, grows and is enqueued again)
-    static const size_t per_row = getenv("GEV_LIST_ARENA") ? (size_t)atol(getenv("GEV_LIST_ARENA")) : 512;
-    static const bool tight = getenv("GEV_LIST_HEADROOM") && atol(getenv("GEV_LIST_HEADROOM")) == 0;
+    // arena = room for the pieces of many generations (each appends a few entries per row): a tenth of the device memory, shared
+    // out over the active chromosomes, at most 4096 entries per row (GEV_LIST_ARENA: entries per row); when it fills up, the
+    // pieces are compacted (pieces -> whole lists -> pieces).  GEV_LIST_HEADROOM=0: just what is live (tests: every generation
+    // then overflows, grows and is enqueued again)
+    const size_t per_row_env = getenv("GEV_LIST_ARENA") ? (size_t)atol(getenv("GEV_LIST_ARENA")) : 0;      // (read at every call: tests set it per case)
+    const bool tight = getenv("GEV_LIST_HEADROOM") && atol(getenv("GEV_LIST_HEADROOM")) == 0;
     if (tight) return live + 16;
-    return std::min<size_t>(std::max<size_t>(2 * live + 4096, rows * per_row), 0xfffffff0u);
+    size_t per_row = per_row_env;
+    if (!per_row) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = (size_t)64 << 30; }
+        const size_t budget = total_b / 10 / (size_t)std::max(n_active_chr, 1);                 // bytes for this chromosome's two arenas (16 + 8 bytes per entry pair)
+        per_row = std::min<size_t>(std::max<size_t>(budget / (std::max<size_t>(rows, 1) * 24), 128), 4096);
+    }
+    return std::min<size_t>(per_row_env ? live + rows * per_row : std::max<size_t>(2 * live + 4096, rows * per_row), 0xfffffff0u);
 }
 // CSR of buffer P.cur -> pieces (tables of buffer P.cur, arenas restarted): first use, after a CSR-side change, compaction
 static int lp_import_all(gev_ctx* c, PopState& P, int k, hipStream_t st)
@@ -1095,8 +1105,9 @@ static int lp_import_all(gev_ctx* c, PopState& P, int k, hipStream_t st)
         if (track) GEVC(lp.ptab[b].ensure(tab_rows * lp.nseg * sizeof(uint2), st));
         GEVC(lp.mtab[b].ensure(tab_rows * lp.nseg * sizeof(uint2), st));
     }
-    if (track) GEVC(lp.parena.ensure(lp_arena_entries(rows, live_p) * sizeof(LpPart), st));
-    GEVC(lp.marena.ensure(std::max<size_t>(lp_arena_entries(rows, live_m), 16) * sizeof(u64), st));
+    int n_active = 0; for (int q = 0; q < c->nchr; q++) n_active += c->chr_active[q] ? 1 : 0;
+    if (track) GEVC(lp.parena.ensure(lp_arena_entries(rows, live_p, n_active) * sizeof(LpPart), st));
+    GEVC(lp.marena.ensure(std::max<size_t>(lp_arena_entries(rows, live_m, n_active), 16) * sizeof(u64), st));
     GEVC(lp.ctr.ensure(4 * sizeof(u32), st));
     HIPC(hipMemsetAsync(lp.ctr.p, 0, 4 * sizeof(u32), st));
     if (rows)
@@ -1112,6 +1123,44 @@ static int lp_import_all(gev_ctx* c, PopState& P, int k, hipStream_t st)
     HIPC(hipStreamSynchronize(st));
     if (h[2]) return fail(GEV_EDEVICE, "list pieces: import overflowed its arena (internal error: %u of %zu interval, %u of %zu mutation entries)", h[0], lp.parena.bytes / sizeof(LpPart), h[1], lp.marena.bytes / sizeof(u64));
     lp.p_used = h[0]; lp.m_used = h[1]; lp.p_last = 0; lp.m_last = 0; lp.valid = true; lp.grow_p = lp.grow_m = false; lp.imports++;
+    return GEV_OK;
+}
+// one arena of the current generation's pieces compacted in place, sharing kept (gev_lists.h); *used = entries in use afterwards
+static int lp_compact_arena(gev_ctx* c, uint2* tab, size_t n_entries, u32 extra, DevBuf& arena, size_t elem_bytes, u32* used, hipStream_t st)
+{
+    const size_t n_words = ceil_div(std::max<size_t>(*used, 1), 32);
+    GEVC(c->d_lpc_bits.ensure(n_words * sizeof(u32), st)); GEVC(c->d_lpc_cnt.ensure((n_words + 1) * sizeof(u32), st)); GEVC(c->d_lpc_wpre.ensure((n_words + 1) * sizeof(u32), st));
+    HIPC(hipMemsetAsync(c->d_lpc_bits.p, 0, n_words * sizeof(u32), st));
+    const unsigned eb = (unsigned)ceil_div(std::max<size_t>(n_entries, 1), 256);
+    hipLaunchKernelGGL(k_lpc_mark, dim3(eb), dim3(256), 0, st, (const uint2*)tab, n_entries, extra, c->d_lpc_bits.as<u32>());
+    hipLaunchKernelGGL(k_lpc_popc, dim3((unsigned)ceil_div(n_words, 256)), dim3(256), 0, st, c->d_lpc_bits.as<u32>(), n_words, c->d_lpc_cnt.as<u32>());
+    KCHECK();
+    u32 n_pieces = 0, total = 0;
+    GEVC(scan_u32(c, c->d_lpc_cnt.as<u32>(), n_words, c->d_lpc_wpre.as<u32>(), &n_pieces));
+    GEVC(c->d_lpc_len.ensure(((size_t)n_pieces + 1) * sizeof(u32), st)); GEVC(c->d_lpc_old.ensure(((size_t)n_pieces + 1) * sizeof(u32), st)); GEVC(c->d_lpc_new.ensure(((size_t)n_pieces + 2) * sizeof(u32), st));
+    hipLaunchKernelGGL(k_lpc_collect, dim3(eb), dim3(256), 0, st, (const uint2*)tab, n_entries, extra, c->d_lpc_bits.as<u32>(), c->d_lpc_wpre.as<u32>(), c->d_lpc_len.as<u32>(), c->d_lpc_old.as<u32>());
+    KCHECK();
+    GEVC(scan_u32(c, c->d_lpc_len.as<u32>(), n_pieces, c->d_lpc_new.as<u32>(), &total));
+    if (n_pieces) {
+        GEVC(c->d_lpc_tmp.ensure(std::max<size_t>(total, 1) * elem_bytes, st));
+        hipLaunchKernelGGL(k_lpc_copy, dim3((unsigned)ceil_div(n_pieces, 256)), dim3(256), 0, st, (const u64*)arena.p, c->d_lpc_tmp.as<u64>(), c->d_lpc_len.as<u32>(), c->d_lpc_old.as<u32>(), c->d_lpc_new.as<u32>(), (size_t)n_pieces, (u32)(elem_bytes / 8));
+        KCHECK();
+        HIPC(hipMemcpyAsync(arena.p, c->d_lpc_tmp.p, (size_t)total * elem_bytes, hipMemcpyDeviceToDevice, st));
+    }
+    hipLaunchKernelGGL(k_lpc_rewrite, dim3(eb), dim3(256), 0, st, tab, n_entries, extra, c->d_lpc_bits.as<u32>(), c->d_lpc_wpre.as<u32>(), c->d_lpc_new.as<u32>());
+    KCHECK();
+    *used = total;
+    return GEV_OK;
+}
+static int lp_compact(gev_ctx* c, PopState& P, int k, hipStream_t st)
+{
+    ChrState::LpState& lp = P.st[k].lp;
+    const size_t n_entries = 2 * P.n_phys * (size_t)lp.nseg;
+    if (st != c->stream) HIPC(hipStreamSynchronize(st));
+    if (c->track_intervals) GEVC(lp_compact_arena(c, lp.ptab[P.cur].as<uint2>(), n_entries, 1u, lp.parena, sizeof(LpPart), &lp.p_used, c->stream));
+    GEVC(lp_compact_arena(c, lp.mtab[P.cur].as<uint2>(), n_entries, 0u, lp.marena, sizeof(u64), &lp.m_used, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    lp.compactions++;
     return GEV_OK;
 }
 // the CSR form of the current generation (buffer P.cur), materialised from the pieces when it is not there
@@ -1152,7 +1201,6 @@ static void lists_changed_in_csr(gev_ctx* c, PopState& P)
     for (int k = 0; k < c->nchr; k++) { P.st[k].csr_valid = true; P.st[k].lp.valid = false; }
 }
 static const size_t LIST_HEADROOM = getenv("GEV_LIST_HEADROOM") ? (size_t)atol(getenv("GEV_LIST_HEADROOM")) : 48;    // spare list entries per haplotype row when a list buffer is (re)allocated (tests force redos with 0)
-static const double LIST_GROW = LIST_HEADROOM ? 1.5 : 1.0; static const size_t LIST_SLACK = LIST_HEADROOM ? 4096 : 16;   // (no headroom: every generation that lengthens the lists is enqueued twice)
 // K4/K6 + grouping: everything of the small work that needs the couples (parents) on top of the sampling results.
 // Every kernel covers ALL active chromosomes in one launch (blockIdx.y = entry of the generation's ChrWork / CvWork table).
 // work tables of the generation (one ChrWork per active chromosome, one CvWork per (phenotype, active chromosome)): list buffers
@@ -1187,13 +1235,17 @@ static int enqueue_tables(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         const size_t rows_cur = 2 * P.n_phys;
         const size_t guess_p = std::max<size_t>(4 * (size_t)lp.p_last, 8 * rows), guess_m = std::max<size_t>(4 * (size_t)lp.m_last, 4 * rows);
         const bool tight = LIST_HEADROOM == 0;
-        if (lp.valid && !lp.grow_p && !lp.grow_m && !tight) {
-            const bool full_p = c->track_intervals && lp.p_used + guess_p > lp.parena.bytes / sizeof(LpPart);
-            const bool full_m = lp.m_used + guess_m > lp.marena.bytes / sizeof(u64);
-            if (full_p || full_m) { GEVC(ensure_csr(c, pop)); lp.valid = false; }
-        }
         // room the arenas must have on top of what is used: an attempt overflowed (its status block holds what it wanted to append) ...
         size_t need_p = lp.grow_p ? (size_t)lp.p_last * 5 / 4 + 1024 : 0, need_m = lp.grow_m ? (size_t)lp.m_last * 5 / 4 + 1024 : 0;
+        if (lp.valid && !tight) {
+            const size_t want_p = c->track_intervals ? std::max(need_p, guess_p) : 0, want_m = std::max(need_m, guess_m);
+            const bool full_p = c->track_intervals && lp.p_used + want_p > lp.parena.bytes / sizeof(LpPart);
+            const bool full_m = lp.m_used + want_m > lp.marena.bytes / sizeof(u64);
+            if (full_p || full_m) {                           // drop the pieces nobody names any more; should that not make room, the arena grows below
+                GEVC(lp_compact(c, P, k, st));
+                need_p = want_p; need_m = want_m;
+            }
+        }
         if (!lp.valid) {
             GEVC(lp_import_all(c, P, k, st));
             if (!tight) { need_p = c->track_intervals ? guess_p : 0; need_m = guess_m; }     // ... or a fresh import has to leave room for this generation
@@ -3071,6 +3123,15 @@ int gev_set_track_intervals(gev_ctx* c, int on)
     if (c->track_intervals == (on != 0)) return GEV_OK;
     for (int p = 0; p < c->n_pop; p++) if (c->pop[p].gen0) { GEVC(ensure_csr(c, p)); lists_changed_in_csr(c, c->pop[p]); }   // the pieces are rebuilt with / without the interval tables
     c->track_intervals = on != 0;
+    return GEV_OK;
+}
+int gev_list_stats(gev_ctx* c, int pop, int chr, unsigned long long out[10])
+{
+    GEVC(check_idx(c, pop, chr));
+    if (!out) return fail(GEV_EINVAL, "list_stats: null argument");
+    const ChrState::LpState& lp = c->pop[pop].st[chr].lp;
+    out[0] = lp.imports; out[1] = lp.p_used; out[2] = lp.m_used; out[3] = lp.parena.bytes / sizeof(LpPart); out[4] = lp.marena.bytes / sizeof(u64);
+    out[5] = lp.nseg; out[6] = lp.p_last; out[7] = lp.m_last; out[8] = lp.compactions; out[9] = 0;
     return GEV_OK;
 }
 int gev_redo_count(gev_ctx* c, unsigned long long* n) { if (!c || !n) return fail(GEV_EINVAL, "null"); *n = c->redo_count; return GEV_OK; }

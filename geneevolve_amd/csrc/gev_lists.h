@@ -375,4 +375,54 @@ __global__ void __launch_bounds__(256) k_lp_gather_rows(const uint2* __restrict_
     if (sp) dp[d] = sp[s];
     dm[d] = sm[s];
 }
+// ------------------------------------------------------------------------------------------
+// Compaction of an arena that keeps the sharing.  Pieces no table entry names any more are dropped (a piece is named by the rows
+// that inherited it unchanged: after k generations only ~2/k of a generation's pieces still are), the others move to the front in
+// arena order: bit per entry = "a named piece starts here" (k_lpc_mark), rank of a piece = set bits in front of it (word popcounts
+// + scan), length and old offset per rank (k_lpc_collect: every entry that names the piece writes the same values), scan of the
+// lengths = new offsets, copy (k_lpc_copy), table rewritten (k_lpc_rewrite).  extra = 1 for interval pieces (carry-in entry).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 lpc_rank(const u32* __restrict__ bits, const u32* __restrict__ wpre, u32 off)
+{
+    return wpre[off >> 5] + (u32)__popc(bits[off >> 5] & ((1u << (off & 31u)) - 1u));
+}
+__global__ void __launch_bounds__(256) k_lpc_mark(const uint2* __restrict__ tab, size_t n_entries, u32 extra, u32* __restrict__ bits)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_entries) return;
+    const uint2 v = tab[e];
+    if (v.y + extra) atomicOr(&bits[v.x >> 5], 1u << (v.x & 31u));
+}
+__global__ void __launch_bounds__(256) k_lpc_popc(const u32* __restrict__ bits, size_t n_words, u32* __restrict__ cnt)
+{
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (w < n_words) cnt[w] = (u32)__popc(bits[w]);
+}
+__global__ void __launch_bounds__(256) k_lpc_collect(const uint2* __restrict__ tab, size_t n_entries, u32 extra, const u32* __restrict__ bits, const u32* __restrict__ wpre,
+                                                     u32* __restrict__ plen, u32* __restrict__ pold)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_entries) return;
+    const uint2 v = tab[e];
+    if (!(v.y + extra)) return;
+    const u32 r = lpc_rank(bits, wpre, v.x);
+    plen[r] = v.y + extra; pold[r] = v.x;
+}
+// (ew = 8-byte words per entry: 2 for interval entries, 1 for mutation positions)
+__global__ void __launch_bounds__(256) k_lpc_copy(const u64* __restrict__ src, u64* __restrict__ dst, const u32* __restrict__ plen, const u32* __restrict__ pold, const u32* __restrict__ pnew, size_t n_pieces, u32 ew)
+{
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_pieces) return;
+    const u64* a = src + (size_t)pold[r] * ew; u64* o = dst + (size_t)pnew[r] * ew;
+    const u32 n = plen[r] * ew;
+    for (u32 j = 0; j < n; j++) o[j] = a[j];
+}
+__global__ void __launch_bounds__(256) k_lpc_rewrite(uint2* __restrict__ tab, size_t n_entries, u32 extra, const u32* __restrict__ bits, const u32* __restrict__ wpre, const u32* __restrict__ pnew)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_entries) return;
+    uint2 v = tab[e];
+    v.x = (v.y + extra) ? pnew[lpc_rank(bits, wpre, v.x)] : 0u;
+    tab[e] = v;
+}
 #endif   // GEV_LISTS_KERNELS

@@ -386,6 +386,12 @@ int gev_last_reproduce_ms(gev_ctx*, float ms[4]);
 int gev_timing_totals(gev_ctx*, double ms_sum[4], unsigned long long* n_generations);
 /* generations that outgrew a buffer and were enqueued again (inside gev_reproduce_end / gev_generation_end), over the context's life */
 int gev_redo_count(gev_ctx*, unsigned long long* n);
+/* state of the shared list pieces of one (population, chromosome) (csrc/gev_lists.h): out[0] = times the pieces were (re)built from
+ * whole lists (first use, after a migration / import / upload, arena compactions), out[1] / out[2] = interval / mutation arena
+ * entries in use, out[3] / out[4] = their capacities, out[5] = position ranges per row, out[6] / out[7] = entries the last
+ * generation appended, out[8] = arena compactions (unnamed pieces dropped, sharing kept), out[9] = 0.  Diagnostic: nothing observable
+ * depends on it (the oracle build reports zeros). */
+int gev_list_stats(gev_ctx*, int pop, int chr, unsigned long long out[10]);
 /* enable/disable keeping the ancestry interval state on the device (default on) */
 int gev_set_track_intervals(gev_ctx*, int on);
 /* dense-stitch kernel: 0 = k_stitch_segments (default: one workgroup per entry of the list of segments to write), 1 = gamete-major

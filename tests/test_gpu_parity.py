@@ -91,7 +91,7 @@ def test_gpu_replays_reference_generations_bit_exact(gpu_lib, oracle_lib, case):
     assert n_dense >= 1
 
 
-def run_pair(gpu_lib, oracle_lib, cfg, n_gen, seed, check_every=1, stitch_mode=0, family=None):
+def run_pair(gpu_lib, oracle_lib, cfg, n_gen, seed, check_every=1, stitch_mode=0, family=None, at_end=None):
     """same seeded synthetic scenario through the HIP library and the oracle"""
     g = gpu_lib.create(1, cfg.nchr, cfg.nphen)
     g.set_stitch_mode(stitch_mode)
@@ -132,6 +132,8 @@ def run_pair(gpu_lib, oracle_lib, cfg, n_gen, seed, check_every=1, stitch_mode=0
                 for p in range(cfg.nphen):
                     assert np.array_equal(g.download_cv(0, p, c), o.download_cv(0, p, c))
                     assert helpers.bits_equal(g.get_cv_freq(0, p, c), o.get_cv_freq(0, p, c))
+    if at_end is not None:
+        at_end(g)
     g.close(); o.close()
 
 
@@ -162,16 +164,32 @@ def _read_device_u32(ptr, n):
     return out
 
 
-@pytest.mark.parametrize("lanes_from", [0, 1000000])
-def test_list_fill_kernels_thread_per_row_and_eight_lanes_per_row(gpu_lib, oracle_lib, monkeypatch, lanes_from):
-    """the mutation / interval list fill kernels exist in two forms (one thread per row; eight lanes per row copying the
-    inherited ranges together, used from GEV_LIST_LONG entries per row on): both forced in turn, hot maps (many crossovers and
-    new mutations per row: many short ranges, inserts inside ranges) and cold maps (long plain copies)"""
-    monkeypatch.setenv("GEV_LIST_LONG", str(lanes_from))
+@pytest.mark.parametrize("max_ranges,arena", [(32, 0), (1, 0), (5, 0), (32, 6), (7, 3)])
+def test_lists_as_shared_pieces_per_position_range(gpu_lib, oracle_lib, monkeypatch, max_ranges, arena):
+    """the mutation / interval lists live as pieces per position range, shared between parent and offspring where a gamete has
+    no crossover and no new mutation (csrc/gev_lists.h); the whole lists every other function reads are made from them on demand.
+    Compared with the oracle's lists every generation (or every third: generations in between are then never materialised):
+    32 ranges (default), ONE range (= a piece is a whole list), 5 and 7 ranges (boundaries and mutations on range edges shift),
+    and arenas of 6 / 3 entries per row, which fill up every few generations and are compacted (pieces nobody names are
+    dropped, the sharing is kept).  Hot maps (many crossovers and new mutations per row: every range has events, inserts inside
+    ranges) and cold maps (most ranges name the parent's piece)."""
+    monkeypatch.setenv("GEV_LIST_SEGS", str(max_ranges))
+    if arena:
+        monkeypatch.setenv("GEV_LIST_ARENA", str(arena))
+    seen = {}
+
+    def stats(g):
+        seen.update(g.list_stats(0, 0))
     cfg = SyntheticConfig(200, 5000, nchr=2, chrom_bp=2_000_000, map_step=1000, rec_per_row=5e-3, mut_per_row=8e-3, n_cv=100, seed=61)
-    run_pair(gpu_lib, oracle_lib, cfg, n_gen=6, seed=62)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=6, seed=62, at_end=stats)
+    assert 1 <= seen["ranges_per_row"] <= max_ranges and (max_ranges != 32 or seen["ranges_per_row"] == 31) and seen["rebuilds"] == 1   # 2 Mb in 2^16-bp ranges: 31 of them
     cfg = SyntheticConfig(200, 5000, nchr=1, chrom_bp=2_000_000, map_step=1000, rec_per_row=2e-4, mut_per_row=2e-3, n_cv=100, seed=63)
-    run_pair(gpu_lib, oracle_lib, cfg, n_gen=12, seed=64, check_every=3)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=12, seed=64, check_every=3, at_end=stats)
+    if arena:
+        assert seen["compactions"] >= 2, seen
+    elif max_ranges == 32:
+        # cold maps: ~0.4 crossovers and ~4 new mutations per row and generation: far fewer new interval entries than rows x ranges
+        assert seen["interval_entries_last_generation"] < 400 * 31 // 4, seen
 
 
 @pytest.mark.parametrize("mode,alias,seg_chunks", [(0, 1, 16), (1, 1, 16), (0, 0, 16), (1, 0, 64), (0, 1, 1024), (0, 1, 4)])
