@@ -18,9 +18,9 @@
 //                    position already is in the covering part's set (k_cv_newmut looks it up in the
 //                    parental list).  A/D reads this plane only -- it never scans the mutation
 //                    lists, whose length grows with the age of the run
-//   mutation lists   CSR  off[2n+1] (u32), pos[] (u64, ascending per row)
-//   interval lists   CSR  off[2n+1] (u32), gev_part[] -- the reference's own state, kept for
-//                    --out_interval parity
+//   mutation lists / interval lists: per (row, position range) pieces shared between parent and offspring (gev_lists.h);
+//                    the CSR form -- off[2n+1] (u32) + pos[] (u64, ascending per row) / gev_part[] (the reference's own
+//                    state, --out_interval) -- is made from the pieces when somebody asks for whole lists
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -83,7 +83,7 @@ struct SampleDev {
 // Every per-chromosome kernel of a generation is ONE launch whose blockIdx.y (or .z) selects the entry, instead of one launch
 // per chromosome (a 22-chromosome genome used to cost ~300 launches per generation).
 // Genotype rows live in ONE pool of SEGMENTS per (population, chromosome).  A haplotype row (slot s = 2*individual + chromatid)
-// is cut into nseg segments of 2^seg_shift 16-byte chunks (8 KiB by default); segment g of slot s is pool unit
+// is cut into nseg segments of 2^seg_shift 16-byte chunks (2 KiB by default); segment g of slot s is pool unit
 // phys[s * nseg + g].  In a segment that contains none of its crossover boundaries an offspring gamete IS one parental haplotype
 // (Simulation::recombine copies the parent's parts unchanged between two crossovers, src/Simulation.cpp:2939-2946; without any
 // crossover it returns the parental Hap itself, :2910): that segment of the offspring slot then names the parent's unit and no
@@ -487,8 +487,8 @@ __global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict
 // gamete row is a concatenation of bit ranges of the parent's two rows AT THE SAME OFFSETS, so
 // between two boundaries it IS one parental row.  Rows are stored as segments (PoolWork): a segment
 // without a boundary is not copied at all -- the offspring's table entry names the parent's unit
-// (k_pool_assign) -- and the stitch writes only the segments that contain a boundary: about one
-// 8 KiB segment per crossover instead of the whole row.  Per unit of work (one written segment):
+// (k_pool_inherit) -- and the stitch writes only the segments that contain a boundary: about one
+// 2 KiB segment per crossover instead of the whole row.  Per unit of work (one written segment):
 // segment bytes read + segment bytes written.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 lower_bound_u64(const u64* __restrict__ a, u32 n, u64 v)   // #{a[i] < v}
