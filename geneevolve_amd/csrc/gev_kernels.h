@@ -477,6 +477,120 @@ __global__ void __launch_bounds__(64) k_rec_chain(const GevRngTables* __restrict
     }
 }
 
+// The same chain with a WORKGROUP per link (no mutation map: the seed of every gamete is a rand() of the srand() of the gamete
+// before it, src/Simulation.cpp:2447-2455, so the gametes of a generation form one serial chain).  One wave per link pays a
+// 31-step srand, 32 scan steps for 2001 map rows and two or three dependent global loads -- about 10 us per gamete.  Here wave 0
+// seeds glibc's generator (srand) WHILE waves 1..8 scan 256 map rows each (one scan step: 2048 rows) against thresholds staged in
+// LDS; every hit is left in LDS with its map position already loaded; after one barrier wave 0 turns the hits into breakpoints
+// (bp[row] + rand() % dist, in row order), reads the start haplotype and the next seed off the generator and publishes the seed
+// for the next link behind a second barrier.  Same arithmetic, same records as k_rec_chain.
+#define CHAIN_SCAN_WAVES 8
+#define CHAIN_THREADS (64 * (CHAIN_SCAN_WAVES + 1))
+#define CHAIN_HITS 64                       // hits a scanning wave can leave per link; more (hot maps): wave 0 samples the gamete alone, as k_rec_chain does
+__global__ void __launch_bounds__(CHAIN_THREADS) k_rec_chain_wg(const GevRngTables* __restrict__ Tg, const ChrDev* __restrict__ chrs, int nchr,
+                                                                u32 seed_reproduce, const u32* __restrict__ seed_ptr, size_t n_tasks, SampleDev sd, u32 thr_rows_lds)
+{
+    __shared__ __attribute__((aligned(16))) GevRngTables s_T;
+    __shared__ u32 s_hit_row[CHAIN_SCAN_WAVES][CHAIN_HITS];
+    __shared__ u64 s_hit_bp[CHAIN_SCAN_WAVES][CHAIN_HITS];
+    __shared__ u32 s_nhit[CHAIN_SCAN_WAVES];
+    __shared__ u32 s_seed, s_pw[64];
+    extern __shared__ __attribute__((aligned(16))) GevThr s_thr[];          // [thr_rows_lds] thresholds of all chromosomes, back to back (0: read from global)
+    const GevRngTables* T = stage_tables(Tg, &s_T);
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // 16807^(512 j): engine steps in front of draw 256 j
+    if (threadIdx.x < 64) s_pw[threadIdx.x] = powmod31(16807u, 512ull * threadIdx.x);
+    if (thr_rows_lds) {
+        u32 base = 0;
+        for (int c = 0; c < nchr; c++) { for (u32 e = threadIdx.x; e < chrs[c].R; e += CHAIN_THREADS) s_thr[base + e] = chrs[c].rthr[e]; base += chrs[c].R; }
+    }
+    GlibcWave g;
+    if (wave == 0) { g.seed(T, seed_ptr ? *seed_ptr : seed_reproduce); const u32 first = g.out(T, 0); if (lane == 0) s_seed = first; }
+    __syncthreads();
+    for (size_t t = 0; t < n_tasks; t++) {
+        const int c = (int)(t % nchr);
+        const ChrDev& C = chrs[c];
+        u32 thr_base = 0;
+        if (thr_rows_lds) for (int q = 0; q < c; q++) thr_base += chrs[q].R;
+        const GevThr* thr = thr_rows_lds ? s_thr + thr_base : C.rthr;
+        u32 k_mat = 0;
+        for (u32 gam = 0; gam < 2; gam++) {                               // paternal, then maternal gamete (:2447-2456)
+            const u32 seed = s_seed;
+            const size_t G = 2 * t + gam;
+            u32 k = 0, off = 0;
+            bool crowded = false;                                         // (wave 0 only)
+            for (u32 row0 = 0; row0 < C.R; row0 += 256 * CHAIN_SCAN_WAVES) {      // one round for maps of up to 2048 rows
+                if (wave == 0) { if (row0 == 0) g.seed(T, seed); }                  // srand(seed_loc), :2977
+                else {
+                    const u32 d0 = row0 + 256 * (wave - 1);
+                    u32 n = 0;
+                    if (d0 < C.R) {
+                        const u32 s0 = mulmod31(d0 >> 8 < 64 ? s_pw[d0 >> 8] : powmod31(16807u, 2ull * d0), minstd_seed(seed + 1u));   // generator(seed+1) in front of draw d0, :2978
+                        wave_scan_hits_state(T, s0, thr, C.r_amax, d0, min(256u, C.R - d0), [&](u32 row) {
+                            if (lane == 0 && n < CHAIN_HITS) { s_hit_row[wave - 1][n] = row; s_hit_bp[wave - 1][n] = C.rbp[row]; }
+                            n++;
+                        });
+                    }
+                    if (lane == 0) s_nhit[wave - 1] = n;
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    for (u32 w = 0; w < CHAIN_SCAN_WAVES; w++) {
+                        const u32 n = s_nhit[w];
+                        if (n > CHAIN_HITS) crowded = true;
+                        for (u32 j = 0; j < n && !crowded; j++) {
+                            if (k < GEV_BK_CAP) {
+                                const u64 v = s_hit_bp[w][j] + (u64)g.out(T, k) % C.bp_dist;                              // :2990
+                                if (lane == 0) { sd.bk[G * GEV_BK_CAP + k] = v; sd.bk_idx[G * GEV_BK_CAP + k] = snp_lower_bound(C, v); }
+                            }
+                            k++;
+                        }
+                    }
+                }
+                __syncthreads();                                                                                          // the hit lists are free again
+            }
+            if (wave == 0 && crowded) {                                   // more hits than a wave's list holds: the whole gamete by this wave alone
+                k = gamete_sample(T, C, seed, G, g, sd);
+                const u32 start = g.out(T, k) & 1u;
+                if (lane == 0) { sd.start[G] = (uint8_t)start; if (gam == 0) sd.seed_pat[t] = seed; else sd.seed_mat[t] = seed; }
+                if (gam == 0) { const u32 nxt = g.out(T, k + 1); if (lane == 0) s_seed = nxt; } else k_mat = k;
+            } else if (wave == 0) {
+                u32 k_store = k;
+                off = (u32)G * GEV_BK_CAP;
+                if (k > GEV_BK_CAP) {                                     // rare (hot maps): a range of the overflow region, the whole gamete once more by this wave alone
+                    u32 o = 0;
+                    if (lane == 0) o = atomicAdd(&sd.status[ST_BK_OVF_USED], k);
+                    o = rl_u32(o, 0);
+                    if (o + k <= sd.bk_ovf_cap) {
+                        off = sd.bk_ovf_base + o;
+                        g.seed(T, seed);
+                        rec_scan_write(T, C, seed, g, sd.bk + off, sd.bk_idx + off, k);
+                    } else { if (lane == 0) atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_BK_OVF); k_store = 0; }
+                }
+                const u32 start = g.out(T, k) & 1u;                       // rand()%2 behind the k position draws, :2449 / :2455
+                if (lane == 0) {
+                    sd.k[G] = k_store; sd.bk_off[G] = off; sd.start[G] = (uint8_t)start;
+                    if (gam == 0) sd.seed_pat[t] = seed; else sd.seed_mat[t] = seed;
+                }
+                if (gam == 0) { const u32 nxt = g.out(T, k + 1); if (lane == 0) s_seed = nxt; }                           // seed_loc of the maternal gamete, :2453
+                else k_mat = k;
+            }
+            if (gam == 0) __syncthreads();
+        }
+        if (wave == 0) {
+            u32 n = k_mat + 1;
+            if (c == nchr - 1) {                                          // :2472
+                const u32 sx = (g.out(T, n) & 1u) + 1u;
+                if (lane == 0) sd.sex[t / nchr] = (uint8_t)sx;
+                n++;
+            }
+            const u32 nxt = g.out(T, n);                                  // seed_loc of the next task's paternal gamete, :2447
+            if (lane == 0) s_seed = nxt;
+        }
+        __syncthreads();
+    }
+}
+
 #include "gev_sample8.h"
 
 // ------------------------------------------------------------------------------------------

@@ -921,6 +921,7 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready 
 static int enqueue_chain_head_start(gev_ctx* c);
 static int prepare_eager_ad(gev_ctx* c, int pop);
 static int check_not_pending(gev_ctx* c);
+static int check_chain_size(size_t T);
 static int materialize_order(gev_ctx* c, int pop);
 static int ensure_csr(gev_ctx* c, int pop);
 extern "C" int gev_presample(gev_ctx* c, int pop, uint32_t seed_reproduce, const uint32_t* mut_seeds, size_t n_mut_seeds, size_t n_people);
@@ -1057,7 +1058,15 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
         hipLaunchKernelGGL(k_mut_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, mseeds, T, sd, (const u32*)nullptr, (const u32*)nullptr);
         hipLaunchKernelGGL(k_rec_sample, dim3(task_blocks), dim3(256), 0, st, Tb, chrs, nchr, seed_reproduce, seed_ptr, T, sd, (const u32*)nullptr, (const u32*)nullptr);
     } else {
-        hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, seed_reproduce, seed_ptr, T, sd);
+        // no mutation map: the gametes of a generation form ONE serial chain (src/Simulation.cpp:2447-2455).  A workgroup per link
+        // (k_rec_chain_wg); GEV_CHAIN_WG=0: the one-wave form
+        static const bool wg = !(getenv("GEV_CHAIN_WG") && atoi(getenv("GEV_CHAIN_WG")) == 0);
+        if (wg) {
+            size_t rows_all = 0;
+            for (int k = 0; k < nchr; k++) rows_all += c->pop[pop].cs[k].rbp.size();
+            const u32 thr_lds = rows_all <= 2048 ? (u32)rows_all : 0u;            // thresholds of all chromosomes in LDS when they fit into 32 KiB
+            hipLaunchKernelGGL(k_rec_chain_wg, dim3(1), dim3(CHAIN_THREADS), (size_t)thr_lds * sizeof(GevThr), st, Tb, chrs, nchr, seed_reproduce, seed_ptr, T, sd, thr_lds);
+        } else hipLaunchKernelGGL(k_rec_chain, dim3(1), dim3(64), 0, st, Tb, chrs, nchr, seed_reproduce, seed_ptr, T, sd);
     }
     KCHECK();
     HIPC(hipEventRecord(sc.t[1], st));
@@ -1569,6 +1578,7 @@ int gev_reproduce_begin(gev_ctx* c, int pop, const gev_couple* couples, size_t n
     if (2 * T * GEV_BK_CAP >= 0xf0000000ull) return fail(GEV_EINVAL, "reproduce: too many gametes");
     const bool has_mut = mut_seeds != nullptr;
     if (has_mut && n_mut_seeds != T) return fail(GEV_EINVAL, "reproduce: n_mut_seeds=%zu, expected n_people*nchr=%zu", n_mut_seeds, T);
+    if (!has_mut) GEVC(check_chain_size(T));
     gev_ctx::Scratch& sc = c->sc[c->gen_counter & 1];
     // couples == NULL: the couples gev_random_mate left on the device for this population
     const bool dev_couples = couples == nullptr;
@@ -1657,6 +1667,16 @@ static int prepare_eager_ad(gev_ctx* c, int pop)
     return check_multipop(c);
 }
 // does every chromosome of the population have a mutation map (Simulation::reproduce's `_mutation_map.size() > 0`, :2459)?
+// Without a mutation map every gamete's seed is a rand() of the srand() of the gamete before it (src/Simulation.cpp:2447-2455):
+// the 2 T gametes form one serial chain, a few microseconds each on one workgroup (k_rec_chain_wg).  Beyond GEV_CHAIN_MAX_TASKS
+// (default 4 000 000 tasks: tens of seconds per generation) the call refuses instead of running for minutes.
+static int check_chain_size(size_t T)
+{
+    const size_t chain_max = getenv("GEV_CHAIN_MAX_TASKS") ? (size_t)atoll(getenv("GEV_CHAIN_MAX_TASKS")) : (size_t)4000000;
+    if (T > chain_max)
+        return fail(GEV_EUNSUPPORTED, "Error: %zu (offspring, chromosome) tasks without a mutation map form one serial rand() chain; more than %zu are refused (GEV_CHAIN_MAX_TASKS) -- give a mutation map (rates may be 0) to sample the tasks in parallel", T, chain_max);
+    return GEV_OK;
+}
 static int population_has_mutmap(gev_ctx* c, int pop, bool& has_mut)
 {
     PopState& P = c->pop[pop];
@@ -1681,6 +1701,7 @@ int gev_generation_begin(gev_ctx* c, int pop, uint32_t glob_state, size_t pop_si
     if (2 * T * GEV_BK_CAP >= 0xf0000000ull) return fail(GEV_EINVAL, "generation: too many gametes");
     bool has_mut = false;
     GEVC(population_has_mutmap(c, pop, has_mut));
+    if (!has_mut) GEVC(check_chain_size(T));
     const size_t n_status = ST_TOTALS + ST_PER_CHR * (size_t)nchr;
     // pinned: [status | the two seeds | sexes]
     GEVC(ensure_stage(c, (n_status + 2) * 4 + n_people + 16));

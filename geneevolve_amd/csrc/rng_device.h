@@ -89,13 +89,13 @@ __device__ __forceinline__ bool thr_hit(const GevThr t, uint32_t x1, uint32_t x2
 // largest a_hi of the map, so the threshold row and the low digit (x1 = x2 * 16807^-1) are
 // fetched for those rare candidates alone.  Calls on_hit(row) wave-uniformly for every hit, in
 // row order.  Returns the number of hits.  All 64 lanes must call it.
+// (s0 = the engine state in front of the first draw: minstd_seed(seed), or that state advanced by 2 d0 steps for draw d0)
 template <class F>
-__device__ __forceinline__ uint32_t wave_scan_hits(const GevRngTables* __restrict__ T, uint32_t engine_seed,
-                                                   const GevThr* __restrict__ thr, uint32_t amax, uint32_t first_row,
-                                                   uint32_t n_draws, F on_hit)
+__device__ __forceinline__ uint32_t wave_scan_hits_state(const GevRngTables* __restrict__ T, uint32_t s0,
+                                                         const GevThr* __restrict__ thr, uint32_t amax, uint32_t first_row,
+                                                         uint32_t n_draws, F on_hit)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t s0 = minstd_seed(engine_seed);
     const uint32_t p128 = T->pow128, inv = T->inv16807;
     // four independent LCG chains per lane (draws d, d+64, d+128, d+192; step 16807^512) hide the
     // latency of the dependent modular multiply
@@ -128,6 +128,14 @@ __device__ __forceinline__ uint32_t wave_scan_hits(const GevRngTables* __restric
         xa = mulmod31(xa, p512); xb = mulmod31(xb, p512); xc = mulmod31(xc, p512); xd = mulmod31(xd, p512);
     }
     return n_hits;
+}
+
+template <class F>
+__device__ __forceinline__ uint32_t wave_scan_hits(const GevRngTables* __restrict__ T, uint32_t engine_seed,
+                                                   const GevThr* __restrict__ thr, uint32_t amax, uint32_t first_row,
+                                                   uint32_t n_draws, F on_hit)
+{
+    return wave_scan_hits_state(T, minstd_seed(engine_seed), thr, amax, first_row, n_draws, on_hit);
 }
 
 // wave-uniform lane index -> v_readlane_b32 (SGPR broadcast) instead of the LDS crossbar (ds_bpermute) of __shfl

@@ -290,9 +290,40 @@ def test_large_families_many_gametes_per_parent(gpu_lib, oracle_lib):
     run_pair(gpu_lib, oracle_lib, cfg, n_gen=3, seed=32, family=40)
 
 
-def test_gpu_vs_oracle_serial_chain_mode(gpu_lib, oracle_lib):
-    cfg = SyntheticConfig(200, 3000, nchr=3, chrom_bp=1_000_000, map_step=1000, rec_per_row=3e-3, n_cv=100, seed=5, with_mutation=False)
+@pytest.mark.parametrize("wg", [1, 0])
+def test_gpu_vs_oracle_serial_chain_mode(gpu_lib, oracle_lib, monkeypatch, wg):
+    """no mutation map: gamete seeds chain through crossover counts (Example1-style; src/Simulation.cpp:2447-2455).  wg = 1: a workgroup
+    per link of the chain (k_rec_chain_wg: one wave seeds glibc's generator while eight scan the map), 0: the one-wave form.  Cold
+    and hot maps (more hits than a scanning wave's list holds: the link falls back to the one-wave walk; more than GEV_BK_CAP
+    crossovers per gamete: overflow records), maps longer than one 2048-row round, thresholds in LDS and (many rows) in global memory."""
+    monkeypatch.setenv("GEV_CHAIN_WG", str(wg))
+    cfg = SyntheticConfig(200, 3000, nchr=3, chrom_bp=1_000_000, map_step=1000, rec_per_row=3e-3, n_cv=100, seed=5, with_mutation=False)   # 3 x 1001 rows: thresholds from global memory
     run_pair(gpu_lib, oracle_lib, cfg, n_gen=4, seed=99)
+    cfg = SyntheticConfig(60, 3000, nchr=1, chrom_bp=1_000_000, map_step=400, rec_per_row=3e-3, with_mutation=False, n_cv=100, seed=6)      # 2501 rows: two rounds
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=2, seed=98)
+    cfg = SyntheticConfig(60, 3000, nchr=1, chrom_bp=1_000_000, map_step=1000, rec_per_row=2e-3, with_mutation=False, n_cv=100, seed=8)     # 1001 rows: thresholds in LDS
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=3, seed=96)
+    cfg = SyntheticConfig(30, 3000, nchr=2, chrom_bp=400_000, map_step=1000, rec_per_row=0.4, with_mutation=False, n_cv=100, seed=7)       # ~160 crossovers per gamete
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=2, seed=97)
+
+
+def test_serial_chain_refuses_sizes_that_would_run_for_minutes(gpu_lib, monkeypatch):
+    """GEV_EUNSUPPORTED with a reference-style message above GEV_CHAIN_MAX_TASKS (offspring x chromosomes without a mutation map)"""
+    from geneevolve_amd.capi import GevError
+    monkeypatch.setenv("GEV_CHAIN_MAX_TASKS", "100")
+    cfg = SyntheticConfig(120, 3000, nchr=1, chrom_bp=1_000_000, map_step=2000, rec_per_row=8e-3, with_mutation=False, n_cv=50, seed=5)
+    g = gpu_lib.create(1, 1, 1)
+    cfg.apply_static(g)
+    g.synth_founders(0, 0, 240, 5); g.synth_cv_founders(0, 0, 0, 240, 6)
+    sg = Simulation(g, 3, 1, False)
+    sg.ras_initial_human_gen0(0, 120)
+    sg.couples[0] = synthetic_random_mate(sg.sex[0], 120, np.random.default_rng(1))
+    with pytest.raises(GevError) as e:
+        sg.reproduce(0, 1)
+    assert e.value.code == -5 and "serial rand() chain" in str(e.value)
+    monkeypatch.setenv("GEV_CHAIN_MAX_TASKS", "1000")
+    sg.reproduce(0, 1)
+    g.close()
 
 
 def test_gpu_vs_oracle_many_crossovers_per_gamete(gpu_lib, oracle_lib):
