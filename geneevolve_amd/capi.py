@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "reproduce", "presample", "compute_ad", "scale_ad_compute_gef", "set_ad", "get_cv_freq", "migrate", "export_size", "export_rows", "remove_rows",
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "stitch_totals", "reproduce_begin", "reproduce_end", "presample_sex", "set_overlap",
-    "random_mate", "glob_seeds", "generation_begin", "generation_end", "set_generation_chain", "redo_count", "list_stats",
+    "random_mate", "glob_seeds", "generation_begin", "generation_end", "set_generation_chain", "redo_count", "list_stats", "compute_ad_device", "ad_finish_device",
     "dbg_verify_planes", "dbg_prefilter_sweep", "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -277,6 +277,20 @@ class GevContext:
     def set_generation_chain(self, draws_between):
         """ras_glob_seed() draws the host makes itself between two generation_begin() calls (None: unknown, no head start)"""
         self._call("set_generation_chain", C.c_int(-1 if draws_between is None else int(draws_between)))
+
+    def compute_ad_device(self, pop):
+        """gev_compute_ad_device: (device pointer of the per-chromosome additive array, ... of the dominance array, length in doubles)"""
+        a, d, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._call("compute_ad_device", C.c_int(pop), C.byref(a), C.byref(d), C.byref(n))
+        return int(a.value), int(d.value), int(n.value)
+
+    def ad_finish_device(self, pop, per_chr=True):
+        """gev_ad_finish_device -> (additive, dominance, additive_chr, dominance_chr) after the caller's in-place all-reduce"""
+        n = self.pop_size(pop)
+        add = np.zeros((n, self.nphen)); dom = np.zeros((n, self.nphen))
+        addc = np.zeros((n, self.nchr, self.nphen)) if per_chr else None; domc = np.zeros((n, self.nchr, self.nphen)) if per_chr else None
+        self._call("ad_finish_device", C.c_int(pop), _p(add), _p(dom), _p(addc) if per_chr else None, _p(domc) if per_chr else None)
+        return add, dom, addc, domc
 
     def list_stats(self, pop=0, chrom=0):
         """gev_list_stats as a dict"""

@@ -2162,6 +2162,38 @@ int gev_compute_ad(gev_ctx* c, int pop, double* additive, double* dominance, dou
     if (flag != 0xffffffffu) return fail(GEV_ENAN, "Error: A or D is nan for human %u", flag);
     return GEV_OK;
 }
+int gev_compute_ad_device(gev_ctx* c, int pop, double** add_chr, double** dom_chr, size_t* n_doubles)
+{
+    GEVC(check_idx(c, pop, 0));
+    GEVC(check_not_pending(c));
+    if (!add_chr || !dom_chr || !n_doubles) return fail(GEV_EINVAL, "compute_ad_device: null argument");
+    GEVC(gev_compute_ad(c, pop, nullptr, nullptr, nullptr, nullptr));          // (computes unless the last generation already did; checks the NaN flag)
+    PopState& P = c->pop[pop];
+    *add_chr = c->d_addchr.as<double>(); *dom_chr = c->d_domchr.as<double>(); *n_doubles = P.n_people * (size_t)c->nchr * c->nphen;
+    return GEV_OK;
+}
+int gev_ad_finish_device(gev_ctx* c, int pop, double* additive, double* dominance, double* add_chr_out, double* dom_chr_out)
+{
+    GEVC(check_idx(c, pop, 0));
+    GEVC(check_not_pending(c));
+    PopState& P = c->pop[pop];
+    if (!P.gen0 || c->ad_cached_pop != pop) return fail(GEV_ESTATE, "ad_finish_device: call gev_compute_ad_device for population %d first", pop);
+    HIPC(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t n = P.n_people; const int nchr = c->nchr, nphen = c->nphen;
+    const size_t nd = n * nphen, ndc = nd * nchr;
+    GEVC(c->d_add.ensure(nd * sizeof(double), st)); GEVC(c->d_dom.ensure(nd * sizeof(double), st));
+    hipLaunchKernelGGL(k_ad_sum_chr, dim3((unsigned)ceil_div(n * nphen, 256)), dim3(256), 0, st, c->d_addchr.as<double>(), c->d_domchr.as<double>(), c->d_add.as<double>(), c->d_dom.as<double>(), n, nchr, nphen);
+    KCHECK();
+    if (additive) HIPC(hipMemcpyAsync(additive, c->d_add.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (dominance) HIPC(hipMemcpyAsync(dominance, c->d_dom.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (add_chr_out) HIPC(hipMemcpyAsync(add_chr_out, c->d_addchr.p, ndc * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (dom_chr_out) HIPC(hipMemcpyAsync(dom_chr_out, c->d_domchr.p, ndc * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    c->ad_host_set_pop = pop;                                  // the totals in d_add / d_dom are the population's (as after gev_set_ad); the pinned cache holds this context's share only
+    c->ad_cached_pop = -1;
+    return GEV_OK;
+}
 // ---- Simulation::ras_scale_AD_compute_GEF ---------------------------------
 static int normal_stream(gev_ctx* c, u32 engine_seed, size_t n, double sd, double* d_out)
 {

@@ -92,6 +92,16 @@ def migrate_all_to_all(ctx, outgoing, local_pop, device=None, group=None, trace=
     return recv_n
 
 
+class _DevicePtr:
+    """a device pointer of the library as a zero-copy tensor source (__cuda_array_interface__)"""
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3, "strides": None}
+
+
+def _device_tensor_f64(ptr, n, device):
+    return torch.as_tensor(_DevicePtr(ptr, n), device=torch.device(device))
+
+
 def compute_ad_locus_split(ctx, pop, group=None, device=None):
     """Simulation::ras_compute_AD (reference src/Simulation.cpp:2624-2749) for a population whose chromosomes are split
     over the ranks of `group` (gev_set_chr_active): every rank holds exact zeros for the chromosomes it does not own, so
@@ -101,9 +111,17 @@ def compute_ad_locus_split(ctx, pop, group=None, device=None):
     Returns (additive, dominance, additive_chr, dominance_chr), identical on every rank of the group."""
     import torch
     import torch.distributed as dist
+    backend = dist.get_backend(group)
+    if backend == "nccl" and device is not None and torch.device(device).type == "cuda" and ctx.L.exports("compute_ad_device"):
+        # RCCL: all-reduce the library's own device arrays in place -- no host round trip of the N x nchr x nphen doubles
+        pa, pd, n = ctx.compute_ad_device(pop)                      # (returns after the library's stream has finished)
+        ta, td = _device_tensor_f64(pa, n, device), _device_tensor_f64(pd, n, device)
+        dist.all_reduce(ta, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(td, op=dist.ReduceOp.SUM, group=group)
+        torch.cuda.current_stream().synchronize()                   # RCCL only enqueued on torch's stream: the library reads the arrays next
+        return ctx.ad_finish_device(pop)                            # chromosome-ordered FP64 sums on the device (:2729-2746)
     _, _, addc, domc = ctx.compute_ad(pop, per_chr=True)
     both = np.stack([addc, domc])                                   # [2][n][nchr][nphen]
-    backend = dist.get_backend(group)
     dev = device if device is not None else ("cuda" if backend == "nccl" else "cpu")
     t = torch.from_numpy(both).to(dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)

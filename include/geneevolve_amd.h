@@ -386,6 +386,16 @@ int gev_last_reproduce_ms(gev_ctx*, float ms[4]);
 int gev_timing_totals(gev_ctx*, double ms_sum[4], unsigned long long* n_generations);
 /* generations that outgrew a buffer and were enqueued again (inside gev_reproduce_end / gev_generation_end), over the context's life */
 int gev_redo_count(gev_ctx*, unsigned long long* n);
+/* Simulation::ras_compute_AD (src/Simulation.cpp:2624-2749) for a population split along chromosomes over several contexts
+ * (gev_set_chr_active) WITHOUT a host round trip: the per-chromosome arrays of the current generation stay on the device.
+ * *add_chr / *dom_chr = device pointers to [n_people][nchr][nphen] doubles (exact zeros for the chromosomes this context does not hold),
+ * *n_doubles = their length; valid until the next call that changes the population.  The caller all-reduces (SUM) both arrays in place
+ * across the population's group (RCCL; every entry is x + 0 + ... + 0: bit for bit) and then calls gev_ad_finish_device. */
+int gev_compute_ad_device(gev_ctx*, int pop, double** add_chr, double** dom_chr, size_t* n_doubles);
+/* ... behind the in-place all-reduce: Human::additive / dominance = the sum over chromosomes in order (:2729-2746), computed on the device
+ * from the (reduced) per-chromosome arrays.  The totals stay in the context for gev_scale_ad_compute_gef (as after gev_set_ad) and are
+ * copied out; add_chr_out / dom_chr_out receive the reduced per-chromosome arrays.  Any of the four pointers may be NULL. */
+int gev_ad_finish_device(gev_ctx*, int pop, double* additive, double* dominance, double* add_chr_out, double* dom_chr_out);
 /* state of the shared list pieces of one (population, chromosome) (csrc/gev_lists.h): out[0] = times the pieces were (re)built from
  * whole lists (first use, after a migration / import / upload, arena compactions), out[1] / out[2] = interval / mutation arena
  * entries in use, out[3] / out[4] = their capacities, out[5] = position ranges per row, out[6] / out[7] = entries the last

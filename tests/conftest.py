@@ -35,3 +35,16 @@ def gpu_lib():
     """The product library (HIP).  Fails loudly when it is missing: there is no fallback."""
     from geneevolve_amd.capi import GevLibrary
     return GevLibrary()
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The reference-built binaries (oracle/_ref/, git-ignored, built where the reference tree is and travelling with the working
+    tree) are what the drop-in CLI tests and bench.py's `cpu_baseline.kind = "reference"` depend on: say plainly whether they are
+    here and how many tests were skipped because one was not."""
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    names = ("ref_harness", "GeneEvolve_ref", "GeneEvolve_ref_vcf", "GeneEvolve_gpu", "GeneEvolve_glue_on_oracle")
+    have = [n for n in names if os.path.exists(os.path.join(ref, n))]
+    skipped = [r for r in terminalreporter.stats.get("skipped", []) if "oracle/_ref" in str(getattr(r, "longrepr", ""))]
+    terminalreporter.write_line(f"oracle/_ref binaries present: {', '.join(have) if have else 'none'}"
+                                + (f"; MISSING: {', '.join(n for n in names if n not in have)}" if len(have) < len(names) else "")
+                                + f"; {len(skipped)} test(s) skipped for a missing oracle/_ref binary")

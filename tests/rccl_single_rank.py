@@ -36,8 +36,12 @@ def main():
     trace = []
     got = migrate_all_to_all(g, [np.empty(0, dtype=np.uint64)], 0, device="cuda:0", trace=trace)
     assert got == [0] and "a2a_meta" in trace and trace.count("fence") == 2, trace
-    add, dom, addc, domc = compute_ad_locus_split(g, 0, device="cuda:0")        # all_reduce over RCCL on device memory
-    assert helpers.bits_equal(add, add0) and helpers.bits_equal(addc, addc0)
+    add, dom, addc, domc = compute_ad_locus_split(g, 0, device="cuda:0")        # all_reduce over RCCL IN PLACE on the library's own device arrays
+    assert helpers.bits_equal(add, add0) and helpers.bits_equal(addc, addc0) and helpers.bits_equal(dom, dom0) and helpers.bits_equal(domc, domc0)
+    pa, pd, n = g.compute_ad_device(0)                                          # (the pointers are the library's; a second reduction over one rank changes nothing)
+    assert n == 200 * 2 * 1 and pa and pd
+    add2, dom2, addc2, domc2 = g.ad_finish_device(0)
+    assert helpers.bits_equal(add2, add0) and helpers.bits_equal(addc2, addc0)
     for c in range(2):
         assert np.array_equal(g.download_haps(0, c), before[c])
     g.close()
