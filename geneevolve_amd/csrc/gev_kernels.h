@@ -808,9 +808,14 @@ __global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restri
     const u32 n_items = ((const u32*)&pw.items[pw.items_cap])[0];
     const u32 lane = threadIdx.x & 63u;
     const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    uint4 d0 = make_uint4(0u, 0u, 0u, 0u), d1 = d0;
+    if (wave0 < n_items) { const uint4* dp = (const uint4*)&pw.items[wave0]; d0 = dp[0]; d1 = dp[1]; }
     for (u32 it = wave0; it < n_items; it += gridDim.x * 4u) {
-        const uint4* dp = (const uint4*)&pw.items[it];
-        const uint4 d0 = dp[0], d1 = dp[1];
+        // the next entry's descriptor is loaded while this entry's chunks are copied (a wave that takes several entries does not
+        // pay the descriptor's latency in front of each of them)
+        const u32 nx = it + gridDim.x * 4u;
+        uint4 e0 = d0, e1 = d1;
+        if (nx < n_items) { const uint4* dq = (const uint4*)&pw.items[nx]; e0 = dq[0]; e1 = dq[1]; }
         const u32 g = (d0.w >> 8) & 0xffu, code = (d0.w >> 1) & 7u, sel0 = d0.w & 1u;
         const u32 q0 = g << sh, nq = min(SC, w.chunks - q0);
         const v4u* __restrict__ R0 = (const v4u*)(pw.pool + ((size_t)d0.x << (sh + 4)));
@@ -868,6 +873,7 @@ __global__ void __launch_bounds__(256) k_stitch_segments(const ChrWork* __restri
                 D[qq] = mx ? blend_chunk(R0[qq], R1[qq], sel, in, c, nin, bit0) : (sel ? R1[qq] : R0[qq]);
             }
         }
+        d0 = e0; d1 = e1;
     }
 }
 // K5, gamete-major form (cross-check, gev_set_stitch_mode(1)): one workgroup per OUTPUT ROW walks all its chunks and decides
