@@ -235,7 +235,7 @@ struct gev_ctx {
     int ad_cached_pop = -1;                                  // population whose current-generation A/D sits in h_ad
     int ad_host_set_pop = -1;                                // population whose raw A/D totals on the device were supplied by gev_set_ad (locus-split: all-reduced)
     bool eager_ad = true;                                    // compute A/D inside gev_reproduce (same enqueue, same sync)
-    int stitch_start = 0;          // when the dense stitch of a generation may start: 0 behind the unit table, 1 behind the CV planes (default: measured best), 2 behind the whole small work incl. A/D (GEV_STITCH_START)
+    int stitch_start = 2;          // when the dense stitch of a generation may start: 0 behind the unit table, 1 behind the CV planes, 2 behind the whole small work incl. A/D (default: with the stitch at the small kernels' priority it then runs alone for 0.16 ms, next to the host's turn-around; GEV_STITCH_START)
     unsigned cv_threads = 512; bool cv_count_fused_ok = true;   // k_stitch_small: threads per block (GEV_CV_THREADS=256|512|1024), column counts in the same pass (GEV_CV_COUNT_FUSED=0: separate k_cv_count)
     int stitch_u = 1;              // 16-byte chunks per lane in flight in the segment stitch: a 2 KiB segment is one step of a wave (GEV_STITCH_U=1|2|4; 8 KiB segments: 2: 722, 4: 778 generations/s)
     bool side_streams = true;      // mate + free list next to the sampling, lists next to CV planes + A/D (GEV_SIDE_STREAMS=0: one stream)
@@ -249,7 +249,7 @@ struct gev_ctx {
     int overlap_mode = 1;          // 1 everything (default), 0 never, 2 sampling only, -1 decide after two serialised generations
     bool sparse_after_stitch = false;   // mode 2: the memory-bound sparse/CV/A-D kernels wait for the running stitch, only the ALU-bound sampling shares the GPU with it
     int auto_gens = 0; double auto_small_ms = 0, auto_stitch_ms = 0;
-    size_t stitch_grid = 8192;    // most workgroups (4 waves = 4 work-list entries each) of the segment stitch per chromosome (GEV_STITCH_GRID)
+    size_t stitch_grid = 16384;   // most workgroups (4 waves = 4 work-list entries each) of the segment stitch per chromosome (GEV_STITCH_GRID)
     int stitch_wave_prio = 0;      // s_setprio level of the stitch kernel's waves (GEV_STITCH_WAVE_PRIO)
     size_t list_long = LIST_LONG;  // average list entries per row from which the list fill kernels use LIST_LANES lanes per row (GEV_LIST_LONG)
     u32 seg_shift = 7;             // log2(16-byte chunks per row segment): 2 KiB.  Smaller: more table entries to manage per generation; larger: more bytes copied per
@@ -408,8 +408,12 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     auto level = [&](int i, int dflt) { if (!pr || strlen(pr) != 5) return dflt; return pr[i] == 'h' ? prio_greatest : (pr[i] == 'l' ? prio_least : (prio_least + prio_greatest) / 2); };
     HIPC(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, level(0, prio_greatest)));
     HIPC(hipStreamCreateWithPriority(&c->stream_samp, hipStreamNonBlocking, level(1, prio_greatest)));
+    // (the runtime maps streams of one priority onto four hardware queues: the fifth stream created shares a queue with an earlier one.
+    //  GEV_STREAM_ORDER=1 creates the list stream before the mating stream -- an experiment on which two share)
+    static const bool swap_order = getenv("GEV_STREAM_ORDER") && atoi(getenv("GEV_STREAM_ORDER")) == 1;
+    if (swap_order) HIPC(hipStreamCreateWithPriority(&c->stream_list, hipStreamNonBlocking, level(3, prio_greatest)));
     HIPC(hipStreamCreateWithPriority(&c->stream_aux, hipStreamNonBlocking, level(2, prio_greatest)));
-    HIPC(hipStreamCreateWithPriority(&c->stream_list, hipStreamNonBlocking, level(3, prio_greatest)));
+    if (!swap_order) HIPC(hipStreamCreateWithPriority(&c->stream_list, hipStreamNonBlocking, level(3, prio_greatest)));
     for (auto& ev : c->ev) HIPC(hipEventCreate(&ev));
     HIPC(hipStreamCreateWithPriority(&c->stream_big, hipStreamNonBlocking, level(4, prio_greatest)));
     // Events that only order DEVICE work against device work carry no system-scope fence (by default recording an event makes the
