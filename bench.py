@@ -394,6 +394,11 @@ def main():
             sim.sex[P] = None                                                    # (after a migration the host of this loop would need the migrants' sexes: --mating host does not combine with --migration-rate)
         mate_ms.append((t1 - t0) * 1e3); repro_ms.append((t2 - t1) * 1e3); ad_ms.append((t3 - t2) * 1e3); step_ms.append((time.perf_counter() - t0) * 1e3)
 
+    # The host loop allocates a few numpy arrays per generation; CPython's cyclic collector would eventually run a FULL collection
+    # over everything torch and numpy have imported (hundreds of thousands of objects: 40-60 ms, once, about 300 generations into
+    # the loop -- it showed up as one 45 ms step in `sustained_300`).  What exists now is long-lived: move it out of the collector's way.
+    import gc
+    gc.collect(); gc.freeze()
     for i in range(args.warmup):
         step(i)
     if state.get("begun"):                               # (timing_totals below needs an idle context)
