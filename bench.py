@@ -26,7 +26,7 @@ Prints ONE JSON line (rank 0).
                 per crossover; gev_stitch_totals); algorithmic bytes per launch = bytes written x 2 (read once, written once;
                 SURVEY.md 8(d)'s per-gamete figure restricted to the bytes that change hands), divided by the kernel's duration
                 measured with HIP events on the library's own stream.  frac / kernel_ms = live, inside the timed region, where the
-                kernel shares the GPU with the next generation's sampling and this generation's A/D chain; isolated_* = the same
+                kernel runs behind the generation's small work while the host turns the generation around; isolated_* = the same
                 kernel alone (extra untimed generations with the streams serialised).  `traffic` = measured HBM bytes (newest
                 committed rocprofv3 PMC passes of the same launch) or null.
   sampling_kernels   the Bernoulli-draw kernels (k_rec_sample8, k_mut_sample8 + the slow-task kernels): draws/s live and alone, and
@@ -536,9 +536,10 @@ def main():
                          "note": "units of a launch = the row segments it writes (segment_bytes each on average; those that contain a crossover boundary -- every other segment "
                                  "of an offspring row names the parental unit and is not copied); algorithmic bytes = bytes written x 2 (each is read once "
                                  "and written once); every_gamete_copied_equivalent_* prices all 2N whole rows (N*L/2 bytes, the definition of round 1) "
-                                 "and can exceed the peak; kernel time measured live with HIP events on the library's stitch stream inside the timed region, where the "
-                                 "kernel shares the GPU with the next generation's sampling/A-D kernels; isolated_* = same kernel with the two "
-                                 "streams serialised (extra untimed generations); traffic = rocprofv3 PMC measurement committed under profiles/",
+                                 "and can exceed the peak; kernel time measured live with HIP events on the library's stitch stream inside the timed region (the stitch is "
+                                 "enqueued behind the generation's small work and runs while the host turns the generation around; whatever else is on the GPU "
+                                 "then -- the next generation's first kernels, its sampling -- shares it); isolated_* = same kernel with the streams "
+                                 "serialised (extra untimed generations); traffic = rocprofv3 PMC measurement committed under profiles/",
                          "isolated_kernel_ms": iso, "isolated_achieved": (alg_bytes / (iso * 1e-3) / 1e9) if iso else None,
                          "isolated_frac": (alg_bytes / (iso * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso else None,
                          "isolated_hbm_actual_GBps": (traffic / (iso * 1e-3) / 1e9) if (iso and traffic) else None},
