@@ -13,8 +13,18 @@
 //   GEV_STITCH_WG_PER_CU=n|auto stitch workgroups per CU, by dynamic LDS padding (default: unlimited; auto: measured at run time)
 //   GEV_STITCH_LDS_PAD=bytes  (experiments) that padding directly
 //   GEV_ALIAS_ROWS=0|1        write every segment of every gamete row | segments without a crossover boundary share the parental unit (default)
-//   GEV_LIST_LONG=n           average list entries per row from which the list fill kernels put eight lanes on a row (default 20)
-//   GEV_STITCH_PRIORITY=1|2   stitch stream high / all streams equal (default: small streams high, stitch low)
+//   GEV_LIST_SEGS=n           most position ranges per row the mutation / interval lists are cut into (default 32; 1 = a piece is a whole list)
+//   GEV_LIST_ARENA=n          entries per row of the list-piece arenas (default: a tenth of the device memory, at most 4096 per row)
+//   GEV_LIST_HEADROOM=0       size every list buffer exactly (tests: every generation overflows, grows and is enqueued again)
+//   GEV_STREAM_PRIO=xxxxx     h|m|l for the main, head-start, mating, list and stitch streams (default hhhhh)
+//   GEV_STITCH_PRIORITY=1|2   (older form) stitch stream high and the others low / all streams equal
+//   GEV_STITCH_START=0|1|2    the stitch starts behind the unit table | the CV planes | the generation's whole small work (default 2)
+//   GEV_STITCH_U=1|2|4        16-byte chunks per lane in flight in the segment stitch (default 1)
+//   GEV_SIDE_STREAMS=0        mating and list kernels on the main stream
+//   GEV_AD_WIDE=0             A/D sums with the 128-CV table pieces of k_ad_accumulate_tab instead of k_ad_accumulate_wide
+//   GEV_CHAIN_WG=0            serial-chain mode (no mutation map): one wave per link instead of a workgroup
+//   GEV_CHAIN_MAX_TASKS=n     most (offspring, chromosome) tasks accepted without a mutation map (default 4 000 000)
+//   GEV_POOL_REBUILD=1        rebuild the free list of the segment pool every generation
 //   GEV_STITCH_GRID=n         persistent workgroups of the segment stitch per chromosome (default 16384)
 //   GEV_SEG_CHUNKS=2^k        16-byte chunks per row segment (default 128 = 2 KiB)
 //   GEV_STITCH_WAVE_PRIO=0..3 s_setprio level of the stitch kernel's waves (default 0; measured: no effect next to the sampling kernels)
@@ -82,8 +92,6 @@ static Graveyard g_graveyard;                 // one host thread calls the seam 
 
 static const size_t GRAVEYARD_LIMIT = (size_t)16 << 30;
 
-#define LIST_LANES 8      // lanes per row in the cooperative form of the list fill kernels
-#define LIST_LONG 20      // default switch-over: average inherited entries per row
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -251,7 +259,6 @@ struct gev_ctx {
     int auto_gens = 0; double auto_small_ms = 0, auto_stitch_ms = 0;
     size_t stitch_grid = 16384;   // most workgroups (4 waves = 4 work-list entries each) of the segment stitch per chromosome (GEV_STITCH_GRID)
     int stitch_wave_prio = 0;      // s_setprio level of the stitch kernel's waves (GEV_STITCH_WAVE_PRIO)
-    size_t list_long = LIST_LONG;  // average list entries per row from which the list fill kernels use LIST_LANES lanes per row (GEV_LIST_LONG)
     u32 seg_shift = 7;             // log2(16-byte chunks per row segment): 2 KiB.  Smaller: more table entries to manage per generation; larger: more bytes copied per
                                    // crossover.  Round 3 (free list kept across generations, one thread per table entry), config 2: 128 chunks 906, 256: 845, 512: 745
                                    // generations/s; round 2 (list rebuilt and every row's entries walked by one thread every generation): 256: 370, 512: 457, 1024: 450.
@@ -446,7 +453,6 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     c->sparse_after_stitch = c->overlap_mode == 2;
     if (const char* e = getenv("GEV_SAMPLE_BATCHED")) c->sample_batched = atoi(e) != 0;
     if (const char* e = getenv("GEV_STITCH_GRID")) c->stitch_grid = (size_t)std::max(1, atoi(e));
-    if (const char* e = getenv("GEV_LIST_LONG")) c->list_long = (size_t)std::max(0, atoi(e));
     if (const char* e = getenv("GEV_SEG_CHUNKS")) { const int v = atoi(e); u32 sh = 0; while ((1 << (sh + 1)) <= v) sh++; if (v >= 1 && sh <= 20) c->seg_shift = sh; }
     if (const char* e = getenv("GEV_ALIAS_ROWS")) c->alias_rows = atoi(e) != 0;
     if (const char* e = getenv("GEV_STITCH_WAVE_PRIO")) c->stitch_wave_prio = std::max(0, std::min(atoi(e), 3));
@@ -2089,7 +2095,7 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready,
             for (const AdWork& a : aw) direct &= a.cols_sorted != 0;
             bool chunked = direct, skip_d = true;                 // ... in whole 16-byte chunks: the term table in few large pieces (k_ad_accumulate_wide)
             for (const AdWork& a : aw) { chunked &= (a.sub_w32 & 3u) == 0 && (a.stride_w32 & 3u) == 0 && a.C > 0 && (size_t)a.sub_w32 * 32 >= (((size_t)a.C + 127) & ~(size_t)127); skip_d &= a.vd == 0; }
-            static const bool no_dir = getenv("GEV_AD_DIR") && atoi(getenv("GEV_AD_DIR")) == 0;
+            static const bool no_dir = getenv("GEV_AD_WIDE") && atoi(getenv("GEV_AD_WIDE")) == 0;
             if (chunked && !no_dir) {
                 const unsigned nb = (unsigned)ceil_div(n, 256);
                 if (skip_d) hipLaunchKernelGGL((k_ad_accumulate_wide<true>), dim3(nb, nw), dim3(256), 0, st, At, n, out_stride, tot_stride, flag);

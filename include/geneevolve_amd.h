@@ -99,7 +99,11 @@ const char* gev_version(void);
  *   GEV_STITCH_MODE=0|1         stitch kernel (gev_set_stitch_mode)
  *   GEV_STITCH_LDS_PAD=bytes    (experiments) dynamic LDS padding of the stitch workgroups, overriding the one derived from WG_PER_CU
  *   GEV_SAMPLE_BATCHED=0        one sampling task per wave (the round-1 kernels) instead of eight
- *   GEV_LIST_LONG=n             average list entries per row from which the list fill kernels put 8 lanes on a row (default 20)
+ *   GEV_LIST_SEGS=n             most position ranges per row of the shared list pieces (default 32; 1 = one piece per list), GEV_LIST_ARENA=n
+ *                               entries per row of their arenas (default: a tenth of the device memory) -- csrc/gev_lists.h
+ *   GEV_STREAM_PRIO=xxxxx       h|m|l: priorities of the main, head-start, mating, list and stitch streams (default hhhhh);
+ *                               GEV_STITCH_START=0|1|2: where in a generation the stitch is enqueued (default 2: behind the small work)
+ *   GEV_CHAIN_WG=0              serial-chain mode with one wave per link; GEV_CHAIN_MAX_TASKS=n: most tasks accepted without a mutation map
  *   GEV_TABLE_RING_BYTES=n      minimum size of the pinned ring the per-generation work tables are staged through
  *   GEV_OVF_CAP=n, GEV_LIST_HEADROOM=n  (tests) initial size of the breakpoint / new-mutation overflow regions, spare list entries per row:
  *                               tiny values make generations overflow their buffers, so that the grow-and-enqueue-again path runs */
