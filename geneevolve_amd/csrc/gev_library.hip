@@ -2432,7 +2432,6 @@ static int gather_population(gev_ctx* c, int dst, const std::vector<Seg>& segs, 
 static int materialize_order(gev_ctx* c, int pop)
 {
     PopState& P = c->pop[pop];
-    GEVC(ensure_csr(c, pop));                     // every caller reads whole lists next
     if (P.logical.empty()) return GEV_OK;
     GEVC(gev_sync(c));
     Seg all; all.src_pop = pop; all.people = P.logical;
@@ -2531,13 +2530,28 @@ static int export_counts(gev_ctx* c, int pop, const uint64_t* positions, size_t 
     }
     counts.assign(n * nchr * 4, 0);
     if (!n) return GEV_OK;
-    GEVC(ensure_csr(c, pop));
     GEVC(h2d(c, c->d_map, map.data(), map.size() * sizeof(u32)));
     GEVC(c->d_cnt.ensure(2 * n * sizeof(u32) * 2 + 16, c->stream));
     std::vector<u32> tmp(2 * n);
-    for (int k = 0; k < nchr; k++)
+    for (int k = 0; k < nchr; k++) {
+        if (!c->chr_active[k]) continue;
+        ChrState::LpState& lp = P.st[k].lp;
+        if (lp.valid) {                                   // the lists live as pieces: lengths of the selected rows straight from the tables
+            u32* mcnt = c->d_cnt.as<u32>(); u32* pcnt = mcnt + 2 * n;
+            hipLaunchKernelGGL(k_lp_count, dim3((unsigned)ceil_div(2 * n * LP_MAXSEG, 256)), dim3(256), 0, c->stream,
+                               c->track_intervals ? lp.ptab[P.cur].as<uint2>() : (const uint2*)nullptr, lp.mtab[P.cur].as<uint2>(), lp.nseg, c->d_map.as<u32>(), 2 * n,
+                               c->track_intervals ? pcnt : (u32*)nullptr, mcnt);
+            KCHECK();
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 1 && !c->track_intervals) continue;
+                HIPC(hipMemcpyAsync(tmp.data(), pass == 0 ? mcnt : pcnt, 2 * n * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+                HIPC(hipStreamSynchronize(c->stream));
+                for (size_t i = 0; i < n; i++) for (int h = 0; h < 2; h++) counts[((i * nchr + k) * 2 + h) * 2 + pass] = tmp[2 * i + h];
+            }
+            continue;
+        }
         for (int pass = 0; pass < 2; pass++) {
-            if (!c->chr_active[k] || (pass == 1 && !c->track_intervals)) continue;
+            if (pass == 1 && !c->track_intervals) continue;
             const u32* soff = pass == 0 ? P.st[k].moff[P.cur].as<u32>() : P.st[k].poff[P.cur].as<u32>();
             hipLaunchKernelGGL(k_csr_gather_count, dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, c->stream, soff, c->d_map.as<u32>(), 2 * n, c->d_cnt.as<u32>());
             KCHECK();
@@ -2545,6 +2559,7 @@ static int export_counts(gev_ctx* c, int pop, const uint64_t* positions, size_t 
             HIPC(hipStreamSynchronize(c->stream));
             for (size_t i = 0; i < n; i++) for (int h = 0; h < 2; h++) counts[((i * nchr + k) * 2 + h) * 2 + pass] = tmp[2 * i + h];
         }
+    }
     return GEV_OK;
 }
 int gev_export_size(gev_ctx* c, int pop, const uint64_t* positions, size_t n, size_t* bytes)
@@ -2578,7 +2593,7 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
     HIPC(hipMemcpyAsync(out + L.counts, counts.data(), counts.size() * sizeof(u32), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_gather_u8, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, out + L.sex, P.d_sex[P.cur].as<uint8_t>(), c->d_map.as<u32>(), 1u, n);   // d_map holds haplotype rows 2*individual, 2*individual+1
     size_t po = L.planes, co = L.cv, mo = L.muts, pa = L.parts;
-    GEVC(c->d_cnt.ensure((2 * n + 1) * sizeof(u32) * 2, st));
+    GEVC(c->d_cnt.ensure((2 * n + 1) * sizeof(u32) * 4, st));
     u32* d_off = c->d_cnt.as<u32>() + 2 * n + 1;
     for (int k = 0; k < nchr; k++) {
         if (!c->chr_active[k]) continue;
@@ -2589,7 +2604,21 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
                                pool_rows(P, k, cs.phys[P.pcur].as<u32>()), c->d_map.as<u32>(), (size_t)0, 2 * n, chunks);
             po = al16(po + 2 * n * S.stride);
         }
-        for (int pass = 0; pass < 2; pass++) {
+        if (cs.lp.valid) {                                // pieces -> the records' lists, for the selected rows only
+            ChrState::LpState& lp = cs.lp;
+            const bool track = c->track_intervals;
+            u32* mcnt = c->d_cnt.as<u32>(); u32* moff = mcnt + (2 * n + 1); u32* pcnt = moff + (2 * n + 1); u32* poff = pcnt + (2 * n + 1);
+            const unsigned blocks = (unsigned)ceil_div(2 * n * LP_MAXSEG, 256);
+            hipLaunchKernelGGL(k_lp_count, dim3(blocks), dim3(256), 0, st, track ? lp.ptab[P.cur].as<uint2>() : (const uint2*)nullptr, lp.mtab[P.cur].as<uint2>(), lp.nseg,
+                               c->d_map.as<u32>(), 2 * n, track ? pcnt : (u32*)nullptr, mcnt);
+            KCHECK();
+            GEVC(scan_u32(c, mcnt, 2 * n, moff, nullptr));
+            if (track) GEVC(scan_u32(c, pcnt, 2 * n, poff, nullptr));
+            hipLaunchKernelGGL(k_lp_fill, dim3(blocks), dim3(256), 0, st, track ? lp.ptab[P.cur].as<uint2>() : (const uint2*)nullptr, lp.mtab[P.cur].as<uint2>(),
+                               lp.parena.as<LpPart>(), lp.marena.as<u64>(), lp.nseg, c->d_map.as<u32>(), 2 * n, (u64)S.rbp.back(),
+                               poff, (gev_part*)(out + pa), moff, (u64*)(out + mo));
+            KCHECK();
+        } else for (int pass = 0; pass < 2; pass++) {
             if (pass == 1 && !c->track_intervals) continue;
             const u32* soff = pass == 0 ? cs.moff[P.cur].as<u32>() : cs.poff[P.cur].as<u32>();
             hipLaunchKernelGGL(k_csr_gather_count, dim3((unsigned)ceil_div(2 * n, 256)), dim3(256), 0, st, soff, c->d_map.as<u32>(), 2 * n, c->d_cnt.as<u32>());
@@ -2640,7 +2669,6 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
     if (!device_buf) return fail(GEV_EINVAL, "import_rows: null buffer");
     HIPC(hipSetDevice(c->device));
     GEVC(gev_sync(c));
-    GEVC(ensure_csr(c, pop));                     // the immigrants' lists are appended to the CSR form; the pieces are made from it again
     hipStream_t st = c->stream;
     const int nchr = c->nchr;
     const uint8_t* in = (const uint8_t*)device_buf;
@@ -2670,7 +2698,41 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
             KCHECK();
             po = al16(po + 2 * n * S.stride);
         }
-        for (int pass = 0; pass < 2; pass++) {
+        if (cs.lp.valid) {
+            // the lists live as pieces: the immigrants' lists are cut into pieces of their own, appended to the arenas, and their
+            // table rows written behind the existing ones; nothing of the residents is touched
+            ChrState::LpState& lp = cs.lp;
+            const bool track = c->track_intervals;
+            std::vector<u32> offm(2 * n + 1, 0), offp(2 * n + 1, 0);
+            for (size_t i = 0; i < n; i++) for (int h = 0; h < 2; h++) {
+                offm[2 * i + h + 1] = offm[2 * i + h] + counts[((i * nchr + k) * 2 + h) * 2];
+                offp[2 * i + h + 1] = offp[2 * i + h] + counts[((i * nchr + k) * 2 + h) * 2 + 1];
+            }
+            GEVC(c->d_cnt.ensure((2 * n + 1) * sizeof(u32) * 2, st));
+            u32* d_offm = c->d_cnt.as<u32>(); u32* d_offp = d_offm + (2 * n + 1);
+            HIPC(hipMemcpyAsync(d_offm, offm.data(), (2 * n + 1) * sizeof(u32), hipMemcpyHostToDevice, st));
+            HIPC(hipMemcpyAsync(d_offp, offp.data(), (2 * n + 1) * sizeof(u32), hipMemcpyHostToDevice, st));
+            const size_t tab_bytes = (r_old + 2 * n) * lp.nseg * sizeof(uint2);
+            if (track) GEVC(lp.ptab[P.cur].ensure(tab_bytes, st, /*keep=*/true, 1.25));
+            GEVC(lp.mtab[P.cur].ensure(tab_bytes, st, /*keep=*/true, 1.25));
+            const size_t need_p = track ? (size_t)lp.p_used + offp[2 * n] + 2 * n * lp.nseg : 0, need_m = (size_t)lp.m_used + offm[2 * n];
+            if (need_p >= 0xfffffff0u || need_m >= 0xfffffff0u) return fail(GEV_EDEVICE, "import_rows: list arenas beyond 2^32 entries");
+            if (track && need_p > lp.parena.bytes / sizeof(LpPart)) GEVC(lp.parena.ensure(need_p * sizeof(LpPart), st, true, 1.5));
+            if (need_m > lp.marena.bytes / sizeof(u64)) GEVC(lp.marena.ensure(std::max<size_t>(need_m, 16) * sizeof(u64), st, true, 1.5));
+            HIPC(hipMemsetAsync(lp.ctr.p, 0, 4 * sizeof(u32), st));
+            hipLaunchKernelGGL(k_lp_import, dim3((unsigned)ceil_div(2 * n * LP_MAXSEG, 256)), dim3(256), 0, st,
+                               track ? d_offp : (const u32*)nullptr, track ? (const gev_part*)(in + pa) : (const gev_part*)nullptr, d_offm, (const u64*)(in + mo),
+                               r_old, 2 * n, track ? lp.ptab[P.cur].as<uint2>() : (uint2*)nullptr, lp.mtab[P.cur].as<uint2>(), lp.parena.as<LpPart>(), lp.marena.as<u64>(),
+                               lp.p_used, lp.m_used, (u32)(lp.parena.bytes / sizeof(LpPart)), (u32)(lp.marena.bytes / sizeof(u64)), lp.nseg, lp.lgw, (u64)S.rbp.front(),
+                               lp.ctr.as<u32>(), lp.ctr.as<u32>() + 2);
+            KCHECK();
+            u32 h[4] = {0, 0, 0, 0};
+            HIPC(hipMemcpyAsync(h, lp.ctr.p, sizeof h, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            if (h[2]) return fail(GEV_EDEVICE, "import_rows: list arena overflow (internal error)");
+            lp.p_used += h[0]; lp.m_used += h[1];
+            cs.csr_valid = false;
+        } else for (int pass = 0; pass < 2; pass++) {
             if (pass == 1 && !c->track_intervals) continue;
             size_t& total = pass == 0 ? cs.mut_total[P.cur] : cs.parts_total[P.cur];
             std::vector<u32> off(2 * n + 1);
@@ -2703,7 +2765,6 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
     if (P.logical.empty()) { P.logical.resize(P.n_people); for (size_t i = 0; i < P.n_people; i++) P.logical[i] = (u32)i; }
     for (size_t i = 0; i < n; i++) P.logical.push_back((u32)(n_old + i));
     P.n_phys = n_new; P.n_people = P.logical.size(); c->ad_cached_pop = c->ad_host_set_pop = -1;
-    lists_changed_in_csr(c, P);
     return GEV_OK;
 }
 
@@ -2727,6 +2788,7 @@ int gev_download_haps(gev_ctx* c, int pop, int chr, size_t row_begin, size_t n_r
     PopState& P = c->pop[pop]; ChrStatic& S = P.cs[chr]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_haps: population %d has no current generation", pop);
     GEVC(materialize_order(c, pop));
+    GEVC(ensure_csr(c, pop));                     // (the mutation overlay reads whole lists)
     if (row_begin + n_rows > 2 * P.n_people) return fail(GEV_EINVAL, "download_haps: rows [%zu,%zu) beyond 2*n_people=%zu", row_begin, row_begin + n_rows, 2 * P.n_people);
     if (n_rows && (!bits || row_stride_words * 64 < S.L)) return fail(GEV_EINVAL, "download_haps: bad output buffer");
     HIPC(hipSetDevice(c->device));
@@ -3122,6 +3184,7 @@ int gev_download_intervals(gev_ctx* c, int pop, int chr, gev_part* out, u64* hap
     PopState& P = c->pop[pop]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_intervals: population %d has no current generation", pop);
     GEVC(materialize_order(c, pop));
+    GEVC(ensure_csr(c, pop));
     if (!c->track_intervals) return fail(GEV_ESTATE, "download_intervals: interval tracking is disabled");
     if (!n_parts) return fail(GEV_EINVAL, "download_intervals: n_parts is null");
     HIPC(hipSetDevice(c->device));
@@ -3144,6 +3207,7 @@ int gev_download_mutations(gev_ctx* c, int pop, int chr, u64* out, u64* hap_offs
     PopState& P = c->pop[pop]; ChrState& cs = P.st[chr];
     if (!P.gen0) return fail(GEV_ESTATE, "download_mutations: population %d has no current generation", pop);
     GEVC(materialize_order(c, pop));
+    GEVC(ensure_csr(c, pop));
     if (!n_mut) return fail(GEV_EINVAL, "download_mutations: n_mut is null");
     HIPC(hipSetDevice(c->device));
     const size_t rows = 2 * P.n_people;
@@ -3247,6 +3311,7 @@ int gev_dbg_verify_planes(gev_ctx* c, int pop, int chr, const uint64_t* founder_
     if (!founder_seeds || !n_bad_words || !n_bad_parts) return fail(GEV_EINVAL, "dbg_verify_planes: null argument");
     HIPC(hipSetDevice(c->device));
     GEVC(materialize_order(c, pop));
+    GEVC(ensure_csr(c, pop));
     GEVC(gev_sync(c));
     hipStream_t st = c->stream;
     const size_t rows = 2 * P.n_people, words = ceil_div(S.L, 32);
