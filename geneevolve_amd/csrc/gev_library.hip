@@ -1354,7 +1354,10 @@ static int enqueue_lists(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, bool
     // one launch: every (offspring row, position range) either names the parent's pieces or builds its own (gev_lists.h)
     HIPC(hipMemsetAsync(c->d_lp_nitems.p, 0, c->d_lp_nitems.bytes, st));
     hipLaunchKernelGGL(k_lp_inherit, dim3((unsigned)ceil_div(rows, 256), na), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, nchr, (int)has_mut, sd);
-    hipLaunchKernelGGL(k_lp_build, dim3((unsigned)std::min<size_t>(ceil_div(rows * 4, 256), 2048), na), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), nchr, (int)has_mut, sd);
+    const bool literal = getenv("GEV_LP_LITERAL") && atoi(getenv("GEV_LP_LITERAL")) != 0;      // recombine's statements one by one instead of their closed form (cross-check)
+    const dim3 bgrid((unsigned)std::min<size_t>(ceil_div(rows * 4, 256), 2048), na);
+    if (literal) hipLaunchKernelGGL((k_lp_build<true>), bgrid, dim3(256), 0, st, sc.chrwork.as<ChrWork>(), nchr, (int)has_mut, sd);
+    else hipLaunchKernelGGL((k_lp_build<false>), bgrid, dim3(256), 0, st, sc.chrwork.as<ChrWork>(), nchr, (int)has_mut, sd);
     KCHECK();
     return GEV_OK;
 }

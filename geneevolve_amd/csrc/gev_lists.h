@@ -84,7 +84,37 @@ __device__ __forceinline__ u32 lp_interval(const LpPart* __restrict__ e, u32 n, 
 // one generation: thread (offspring row, range t).  Ranges without an event copy two table entries; the others build their
 // pieces in two passes over the (short) source pieces -- count, one atomic per workgroup and arena, fill.
 // ------------------------------------------------------------------------------------------
+// The same interval in closed form.  With c(x) = number of owned entries whose st is <= x (a bisection), recombine's statements
+// come to: in an interval that starts here, the entry e[c(Lc)] covers Lc -- it is emitted clipped (st = Lc) if it starts in front
+// of Lc, as it is otherwise (zero-length parts [Lc, Lc) in front of it are skipped by :2918); then every owned entry up to
+// e[c(Rc)] follows, the last one only if it starts in front of Rc (a part that starts AT Rc belongs to the next interval; zero-
+// length parts [Rc, Rc) in front of it do not: their en <= Rc, :2939).  An interval that starts at or behind the end of the map
+// (Lc >= bp_end, last range) emits nothing.  lp_interval is the literal form (GEV_LP_LITERAL=1 builds with it: a cross-check).
+__device__ __forceinline__ u32 lp_count_le(const LpPart* __restrict__ e, u32 n, u64 x)
+{
+    u32 lo = 0, hi = n;                                            // over e[1..n]
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (e[mid + 1].st <= x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
 template <bool FILL>
+__device__ __forceinline__ u32 lp_interval_fast(const LpPart* __restrict__ e, u32 n, u64 en_last, bool head, u64 Lc, u64 Rc, LpPart* __restrict__ out, u32 at)
+{
+    u32 emitted = 0, first = 1;
+    if (head) {
+        if (Lc >= en_last) return 0u;                              // (only the last range knows a finite en_last)
+        const u32 c0 = lp_count_le(e, n, Lc);
+        if (e[c0].st < Lc) { if (FILL) { LpPart p = e[c0]; p.st = Lc; out[at] = p; } emitted = 1; first = c0 + 1; }
+        else first = c0;
+    }
+    u32 last = Rc == LP_INF ? n : lp_count_le(e, n, Rc);
+    if (last >= 1 && e[last].st == Rc) last--;
+    if (first >= 1 && first <= last) {
+        if (FILL) for (u32 j = first; j <= last; j++) out[at + emitted + (j - first)] = e[j];
+        emitted += last - first + 1;
+    }
+    return emitted;
+}
+template <bool FILL, bool LITERAL>
 __device__ __forceinline__ u32 lp_build_parts(const LpWork& lp, const u32 parent, const u32 start, const u64* __restrict__ bk, const u32 j0, const u32 j1,
                                               const u32 t, const u64 bp0, const u64 bp_end, LpPart* __restrict__ out)
 {
@@ -99,7 +129,7 @@ __device__ __forceinline__ u32 lp_build_parts(const LpWork& lp, const u32 parent
         const u64 Lc = q > j0 ? bk[q - 1] : bp0;
         const u64 Rc = q < j1 ? bk[q] : (last ? bp_end : LP_INF);
         if (FILL && q == j0) out[0] = e[0];                        // carry-in: the part that covers the range's first position
-        n += lp_interval<FILL>(e, pe.y, en_last, head, Lc, Rc, out, 1 + n);
+        n += LITERAL ? lp_interval<FILL>(e, pe.y, en_last, head, Lc, Rc, out, 1 + n) : lp_interval_fast<FILL>(e, pe.y, en_last, head, Lc, Rc, out, 1 + n);
     }
     return n;
 }
@@ -206,6 +236,7 @@ __global__ void __launch_bounds__(256) k_lp_inherit(const ChrWork* __restrict__ 
 }
 // pass 2, thread per item (persistent grid): the pieces of a range with an event, in two walks over the (short) source pieces --
 // count, one atomic per workgroup and arena, fill
+template <bool LITERAL>
 __global__ void __launch_bounds__(256) k_lp_build(const ChrWork* __restrict__ Wt, int nchr, int has_mut, SampleDev sd)
 {
     __shared__ u32 lds[8];
@@ -223,7 +254,7 @@ __global__ void __launch_bounds__(256) k_lp_build(const ChrWork* __restrict__ Wt
             const u32 it = lp.items[q];
             row = it / LP_MAXSEG; t = it % LP_MAXSEG;
             ev = lp_events(w, row, t, nchr, has_mut, sd);
-            if (ev.fresh_p) np = 1 + lp_build_parts<false>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, bp0, bp_end, nullptr);
+            if (ev.fresh_p) np = 1 + lp_build_parts<false, LITERAL>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, bp0, bp_end, nullptr);
             if (ev.fresh_m) nm = lp_build_muts<false>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, sd.nm_pos, sd.nm_side, ev.in, ev.nn, ev.s, bp0, bp_end, nullptr);
         }
         u32 tot_p, tot_m;
@@ -239,7 +270,7 @@ __global__ void __launch_bounds__(256) k_lp_build(const ChrWork* __restrict__ Wt
             if (ev.fresh_p) {
                 const u64 off = (u64)lp.pbase + s_base[0] + ex_p;
                 if (off + np > lp.pcap) { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_PARTS_CAP); lp.ptab_alt[dst] = make_uint2(0u, 0u); }
-                else { lp_build_parts<true>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, bp0, bp_end, lp.parena + off); lp.ptab_alt[dst] = make_uint2((u32)off, np - 1u); }
+                else { lp_build_parts<true, LITERAL>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, bp0, bp_end, lp.parena + off); lp.ptab_alt[dst] = make_uint2((u32)off, np - 1u); }
             }
             if (ev.fresh_m) {
                 const u64 off = (u64)lp.mbase + s_base[1] + ex_m;

@@ -164,8 +164,8 @@ def _read_device_u32(ptr, n):
     return out
 
 
-@pytest.mark.parametrize("max_ranges,arena", [(32, 0), (1, 0), (5, 0), (32, 6), (7, 3)])
-def test_lists_as_shared_pieces_per_position_range(gpu_lib, oracle_lib, monkeypatch, max_ranges, arena):
+@pytest.mark.parametrize("max_ranges,arena,literal", [(32, 0, 0), (32, 0, 1), (1, 0, 0), (5, 0, 1), (32, 6, 0), (7, 3, 0)])
+def test_lists_as_shared_pieces_per_position_range(gpu_lib, oracle_lib, monkeypatch, max_ranges, arena, literal):
     """the mutation / interval lists live as pieces per position range, shared between parent and offspring where a gamete has
     no crossover and no new mutation (csrc/gev_lists.h); the whole lists every other function reads are made from them on demand.
     Compared with the oracle's lists every generation (or every third: generations in between are then never materialised):
@@ -174,6 +174,7 @@ def test_lists_as_shared_pieces_per_position_range(gpu_lib, oracle_lib, monkeypa
     dropped, the sharing is kept).  Hot maps (many crossovers and new mutations per row: every range has events, inserts inside
     ranges) and cold maps (most ranges name the parent's piece)."""
     monkeypatch.setenv("GEV_LIST_SEGS", str(max_ranges))
+    monkeypatch.setenv("GEV_LP_LITERAL", str(literal))       # interval pieces built by recombine's statements one by one (1) or by their closed form (0, default)
     if arena:
         monkeypatch.setenv("GEV_LIST_ARENA", str(arena))
     seen = {}
@@ -185,6 +186,10 @@ def test_lists_as_shared_pieces_per_position_range(gpu_lib, oracle_lib, monkeypa
     assert 1 <= seen["ranges_per_row"] <= max_ranges and (max_ranges != 32 or seen["ranges_per_row"] == 31) and seen["rebuilds"] == 1   # 2 Mb in 2^16-bp ranges: 31 of them
     cfg = SyntheticConfig(200, 5000, nchr=1, chrom_bp=2_000_000, map_step=1000, rec_per_row=2e-4, mut_per_row=2e-3, n_cv=100, seed=63)
     run_pair(gpu_lib, oracle_lib, cfg, n_gen=12, seed=64, check_every=3, at_end=stats)
+    # a map whose rows are 3 bp apart: breakpoints of different rows coincide all the time (zero-length parts, parts that start
+    # exactly at a breakpoint -- the equality cases of recombine's comparisons)
+    cfg = SyntheticConfig(60, 600, nchr=1, chrom_bp=30000, map_step=3, rec_per_row=6e-4, mut_per_row=4e-4, n_cv=40, seed=65)
+    run_pair(gpu_lib, oracle_lib, cfg, n_gen=8, seed=66)
     if arena:
         assert seen["compactions"] >= 2, seen
     elif max_ranges == 32:
