@@ -206,7 +206,7 @@ struct gev_ctx {
         DevBuf father, mother, mutseeds, globvals /* [2 + T] ras_glob_seed() values drawn on the device: mate seed, reproduce seed, mutation seeds */, seed_pat, seed_mat, k, bk_off, bk, bk_idx, start, nmut, nm_off, nm_pos, nm_side, sex, status, slow_mut, slow_rec, chrwork, cvwork;
         std::vector<uint8_t> chrwork_shadow, cvwork_shadow;     // what the device copies of the tables hold (upload_table_cached)
         unsigned n_chrwork = 0, n_cvwork = 0; float sampling_ms_saved = -1;
-        size_t nseg_max = 1, cv_used_max = 0; u32 cv_max = 0;     // launch shapes of the generation (enqueue_tables)
+        size_t nseg_max = 1, cv_used_max = 0, lp_entries_per_row = 0; u32 cv_max = 0;     // launch shapes of the generation (enqueue_tables)
         bool pool_rebuild = false;                                                            // this attempt rebuilds the free list of the segment pool
         bool cv_count_fused = false;                                                          // k_stitch_small also counts the alleles per CV column (every grid <= 1024 columns)
         hipEvent_t ev_fork = nullptr, ev_aux = nullptr, ev_lists = nullptr, ev_forked = nullptr;   // joins of the attempt's side streams
@@ -1304,6 +1304,8 @@ static int enqueue_tables(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_pe
         }
     }
     sc.n_chrwork = (unsigned)cw.size(); sc.n_cvwork = (unsigned)vw.size();
+    sc.lp_entries_per_row = 0;                            // interval entries the last generation appended per row (its new pieces' lengths)
+    for (int k = 0; k < nchr; k++) if (c->chr_active[k]) sc.lp_entries_per_row = std::max<size_t>(sc.lp_entries_per_row, P.st[k].lp.p_last / std::max<size_t>(rows, 1));
     sc.nseg_max = 1; sc.cv_used_max = 0; sc.cv_max = 0;
     for (const ChrWork& w : cw) sc.nseg_max = std::max<size_t>(sc.nseg_max, w.pw.nseg);
     const u32 nsub = 1 + c->rp_bits;
@@ -1356,8 +1358,14 @@ static int enqueue_lists(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, bool
     hipLaunchKernelGGL(k_lp_inherit, dim3((unsigned)ceil_div(rows, 256), na), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, nchr, (int)has_mut, sd);
     const bool literal = getenv("GEV_LP_LITERAL") && atoi(getenv("GEV_LP_LITERAL")) != 0;      // recombine's statements one by one instead of their closed form (cross-check)
     const dim3 bgrid((unsigned)std::min<size_t>(ceil_div(rows * 4, 256), 2048), na);
+    // one lane per piece while pieces are short, a group of eight once they are long (the one-lane kernel is faster up to about 20
+    // interval entries per new piece -- generation ~450 at config 2 -- and its time grows with the piece length; the eight-lane
+    // kernel's hardly does: 0.77 -> 0.89 ms per generation over 700 generations against 0.67 -> 0.97).  GEV_LP_LANES=1|8 fixes it.
+    int lanes = getenv("GEV_LP_LANES") ? atoi(getenv("GEV_LP_LANES")) : 0;
+    if (lanes != 1 && lanes != 8) lanes = sc.lp_entries_per_row >= 20 ? 8 : 1;
     if (literal) hipLaunchKernelGGL((k_lp_build<true>), bgrid, dim3(256), 0, st, sc.chrwork.as<ChrWork>(), nchr, (int)has_mut, sd);
-    else hipLaunchKernelGGL((k_lp_build<false>), bgrid, dim3(256), 0, st, sc.chrwork.as<ChrWork>(), nchr, (int)has_mut, sd);
+    else if (lanes == 1) hipLaunchKernelGGL((k_lp_build<false>), bgrid, dim3(256), 0, st, sc.chrwork.as<ChrWork>(), nchr, (int)has_mut, sd);
+    else hipLaunchKernelGGL(k_lp_build8, dim3((unsigned)std::min<size_t>(ceil_div(rows * 4, 32), 8192), na), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), nchr, (int)has_mut, sd);
     KCHECK();
     return GEV_OK;
 }

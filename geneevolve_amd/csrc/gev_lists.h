@@ -281,6 +281,144 @@ __global__ void __launch_bounds__(256) k_lp_build(const ChrWork* __restrict__ Wt
         __syncthreads();                                  // s_base is written again in the next round
     }
 }
+// pass 2 with EIGHT lanes per item (the default): a piece is short (a few to a few dozen entries), and one lane that bisects it and
+// copies it entry by entry spends its time in chains of dependent loads.  The eight lanes of a group load the piece's entries
+// strided, all at once; c(Lc) and c(Rc) are the group's sums of two comparisons per entry (the entries are sorted: the number
+// of entries <= x is all the closed form needs); the runs are copied eight entries (128 bytes) per step.  The mutation piece is
+// merged the same way: an inherited entry moves up by the number of new positions in front of it, a new position goes behind the
+// inherited entries that are not larger -- counted while they are copied.  More than LP8_NEW new mutations in one range of one
+// row (hot maps): lane 0 merges sequentially.
+#define LP8_NEW 4
+__device__ __forceinline__ u32 lp_grp_sum8(u32 v) { v += (u32)__shfl_xor((int)v, 1, 8); v += (u32)__shfl_xor((int)v, 2, 8); v += (u32)__shfl_xor((int)v, 4, 8); return v; }
+template <bool FILL>
+__device__ __forceinline__ u32 lp_interval8(const LpPart* __restrict__ e, u32 n, u64 en_last, bool head, u64 Lc, u64 Rc, LpPart* __restrict__ out, u32 at, u32 sub)
+{
+    if (head && Lc >= en_last) return 0u;
+    u32 x = 0, y = 0;
+    for (u32 j = 1 + sub; j <= n; j += 8) { const u64 st = e[j].st; x += st <= Lc; y += st <= Rc; }
+    const u32 c0 = lp_grp_sum8(x);
+    u32 last = lp_grp_sum8(y);                                       // (Rc == LP_INF: every entry)
+    u32 emitted = 0, first = 1;
+    if (head) {
+        const LpPart cov = e[c0];
+        if (cov.st < Lc) { if (FILL && sub == 0) { LpPart p = cov; p.st = Lc; out[at] = p; } emitted = 1; first = c0 + 1; }
+        else first = c0;
+    }
+    if (last >= 1 && Rc != LP_INF && e[last].st == Rc) last--;
+    if (first >= 1 && first <= last) {
+        if (FILL) for (u32 j = first + sub; j <= last; j += 8) out[at + emitted + (j - first)] = e[j];
+        emitted += last - first + 1;
+    }
+    return emitted;
+}
+template <bool FILL>
+__device__ __forceinline__ u32 lp_build_parts8(const LpWork& lp, const u32 parent, const u32 start, const u64* __restrict__ bk, const u32 j0, const u32 j1,
+                                               const u32 t, const u64 bp0, const u64 bp_end, LpPart* __restrict__ out, u32 sub)
+{
+    const bool last = t + 1 >= lp.nseg;
+    const u64 en_last = last ? bp_end : LP_INF;
+    u32 n = 0;
+    for (u32 q = j0; q <= j1; q++) {
+        const u32 h = (start ^ q) & 1u;
+        const uint2 pe = lp.ptab_cur[((size_t)2 * parent + h) * lp.nseg + t];
+        const LpPart* e = lp.parena + pe.x;
+        const bool head = q > j0 || t == 0;
+        const u64 Lc = q > j0 ? bk[q - 1] : bp0;
+        const u64 Rc = q < j1 ? bk[q] : (last ? bp_end : LP_INF);
+        if (FILL && q == j0 && sub == 0) out[0] = e[0];
+        n += lp_interval8<FILL>(e, pe.y, en_last, head, Lc, Rc, out, 1 + n, sub);
+    }
+    return n;
+}
+template <bool FILL>
+__device__ __forceinline__ u32 lp_build_muts8(const LpWork& lp, const u32 parent, const u32 start, const u64* __restrict__ bk, const u32 j0, const u32 j1,
+                                              const u32 t, const u64* __restrict__ nv, const u32 n_new, u64* __restrict__ out, u32 sub)
+{
+    u32 g = 0, cnt[LP8_NEW];
+#pragma unroll
+    for (int i = 0; i < LP8_NEW; i++) cnt[i] = 0;
+    for (u32 q = j0; q <= j1; q++) {
+        const u32 h = (start ^ q) & 1u;
+        const uint2 me = lp.mtab_cur[((size_t)2 * parent + h) * lp.nseg + t];
+        const u64* a = lp.marena + me.x;
+        const u64 vlo = q > j0 ? bk[q - 1] : 0ull, vhi = q < j1 ? bk[q] : LP_INF;     // the run [lower_bound(vlo), lower_bound(vhi))
+        u32 x = 0, y = 0;
+        for (u32 j = sub; j < me.y; j += 8) { const u64 v = a[j]; x += v < vlo; y += (vhi == LP_INF) ? 1u : (u32)(v < vhi); }
+        const u32 lo = lp_grp_sum8(x), hi = lp_grp_sum8(y);
+        if (FILL)
+            for (u32 j = lo + sub; j < hi; j += 8) {
+                const u64 v = a[j];
+                u32 shift = 0;
+#pragma unroll
+                for (int i = 0; i < LP8_NEW; i++) if ((u32)i < n_new) { shift += nv[i] < v; cnt[i] += v <= nv[i]; }
+                out[g + (j - lo) + shift] = v;
+            }
+        g += hi > lo ? hi - lo : 0u;
+    }
+    if (FILL) {
+#pragma unroll
+        for (int i = 0; i < LP8_NEW; i++) if ((u32)i < n_new) { const u32 tot = lp_grp_sum8(cnt[i]); if (sub == 0) out[(u32)i + tot] = nv[i]; }
+    }
+    return g + n_new;
+}
+__global__ void __launch_bounds__(256) k_lp_build8(const ChrWork* __restrict__ Wt, int nchr, int has_mut, SampleDev sd)
+{
+    __shared__ u32 lds[8];
+    __shared__ u32 s_base[2];
+    const ChrWork& w = Wt[blockIdx.y];
+    const LpWork& lp = w.lp;
+    const u32 n_items = *lp.n_items;
+    const u64 bp0 = w.bp0, bp_end = w.bp_end;
+    const u32 sub = threadIdx.x & 7u, grp = threadIdx.x >> 3;
+    for (u32 base = blockIdx.x * 32u; base < n_items; base += gridDim.x * 32u) {       // (uniform per workgroup)
+        const u32 q = base + grp;
+        const bool live = q < n_items;
+        size_t row = 0; u32 t = 0, np = 0, nm = 0, n_new = 0;
+        u64 nv[LP8_NEW];
+#pragma unroll
+        for (int i = 0; i < LP8_NEW; i++) nv[i] = 0;
+        LpEvents ev{};
+        if (live) {
+            const u32 it = lp.items[q];
+            row = it / LP_MAXSEG; t = it % LP_MAXSEG;
+            ev = lp_events(w, row, t, nchr, has_mut, sd);
+            for (u32 m = ev.in; m < ev.nn; m++) {                         // the new mutations of this row's side that lie in the range, ascending
+                const u64 x = sd.nm_pos[m];
+                if (sd.nm_side[m] == ev.s && x >= bp0 && x < bp_end && lp_seg(x, bp0, lp.lgw, lp.nseg) == t) { if (n_new < LP8_NEW) nv[n_new] = x; n_new++; }
+            }
+            if (ev.fresh_p) np = 1 + lp_build_parts8<false>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, bp0, bp_end, nullptr, sub);
+            if (ev.fresh_m) nm = n_new <= LP8_NEW ? lp_build_muts8<false>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, nv, n_new, nullptr, sub)
+                                                   : lp_build_muts<false>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, sd.nm_pos, sd.nm_side, ev.in, ev.nn, ev.s, bp0, bp_end, nullptr);
+        }
+        u32 tot_p, tot_m;
+        u32 ex_p = block_exclusive_scan_256(sub == 0 ? np : 0u, lds, tot_p);
+        u32 ex_m = block_exclusive_scan_256(sub == 0 ? nm : 0u, lds, tot_m);
+        ex_p = (u32)__shfl((int)ex_p, 0, 8); ex_m = (u32)__shfl((int)ex_m, 0, 8);
+        if (threadIdx.x == 0) {
+            s_base[0] = tot_p ? atomicAdd(&sd.status[ST_TOTALS + ST_PER_CHR * w.chr + 1], tot_p) : 0u;
+            s_base[1] = tot_m ? atomicAdd(&sd.status[ST_TOTALS + ST_PER_CHR * w.chr + 0], tot_m) : 0u;
+        }
+        __syncthreads();
+        if (live) {
+            const size_t dst = row * lp.nseg + t;
+            if (ev.fresh_p) {
+                const u64 off = (u64)lp.pbase + s_base[0] + ex_p;
+                if (off + np > lp.pcap) { if (sub == 0) { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_PARTS_CAP); lp.ptab_alt[dst] = make_uint2(0u, 0u); } }
+                else { lp_build_parts8<true>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, bp0, bp_end, lp.parena + off, sub); if (sub == 0) lp.ptab_alt[dst] = make_uint2((u32)off, np - 1u); }
+            }
+            if (ev.fresh_m) {
+                const u64 off = (u64)lp.mbase + s_base[1] + ex_m;
+                if (off + nm > lp.mcap) { if (sub == 0) { atomicOr(&sd.status[ST_FLAGS], (u32)FLAG_MUT_CAP); lp.mtab_alt[dst] = make_uint2(0u, 0u); } }
+                else {
+                    if (n_new <= LP8_NEW) lp_build_muts8<true>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, nv, n_new, lp.marena + off, sub);
+                    else if (sub == 0) lp_build_muts<true>(lp, ev.parent, ev.start, ev.bk, ev.j0, ev.j1, t, sd.nm_pos, sd.nm_side, ev.in, ev.nn, ev.s, bp0, bp_end, lp.marena + off);
+                    if (sub == 0) lp.mtab_alt[dst] = make_uint2((u32)off, nm);
+                }
+            }
+        }
+        __syncthreads();                                  // s_base is written again in the next round
+    }
+}
 // ------------------------------------------------------------------------------------------
 // pieces -> CSR (downloads, output, migration, plane-less assembly, compaction).  Row r of the output is table row
 // (map ? map[r] : r).  Half a wave per row (LP_MAXSEG = 32 lanes): counts by a butterfly sum, offsets by a 32-lane scan.

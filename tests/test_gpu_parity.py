@@ -164,8 +164,8 @@ def _read_device_u32(ptr, n):
     return out
 
 
-@pytest.mark.parametrize("max_ranges,arena,literal", [(32, 0, 0), (32, 0, 1), (1, 0, 0), (5, 0, 1), (32, 6, 0), (7, 3, 0)])
-def test_lists_as_shared_pieces_per_position_range(gpu_lib, oracle_lib, monkeypatch, max_ranges, arena, literal):
+@pytest.mark.parametrize("max_ranges,arena,literal,lanes", [(32, 0, 0, 8), (32, 0, 1, 1), (32, 0, 0, 1), (1, 0, 0, 8), (5, 0, 1, 1), (32, 6, 0, 8), (7, 3, 0, 8)])
+def test_lists_as_shared_pieces_per_position_range(gpu_lib, oracle_lib, monkeypatch, max_ranges, arena, literal, lanes):
     """the mutation / interval lists live as pieces per position range, shared between parent and offspring where a gamete has
     no crossover and no new mutation (csrc/gev_lists.h); the whole lists every other function reads are made from them on demand.
     Compared with the oracle's lists every generation (or every third: generations in between are then never materialised):
@@ -175,6 +175,7 @@ def test_lists_as_shared_pieces_per_position_range(gpu_lib, oracle_lib, monkeypa
     ranges) and cold maps (most ranges name the parent's piece)."""
     monkeypatch.setenv("GEV_LIST_SEGS", str(max_ranges))
     monkeypatch.setenv("GEV_LP_LITERAL", str(literal))       # interval pieces built by recombine's statements one by one (1) or by their closed form (0, default)
+    monkeypatch.setenv("GEV_LP_LANES", str(lanes))           # ... by a group of eight lanes per piece (default) or by one lane
     if arena:
         monkeypatch.setenv("GEV_LIST_ARENA", str(arena))
     seen = {}
