@@ -250,6 +250,7 @@ struct gev_ctx {
     int stitch_mode = 0;           // 0 = work-list form (production, k_stitch_segments), 1 = gamete-major (k_stitch_rows)
     bool sample_batched = true;               // K1-K3 as eight tasks per wave (gev_sample8.h); GEV_SAMPLE_BATCHED=0: one task per wave
     unsigned sample_grid = SAMPLE_GRID_MAX;   // persistent workgroups of the sampling kernels when they have the GPU to themselves (GEV_SAMPLE_GRID)
+    bool sample_grid_env = false;             // GEV_SAMPLE_GRID fixed both
     unsigned sample_grid_shared = 768;        // ... and next to the other streams' kernels.  Next to the 5 ms whole-row stitch of the first half of round 2, 384 was
                                               // best (fewer of the stitch's slots taken for longer); with the 0.7 ms segment stitch and the pipelined host loop the
                                               // sampling is what gev_presample_sex waits for: 768 finishes in 0.45 instead of 0.95 ms (config 2 +4 %, the shard unchanged)
@@ -463,7 +464,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     if (const char* e = getenv("GEV_CV_COUNT_FUSED")) c->cv_count_fused_ok = atoi(e) != 0;
     if (const char* e = getenv("GEV_OVF_CAP")) { const long v = atol(e); if (v >= 1) c->bk_ovf_cap = c->nm_ovf_cap = (size_t)v; }
     if (const char* e = getenv("GEV_STITCH_MODE")) c->stitch_mode = std::max(0, std::min(atoi(e), 1));
-    if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) c->sample_grid = c->sample_grid_shared = (unsigned)g; }
+    if (const char* e = getenv("GEV_SAMPLE_GRID")) { const int g = atoi(e); if (g >= 1) { c->sample_grid = c->sample_grid_shared = (unsigned)g; c->sample_grid_env = true; } }
     if (const char* e = getenv("GEV_STITCH_WG_PER_CU")) {       // fixed stitch workgroups per CU (default: measured, see OccTune)
         const int occ = atoi(e);
         if (!strcmp(e, "auto")) c->stitch_occ_auto = true;
@@ -1060,7 +1061,11 @@ static int enqueue_sampling(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t n_
 
     HIPC(hipEventRecord(sc.t[0], st));
     // ---- sampling: one map scan per gamete / per mutation task
-    const unsigned task_blocks = (unsigned)std::min<size_t>(ceil_div(T, 4), (c->dense && !c->serialize) ? c->sample_grid_shared : c->sample_grid);
+    // persistent sampling workgroups.  Next to the other streams' kernels: 1792 (7 waves per SIMD: the kernels stall on dependent
+    // integer chains and LDS, and more waves hide that -- +2 % at config 2) while the generation has few tasks; 768 for many tasks
+    // (the 1.4 M tasks of the config-4 shard: its list and table kernels are the bound, and the sampling grid is in their way)
+    const unsigned shared_grid = c->sample_grid_env ? c->sample_grid_shared : (T <= 400000 ? 1792u : c->sample_grid_shared);
+    const unsigned task_blocks = (unsigned)std::min<size_t>(ceil_div(T, 4), (c->dense && !c->serialize) ? shared_grid : c->sample_grid);
     if (has_mut && c->sample_batched) {
         // eight tasks per wave; the rare tasks that need more than 8 rand() outputs go to the one-task-per-wave kernels
         const unsigned batch_blocks = (unsigned)std::min<size_t>(ceil_div(ceil_div(T, SB_TASKS), 4), task_blocks);
