@@ -9,7 +9,7 @@
 //   GEV_SERIALIZE=1           same as GEV_OVERLAP=0
 //   GEV_SAMPLE_BATCHED=0|1    sampling kernels: one task per wave | eight tasks per wave (default)
 //   GEV_STITCH_MODE=0|1       dense stitch kernel: k_stitch_segments (default) | k_stitch_rows (same results)
-//   GEV_SAMPLE_GRID=n         persistent workgroups of the sampling kernels (default 768 next to other kernels, 1024 alone)
+//   GEV_SAMPLE_GRID=n         persistent workgroups of the sampling kernels (default 1792 up to 400k tasks per generation, 768 above; 1024 alone)
 //   GEV_STITCH_WG_PER_CU=n|auto stitch workgroups per CU, by dynamic LDS padding (default: unlimited; auto: measured at run time)
 //   GEV_STITCH_LDS_PAD=bytes  (experiments) that padding directly
 //   GEV_ALIAS_ROWS=0|1        write every segment of every gamete row | segments without a crossover boundary share the parental unit (default)
@@ -21,6 +21,8 @@
 //   GEV_STITCH_START=0|1|2    the stitch starts behind the unit table | the CV planes | the generation's whole small work (default 2)
 //   GEV_STITCH_U=1|2|4        16-byte chunks per lane in flight in the segment stitch (default 1)
 //   GEV_SIDE_STREAMS=0        mating and list kernels on the main stream
+//   GEV_HEAD_START=1          the next generation's seeds + sampling are enqueued in front of this generation's work, and only the next
+//                             generation's unit table waits for the sampling (default 0: behind this generation's work, waited for as a whole)
 //   GEV_AD_WIDE=0             A/D sums with the 128-CV table pieces of k_ad_accumulate_tab instead of k_ad_accumulate_wide
 //   GEV_CHAIN_WG=0            serial-chain mode (no mutation map): one wave per link instead of a workgroup
 //   GEV_CHAIN_MAX_TASKS=n     most (offspring, chromosome) tasks accepted without a mutation map (default 4 000 000)
@@ -29,7 +31,8 @@
 //   GEV_SEG_CHUNKS=2^k        16-byte chunks per row segment (default 128 = 2 KiB)
 //   GEV_STITCH_WAVE_PRIO=0..3 s_setprio level of the stitch kernel's waves (default 0; measured: no effect next to the sampling kernels)
 //   GEV_TABLE_RING_BYTES=n    minimum size of the pinned ring the per-generation work tables are staged in (default 256 KiB)
-//   GEV_TRACE_HOST=1          stderr: host time per phase of gev_reproduce, allocations, deferred frees
+//   GEV_TRACE_HOST=1          stderr: host time per phase of gev_reproduce, per generation the host's and the main stream's time split by
+//                             phase (timed events), allocations, deferred frees
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <algorithm>
@@ -210,8 +213,10 @@ struct gev_ctx {
         bool pool_rebuild = false;                                                            // this attempt rebuilds the free list of the segment pool
         bool cv_count_fused = false;                                                          // k_stitch_small also counts the alleles per CV column (every grid <= 1024 columns)
         hipEvent_t ev_fork = nullptr, ev_aux = nullptr, ev_lists = nullptr, ev_forked = nullptr;   // joins of the attempt's side streams
-        hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_status = nullptr, ev_sampled = nullptr;   // the generation's status block (and A/D results) have arrived on the host
+        hipEvent_t ev_small_done = nullptr, ev_stitch_done = nullptr, t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_status = nullptr, ev_sampled = nullptr, ev_seeded = nullptr;   // the generation's status block (and A/D results) have arrived on the host
         bool timing_pending = false, stitch_pending = false;
+        hipEvent_t tc[3] = {nullptr, nullptr, nullptr};   // GEV_TRACE_HOST: start of the attempt's main stream, A/D done, lists joined
+        double th_enq = 0;
         // gev_presample: the sampling kernels of the next gev_reproduce were already enqueued for exactly these inputs
         bool presampled = false; int ps_pop = -1; u32 ps_seed = 0; size_t ps_n_people = 0; bool ps_has_mut = false;
         bool ps_stale = false;      // the head start was dropped by a redo of the generation in flight (record capacities changed): gev_presample_sex samples again from the retained inputs
@@ -246,6 +251,7 @@ struct gev_ctx {
     int stitch_start = 2;          // when the dense stitch of a generation may start: 0 behind the unit table, 1 behind the CV planes, 2 behind the whole small work incl. A/D (default: with the stitch at the small kernels' priority it then runs alone for 0.16 ms, next to the host's turn-around; GEV_STITCH_START)
     unsigned cv_threads = 512; bool cv_count_fused_ok = true;   // k_stitch_small: threads per block (GEV_CV_THREADS=256|512|1024), column counts in the same pass (GEV_CV_COUNT_FUSED=0: separate k_cv_count)
     int stitch_u = 1;              // 16-byte chunks per lane in flight in the segment stitch: a 2 KiB segment is one step of a wave (GEV_STITCH_U=1|2|4; 8 KiB segments: 2: 722, 4: 778 generations/s)
+    int head_start = 0;            // the next generation's seeds + sampling: 0 = enqueued behind this generation's work, the whole next generation waits for them; 1 = enqueued first, the next generation's mating waits for the seeds and its unit table for the sampling (GEV_HEAD_START; same rate at config 2)
     bool side_streams = true;      // mate + free list next to the sampling, lists next to CV planes + A/D (GEV_SIDE_STREAMS=0: one stream)
     int stitch_mode = 0;           // 0 = work-list form (production, k_stitch_segments), 1 = gamete-major (k_stitch_rows)
     bool sample_batched = true;               // K1-K3 as eight tasks per wave (gev_sample8.h); GEV_SAMPLE_BATCHED=0: one task per wave
@@ -435,10 +441,11 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
         HIPC(hipEventCreateWithFlags(&sc.ev_small_done, dev_only));
         HIPC(hipEventCreateWithFlags(&sc.ev_stitch_done, dev_only));
         HIPC(hipEventCreateWithFlags(&sc.ev_status, hipEventDisableTiming));
-        HIPC(hipEventCreateWithFlags(&sc.ev_sampled, dev_only));
+        HIPC(hipEventCreateWithFlags(&sc.ev_sampled, dev_only)); HIPC(hipEventCreateWithFlags(&sc.ev_seeded, dev_only));
         HIPC(hipEventCreateWithFlags(&sc.ev_fork, dev_only)); HIPC(hipEventCreateWithFlags(&sc.ev_aux, dev_only)); HIPC(hipEventCreateWithFlags(&sc.ev_lists, dev_only));
         HIPC(hipEventCreateWithFlags(&sc.ev_forked, dev_only)); HIPC(hipEventCreateWithFlags(&sc.ev_chain, dev_only)); HIPC(hipEventCreateWithFlags(&sc.ev_tab, dev_only));
         for (auto& e : sc.t) HIPC(hipEventCreateWithFlags(&e, timed));
+        if (g_trace_host) for (auto& e : sc.tc) HIPC(hipEventCreateWithFlags(&e, timed));
     }
     c->pop.resize(n_pop);
     for (auto& P : c->pop) {
@@ -459,6 +466,7 @@ int gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen)
     if (const char* e = getenv("GEV_STITCH_WAVE_PRIO")) c->stitch_wave_prio = std::max(0, std::min(atoi(e), 3));
     if (const char* e = getenv("GEV_STITCH_START")) c->stitch_start = std::max(0, std::min(atoi(e), 2));
     if (const char* e = getenv("GEV_SIDE_STREAMS")) c->side_streams = atoi(e) != 0;
+    if (const char* e = getenv("GEV_HEAD_START")) c->head_start = atoi(e) == 1 ? 1 : 0;
     if (const char* e = getenv("GEV_STITCH_U")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) c->stitch_u = v; }
     if (const char* e = getenv("GEV_CV_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) c->cv_threads = (unsigned)v; }
     if (const char* e = getenv("GEV_CV_COUNT_FUSED")) c->cv_count_fused_ok = atoi(e) != 0;
@@ -485,7 +493,7 @@ void gev_destroy(gev_ctx* c)
     if (g_graveyard.bytes) g_graveyard.drain(c->device, false);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
-    for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); if (sc.ev_status) (void)hipEventDestroy(sc.ev_status); if (sc.ev_sampled) (void)hipEventDestroy(sc.ev_sampled); if (sc.ev_fork) (void)hipEventDestroy(sc.ev_fork); if (sc.ev_aux) (void)hipEventDestroy(sc.ev_aux); if (sc.ev_lists) (void)hipEventDestroy(sc.ev_lists); if (sc.ev_forked) (void)hipEventDestroy(sc.ev_forked); if (sc.ev_chain) (void)hipEventDestroy(sc.ev_chain); if (sc.ev_tab) (void)hipEventDestroy(sc.ev_tab); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); }
+    for (auto& sc : c->sc) { if (sc.ev_small_done) (void)hipEventDestroy(sc.ev_small_done); if (sc.ev_stitch_done) (void)hipEventDestroy(sc.ev_stitch_done); if (sc.ev_status) (void)hipEventDestroy(sc.ev_status); if (sc.ev_sampled) (void)hipEventDestroy(sc.ev_sampled); if (sc.ev_seeded) (void)hipEventDestroy(sc.ev_seeded); if (sc.ev_fork) (void)hipEventDestroy(sc.ev_fork); if (sc.ev_aux) (void)hipEventDestroy(sc.ev_aux); if (sc.ev_lists) (void)hipEventDestroy(sc.ev_lists); if (sc.ev_forked) (void)hipEventDestroy(sc.ev_forked); if (sc.ev_chain) (void)hipEventDestroy(sc.ev_chain); if (sc.ev_tab) (void)hipEventDestroy(sc.ev_tab); for (auto& e : sc.t) if (e) (void)hipEventDestroy(e); for (auto& e : sc.tc) if (e) (void)hipEventDestroy(e); }
     hipStream_t s = c->stream;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_seeds) (void)hipHostFree(c->h_seeds);
@@ -1521,6 +1529,7 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     hipStream_t S = c->stream, X = (c->serialize || !c->side_streams) ? S : c->stream_aux, L = (c->serialize || !c->side_streams) ? S : c->stream_list;
     const size_t T = q.n_people * (size_t)c->nchr;
     q.th0 = host_ms();
+    if (g_trace_host) HIPC(hipEventRecord(sc.tc[0], S));
     if (attempt == 0) GEVC(harvest_timing(c, sc));          // kernel times of the set's previous generation, before its events are recorded again
     u32* gv = sc.globvals.as<u32>(); u32* status = sc.status.as<u32>();
     const bool sampled = q.pre && attempt == 0;              // seeds drawn and sampling done by a head start
@@ -1533,6 +1542,9 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
         hipLaunchKernelGGL(k_glob_skip, dim3(1), dim3(64), 0, S, (const u32*)(status + ST_GLOB_STATE), (u32)c->chain_draws, status + ST_NEXT_STATE);
         KCHECK();
         HIPC(hipEventRecord(sc.ev_chain, S));
+        // the NEXT generation's seeds and sampling go to their stream right away: they take most of a generation's time next to this
+        // generation's chain, and the next generation's unit table cannot start before they are through
+        if (attempt == 0 && c->head_start == 1) GEVC(enqueue_chain_head_start(c));
     }
     if (X != S) { HIPC(hipEventRecord(sc.ev_fork, S)); HIPC(hipStreamWaitEvent(X, sc.ev_fork, 0)); }
     // overlap mode 2: only the ALU-bound sampling shares the GPU with the previous generation's stitch; everything latency-bound waits for it
@@ -1551,6 +1563,7 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     q.th1 = host_ms();
     if (c->sparse_after_stitch && c->planes_pending && X != S) HIPC(hipStreamWaitEvent(S, c->ev_planes, 0));
     if (X != S) HIPC(hipStreamWaitEvent(S, sc.ev_aux, 0));
+    if (sampled && q.fused && c->head_start == 1) HIPC(hipStreamWaitEvent(S, sc.ev_sampled, 0));   // crossovers and new mutations of this generation (head start)
     HIPC(hipEventRecord(sc.t[5], S));
     GEVC(enqueue_pool_assign(c, sc, q.n_people, S));
     // The dense stitch needs the sampling results, the couples and the unit table only.  It saturates HBM, and every latency-bound
@@ -1571,6 +1584,7 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     if (c->ad_cached_pop != q.pop) c->ad_cached_pop = -1;    // (the device-side arrays are about to be rewritten; the published values of q.pop stay readable in their pinned buffer)
     c->ad_host_set_pop = -1;
     if (ad_now) GEVC(enqueue_ad(c, q.pop, c->pop[q.pop].cur ^ 1, q.n_people, count_cols, (int)(c->gen_counter & 1)));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
+    if (g_trace_host) HIPC(hipEventRecord(sc.tc[1], S));
     if (L != S) HIPC(hipStreamWaitEvent(L, sc.ev_forked, 0));
     // Human::sex of the new generation (:2472) for the next gev_random_mate; a fused generation also sends them to the host with the status block
     HIPC(hipMemcpyAsync(P.d_sex[P.cur ^ 1].p, sc.sex.p, q.n_people, hipMemcpyDeviceToDevice, L));
@@ -1578,9 +1592,11 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     GEVC(enqueue_lists(c, sc, q.n_people, q.has_mut, L));
     if (L != S) HIPC(hipEventRecord(sc.ev_lists, L));
     if (L != S) HIPC(hipStreamWaitEvent(S, sc.ev_lists, 0));
+    if (g_trace_host) HIPC(hipEventRecord(sc.tc[2], S));
     if (c->stitch_start >= 2) { HIPC(hipEventRecord(sc.ev_small_done, S)); GEVC(enqueue_stitch(c, sc, q.pop, q.n_people)); }
     HIPC(hipMemcpyAsync(q.hstatus, sc.status.p, q.n_status * sizeof(u32), hipMemcpyDeviceToHost, S));
     HIPC(hipEventRecord(sc.ev_status, S));                  // gev_reproduce_end waits for THIS, not for whatever a head start queued behind it
+    sc.th_enq = host_ms();
     return GEV_OK;
 }
 static int ensure_stage(gev_ctx* c, size_t bytes)
@@ -1680,6 +1696,7 @@ static int enqueue_chain_head_start(gev_ctx* c)
     u32* gv = nx.globvals.as<u32>(); u32* status = nx.status.as<u32>();
     HIPC(hipMemsetAsync(nx.status.p, 0, q.n_status * sizeof(u32), SS));
     GEVC(enqueue_glob(c, SS, 0u, sc.status.as<u32>() + ST_NEXT_STATE, 2 + (q.has_mut ? T : 0), gv, status + ST_GLOB_STATE, status + ST_FLAGS));
+    HIPC(hipEventRecord(nx.ev_seeded, SS));               // status block cleared, seeds drawn: all that the next generation's mating needs
     GEVC(enqueue_sampling(c, nx, q.pop, q.n_people, q.has_mut, 0u, SS, gv + 1, gv + 2, /*clear_status=*/false));
     HIPC(hipEventRecord(nx.ev_sampled, SS));
     nx.fused_ahead = true; nx.fa_dropped = false; nx.fa_pop = q.pop; nx.fa_n = q.n_people; nx.fa_has_mut = q.has_mut;
@@ -1747,7 +1764,8 @@ int gev_generation_begin(gev_ctx* c, int pop, uint32_t glob_state, size_t pop_si
     if (sc.presampled || sc.fa_dropped || (sc.fused_ahead && !pre)) HIPC(hipStreamSynchronize(c->stream_samp));     // a head start that does not match must not write into the set any more
     if (sc.fused_ahead) { if (pre) c->chain_hits++; else c->chain_misses++; }
     sc.presampled = false; sc.ps_stale = false; sc.mated = false; sc.fused_ahead = false; sc.fa_dropped = false; c->chain_valid = false;
-    if (pre) HIPC(hipStreamWaitEvent(st, sc.ev_sampled, 0));           // the head start ran on its own stream
+    // the head start ran on its own stream: mating needs its seeds, the unit table its crossovers (waited for in enqueue_attempt)
+    if (pre) HIPC(hipStreamWaitEvent(st, c->head_start == 1 ? sc.ev_seeded : sc.ev_sampled, 0));
     else {
         GEVC(harvest_timing(c, sc));
         if (sc.stitch_pending) { HIPC(hipStreamWaitEvent(st, sc.ev_stitch_done, 0)); sc.stitch_pending = false; }
@@ -1766,7 +1784,7 @@ int gev_generation_begin(gev_ctx* c, int pop, uint32_t glob_state, size_t pop_si
     q.fused = true; q.has_svf = selection_value_func != nullptr; q.glob_state = glob_state; q.hseeds2 = hstatus + n_status; q.hsex = (uint8_t*)(hstatus + n_status + 2);
     GEVC(enqueue_attempt(c, 0));
     q.active = true;
-    if (c->chain_draws >= 0) GEVC(enqueue_chain_head_start(c));
+    if (c->chain_draws >= 0 && c->head_start == 0) GEVC(enqueue_chain_head_start(c));
     return GEV_OK;
 }
 // The host announced how many ras_glob_seed() values it draws itself between two generations (gev_set_generation_chain): the state
@@ -1801,8 +1819,17 @@ static int generation_finish_inner(gev_ctx* c, uint8_t* sex_out, gev_generation_
     const int alt = P.cur ^ 1;
     for (int attempt = q.attempt;; attempt++) {
         if (attempt > 0) GEVC(enqueue_attempt(c, attempt));
+        const double th_w0 = host_ms();
         HIPC(hipEventSynchronize(sc.ev_status));
         const u32 flags = hstatus[ST_FLAGS];
+        if (g_trace_host) {
+            static double last_status = 0; const double now = host_ms();
+            float a = 0, b = 0, d = 0, e = 0;
+            (void)hipEventSynchronize(sc.tc[2]); (void)hipEventElapsedTime(&a, sc.tc[0], sc.t[5]); (void)hipEventElapsedTime(&b, sc.t[5], sc.t[2]); (void)hipEventElapsedTime(&d, sc.t[2], sc.tc[1]); (void)hipEventElapsedTime(&e, sc.tc[1], sc.tc[2]);
+            fprintf(stderr, "[gev] gen %u host: since last status %.3f = to first launch %.3f + enqueue %.3f + host idle %.3f + wait %.3f | device chain: to unit table %.3f, unit table + CV planes %.3f, A/D %.3f, lists after A/D %.3f\n",
+                    c->gen_counter, now - last_status, q.th0 - last_status, sc.th_enq - q.th0, th_w0 - sc.th_enq, now - th_w0, a, b, d, e);
+            last_status = now;
+        }
         if (g_trace_host) fprintf(stderr, "[gev] gen %u attempt %d pre %d: enqueue sampling %.2f ms, sparse %.2f ms, A/D + wait %.2f ms, flags %u, graveyard %.1f MiB\n",
                                   c->gen_counter, attempt, (int)q.pre, q.th1 - q.th0, q.th2 - q.th1, host_ms() - q.th2, flags, g_graveyard.bytes / 1048576.0);
         if (g_trace_host && g_malloc_n) { fprintf(stderr, "[gev]   %zu hipMalloc calls, %.1f MiB, %.2f ms\n", g_malloc_n, g_malloc_bytes / 1048576.0, g_malloc_ms); g_malloc_ms = 0; g_malloc_n = 0; g_malloc_bytes = 0; }

@@ -103,6 +103,8 @@ const char* gev_version(void);
  *                               entries per row of their arenas (default: a tenth of the device memory) -- csrc/gev_lists.h
  *   GEV_STREAM_PRIO=xxxxx       h|m|l: priorities of the main, head-start, mating, list and stitch streams (default hhhhh);
  *                               GEV_STITCH_START=0|1|2: where in a generation the stitch is enqueued (default 2: behind the small work)
+ *                               GEV_HEAD_START=1: the next generation's seeds and sampling are enqueued in front of the generation's own
+ *                               work and waited for separately (seeds: mating, sampling: unit table); default 0 (same rate at config 2)
  *   GEV_CHAIN_WG=0              serial-chain mode with one wave per link; GEV_CHAIN_MAX_TASKS=n: most tasks accepted without a mutation map
  *   GEV_TABLE_RING_BYTES=n      minimum size of the pinned ring the per-generation work tables are staged through
  *   GEV_OVF_CAP=n, GEV_LIST_HEADROOM=n  (tests) initial size of the breakpoint / new-mutation overflow regions, spare list entries per row:

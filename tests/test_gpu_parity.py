@@ -1530,10 +1530,16 @@ def test_mutations_on_cv_positions_flip_the_resolved_allele_once_and_are_inherit
     g.close(); o.close()
 
 
-def test_head_start_across_generations_is_only_a_schedule(gpu_lib, oracle_lib):
+@pytest.mark.parametrize("head_start,tight", [("0", False), ("1", False), ("0", True), ("1", True)])
+def test_head_start_across_generations_is_only_a_schedule(gpu_lib, oracle_lib, monkeypatch, head_start, tight):
     """gev_set_generation_chain: the library draws the next generation's seeds from the PREDICTED glob_generator state and samples
     ahead.  Generations whose gev_generation_begin arrives with the predicted state use the head start, the others (the host drew a
-    different number of values in between, another size, a redo in between) sample again -- states are the oracle's either way."""
+    different number of values in between, another size, a redo in between) sample again -- states are the oracle's either way.
+    GEV_HEAD_START=1: the head start is enqueued in front of the generation's own work and the next generation waits for its seeds
+    and its sampling separately.  tight: buffers too small on purpose, generations are enqueued again while a head start is queued."""
+    monkeypatch.setenv("GEV_HEAD_START", head_start)
+    if tight:
+        monkeypatch.setenv("GEV_OVF_CAP", "8"); monkeypatch.setenv("GEV_LIST_HEADROOM", "0")
     cfg = SyntheticConfig(200, 3000, nchr=2, chrom_bp=2_000_000, map_step=10_000, rec_per_row=0.01, mut_per_row=0.01, n_cv=40, seed=19)
     g, o = _pair(gpu_lib, oracle_lib, cfg, 200)
     sg, so = Simulation(g, 21, 2, True), Simulation(o, 21, 2, True)
@@ -1563,4 +1569,6 @@ def test_head_start_across_generations_is_only_a_schedule(gpu_lib, oracle_lib):
     ra = sg.next_generation_rm(0, 200, want_couples=True); rb = so.next_generation_rm(0, 200, want_couples=True)
     assert np.array_equal(ra["couples"], rb["couples"]) and np.array_equal(ra["sex"], rb["sex"])
     _same_state(g, o, 2, "end")
+    if tight:
+        assert g.redo_count() >= 1, "the undersized buffers were meant to force generations to be enqueued again"
     g.close(); o.close()
