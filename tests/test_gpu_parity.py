@@ -1545,10 +1545,18 @@ def test_head_start_across_generations_is_only_a_schedule(gpu_lib, oracle_lib, m
     sg, so = Simulation(g, 21, 2, True), Simulation(o, 21, 2, True)
     sg.ras_initial_human_gen0(0, 200); so.ras_initial_human_gen0(0, 200)
     g.set_generation_chain(2)                                   # "I draw two values between generations" ...
-    for gen in range(1, 13):
+    rng = np.random.default_rng(5)
+    for gen in range(1, 15):
         n = 200 if gen != 7 else 230                              # (a size the head start was not made for)
-        ra = sg.next_generation_rm(0, n, want_couples=True); rb = so.next_generation_rm(0, n, want_couples=True)
+        # selection values on some generations, and people who leave between two generations (positions are no longer rows)
+        svf = rng.uniform(0.3, 1.5, len(sg.sex[0])) if gen in (4, 10) else None
+        ra = sg.next_generation_rm(0, n, svf, want_couples=True); rb = so.next_generation_rm(0, n, svf, want_couples=True)
         assert ra["glob_state"] == rb["glob_state"] and np.array_equal(ra["couples"], rb["couples"]) and np.array_equal(ra["sex"], rb["sex"]), gen
+        assert ra["num_males_mate"] == rb["num_males_mate"] and ra["num_females_mate"] == rb["num_females_mate"] and ra["seed_mate"] == rb["seed_mate"], gen
+        if gen in (5, 11):
+            gone = [3, 10, 57, 199]
+            g.remove_rows(0, gone); o.remove_rows(0, gone)
+            sg.sex[0] = np.delete(sg.sex[0], gone); so.sex[0] = np.delete(so.sex[0], gone)
         for x, y in zip(g.compute_ad(0), o.compute_ad(0)):
             assert helpers.bits_equal(x, y), f"A/D gen {gen}"
         k = 2 if gen % 3 else 5                                   # ... and keep the promise two times out of three
