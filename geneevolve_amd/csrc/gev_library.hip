@@ -652,6 +652,8 @@ static int ensure_capacity(gev_ctx* c, int pop, size_t people)
     PopState& P = c->pop[pop];
     if (people <= P.cap_people) return GEV_OK;
     const size_t rows = 2 * people;
+    // (row, position range) pairs of the list pieces are 32-bit work items (gev_lists.h): 2^27 haplotype rows per population
+    if (rows * LP_MAXSEG > 0xffffffffull) return fail(GEV_EINVAL, "population %d: %zu individuals are more than this library holds (%llu)", pop, people, 0xffffffffull / LP_MAXSEG / 2);
     // Growth copies the CURRENT buffers (keep = true) on `stream`; the stitch that produces the current planes may still be
     // running on stream_big (gev_reproduce does not wait for it), so order the copies behind it -- otherwise the new buffer
     // would receive a half-written generation.
