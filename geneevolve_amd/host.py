@@ -438,6 +438,43 @@ def comm_var(x):
     return s2 / (len(xs) - 1)
 
 
+def ras_combined_variance(phens, gamma, a):
+    """Simulation::ras_combined_variance (reference src/Simulation.cpp:3254-3282): s2y - (1 + gamma) * s2x over the phenotype
+    values of ALL populations in population order, y = x + a * (2*ipop/(n_pop-1) - 1) -- the factor is an INTEGER expression
+    there (-1, 0 or 1; two populations: -1 and +1)"""
+    n_pop = len(phens)
+    x, y = [], []
+    for ipop, ph in enumerate(phens):
+        bi = a * float((2 * ipop) // (n_pop - 1) - 1)
+        v = np.asarray(ph, dtype=np.float64)
+        x.append(v); y.append(v + bi)
+    return comm_var(np.concatenate(y)) - (1 + gamma) * comm_var(np.concatenate(x))
+
+
+def environmental_effects_specific_to_each_population(phens, gamma, x0=10.0, precision=1e-4):
+    """Simulation::sim_environmental_effects_specific_to_each_population (:3345-3382) for one phenotype: solves
+    ras_combined_variance(a) = 0 by Simulation::NewtonRaphson (:44-63; derivative by central differences, dx = 0.001, :32-36;
+    stops on |f(x1)| < precision) and adds a * (2*ipop/(n_pop-1) - 1) to every phenotype value of population ipop (:3285-3297).
+    phens: one array per population, changed in place; returns a (0.0 and nothing changed when gamma == 0)."""
+    if gamma == 0:
+        return 0.0
+    f = lambda a: ras_combined_variance(phens, gamma, a)
+    dx = 0.001
+    x = x0
+    for _ in range(1000):                                       # (the reference recurses without a bound)
+        fx0 = f(x)
+        x1 = x - fx0 / ((f(x + dx) - f(x - dx)) / (2 * dx))
+        x = x1
+        if abs(f(x1)) < precision:
+            break
+    else:
+        raise RuntimeError("environmental effects: Newton-Raphson did not converge")
+    n_pop = len(phens)
+    for ipop in range(n_pop):
+        phens[ipop] += x * float((2 * ipop) // (n_pop - 1) - 1)
+    return x
+
+
 def selection_func(kind, p1, p2, z):
     """Simulation::ras_selection_func (reference src/Simulation.cpp:3386-3428) for generations >= 1 (generation 0: 1 for all);
     logit and thr; z = selection value standardised to generation 0 (ras_compute_mating_value_selection_value, :3300-3342)"""

@@ -562,9 +562,31 @@ def extra_cases(which):
               own map file), assortative mating (mat_cor 0.4, Poisson family sizes), mutation map, migration
       vcf1    VCF reference panels, two populations with migration and mutation: .vcf, .hap, .ped/.map and .int files of the
               VCF-panel run (GeneEvolve_ref_vcf)
+      gam2    --gamma: environmental effects specific to each population, two populations with migration and logit selection
       vt2     --vt_type 2: the parental effect of a child is beta * (the parents' PARENTAL EFFECTS, not their phenotypes)
               (src/Simulation.cpp:3128-3131), beta adjusted on var(F) after generation 0 (:653-657); two phenotypes (vf > 0 and
               vf = 0), random mating with a logit selection function, mutation map"""
+    if "gam2" in which:
+        # mig2's shape with --gamma: environmental effects specific to each population (src/Simulation.cpp:3345-3382: Newton-Raphson
+        # on the combined variance of all populations' phenotype values, then -a / +a added per population), logit selection so that
+        # the shifted phenotypes decide who marries
+        rs = np.random.RandomState(808)
+        R = 201
+        rbp = (1000 + 100 * np.arange(R)).astype(np.uint64)
+        rcM = np.cumsum(np.r_[0.0, np.full(R - 1, 0.5)])
+        snp = np.arange(950, 21100, 17).astype(np.uint64)
+        cvbp = np.sort(rs.choice(np.arange(1000, 21000), size=60, replace=False)).astype(np.uint64)
+        c = Case("gam2")
+        for ip in range(2):
+            f2 = (rs.rand(160, len(snp)) < rs.uniform(0.05, 0.5, len(snp))).astype(np.uint8)
+            ph = {"bp": [cvbp], "a": [rs.randn(60)], "d": [rs.randn(60) * 0.2], "val": [(rs.rand(160, 60) < 0.4).astype(np.uint8)], "va": 0.5, "ve": 0.5}
+            c.add_pop(chrs=[1], founders=[f2], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph], RM=True,
+                      mut_bp=[rbp], mut_rate=[np.full(R, 0.01)], popinfo=["100 0 p logit 1 1", "110 0 p logit 0.5 1", "100 0 p thr 1 1", "105 0 p logit 1 1"])
+        with open(os.path.join(WORK, "mig_gam2.txt"), "w") as f:
+            for g in range(4):
+                f.write("0.9 0.1 0.15 0.85\n")
+        c.args_extra = ["--file_migration", os.path.join(WORK, "mig_gam2.txt"), "--gamma", "0.35"]
+        run_case(c, 6021, dense_gens={4})
     if "mig3c" in which:
         rs = np.random.RandomState(555)
         R = 151

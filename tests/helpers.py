@@ -436,9 +436,11 @@ def closed_loop_migration_case(lib, fx, label, device=-1, exact=True, mate="host
     ras_do_migration -- WHO moves is restated on the host (selection sampling on the reference's process-wide static engine),
     the rows move inside the library -- all from --seed alone; post-migration populations and the .info files of both
     populations are compared with the reference's."""
-    from geneevolve_amd.host import SampleWithoutReplacement, Simulation, ras_do_migration, ras_save_human_info
+    from geneevolve_amd.host import SampleWithoutReplacement, Simulation, ras_do_migration, ras_save_human_info, environmental_effects_specific_to_each_population
     n_pop, nchr, nphen, ngen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"]), int(fx["n_gen"])
     assert nphen == 1 and all(int(fx[f"pop{ip}_rm"]) == 1 for ip in range(n_pop))
+    extra = [str(x) for x in fx["args_extra"]]
+    gamma = float(extra[extra.index("--gamma") + 1]) if "--gamma" in extra else 0.0      # environmental effects specific to each population (:3345)
     ctx = lib.create(n_pop, nchr, nphen, device) if lib.has_device_arg else lib.create(n_pop, nchr, nphen)
     setup_static(ctx, fx)
     sim = Simulation(ctx, int(fx["seed"]), nchr, bool(int(fx["pop0_has_mut"])), track_pedigree=True)
@@ -486,6 +488,7 @@ def closed_loop_migration_case(lib, fx, label, device=-1, exact=True, mate="host
         add, dom, _, _ = ctx.compute_ad(ip)
         s2[ip] = (comm_var(add[:, 0]), comm_var(dom[:, 0]))
         rec[ip]["o"] = scale(ip, 0)
+    environmental_effects_specific_to_each_population([rec[ip]["o"]["phen"] for ip in range(n_pop)], gamma)   # (:578)
     for ip in range(n_pop):
         values(ip, 0, rec[ip]["o"])
     for ip in range(n_pop):
@@ -510,6 +513,7 @@ def closed_loop_migration_case(lib, fx, label, device=-1, exact=True, mate="host
             add, dom, _, _ = ctx.compute_ad(ip)
             assert bits_equal(add, fx[f"g{g}_pop{ip}_additive"]) and bits_equal(dom, fx[f"g{g}_pop{ip}_dominance"]), f"{label}: raw A/D gen {g} pop {ip}"
             rec[ip]["o"] = scale(ip, g)
+        environmental_effects_specific_to_each_population([rec[ip]["o"]["phen"] for ip in range(n_pop)], gamma)   # (:1976)
         for ip in range(n_pop):
             values(ip, g, rec[ip]["o"], funcs[ip])
         # ---- ras_do_migration(gen_num - 1)

@@ -18,7 +18,7 @@ from tests import helpers
 from tests.cli_inputs import write_inputs_from_fixture
 
 REFDIR = os.path.join(os.path.dirname(helpers.GOLDEN), "..", "oracle", "_ref")
-CASES = ["dense", "am1", "am2", "mig2", "ex1mut", "ex1sub", "sel1", "vc1", "ex1full", "vt2"]
+CASES = ["dense", "am1", "am2", "mig2", "ex1mut", "ex1sub", "sel1", "vc1", "ex1full", "vt2", "gam2"]
 
 
 def run_cli(exe, case, tmp_path):

@@ -83,7 +83,7 @@ def test_synth_founders_match_specification(gpu_lib):
     ctx.close()
 
 
-@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini", "vt2", "vcf1"])
+@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini", "vt2", "vcf1", "gam2"])
 def test_gpu_replays_reference_generations_bit_exact(gpu_lib, oracle_lib, case):
     fx = helpers.load_fixture(case)
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
@@ -1282,8 +1282,9 @@ def test_info_files_with_device_phenotype_scaling(gpu_lib, oracle_lib):
     assert differing <= total * 1e-3
 
 
-def test_closed_loop_two_populations_with_migration_on_gpu(gpu_lib):
-    helpers.closed_loop_migration_case(gpu_lib, helpers.load_fixture("mig2"), "gpu/mig2", device=0, exact=False)
+@pytest.mark.parametrize("case", ["mig2", "gam2"])
+def test_closed_loop_two_populations_with_migration_on_gpu(gpu_lib, case):
+    helpers.closed_loop_migration_case(gpu_lib, helpers.load_fixture(case), f"gpu/{case}", device=0, exact=False)
 
 
 def test_nan_effect_sizes_are_reported_like_the_reference(gpu_lib):
@@ -1370,8 +1371,9 @@ def test_closed_loop_from_the_seed_alone_with_device_random_mate(gpu_lib, case, 
 
 
 @pytest.mark.parametrize("mate", ["device", "fused"])
-def test_closed_loop_two_populations_with_migration_and_device_random_mate(gpu_lib, mate):
-    helpers.closed_loop_migration_case(gpu_lib, helpers.load_fixture("mig2"), f"gpu/mig2/{mate}", device=0, exact=False, mate=mate)
+@pytest.mark.parametrize("case", ["mig2", "gam2"])
+def test_closed_loop_two_populations_with_migration_and_device_random_mate(gpu_lib, case, mate):
+    helpers.closed_loop_migration_case(gpu_lib, helpers.load_fixture(case), f"gpu/{case}/{mate}", device=0, exact=False, mate=mate)
 
 
 def _pair(gpu_lib, oracle_lib, cfg, n0, seed_f=70):

@@ -111,7 +111,7 @@ def test_recombine_direct_calls(oracle_lib):
         assert list(om) == wm, f"trial {k}: mutation_pos"
 
 
-@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini", "vt2", "vcf1"])
+@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini", "vt2", "vcf1", "gam2"])
 def test_oracle_replays_reference_generations(oracle_lib, case):
     fx = helpers.load_fixture(case)
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
@@ -148,10 +148,13 @@ def test_closed_loop_from_the_seed_alone(oracle_lib, case):
     helpers.closed_loop_case(oracle_lib, helpers.load_fixture(case), f"oracle/{case}")
 
 
-def test_closed_loop_two_populations_with_migration(oracle_lib):
+@pytest.mark.parametrize("case", ["mig2", "gam2"])
+def test_closed_loop_two_populations_with_migration(oracle_lib, case):
     """BASELINE config 3's shape end to end from the seed alone: two populations, random mating, mutation, migration decided by
-    the host restatement of ras_do_migration (selection sampling on the process-wide static engine), rows moved by the library"""
-    helpers.closed_loop_migration_case(oracle_lib, helpers.load_fixture("mig2"), "oracle/mig2")
+    the host restatement of ras_do_migration (selection sampling on the process-wide static engine), rows moved by the library.
+    gam2: with --gamma, the environmental effects specific to each population (src/Simulation.cpp:3345-3382: Newton-Raphson on the
+    combined variance) shift the phenotypes that the logit selection function and the .info files see"""
+    helpers.closed_loop_migration_case(oracle_lib, helpers.load_fixture(case), f"oracle/{case}")
 
 
 @pytest.mark.parametrize("mate", ["device", "fused"])
@@ -163,8 +166,9 @@ def test_closed_loop_with_the_library_side_random_mate(oracle_lib, case, mate):
 
 
 @pytest.mark.parametrize("mate", ["device", "fused"])
-def test_closed_loop_two_populations_with_migration_and_library_side_random_mate(oracle_lib, mate):
-    helpers.closed_loop_migration_case(oracle_lib, helpers.load_fixture("mig2"), f"oracle/mig2/{mate}", mate=mate)
+@pytest.mark.parametrize("case", ["mig2", "gam2"])
+def test_closed_loop_two_populations_with_migration_and_library_side_random_mate(oracle_lib, case, mate):
+    helpers.closed_loop_migration_case(oracle_lib, helpers.load_fixture(case), f"oracle/{case}/{mate}", mate=mate)
 
 
 def test_oracle_glob_seeds_equal_the_host_stream(oracle_lib):
