@@ -114,6 +114,10 @@ def write_inputs_from_fixture(fx, wd, prefix="out", vcf_panel=False):
                 a += [f"--{key}", repr(float(fx[f"{pre}ph{iph}_var"][j]))]
         for iph in range(nphen):
             a += ["--vc", repr(float(fx[f"{pre}ph{iph}_vc"]))]
+        for key in ("omega", "lambda"):
+            if f"{pre}ph0_{key}" in fx:
+                for iph in range(nphen):
+                    a += [f"--{key}", repr(float(fx[f"{pre}ph{iph}_{key}"]))]
         if ip > 0:
             args.append("--next_population")
         args += a
@@ -125,4 +129,9 @@ def write_inputs_from_fixture(fx, wd, prefix="out", vcf_panel=False):
                 f.write(" ".join(repr(float(v)) for v in row) + "\n")
         extra[extra.index("--file_migration") + 1] = mp
     args += ["--seed", str(int(fx["seed"])), "--prefix", os.path.join(wd, prefix)] + extra
+    if "output_generations" in fx:
+        og = os.path.join(wd, "outgens.txt")
+        with open(og, "w") as f:
+            f.write("".join(f"{int(g)}\n" for g in fx["output_generations"]))
+        args += ["--file_output_generations", og]
     return args

@@ -306,7 +306,8 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             arrs[f"{pre}ph{iph}_vd"] = np.float64(ph.get("vd", -1.0))
             arrs[f"{pre}ph{iph}_var"] = np.array([ph.get(k, dflt) for k, dflt in (("va", -1.0), ("vd", -1.0), ("ve", 1.0), ("vf", 0.0))])   # CLI defaults: parameters.cpp
             arrs[f"{pre}ph{iph}_vc"] = np.float64(ph.get("vc", 0.0))
-        for key in ("va", "vd", "ve", "vf", "vc"):
+            arrs[f"{pre}ph{iph}_omega"] = np.float64(ph.get("omega", 1.0)); arrs[f"{pre}ph{iph}_lambda"] = np.float64(ph.get("lambda", 1.0))   # coefficients of the mating / selection value (:3311-3320)
+        for key in ("va", "vd", "ve", "vf", "vc", "omega", "lambda"):
             for ph in P["phens"]:
                 if key in ph:
                     a += [f"--{key}", repr(float(ph[key]))]
@@ -314,6 +315,12 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             args.append("--next_population")
         args += a
     args += ["--seed", str(seed), "--prefix", os.path.join(wd, "out")] + case.args_extra
+    out_gens = getattr(case, "output_generations", None)           # --file_output_generations: genotype output at these generations only (:2059, :137)
+    if out_gens:
+        with open(os.path.join(wd, "outgens.txt"), "w") as f:
+            f.write("".join(f"{g}\n" for g in out_gens))
+        args += ["--file_output_generations", os.path.join(wd, "outgens.txt")]
+        arrs["output_generations"] = np.array(out_gens, dtype=np.int64)
     arrs["args_extra"] = np.array(case.args_extra if case.args_extra else [""])
     if "--file_migration" in case.args_extra:                      # one row per generation, n_pop^2 row-major entries (:839-896)
         arrs["migration_mat_gen"] = np.loadtxt(case.args_extra[case.args_extra.index("--file_migration") + 1], ndmin=2)
@@ -351,6 +358,11 @@ def run_case(case, seed, dense_gens, out_name=None, hash_only_dense=False, keep_
             arrs[f"cvvalfile_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)   # (:2665-2683; every phenotype writes the same file name: the last one stays)
             raw = open(os.path.join(wd2, f"out.pop{ip+1}.gen{ngen}.chr{c}.int"), "rb").read()      # --out_interval (:1582-1633)
             arrs[f"intfile_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
+            for g in (out_gens or []):               # genotype files written in the middle of the run
+                if g != ngen:
+                    for ext in ("hap", "int"):
+                        raw = open(os.path.join(wd2, f"out.pop{ip+1}.gen{g}.chr{c}.{ext}"), "rb").read()
+                        arrs[f"{ext}file_g{g}_pop{ip}_chr{ic}_sha"] = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
     # the reference's PLINK text of the last generation (format_plink::write_ped_map / write_ped01_map, src/format_plink.cpp):
     # both flags write the same <prefix>.ped, so one CLI run each.  Stored: hash of the whole file, hash of the genotype
     # columns alone (each line after its six id columns = what gev_format_ped_text produces) and the id columns.
@@ -562,10 +574,31 @@ def extra_cases(which):
               own map file), assortative mating (mat_cor 0.4, Poisson family sizes), mutation map, migration
       vcf1    VCF reference panels, two populations with migration and mutation: .vcf, .hap, .ped/.map and .int files of the
               VCF-panel run (GeneEvolve_ref_vcf)
+      om1     --omega / --lambda on two phenotypes under assortative mating, --file_output_generations (genotype files of generation 2
+              and of the last one)
       gam2    --gamma: environmental effects specific to each population, two populations with migration and logit selection
       vt2     --vt_type 2: the parental effect of a child is beta * (the parents' PARENTAL EFFECTS, not their phenotypes)
               (src/Simulation.cpp:3128-3131), beta adjusted on var(F) after generation 0 (:653-657); two phenotypes (vf > 0 and
               vf = 0), random mating with a logit selection function, mutation map"""
+    if "om1" in which:
+        # --omega / --lambda (the coefficients of the phenotypes in the mating and the selection value, :3311-3320) on two phenotypes
+        # under assortative mating with a logit selection function, and --file_output_generations: genotype files written in the
+        # MIDDLE of the run (generation 2) as well as at its end
+        rs = np.random.RandomState(4242)
+        R = 101
+        rbp = (1000 + 1000 * np.arange(R)).astype(np.uint64)
+        rcM = np.cumsum(np.r_[0.0, np.full(R - 1, 1.0)])
+        snp = np.arange(1500, 100000, 400).astype(np.uint64)
+        nf = 240
+        founders = (rs.rand(nf, len(snp)) < 0.3).astype(np.uint8)
+        cvbp = np.sort(rs.choice(np.arange(1100, 100000, 50), size=80, replace=False)).astype(np.uint64)
+        ph_a = {"bp": [cvbp], "a": [rs.randn(80)], "d": [np.zeros(80)], "val": [(rs.rand(nf, 80) < 0.4).astype(np.uint8)], "va": 0.6, "ve": 0.4, "omega": 0.7, "lambda": 0.25}
+        ph_b = {"bp": [cvbp], "a": [rs.randn(80)], "d": [np.zeros(80)], "val": [(rs.rand(nf, 80) < 0.4).astype(np.uint8)], "va": 0.5, "ve": 0.5, "omega": -0.3, "lambda": 1.5}
+        c = Case("om1")
+        c.add_pop(chrs=[1], founders=[founders], snp_pos=[snp], rmap_bp=[rbp], rmap_cM=[rcM], phens=[ph_a, ph_b],
+                  mut_bp=[rbp], mut_rate=[np.full(R, 0.01)], popinfo=["130 0.4 p logit 1 1", "125 0.3 f logit 0.5 1", "128 0.5 p logit 1 1", "120 0.2 p thr 1 1"])
+        c.output_generations = [2, 4]
+        run_case(c, 90210, dense_gens={4})
     if "gam2" in which:
         # mig2's shape with --gamma: environmental effects specific to each population (src/Simulation.cpp:3345-3382: Newton-Raphson
         # on the combined variance of all populations' phenotype values, then -a / +a added per population), logit selection so that

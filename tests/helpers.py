@@ -353,8 +353,10 @@ def closed_loop_case(lib, fx, label, device=-1, exact=True, plane_less=False, at
 
     def values(outs):
         mv = np.zeros(len(sim.sex[0])); sv = np.zeros(len(sim.sex[0]))
-        for o in outs:                                                           # omega = lambda = 1 (:3311-3320)
-            mv = mv + 1.0 * o["phen"]; sv = sv + 1.0 * o["phen"]
+        for p, o in enumerate(outs):                                             # --omega / --lambda, default 1 (:3311-3320)
+            omega = float(fx[f"pop0_ph{p}_omega"]) if f"pop0_ph{p}_omega" in fx else 1.0
+            lam = float(fx[f"pop0_ph{p}_lambda"]) if f"pop0_ph{p}_lambda" in fx else 1.0
+            mv = mv + omega * o["phen"]; sv = sv + lam * o["phen"]
         return mv, sv
 
     def check_info_file(g, outs, mv, z, svf):

@@ -18,7 +18,7 @@ from tests import helpers
 from tests.cli_inputs import write_inputs_from_fixture
 
 REFDIR = os.path.join(os.path.dirname(helpers.GOLDEN), "..", "oracle", "_ref")
-CASES = ["dense", "am1", "am2", "mig2", "ex1mut", "ex1sub", "sel1", "vc1", "ex1full", "vt2", "gam2"]
+CASES = ["dense", "am1", "am2", "mig2", "ex1mut", "ex1sub", "sel1", "vc1", "ex1full", "vt2", "gam2", "om1"]
 
 
 def run_cli(exe, case, tmp_path):
@@ -38,6 +38,11 @@ def run_cli(exe, case, tmp_path):
             base = os.path.join(wd, f"out.pop{ip+1}.gen{ngen}.chr{int(fx[f'pop{ip}_chr{ic}_label'])}")
             assert same(base + ".int", f"intfile_pop{ip}_chr{ic}_sha"), f"{case}: .int (--out_interval) file differs (pop {ip+1} chr index {ic})"
             assert same(base + ".ped", f"pedfile_pop{ip}_chr{ic}_sha"), f"{case}: .ped (--out_plink) file differs (pop {ip+1} chr index {ic})"
+            for g in (fx["output_generations"] if "output_generations" in fx else []):      # --file_output_generations: files written in the middle of the run
+                if int(g) != ngen:
+                    mid = os.path.join(wd, f"out.pop{ip+1}.gen{int(g)}.chr{int(fx[f'pop{ip}_chr{ic}_label'])}")
+                    assert same(mid + ".hap", f"hapfile_g{int(g)}_pop{ip}_chr{ic}_sha"), f"{case}: .hap file of generation {int(g)} differs"
+                    assert same(mid + ".int", f"intfile_g{int(g)}_pop{ip}_chr{ic}_sha"), f"{case}: .int file of generation {int(g)} differs"
     if case in ("dense", "mig2"):               # both PLINK flags write <prefix>.ped: the 0/1 variant needs its own run
         wd01 = str(tmp_path / (case + "_01"))
         r = subprocess.run([exe] + write_inputs_from_fixture(fx, wd01) + ["--out_plink01"], capture_output=True, text=True, timeout=900)

@@ -83,7 +83,7 @@ def test_synth_founders_match_specification(gpu_lib):
     ctx.close()
 
 
-@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini", "vt2", "vcf1", "gam2"])
+@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini", "vt2", "vcf1", "gam2", "om1"])
 def test_gpu_replays_reference_generations_bit_exact(gpu_lib, oracle_lib, case):
     fx = helpers.load_fixture(case)
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
@@ -1211,7 +1211,7 @@ def test_pipelined_host_loop_through_list_growth_and_redo_paths(gpu_lib, oracle_
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1", "ex1full", "vt2"])
+@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1", "ex1full", "vt2", "om1"])
 def test_closed_loop_from_the_seed_alone_on_gpu(gpu_lib, case):
     """the same closed loop on the HIP library (A/D, intervals, genotypes, couples, sexes bit-exact; scaled phenotypes and what
     derives from them within 1e-9 relative: the device's parallel variance / log are not bit-identical to libm's)"""

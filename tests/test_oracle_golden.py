@@ -111,7 +111,7 @@ def test_recombine_direct_calls(oracle_lib):
         assert list(om) == wm, f"trial {k}: mutation_pos"
 
 
-@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini", "vt2", "vcf1", "gam2"])
+@pytest.mark.parametrize("case", ["ex1sub", "ex1mut", "dense", "mig2", "syn1k", "am1", "am2", "sel1", "vc1", "ex1full", "mig3c", "c4mini", "vt2", "vcf1", "gam2", "om1"])
 def test_oracle_replays_reference_generations(oracle_lib, case):
     fx = helpers.load_fixture(case)
     seeds = helpers.find_gen0_seeds(fx, oracle_lib)
@@ -141,7 +141,7 @@ def test_rank_matches_reference_vectors(oracle_lib):
     o.close()
 
 
-@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1", "ex1full", "vt2"])
+@pytest.mark.parametrize("case", ["am1", "am2", "ex1sub", "ex1mut", "dense", "syn1k", "sel1", "vc1", "ex1full", "vt2", "om1"])
 def test_closed_loop_from_the_seed_alone(oracle_lib, case):
     """the reference's whole generation loop (assortative mating, inbreeding avoidance, Poisson / fixed families, logit
     selection) re-driven from --seed by the host mirror on top of the C-ABI (oracle build): bit-identical at every step"""
