@@ -190,8 +190,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ind", type=int, default=20000)
     ap.add_argument("--cpu-sample-gens", type=int, default=4)
-    ap.add_argument("--ref-sample-ind", type=int, default=8000)
-    ap.add_argument("--ref-sample-gens", type=int, default=3)
+    ap.add_argument("--ref-sample-ind", type=int, default=30000, help="cpu_baseline: individuals of the reference's sample run (10-20 s of its reproduce + ras_compute_AD; its cost per individual grows with the size, so a larger sample is the fairer one)")
+    ap.add_argument("--ref-sample-gens", type=int, default=4)
     ap.add_argument("--no-intervals", action="store_true", help="do not keep the ancestry interval state on the device")
     ap.add_argument("--migration-rate", type=float, default=0.0,
                     help="N>1 only: fraction of each population that moves to EACH other population every generation "
