@@ -544,6 +544,51 @@ def test_three_hundred_generations_of_shared_rows_dense_state_equals_interval_st
     g.close()
 
 
+@pytest.mark.parametrize("head_start", ["0", "1"])
+def test_three_hundred_one_call_generations_dense_state_equals_interval_state(gpu_lib, monkeypatch, head_start):
+    """bench.py's loop -- gev_generation_begin / gev_generation_end with the head start across generations, the next generation
+    handed over before this one's A/D is read -- for 300 generations at a size where the streams overlap (20k individuals x 256k
+    SNPs), with list arenas small enough to be compacted many times on the way and a population size that changes now and then
+    (a head start made for another size is dropped).  Every word of the genotype rows must equal the materialised interval state
+    at generations 100, 200 and 300, the lists must tile the map, A/D must be finite and vary."""
+    monkeypatch.setenv("GEV_LIST_ARENA", "48"); monkeypatch.setenv("GEV_HEAD_START", head_start)
+    L = 262_144
+    cfg = SyntheticConfig(20_000, L, chrom_bp=100_000_000, n_cv=200, seed=72)
+    g = gpu_lib.create(1, 1, 1)
+    cfg.apply_static(g)
+    n = 20_000
+    g.synth_founders(0, 0, 2 * n, 9001); g.synth_cv_founders(0, 0, 0, 2 * n, 9002)
+    sim = Simulation(g, 777, 1, True)
+    sim.ras_initial_human_gen0(0, n)
+    g.set_generation_chain(0)
+    state = sim.glob.x
+    size = lambda gen: 20_000 if gen % 40 else 21_000 + 100 * (gen // 40)
+    gen, pending = 0, False
+    while gen < 300:
+        if not pending:
+            g.generation_begin(0, state, size(gen + 1))
+        r = g.generation_end(); pending = False; gen += 1
+        state = int(r["glob_state"])
+        verify = gen % 100 == 0
+        if gen < 300 and not verify:                               # the next generation is in flight while this one's A/D is read
+            g.generation_begin(0, state, size(gen + 1)); pending = True
+        ad = g.compute_ad(0, per_chr=False)
+        assert np.isfinite(ad[0]).all() and np.var(ad[0]) > 0, gen
+        if verify:                                                 # (not allowed while a generation is pending)
+            assert g.dbg_verify_planes(0, 0, 9001) == (0, 0), f"dense state != interval state after {gen} generations"
+    st = g.list_stats(0, 0)
+    assert st["compactions"] >= 3, st
+    parts, off = g.download_intervals(0, 0)
+    n = g.pop_size(0)
+    assert len(off) == 2 * n + 1 and off[-1] == len(parts)
+    pst = parts["st"].astype(np.int64); pen = parts["en"].astype(np.int64)
+    first = off[:-1].astype(np.int64); last = off[1:].astype(np.int64) - 1
+    assert (pst[first] == int(cfg.rmap_bp[0])).all() and (pen[last] == int(cfg.rmap_bp[-1])).all()
+    inner = np.ones(len(parts), dtype=bool); inner[last] = False
+    assert (pen[inner] == pst[1:][inner[:-1]]).all()
+    g.close()
+
+
 def test_population_growth_without_intermediate_sync(gpu_lib, oracle_lib):
     """The population grows every generation (capacity growth reallocates and copies the CURRENT planes) while the previous
     generation's dense stitch may still be running on the library's second stream: nothing between the generations waits
