@@ -1347,7 +1347,17 @@ static int enqueue_pool_free(gev_ctx* c, gev_ctx::Scratch& sc, int pop, size_t /
 }
 // units of the offspring rows (segments with a crossover boundary take a free unit and a work-list entry, the others name the
 // parental unit) + the stitch's work-list length and the segment totals of the status block
-static int enqueue_pool_assign(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, hipStream_t st)
+// publish: k_pool_publish (counters into the status block, length of the stitch's work list) right behind; otherwise the caller
+// launches it (enqueue_pool_publish) on a stream that is joined before the stitch starts and the status block leaves
+static int enqueue_pool_publish(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, hipStream_t st)
+{
+    if (!c->dense || !sc.n_chrwork) return GEV_OK;
+    SampleDev sd = make_sd(c, sc, n_people * (size_t)c->nchr);
+    hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(64), 0, st, sc.chrwork.as<ChrWork>(), sc.n_chrwork, sd.status);
+    KCHECK();
+    return GEV_OK;
+}
+static int enqueue_pool_assign(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people, hipStream_t st, bool publish)
 {
     if (!c->dense || !sc.n_chrwork) return GEV_OK;
     const size_t rows = 2 * n_people, T = n_people * (size_t)c->nchr;
@@ -1355,9 +1365,8 @@ static int enqueue_pool_assign(gev_ctx* c, gev_ctx::Scratch& sc, size_t n_people
     u32 lg = 0; while ((1u << lg) * POOL_INH < sc.nseg_max) lg++;    // threads per row of k_pool_inherit: 2^lg, rows per block: 256 >> lg
     hipLaunchKernelGGL(k_pool_inherit, dim3((unsigned)ceil_div(rows, (size_t)(256u >> lg)), sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, c->nchr, sd, lg);
     hipLaunchKernelGGL(k_pool_fresh, dim3((unsigned)ceil_div(rows, 256), sc.n_chrwork), dim3(256), 0, st, sc.chrwork.as<ChrWork>(), rows, c->nchr, sd);
-    hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(64), 0, st, sc.chrwork.as<ChrWork>(), sc.n_chrwork, sd.status);
     KCHECK();
-    return GEV_OK;
+    return publish ? enqueue_pool_publish(c, sc, n_people, st) : GEV_OK;
 }
 // sparse state: mutation lists + ancestry intervals (count -> segmented scan -> fill).  Needs the sampling results and the couples;
 // nothing of the generation's dense / CV / A-D work reads its output.
@@ -1540,6 +1549,14 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
         // glob_generator's draws in the reference's order: random_mate (:2092), reproduce (:2398), then one per (offspring, chromosome) inside ras_add_mutation (:2500)
         GEVC(enqueue_glob(c, S, q.glob_state, nullptr, 2 + (q.has_mut ? T : 0), gv, status + ST_GLOB_STATE, status + ST_FLAGS));
     }
+    // (the mating stream starts here: it needs the seeds, not the state behind them)
+    if (X != S) { HIPC(hipEventRecord(sc.ev_fork, S)); HIPC(hipStreamWaitEvent(X, sc.ev_fork, 0)); }
+    // overlap mode 2: only the ALU-bound sampling shares the GPU with the previous generation's stitch; everything latency-bound waits for it
+    if (c->sparse_after_stitch && c->planes_pending) HIPC(hipStreamWaitEvent(X, c->ev_planes, 0));
+    if (q.fused) {
+        GEVC(enqueue_mate(c, X, P, 0u, gv, q.has_svf ? c->d_svf.as<double>() : nullptr, q.n_people, sc.father.as<u32>(), sc.mother.as<u32>(),
+                          c->d_couples.as<gev_couple>(), status + ST_NM_MATE, status + ST_FLAGS));
+    }
     if (q.fused && c->chain_draws >= 0) {                    // where glob_generator will stand when the host comes back for the next generation
         hipLaunchKernelGGL(k_glob_skip, dim3(1), dim3(64), 0, S, (const u32*)(status + ST_GLOB_STATE), (u32)c->chain_draws, status + ST_NEXT_STATE);
         KCHECK();
@@ -1547,14 +1564,6 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
         // the NEXT generation's seeds and sampling go to their stream right away: they take most of a generation's time next to this
         // generation's chain, and the next generation's unit table cannot start before they are through
         if (attempt == 0 && c->head_start == 1) GEVC(enqueue_chain_head_start(c));
-    }
-    if (X != S) { HIPC(hipEventRecord(sc.ev_fork, S)); HIPC(hipStreamWaitEvent(X, sc.ev_fork, 0)); }
-    // overlap mode 2: only the ALU-bound sampling shares the GPU with the previous generation's stitch; everything latency-bound waits for it
-    if (c->sparse_after_stitch && c->planes_pending) HIPC(hipStreamWaitEvent(X, c->ev_planes, 0));
-    if (q.fused) {
-        GEVC(enqueue_mate(c, X, P, 0u, gv, q.has_svf ? c->d_svf.as<double>() : nullptr, q.n_people, sc.father.as<u32>(), sc.mother.as<u32>(),
-                          c->d_couples.as<gev_couple>(), status + ST_NM_MATE, status + ST_FLAGS));
-        HIPC(hipMemcpyAsync(q.hseeds2, gv, 2 * sizeof(u32), hipMemcpyDeviceToHost, X));
     }
     GEVC(enqueue_tables(c, sc, q.pop, q.n_people, S));        // (uploaded on S while X mates)
     if (X != S) { HIPC(hipEventRecord(sc.ev_tab, S)); HIPC(hipStreamWaitEvent(X, sc.ev_tab, 0)); }
@@ -1567,7 +1576,10 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     if (X != S) HIPC(hipStreamWaitEvent(S, sc.ev_aux, 0));
     if (sampled && q.fused && c->head_start == 1) HIPC(hipStreamWaitEvent(S, sc.ev_sampled, 0));   // crossovers and new mutations of this generation (head start)
     HIPC(hipEventRecord(sc.t[5], S));
-    GEVC(enqueue_pool_assign(c, sc, q.n_people, S));
+    // (the counters of the unit table concern the stitch and the host only: with the stitch behind the small work they are
+    // published from the list stream, one launch less on the chain the host waits for)
+    const bool publish_aside = c->stitch_start >= 2 && L != S;
+    GEVC(enqueue_pool_assign(c, sc, q.n_people, S, !publish_aside));
     // The dense stitch needs the sampling results, the couples and the unit table only.  It saturates HBM, and every latency-bound
     // kernel that runs next to it takes 2-5 times as long (and slows it down in turn): where it starts is a trade (stitch_start,
     // measured at config 2: behind the CV planes 711, behind the unit table 691, behind A/D 617 generations/s); whatever the
@@ -1588,9 +1600,10 @@ static int enqueue_attempt(gev_ctx* c, int attempt)
     if (ad_now) GEVC(enqueue_ad(c, q.pop, c->pop[q.pop].cur ^ 1, q.n_people, count_cols, (int)(c->gen_counter & 1)));   // Simulation::ras_compute_AD always follows (src/Simulation.cpp:1935)
     if (g_trace_host) HIPC(hipEventRecord(sc.tc[1], S));
     if (L != S) HIPC(hipStreamWaitEvent(L, sc.ev_forked, 0));
+    if (publish_aside) GEVC(enqueue_pool_publish(c, sc, q.n_people, L));
     // Human::sex of the new generation (:2472) for the next gev_random_mate; a fused generation also sends them to the host with the status block
     HIPC(hipMemcpyAsync(P.d_sex[P.cur ^ 1].p, sc.sex.p, q.n_people, hipMemcpyDeviceToDevice, L));
-    if (q.fused) HIPC(hipMemcpyAsync(q.hsex, sc.sex.p, q.n_people, hipMemcpyDeviceToHost, L));
+    if (q.fused) { HIPC(hipMemcpyAsync(q.hsex, sc.sex.p, q.n_people, hipMemcpyDeviceToHost, L)); HIPC(hipMemcpyAsync(q.hseeds2, gv, 2 * sizeof(u32), hipMemcpyDeviceToHost, L)); }   // (copies nothing on the device waits for: off the main stream)
     GEVC(enqueue_lists(c, sc, q.n_people, q.has_mut, L));
     if (L != S) HIPC(hipEventRecord(sc.ev_lists, L));
     if (L != S) HIPC(hipStreamWaitEvent(S, sc.ev_lists, 0));
