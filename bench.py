@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--ref-sample-ind", type=int, default=30000, help="cpu_baseline: individuals of the reference's sample run (10-20 s of its reproduce + ras_compute_AD; its cost per individual grows with the size, so a larger sample is the fairer one)")
     ap.add_argument("--ref-sample-gens", type=int, default=4)
     ap.add_argument("--no-intervals", action="store_true", help="do not keep the ancestry interval state on the device")
+    ap.add_argument("--migrant-rows", action="store_true",
+                    help="with --migration-rate: the migrants' genotype rows travel in the records (250 KB per migrant at config 2); default: they travel as "
+                         "lists and the importing GPU rebuilds the rows from the founder panels of all populations (gev_set_migrant_rows 0)")
     ap.add_argument("--migration-rate", type=float, default=0.0,
                     help="N>1 only: fraction of each population that moves to EACH other population every generation "
                          "(BASELINE config 3 uses 0.01); rows travel by all_to_all over RCCL")
@@ -250,6 +253,13 @@ def main():
         if not args.plane_less:
             ctx.synth_founders(P, c, 2 * args.n_ind, 1000 + 100 * c + rank)
         ctx.synth_cv_founders(P, 0, c, 2 * args.n_ind, 2000 + 100 * c + rank)
+    migrant_lists = migrate and not args.migrant_rows and not args.plane_less and not args.no_intervals
+    if migrant_lists:
+        # every GPU keeps a read-only copy of every population's founder panel (what the reference holds as Population::hap_snps)
+        for p in range(n_pop_ctx):
+            for c in range(args.nchr):
+                ctx.synth_founder_panel(p, c, 2 * args.n_ind, 1000 + 100 * c + p)
+        ctx.set_migrant_rows(False)
     sim = Simulation(ctx, 12345 + rank, args.nchr, True)
     sim.ras_initial_human_gen0(P, args.n_ind)
     if args.mating == "device" and not args.no_chain:
@@ -511,6 +521,7 @@ def main():
                        if (args.n_ind, args.n_loci, args.nchr, args.map_step) == (100_000, 1_000_000, 1, 50_000) else
                        f"config-2 family, non-default size: {args.n_ind} individuals x {args.nchr} chromosome(s) x {args.n_loci} SNPs, map rows every {args.map_step} bp",
                        "n_individuals": args.n_ind, "n_loci": args.n_loci, "n_chromosomes": args.nchr, "n_cv": args.n_cv, "parallelism": f"{world} population(s), 1 per GPU", "migration_rate": args.migration_rate if migrate else 0.0,
+                       "migrants_travel_as": ("lists (rows rebuilt from founder panels)" if migrant_lists else "whole genotype rows") if migrate else None,
                        "interval_state_tracked": not args.no_intervals, "resident_genotype_planes": not args.plane_less,
                        "mating": "reference Simulation::random_mate on the device (gev_generation_begin: random_mate -> reproduce -> ras_compute_AD per step, in the reference's order)" if fused
                                  else "host, numpy stand-in for random_mate (round 2's loop)",

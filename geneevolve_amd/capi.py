@@ -54,6 +54,7 @@ ABI_SYMBOLS = [
     "import_rows", "download_haps", "download_snp_major", "format_hap_text", "format_bed", "format_vcf_gt", "rank_f64", "download_plink_matrix", "format_ped_text", "download_cv", "download_intervals", "download_mutations",
     "pop_size", "plane_ptr", "reserve", "set_chr_active", "set_dense_state", "materialize", "materialize_pops", "materialize_bed", "stream", "last_reproduce_ms", "set_track_intervals", "set_stitch_mode", "sync", "timing_totals", "stitch_totals", "reproduce_begin", "reproduce_end", "presample_sex", "set_overlap",
     "random_mate", "glob_seeds", "generation_begin", "generation_end", "set_generation_chain", "redo_count", "list_stats", "compute_ad_device", "ad_finish_device",
+    "upload_founder_panel", "synth_founder_panel", "set_migrant_rows",
     "dbg_verify_planes", "dbg_prefilter_sweep", "dbg_tables", "dbg_threshold", "dbg_canonical", "dbg_rand", "dbg_sim_loc_rec",
 ]
 
@@ -184,6 +185,18 @@ class GevContext:
 
     def synth_founders(self, pop, chr, nhap, seed):
         self._call("synth_founders", C.c_int(pop), C.c_int(chr), C.c_size_t(nhap), C.c_uint64(seed))
+
+    def upload_founder_panel(self, pop, chr, words, L):
+        words = _arr(words, np.uint64)
+        self._call("upload_founder_panel", C.c_int(pop), C.c_int(chr), _p(words), C.c_size_t(words.shape[1]), C.c_size_t(words.shape[0]), C.c_size_t(L))
+
+    def synth_founder_panel(self, pop, chr, nhap, seed):
+        """read-only founder panel of ROOT population `pop` (immigrants' rows are rebuilt from it, set_migrant_rows(False))"""
+        self._call("synth_founder_panel", C.c_int(pop), C.c_int(chr), C.c_size_t(nhap), C.c_uint64(seed))
+
+    def set_migrant_rows(self, on):
+        """False: export_rows packs no genotype rows, import_rows rebuilds them from the founder panels"""
+        self._call("set_migrant_rows", C.c_int(1 if on else 0))
 
     def synth_cv_founders(self, pop, phen, chr, nhap, seed):
         self._call("synth_cv_founders", C.c_int(pop), C.c_int(phen), C.c_int(chr), C.c_size_t(nhap), C.c_uint64(seed))

@@ -1512,6 +1512,49 @@ __global__ void __launch_bounds__(256) k_copy_rows16(RowRef dst, RowRef src, con
     const size_t l = map ? (size_t)map[r] : base + r;
     *dst.chunk(r, q) = *src.chunk(l, q);
 }
+// Migrants that travel as lists (gev_set_migrant_rows(ctx, 0)): the genotype row of an immigrant is rebuilt where it arrives from
+// its ancestry intervals and the founder panels kept there (gev_upload_founder_panel / gev_synth_founder_panel, one per ROOT
+// population) -- Simulation::ras_convert_interval_to_hap_matrix's rule (src/Simulation.cpp:1198-1211) for the rows of the
+// resident plane, which holds the founder mosaic without the mutation overlay (the mutation list travels and stays sparse).
+// One thread per 16-byte chunk of a row; the parts of a row are disjoint and ascending (bisection on `en`, as k_materialize_tile).
+struct PanelRef { const u32* base; u64 w32; u64 rows; };        // flat rows of w32 words; rows == 0: no panel of this root population here
+__global__ void __launch_bounds__(256) k_rebuild_rows(const u32* __restrict__ p_off /* [n_rows + 1], into `parts` */, const gev_part* __restrict__ parts, size_t n_rows,
+                                                      const u64* __restrict__ pos, u32 L, const PanelRef* __restrict__ panels, int n_pop,
+                                                      RowRef dst, u32 chunks, u32* __restrict__ status /* |1: hap_index out of range, |2: no panel of a root population */)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rows * chunks) return;
+    const size_t r = e / chunks; const u32 q = (u32)(e % chunks);
+    const u32 words = (L + 31) / 32;
+    const u32 begin = p_off[r], end = p_off[r + 1];
+    u32 o[4] = {0u, 0u, 0u, 0u};
+    for (u32 t4 = 0; t4 < 4; t4++) {
+        const u32 w = 4 * q + t4;
+        if (w >= words) break;                                                                        // pad words of the row stay 0
+        const u32 nb = min(32u, L - 32u * w);
+        const u64* wp = pos + 32u * (size_t)w;
+        const u64 x0 = wp[0], x1 = wp[nb - 1];
+        u32 lo = begin, hi = end;
+        while (lo < hi) { const u32 m = (lo + hi) >> 1; if (parts[m].en <= x0) lo = m + 1; else hi = m; }    // first part with en > x0
+        u32 acc = 0;
+        for (u32 i = lo; i < end && parts[i].st <= x1; i++) {
+            const u64 st = parts[i].st, en = parts[i].en;
+            u32 a = 0, b = 0;
+            if (st > x0 || en <= x1) { for (u32 t = 0; t < nb; t++) { a += wp[t] < st ? 1u : 0u; b += wp[t] < en ? 1u : 0u; } }   // loci [a, b) lie in [st, en)
+            else b = nb;                                                                              // the part covers the whole word
+            if (b > a) {
+                const u32 mask = (b - a == 32u) ? 0xffffffffu : (((1u << (b - a)) - 1u) << a);
+                const u64 h = parts[i].hap_index;
+                const int rp = parts[i].root_population;
+                if (rp < 0 || rp >= n_pop || !panels[rp].rows) { atomicOr(status, 2u); continue; }
+                if (h >= panels[rp].rows) { atomicOr(status, 1u); continue; }                          // :1205-1209 "hap_index is not in range"
+                acc |= panels[rp].base[h * panels[rp].w32 + w] & mask;
+            }
+        }
+        o[t4] = acc;
+    }
+    *dst.chunk(r, q) = make_uint4(o[0], o[1], o[2], o[3]);
+}
 // dst[i] = src[map[i << shift] >> shift]: bytes of selected individuals (shift = 1: `map` holds haplotype rows 2*individual, 2*individual+1)
 __global__ void k_gather_u8(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, const u32* __restrict__ map, u32 shift, size_t n)
 {

@@ -139,6 +139,7 @@ struct ChrStatic {                       // one population x one chromosome
     u32 idx_lo = 0, idx_hi = 0;          // loci inside [bp0, bp_end)
     u32 r_amax = 0, m_amax = 0;
     size_t founder_rows = 0;
+    DevBuf panel; size_t panel_rows = 0; // read-only founder panel of this ROOT population, flat rows of `stride` bytes (gev_*_founder_panel): immigrants' rows are rebuilt from it
 };
 struct CvStatic {                        // one population x phenotype x chromosome
     std::vector<u64> bp; std::vector<double> a, d; double vd = 0; bool set = false;
@@ -229,6 +230,8 @@ struct gev_ctx {
     unsigned gen_counter = 0;
     std::vector<uint8_t> chr_active;        // 0: chromosome held by another context (gev_set_chr_active); sampling chain only
     bool any_inactive = false;
+    bool migrant_rows = true;               // false (gev_set_migrant_rows): gev_export_rows packs no genotype rows, gev_import_rows rebuilds them from the founder panels
+    DevBuf d_panels, d_poff;                // rebuild of immigrants' rows: PanelRef per root population, offsets of the rows' parts in the payload
     bool dense = true;                      // false: no resident genotype planes (gev_set_dense_state); lists + CV planes only, output by gev_materialize
     hipStream_t stream_big = nullptr;
     bool planes_pending = false;            // a stitch may still be writing the current planes (stream_big)
@@ -762,6 +765,62 @@ int gev_synth_founders(gev_ctx* c, int pop, int chr, size_t nhap, u64 seed)
     KCHECK();
     HIPC(hipStreamSynchronize(c->stream));
     S.founder_rows = nhap; P.gen0 = false;
+    return GEV_OK;
+}
+// Founder panels kept for good (read-only, flat rows of S.stride bytes), one per ROOT population x chromosome: what
+// Simulation::ras_convert_interval_to_hap_matrix reads as pops[root_population].hap_snps (src/Simulation.cpp:1204).  With them a
+// context can rebuild an immigrant's genotype row from its ancestry intervals, so the migration payload carries lists only
+// (gev_set_migrant_rows).  `pop` is the root population; it need not be a population this context simulates.
+static int panel_prepare(gev_ctx* c, int pop, int chr, size_t nhap, const char* who)
+{
+    if (c) GEVC(check_dense(c, who));
+    GEVC(check_idx(c, pop, chr));
+    ChrStatic& S = c->pop[pop].cs[chr];
+    if (nhap < 2 || (nhap & 1)) return fail(GEV_EINVAL, "%s: need an even number (>=2) of haplotype rows", who);
+    if (!S.L || !S.stride) return fail(GEV_ESTATE, "%s: set_snps first", who);
+    HIPC(hipSetDevice(c->device));
+    GEVC(gev_sync(c));
+    GEVC(S.panel.ensure(nhap * S.stride, c->stream));
+    HIPC(hipMemsetAsync(S.panel.p, 0, nhap * S.stride, c->stream));
+    return GEV_OK;
+}
+int gev_upload_founder_panel(gev_ctx* c, int pop, int chr, const u64* bits, size_t row_stride_words, size_t nhap, size_t L)
+{
+    GEVC(panel_prepare(c, pop, chr, nhap, "upload_founder_panel"));
+    ChrStatic& S = c->pop[pop].cs[chr];
+    if (!bits) return fail(GEV_EINVAL, "upload_founder_panel: null bits");
+    if (L != S.L) return fail(GEV_EINVAL, "upload_founder_panel: L=%zu but set_snps gave %zu loci", L, S.L);
+    if (row_stride_words * 64 < L) return fail(GEV_EINVAL, "upload_founder_panel: row stride too small");
+    HIPC(hipMemcpy2DAsync(S.panel.p, S.stride, bits, row_stride_words * 8, ceil_div(L, 8), nhap, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (L % 8) {   // pad bits of the last byte
+        hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)ceil_div(nhap * (S.stride / 4), 256)), dim3(256), 0, c->stream, S.panel.as<u32>(), S.stride / 4, nhap, 0u, (u32)L);
+        KCHECK();
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    S.panel_rows = nhap;
+    return GEV_OK;
+}
+int gev_synth_founder_panel(gev_ctx* c, int pop, int chr, size_t nhap, u64 seed)
+{
+    GEVC(panel_prepare(c, pop, chr, nhap, "synth_founder_panel"));
+    ChrStatic& S = c->pop[pop].cs[chr];
+    GEVC(c->d_thr32.ensure(S.L * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(k_synth_thresholds, dim3((unsigned)ceil_div(S.L, 256)), dim3(256), 0, c->stream, c->d_thr32.as<u32>(), S.L, seed);
+    hipLaunchKernelGGL(k_synth_rows, dim3((unsigned)ceil_div(nhap * ceil_div(S.L, 64), 256)), dim3(256), 0, c->stream,
+                       S.panel.as<u64>(), S.stride / 8, nhap, S.L, c->d_thr32.as<u32>(), seed);      // the same generator as gev_synth_founders
+    KCHECK();
+    HIPC(hipStreamSynchronize(c->stream));
+    S.panel_rows = nhap;
+    return GEV_OK;
+}
+// 1 (default): gev_export_rows packs the migrants' genotype rows; 0: it packs none and gev_import_rows rebuilds them from the
+// founder panels.  Both ends of an exchange must use the same setting (the payload's size gives a mismatch away).
+int gev_set_migrant_rows(gev_ctx* c, int on)
+{
+    if (!c) return fail(GEV_EINVAL, "null context");
+    if (c->pend.active) return fail(GEV_ESTATE, "a gev_reproduce_begin is pending: call gev_reproduce_end first");
+    c->migrant_rows = on != 0;
     return GEV_OK;
 }
 // CV founders arrive in FILE column order; the plane keeps columns sorted by position
@@ -2564,7 +2623,7 @@ static PackLayout pack_layout(gev_ctx* c, PopState& P, size_t n, const std::vect
     // chromosomes this context does not hold (locus-split population) take no space: both ends of an exchange hold the same set
     L.counts = off; off = al16(off + n * nchr * 4 * sizeof(u32));
     L.sex = off; off = al16(off + n);
-    L.planes = off; for (int k = 0; k < nchr; k++) if (c->chr_active[k] && c->dense) off = al16(off + 2 * n * P.cs[k].stride);
+    L.planes = off; for (int k = 0; k < nchr; k++) if (c->chr_active[k] && c->dense && c->migrant_rows) off = al16(off + 2 * n * P.cs[k].stride);
     L.cv = off; for (int p = 0; p < c->nphen; p++) for (int k = 0; k < nchr; k++) if (c->chr_active[k]) off = al16(off + 2 * n * P.cv[p][k].stride_w32 * sizeof(u32));
     L.mut_chr.assign(nchr, 0); L.parts_chr.assign(nchr, 0);
     for (size_t i = 0; i < n; i++) for (int k = 0; k < nchr; k++) for (int h = 0; h < 2; h++) {
@@ -2657,7 +2716,7 @@ int gev_export_rows(gev_ctx* c, int pop, const uint64_t* positions, size_t n, vo
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         const u32 chunks = (u32)(S.stride / 16);
-        if (c->dense) {
+        if (c->dense && c->migrant_rows) {
             hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, flat_rows(out + po, S.stride),
                                pool_rows(P, k, cs.phys[P.pcur].as<u32>()), c->d_map.as<u32>(), (size_t)0, 2 * n, chunks);
             po = al16(po + 2 * n * S.stride);
@@ -2736,6 +2795,9 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
     HIPC(hipStreamSynchronize(st));
     const PackLayout L = pack_layout(c, P, n, counts);
     if (bytes < L.total) return fail(GEV_EINVAL, "import_rows: buffer of %zu bytes, %zu expected from its header", bytes, L.total);
+    const bool rebuild = c->dense && !c->migrant_rows;
+    if (rebuild && !c->track_intervals) return fail(GEV_ESTATE, "import_rows: migrants without genotype rows need the interval state (gev_set_track_intervals)");
+    if (rebuild) { GEVC(c->d_flag.ensure(16, st)); HIPC(hipMemsetAsync(c->d_flag.p, 0, 4, st)); }
     const size_t n_old = P.n_phys, n_new = n_old + n, r_old = 2 * n_old;     // physical append behind every existing row
     if (n_new * 2 >= 0xffffffffull) return fail(GEV_EINVAL, "import_rows: too many rows");
     GEVC(ensure_capacity(c, pop, n_new));                              // keeps the current buffers' content
@@ -2751,10 +2813,27 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
             GEVC(pool_take(pw, r_old, 2 * n, st));
             cs.pool_list_valid = false;
             const u32 chunks = (u32)(S.stride / 16);
-            hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, pool_rows(P, k, pw.phys_alt + r_old * S.nseg),
-                               flat_rows((void*)(in + po), S.stride), (const u32*)nullptr, (size_t)0, 2 * n, chunks);
-            KCHECK();
-            po = al16(po + 2 * n * S.stride);
+            if (c->migrant_rows) {
+                hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, pool_rows(P, k, pw.phys_alt + r_old * S.nseg),
+                                   flat_rows((void*)(in + po), S.stride), (const u32*)nullptr, (size_t)0, 2 * n, chunks);
+                KCHECK();
+                po = al16(po + 2 * n * S.stride);
+            } else {
+                // the migrants travelled as lists: their rows are the founder mosaic their ancestry intervals describe (:1198-1211),
+                // assembled here from the founder panels of the parts' root populations
+                std::vector<u32> offp(2 * n + 1, 0);
+                for (size_t i = 0; i < n; i++) for (int h = 0; h < 2; h++) offp[2 * i + h + 1] = offp[2 * i + h] + counts[((i * nchr + k) * 2 + h) * 2 + 1];
+                std::vector<PanelRef> pr(c->n_pop);
+                for (int q = 0; q < c->n_pop; q++) {
+                    const ChrStatic& F = c->pop[q].cs[k];
+                    pr[q] = PanelRef{F.panel.as<u32>(), (u64)(F.stride / 4), (F.panel_rows && F.L == S.L) ? (u64)F.panel_rows : 0ull};
+                }
+                GEVC(h2d(c, c->d_poff, offp.data(), offp.size() * sizeof(u32)));
+                GEVC(h2d(c, c->d_panels, pr.data(), pr.size() * sizeof(PanelRef)));
+                hipLaunchKernelGGL(k_rebuild_rows, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, c->d_poff.as<u32>(), (const gev_part*)(in + pa), 2 * n,
+                                   S.d_pos.as<u64>(), (u32)S.L, c->d_panels.as<PanelRef>(), c->n_pop, pool_rows(P, k, pw.phys_alt + r_old * S.nseg), chunks, c->d_flag.as<u32>());
+                KCHECK();
+            }
         }
         if (cs.lp.valid) {
             // the lists live as pieces: the immigrants' lists are cut into pieces of their own, appended to the arenas, and their
@@ -2819,7 +2898,11 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
         co = al16(co + 2 * n * V.stride_w32 * sizeof(u32));
         V.frq_valid = false;
     }
+    u32 rb_flag = 0;
+    if (rebuild) HIPC(hipMemcpyAsync(&rb_flag, c->d_flag.p, sizeof(u32), hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
+    if (rb_flag & 2u) return fail(GEV_ESTATE, "import_rows: an immigrant descends from a root population whose founder panel is not held here (gev_upload_founder_panel / gev_synth_founder_panel)");
+    if (rb_flag & 1u) return fail(GEV_EINVAL, "import_rows: Error: p.hap_index is not in range");
     if (P.logical.empty()) { P.logical.resize(P.n_people); for (size_t i = 0; i < P.n_people; i++) P.logical[i] = (u32)i; }
     for (size_t i = 0; i < n; i++) P.logical.push_back((u32)(n_old + i));
     P.n_phys = n_new; P.n_people = P.logical.size(); c->ad_cached_pop = c->ad_host_set_pop = -1;

@@ -278,6 +278,23 @@ int gev_export_size(gev_ctx*, int pop, const uint64_t* positions, size_t n, size
 int gev_export_rows(gev_ctx*, int pop, const uint64_t* positions, size_t n, void* device_buf, size_t bytes);
 int gev_remove_rows(gev_ctx*, int pop, const uint64_t* positions, size_t n);
 int gev_import_rows(gev_ctx*, int pop, const void* device_buf, size_t bytes, size_t n);
+/* Migrants that travel as lists.  A migrant's genotype row is redundant with what travels beside it: it is the founder mosaic its
+ * ancestry intervals describe -- out[ii] = pops[part.root_population].hap_snps[part.hap_index][ii] for the part that contains
+ * pos[ii], Simulation::ras_convert_interval_to_hap_matrix (src/Simulation.cpp:1198-1211) -- with the mutations kept beside it as
+ * a sparse list.  A context that holds the founder panels of the root populations (read-only copies: what the reference keeps
+ * as Population::hap_snps for the whole run, src/Population.h) can therefore rebuild the rows where they arrive:
+ *  gev_upload_founder_panel / gev_synth_founder_panel : Hap_SNP.hap of ROOT population `pop`, chromosome chr, kept for good
+ *                            (same arguments as gev_upload_founders / gev_synth_founders; `pop` need not be simulated here;
+ *                            gev_set_snps of (pop, chr) first).  Needs resident planes (not gev_set_dense_state 0).
+ *  gev_set_migrant_rows(0) : gev_export_size / gev_export_rows leave the genotype rows out of the records (sexes, CV rows, mutation
+ *                            and interval lists travel as before), gev_import_rows assembles the immigrants' rows from the
+ *                            panels.  Needs the interval state (gev_set_track_intervals 1).  Both ends of an exchange use the
+ *                            same setting; gev_import_rows returns GEV_ESTATE when an immigrant descends from a root population
+ *                            without a panel here, GEV_EINVAL with the reference's "p.hap_index is not in range" (:1205-1209).
+ * At BASELINE config 2's shape a migrant is 250 KB of rows against 0.2-20 KB of lists. */
+int gev_upload_founder_panel(gev_ctx*, int pop, int chr, const uint64_t* bits, size_t row_stride_words, size_t nhap, size_t L);
+int gev_synth_founder_panel(gev_ctx*, int pop, int chr, size_t nhap, uint64_t seed);
+int gev_set_migrant_rows(gev_ctx*, int on);
 
 /* ---- output materialisation --------------------------------------------------------------
  * == Simulation::ras_convert_interval_to_hap_matrix (src/Simulation.cpp:1186-1230):

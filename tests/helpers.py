@@ -45,7 +45,7 @@ def find_gen0_seeds(fx, oracle_lib):
     return seeds
 
 
-def setup_static(ctx, fx, only_chr=None, snp_founders=True):
+def setup_static(ctx, fx, only_chr=None, snp_founders=True, panels=False):
     """ras_init_parameters equivalent: maps, SNP/CV grids, founder panels.  only_chr: the chromosomes whose genotype / CV
     inputs this context is given (locus-split populations); the others get their maps only."""
     n_pop, nchr, nphen = int(fx["n_pop"]), int(fx["nchr"]), int(fx["nphen"])
@@ -62,10 +62,12 @@ def setup_static(ctx, fx, only_chr=None, snp_founders=True):
             ctx.set_snps(ip, ic, pos)
             if not snp_founders:                     # plane-less contexts keep no genotype matrix: founder tiles are passed to gev_materialize
                 pass
-            elif f"{pre}chr{ic}_founders" in fx:
-                ctx.upload_founders(ip, ic, bytes_to_words(fx[f"{pre}chr{ic}_founders"], len(pos)), len(pos))
             else:
-                ctx.upload_founders(ip, ic, synth_packed(int(fx[f"{pre}chr{ic}_founders_synth_seed"]), nh, len(pos)), len(pos))
+                words = (bytes_to_words(fx[f"{pre}chr{ic}_founders"], len(pos)) if f"{pre}chr{ic}_founders" in fx
+                         else synth_packed(int(fx[f"{pre}chr{ic}_founders_synth_seed"]), nh, len(pos)))
+                ctx.upload_founders(ip, ic, words, len(pos))
+                if panels:                           # migrants travel as lists: every root population's panel is kept for good
+                    ctx.upload_founder_panel(ip, ic, words, len(pos))
             for iph in range(nphen):
                 k = f"{pre}ph{iph}_chr{ic}_"
                 ctx.set_cvs(ip, iph, ic, fx[k + "cv_bp"], fx[k + "cv_a"], fx[k + "cv_d"], float(fx[f"{pre}ph{iph}_vd"]))

@@ -423,6 +423,84 @@ def test_two_rank_migration_beyond_fixture_size_with_full_plane_verification():
         assert msg == "ok", f"rank {r}: {msg}"
 
 
+def test_two_rank_migration_with_migrants_as_lists_matches_reference_fixture():
+    """gev_set_migrant_rows(0) on the reference's `mig2` run: the records carry no genotype rows, the importing rank rebuilds them
+    from the founder panels of both root populations (gev_upload_founder_panel) by the rule of
+    Simulation::ras_convert_interval_to_hap_matrix (src/Simulation.cpp:1198-1211); couples, sexes, A/D, lists and the dense
+    matrices after every migration step equal the reference's, as with rows in the payload"""
+    from tests import dist_worker
+    res = dist_worker.launch("gpu_lists")
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
+def test_two_rank_migration_as_lists_beyond_fixture_size_with_full_plane_verification():
+    """tests/dist_worker.py:run_migration_at_scale with the migrants travelling as lists: after three exchanges (5 % of each
+    population, both directions, so parts of both root populations come back) and one more generation every word of the resident
+    planes equals the materialised interval state; the oracle in each rank's shadow moves whole rows"""
+    from tests import dist_worker
+    res = dist_worker.launch("gpu_lists", world=2, target=dist_worker.run_migration_at_scale)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
+def test_migrants_as_lists_payload_size_and_refusals(gpu_lib):
+    """one context, two populations: the lists-only record is smaller by exactly the rows; an import without the root population's
+    panel, or with the other end's setting, is refused; with the panel the imported rows equal the exported individuals' rows"""
+    import torch
+    from geneevolve_amd.capi import GevError
+    n, L = 64, 5000
+    cfg = SyntheticConfig(n, L, chrom_bp=2_000_000, map_step=1000, rec_per_row=1e-3, mut_per_row=1e-3, n_cv=16, seed=5)
+    g = gpu_lib.create(2, 1, 1, 0)
+    for p in range(2):
+        cfg.apply_static(g, p)
+        g.synth_founders(p, 0, 2 * n, 40 + p); g.synth_cv_founders(p, 0, 0, 2 * n, 50 + p)
+    seeds = GlobSeedStream(9)
+    sex = [g.init_gen0(p, n, int(seeds.draw(1)[0])) for p in range(2)]
+    rng = np.random.default_rng(0)
+    for gen in range(3):
+        for p in range(2):
+            sd = seeds.draw(1 + n)
+            sex[p] = g.reproduce(p, synthetic_random_mate(sex[p], n, rng), int(sd[0]), sd[1:])
+    who = np.array([3, 17, 40], dtype=np.uint64)
+    want = g.download_haps(0, 0)[np.stack([2 * who, 2 * who + 1], 1).ravel().astype(np.int64)]
+    full = g.export_size(0, who)
+    g.set_migrant_rows(False)
+    small = g.export_size(0, who)
+    stride = -(-L // 1024) * 128                                                  # bytes of a flat row: multiple of 128
+    assert full - small == 2 * len(who) * stride, (full, small, stride)
+    buf = torch.zeros(small, dtype=torch.uint8, device="cuda:0"); torch.cuda.synchronize()
+    g.export_rows(0, who, buf.data_ptr(), small)
+    with pytest.raises(GevError, match="founder panel is not held here"):
+        g.import_rows(1, buf.data_ptr(), small, len(who))
+    g.close()
+    # again with the panels: rows come out as they went in; with the other end's setting the record's size gives it away
+    g = gpu_lib.create(2, 1, 1, 0)
+    for p in range(2):
+        cfg.apply_static(g, p)
+        g.synth_founders(p, 0, 2 * n, 40 + p); g.synth_cv_founders(p, 0, 0, 2 * n, 50 + p); g.synth_founder_panel(p, 0, 2 * n, 40 + p)
+    seeds = GlobSeedStream(9)
+    sex = [g.init_gen0(p, n, int(seeds.draw(1)[0])) for p in range(2)]
+    rng = np.random.default_rng(0)
+    for gen in range(3):
+        for p in range(2):
+            sd = seeds.draw(1 + n)
+            sex[p] = g.reproduce(p, synthetic_random_mate(sex[p], n, rng), int(sd[0]), sd[1:])
+    assert np.array_equal(g.download_haps(0, 0)[np.stack([2 * who, 2 * who + 1], 1).ravel().astype(np.int64)], want)
+    g.set_migrant_rows(False)
+    g.export_rows(0, who, buf.data_ptr(), small)
+    g.set_migrant_rows(True)
+    with pytest.raises(GevError, match="expected from its header"):
+        g.import_rows(1, buf.data_ptr(), small, len(who))
+    g.set_migrant_rows(False)
+    g.import_rows(1, buf.data_ptr(), small, len(who))
+    assert g.pop_size(1) == n + len(who)
+    got = g.download_haps(1, 0)
+    assert np.array_equal(got[2 * n:], want), "rebuilt rows (mutations applied) != the emigrants' rows"
+    assert g.dbg_verify_planes(1, 0, [40, 41]) == (0, 0)
+    g.close()
+
+
 def test_rccl_backend_single_rank_collectives_drive_the_device_buffer_branch():
     """The test box has ONE GPU, so RCCL cannot carry a two-rank exchange here; a single-rank "nccl" process group still runs the
     collectives of the device-buffer branch for real (all_to_all_single of the size table on a device tensor, all_reduce of the
