@@ -1518,30 +1518,40 @@ __global__ void __launch_bounds__(256) k_copy_rows16(RowRef dst, RowRef src, con
 // resident plane, which holds the founder mosaic without the mutation overlay (the mutation list travels and stays sparse).
 // One thread per 16-byte chunk of a row; the parts of a row are disjoint and ascending (bisection on `en`, as k_materialize_tile).
 struct PanelRef { const u32* base; u64 w32; u64 rows; };        // flat rows of w32 words; rows == 0: no panel of this root population here
-__global__ void __launch_bounds__(256) k_rebuild_rows(const u32* __restrict__ p_off /* [n_rows + 1], into `parts` */, const gev_part* __restrict__ parts, size_t n_rows,
-                                                      const u64* __restrict__ pos, u32 L, const PanelRef* __restrict__ panels, int n_pop,
+// locus range of every part: locus ii lies in [st, en) exactly when lower_bound(pos, st) <= ii < lower_bound(pos, en) (pos ascends)
+__global__ void __launch_bounds__(256) k_parts_locus_range(const gev_part* __restrict__ parts, size_t n_parts, const u64* __restrict__ pos, u32 L, uint2* __restrict__ range)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parts) return;
+    const u32 a = lower_bound_u64(pos, L, parts[i].st), b = lower_bound_u64(pos, L, parts[i].en);
+    range[i] = make_uint2(a, max(a, b));
+}
+__global__ void __launch_bounds__(256) k_rebuild_rows(const u32* __restrict__ p_off /* [n_rows + 1], into `parts` */, const gev_part* __restrict__ parts,
+                                                      const uint2* __restrict__ range /* k_parts_locus_range */, u32 L, const PanelRef* __restrict__ panels, int n_pop,
                                                       RowRef dst, u32 chunks, u32* __restrict__ status /* |1: hap_index out of range, |2: no panel of a root population */)
 {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_rows * chunks) return;
-    const size_t r = e / chunks; const u32 q = (u32)(e % chunks);
+    // grid: x = row, y = blocks of 256 chunks of that row -- the lanes of a wave work on one row, on 256 consecutive words of it
+    const size_t r = blockIdx.x;
+    const u32 q = blockIdx.y * 256u + threadIdx.x;
     const u32 words = (L + 31) / 32;
     const u32 begin = p_off[r], end = p_off[r + 1];
+    // one bisection per wave (the same addresses on every lane: broadcast loads): first part that ends behind the first locus of
+    // the wave's first word; every word then walks on from there (the parts of a row are disjoint and ascending)
+    const u32 l0 = 128u * (blockIdx.y * 256u + (threadIdx.x & ~63u));
+    u32 lo = begin, hi = end;
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (range[m].y <= l0) lo = m + 1; else hi = m; }
+    if (q >= chunks) return;
     u32 o[4] = {0u, 0u, 0u, 0u};
     for (u32 t4 = 0; t4 < 4; t4++) {
         const u32 w = 4 * q + t4;
         if (w >= words) break;                                                                        // pad words of the row stay 0
-        const u32 nb = min(32u, L - 32u * w);
-        const u64* wp = pos + 32u * (size_t)w;
-        const u64 x0 = wp[0], x1 = wp[nb - 1];
-        u32 lo = begin, hi = end;
-        while (lo < hi) { const u32 m = (lo + hi) >> 1; if (parts[m].en <= x0) lo = m + 1; else hi = m; }    // first part with en > x0
+        const u32 i0 = 32u * w, i1 = min(i0 + 32u, L);                                                // the word's loci [i0, i1)
+        while (lo < end && range[lo].y <= i0) lo++;
         u32 acc = 0;
-        for (u32 i = lo; i < end && parts[i].st <= x1; i++) {
-            const u64 st = parts[i].st, en = parts[i].en;
-            u32 a = 0, b = 0;
-            if (st > x0 || en <= x1) { for (u32 t = 0; t < nb; t++) { a += wp[t] < st ? 1u : 0u; b += wp[t] < en ? 1u : 0u; } }   // loci [a, b) lie in [st, en)
-            else b = nb;                                                                              // the part covers the whole word
+        for (u32 i = lo; i < end; i++) {
+            const uint2 g = range[i];
+            if (g.x >= i1) break;
+            const u32 a = max(g.x, i0) - i0, b = min(g.y, i1) - i0;                                    // bits [a, b) of the word
             if (b > a) {
                 const u32 mask = (b - a == 32u) ? 0xffffffffu : (((1u << (b - a)) - 1u) << a);
                 const u64 h = parts[i].hap_index;

@@ -198,6 +198,7 @@ struct PopState {
 struct gev_ctx {
     int device = 0, n_pop = 0, nchr = 0, nphen = 0;
     u32 rp_bits = 0;
+    bool ad_effects_shared = false;         // every root population has the same CV effects bit for bit (check_multipop): A/D uses the one-population term table
     hipStream_t stream = nullptr, stream_samp = nullptr, stream_aux = nullptr, stream_list = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};
@@ -231,7 +232,7 @@ struct gev_ctx {
     std::vector<uint8_t> chr_active;        // 0: chromosome held by another context (gev_set_chr_active); sampling chain only
     bool any_inactive = false;
     bool migrant_rows = true;               // false (gev_set_migrant_rows): gev_export_rows packs no genotype rows, gev_import_rows rebuilds them from the founder panels
-    DevBuf d_panels, d_poff;                // rebuild of immigrants' rows: PanelRef per root population, offsets of the rows' parts in the payload
+    DevBuf d_panels, d_poff, d_prange;               // rebuild of immigrants' rows: PanelRef per root population, offsets of the rows' parts in the payload
     bool dense = true;                      // false: no resident genotype planes (gev_set_dense_state); lists + CV planes only, output by gev_materialize
     hipStream_t stream_big = nullptr;
     bool planes_pending = false;            // a stitch may still be writing the current planes (stream_big)
@@ -928,6 +929,20 @@ static int check_multipop(gev_ctx* c)
             for (int p = 0; p < c->nphen; p++)
                 if (c->pop[0].cv[p][k].bp != c->pop[pop].cv[p][k].bp) return fail(GEV_EUNSUPPORTED, "populations 0 and %d have different CV positions (phenotype %d chromosome %d)", pop, p, k);
         }
+    // Root populations whose CV effects are the same arrays bit for bit (the usual multi-population run: one CV file for all): the mean
+    // of two root populations' values (a0 + a1) / 2 (:2695-2696) is then (a + a) / 2 whatever the roots are, so the one-population
+    // term table serves every haplotype and A/D need not look the root-population bits up
+    c->ad_effects_shared = true;
+    for (int pop = 1; pop < c->n_pop && c->ad_effects_shared; pop++)
+        for (int p = 0; p < c->nphen && c->ad_effects_shared; p++)
+            for (int k = 0; k < c->nchr; k++) {
+                if (!c->chr_active[k]) continue;
+                const CvStatic& A = c->pop[0].cv[p][k]; const CvStatic& B = c->pop[pop].cv[p][k];
+                if (A.a.size() != B.a.size() || A.d.size() != B.d.size() || memcmp(&A.vd, &B.vd, sizeof(double)) ||
+                    (A.a.size() && memcmp(A.a.data(), B.a.data(), A.a.size() * sizeof(double))) || (A.d.size() && memcmp(A.d.data(), B.d.data(), A.d.size() * sizeof(double)))) { c->ad_effects_shared = false; break; }
+            }
+    static const bool no_shared = getenv("GEV_AD_SHARED") && atoi(getenv("GEV_AD_SHARED")) == 0;      // (tests: force the per-haplotype lookup)
+    if (no_shared) c->ad_effects_shared = false;
     // per (phen, chr): table of every population's a[] and d[] device arrays, stored with each population
     for (int pop = 0; pop < c->n_pop; pop++)
         for (int p = 0; p < c->nphen; p++)
@@ -2174,7 +2189,7 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready,
     const u32 S1 = sub_max | 1u;
     int ipb = 0;
     const size_t ad_tab_lds = AD_CHUNK * 4 + AD_CHUNK * 6 * 8 + 8;          // column + table chunk behind the rows
-    if (c->rp_bits == 0 && all_have_cv) { for (int cand : {256, 128, 64}) if ((size_t)2 * cand * S1 * 4 + ad_tab_lds <= 64 * 1024) { ipb = cand; break; } }
+    if ((c->rp_bits == 0 || c->ad_effects_shared) && all_have_cv) { for (int cand : {256, 128, 64}) if ((size_t)2 * cand * S1 * 4 + ad_tab_lds <= 64 * 1024) { ipb = cand; break; } }
     for (int p = 0; p < nphen; p++)
         for (int k = 0; k < nchr; k++) {
             if (!c->chr_active[k]) continue;
@@ -2789,6 +2804,12 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
     hipStream_t st = c->stream;
     const int nchr = c->nchr;
     const uint8_t* in = (const uint8_t*)device_buf;
+    double tr_t = host_ms();
+    auto mark = [&](const char* what) {                   // GEV_TRACE_HOST: where an import's time goes (serialises the steps)
+        if (!g_trace_host) return;
+        (void)hipStreamSynchronize(st);
+        const double now = host_ms(); fprintf(stderr, "[gev] import_rows %s %.3f ms\n", what, now - tr_t); tr_t = now;
+    };
     if (bytes < n * nchr * 4 * sizeof(u32)) return fail(GEV_EINVAL, "import_rows: buffer too small for its own header");
     std::vector<u32> counts(n * nchr * 4);
     HIPC(hipMemcpyAsync(counts.data(), in, counts.size() * sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -2800,7 +2821,9 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
     if (rebuild) { GEVC(c->d_flag.ensure(16, st)); HIPC(hipMemsetAsync(c->d_flag.p, 0, 4, st)); }
     const size_t n_old = P.n_phys, n_new = n_old + n, r_old = 2 * n_old;     // physical append behind every existing row
     if (n_new * 2 >= 0xffffffffull) return fail(GEV_EINVAL, "import_rows: too many rows");
+    mark("header");
     GEVC(ensure_capacity(c, pop, n_new));                              // keeps the current buffers' content
+    mark("capacity");
     HIPC(hipMemcpyAsync(P.d_sex[P.cur].as<uint8_t>() + n_old, in + L.sex, n, hipMemcpyDeviceToDevice, st));
     size_t po = L.planes, co = L.cv, mo = L.muts, pa = L.parts;
     for (int k = 0; k < nchr; k++) {
@@ -2810,8 +2833,10 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
             pool_new_stamp(cs);
             const PoolWork pw = pool_work(c, P, k, P.pcur);           // new slots of the CURRENT generation
             GEVC(pool_free_list(pw, r_old, st));
+            mark("free list");
             GEVC(pool_take(pw, r_old, 2 * n, st));
             cs.pool_list_valid = false;
+            mark("units");
             const u32 chunks = (u32)(S.stride / 16);
             if (c->migrant_rows) {
                 hipLaunchKernelGGL(k_copy_rows16, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, pool_rows(P, k, pw.phys_alt + r_old * S.nseg),
@@ -2830,10 +2855,14 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
                 }
                 GEVC(h2d(c, c->d_poff, offp.data(), offp.size() * sizeof(u32)));
                 GEVC(h2d(c, c->d_panels, pr.data(), pr.size() * sizeof(PanelRef)));
-                hipLaunchKernelGGL(k_rebuild_rows, dim3((unsigned)ceil_div(2 * n * chunks, 256)), dim3(256), 0, st, c->d_poff.as<u32>(), (const gev_part*)(in + pa), 2 * n,
-                                   S.d_pos.as<u64>(), (u32)S.L, c->d_panels.as<PanelRef>(), c->n_pop, pool_rows(P, k, pw.phys_alt + r_old * S.nseg), chunks, c->d_flag.as<u32>());
+                GEVC(c->d_prange.ensure(std::max<size_t>(offp[2 * n], 1) * sizeof(uint2), st));
+                if (offp[2 * n]) hipLaunchKernelGGL(k_parts_locus_range, dim3((unsigned)ceil_div((size_t)offp[2 * n], 256)), dim3(256), 0, st, (const gev_part*)(in + pa), (size_t)offp[2 * n],
+                                                    S.d_pos.as<u64>(), (u32)S.L, c->d_prange.as<uint2>());
+                hipLaunchKernelGGL(k_rebuild_rows, dim3((unsigned)(2 * n), (unsigned)ceil_div(chunks, 256)), dim3(256), 0, st, c->d_poff.as<u32>(), (const gev_part*)(in + pa),
+                                   c->d_prange.as<uint2>(), (u32)S.L, c->d_panels.as<PanelRef>(), c->n_pop, pool_rows(P, k, pw.phys_alt + r_old * S.nseg), chunks, c->d_flag.as<u32>());
                 KCHECK();
             }
+            mark("rows");
         }
         if (cs.lp.valid) {
             // the lists live as pieces: the immigrants' lists are cut into pieces of their own, appended to the arenas, and their
@@ -2869,6 +2898,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
             if (h[2]) return fail(GEV_EDEVICE, "import_rows: list arena overflow (internal error)");
             lp.p_used += h[0]; lp.m_used += h[1];
             cs.csr_valid = false;
+            mark("list pieces");
         } else for (int pass = 0; pass < 2; pass++) {
             if (pass == 1 && !c->track_intervals) continue;
             size_t& total = pass == 0 ? cs.mut_total[P.cur] : cs.parts_total[P.cur];
