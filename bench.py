@@ -249,11 +249,28 @@ def main():
     for p in range(n_pop_ctx):
         cfg.apply_static(ctx, p)
     P = my_pop
+    if migrate:
+        # immigrants are appended behind the residents before the emigrants' slots are reused: room for them from the start, so
+        # that the first exchange does not regrow (and copy) the planes
+        ctx.reserve(P, args.n_ind + int(round(args.migration_rate * args.n_ind)) * (world - 1))
     for c in range(args.nchr):
         if not args.plane_less:
             ctx.synth_founders(P, c, 2 * args.n_ind, 1000 + 100 * c + rank)
         ctx.synth_cv_founders(P, 0, c, 2 * args.n_ind, 2000 + 100 * c + rank)
     migrant_lists = migrate and not args.migrant_rows and not args.plane_less and not args.no_intervals
+    if migrant_lists:
+        # the panels of ALL populations live on every GPU: n_pop x 2N rows of the plane's stride, next to this rank's two plane sets
+        # and its list arenas.  Where they do not fit (config 2 on 8 GPUs: 8 x 25 GB), the rows travel.
+        row_bytes = -(-args.n_loci // 1024) * 128
+        panels = n_pop_ctx * args.nchr * 2 * args.n_ind * row_bytes
+        planes = 2 * args.nchr * 2 * args.n_ind * row_bytes
+        total = torch.cuda.get_device_properties(local_rank).total_memory
+        share = 2 if one_gpu else 1                                  # (rehearsal: the ranks share one GPU)
+        if (panels + planes + 0.12 * total) * share > 0.92 * total:   # (+ list arenas, unit tables, sampling records)
+            migrant_lists = False
+            if rank == 0:
+                print(f"bench: founder panels of {n_pop_ctx} populations ({panels / 2**30:.0f} GiB) + planes ({planes / 2**30:.0f} GiB) do not fit "
+                      f"the GPU's memory: the migrants' genotype rows travel in the records (--migrant-rows)", file=sys.stderr)
     if migrant_lists:
         # every GPU keeps a read-only copy of every population's founder panel (what the reference holds as Population::hap_snps)
         for p in range(n_pop_ctx):
