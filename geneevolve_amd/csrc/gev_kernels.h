@@ -1516,7 +1516,7 @@ __global__ void __launch_bounds__(256) k_copy_rows16(RowRef dst, RowRef src, con
 // its ancestry intervals and the founder panels kept there (gev_upload_founder_panel / gev_synth_founder_panel, one per ROOT
 // population) -- Simulation::ras_convert_interval_to_hap_matrix's rule (src/Simulation.cpp:1198-1211) for the rows of the
 // resident plane, which holds the founder mosaic without the mutation overlay (the mutation list travels and stays sparse).
-// One thread per 16-byte chunk of a row; the parts of a row are disjoint and ascending (bisection on `en`, as k_materialize_tile).
+// The parts of the records are turned into locus ranges once (k_parts_locus_range), the rows are then assembled from the ranges alone.
 struct PanelRef { const u32* base; u64 w32; u64 rows; };        // flat rows of w32 words; rows == 0: no panel of this root population here
 // locus range of every part: locus ii lies in [st, en) exactly when lower_bound(pos, st) <= ii < lower_bound(pos, en) (pos ascends)
 __global__ void __launch_bounds__(256) k_parts_locus_range(const gev_part* __restrict__ parts, size_t n_parts, const u64* __restrict__ pos, u32 L, uint2* __restrict__ range)
@@ -1526,44 +1526,48 @@ __global__ void __launch_bounds__(256) k_parts_locus_range(const gev_part* __res
     const u32 a = lower_bound_u64(pos, L, parts[i].st), b = lower_bound_u64(pos, L, parts[i].en);
     range[i] = make_uint2(a, max(a, b));
 }
+#define REBUILD_CPW 256u        // chunks per wave of k_rebuild_rows: four steps of 64 lanes behind one bisection
 __global__ void __launch_bounds__(256) k_rebuild_rows(const u32* __restrict__ p_off /* [n_rows + 1], into `parts` */, const gev_part* __restrict__ parts,
                                                       const uint2* __restrict__ range /* k_parts_locus_range */, u32 L, const PanelRef* __restrict__ panels, int n_pop,
                                                       RowRef dst, u32 chunks, u32* __restrict__ status /* |1: hap_index out of range, |2: no panel of a root population */)
 {
-    // grid: x = row, y = blocks of 256 chunks of that row -- the lanes of a wave work on one row, on 256 consecutive words of it
+    // grid: x = row, y = blocks of 4 waves x REBUILD_CPW chunks of that row -- a wave works on 1024 consecutive words of one row.
+    // The kernel is a chain of dependent loads (bisection -> range -> part -> panel -> founder words): one bisection per wave
+    // (the same addresses on every lane: broadcast loads), then every word walks on from where the lane's previous word stood
+    // (the parts of a row are disjoint and ascending), and a lane's four chunks keep four founder loads in flight.
     const size_t r = blockIdx.x;
-    const u32 q = blockIdx.y * 256u + threadIdx.x;
+    const u32 qbase = (blockIdx.y * 4u + (threadIdx.x >> 6)) * REBUILD_CPW;
+    if (qbase >= chunks) return;
     const u32 words = (L + 31) / 32;
     const u32 begin = p_off[r], end = p_off[r + 1];
-    // one bisection per wave (the same addresses on every lane: broadcast loads): first part that ends behind the first locus of
-    // the wave's first word; every word then walks on from there (the parts of a row are disjoint and ascending)
-    const u32 l0 = 128u * (blockIdx.y * 256u + (threadIdx.x & ~63u));
+    const u32 l0 = 128u * qbase;                                                                       // first locus of the wave
     u32 lo = begin, hi = end;
-    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (range[m].y <= l0) lo = m + 1; else hi = m; }
-    if (q >= chunks) return;
-    u32 o[4] = {0u, 0u, 0u, 0u};
-    for (u32 t4 = 0; t4 < 4; t4++) {
-        const u32 w = 4 * q + t4;
-        if (w >= words) break;                                                                        // pad words of the row stay 0
-        const u32 i0 = 32u * w, i1 = min(i0 + 32u, L);                                                // the word's loci [i0, i1)
-        while (lo < end && range[lo].y <= i0) lo++;
-        u32 acc = 0;
-        for (u32 i = lo; i < end; i++) {
-            const uint2 g = range[i];
-            if (g.x >= i1) break;
-            const u32 a = max(g.x, i0) - i0, b = min(g.y, i1) - i0;                                    // bits [a, b) of the word
-            if (b > a) {
-                const u32 mask = (b - a == 32u) ? 0xffffffffu : (((1u << (b - a)) - 1u) << a);
-                const u64 h = parts[i].hap_index;
-                const int rp = parts[i].root_population;
-                if (rp < 0 || rp >= n_pop || !panels[rp].rows) { atomicOr(status, 2u); continue; }
-                if (h >= panels[rp].rows) { atomicOr(status, 1u); continue; }                          // :1205-1209 "hap_index is not in range"
-                acc |= panels[rp].base[h * panels[rp].w32 + w] & mask;
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (range[m].y <= l0) lo = m + 1; else hi = m; }    // first part that ends behind it
+    for (u32 q = qbase + (threadIdx.x & 63u); q < min(qbase + REBUILD_CPW, chunks); q += 64u) {
+        u32 o[4] = {0u, 0u, 0u, 0u};
+        for (u32 t4 = 0; t4 < 4; t4++) {
+            const u32 w = 4 * q + t4;
+            if (w >= words) break;                                                                    // pad words of the row stay 0
+            const u32 i0 = 32u * w, i1 = min(i0 + 32u, L);                                            // the word's loci [i0, i1)
+            while (lo < end && range[lo].y <= i0) lo++;
+            u32 acc = 0;
+            for (u32 i = lo; i < end; i++) {
+                const uint2 g = range[i];
+                if (g.x >= i1) break;
+                const u32 a = max(g.x, i0) - i0, b = min(g.y, i1) - i0;                                // bits [a, b) of the word
+                if (b > a) {
+                    const u32 mask = (b - a == 32u) ? 0xffffffffu : (((1u << (b - a)) - 1u) << a);
+                    const u64 h = parts[i].hap_index;
+                    const int rp = parts[i].root_population;
+                    if (rp < 0 || rp >= n_pop || !panels[rp].rows) { atomicOr(status, 2u); continue; }
+                    if (h >= panels[rp].rows) { atomicOr(status, 1u); continue; }                      // :1205-1209 "hap_index is not in range"
+                    acc |= panels[rp].base[h * panels[rp].w32 + w] & mask;
+                }
             }
+            o[t4] = acc;
         }
-        o[t4] = acc;
+        *dst.chunk(r, q) = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    *dst.chunk(r, q) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 // dst[i] = src[map[i << shift] >> shift]: bytes of selected individuals (shift = 1: `map` holds haplotype rows 2*individual, 2*individual+1)
 __global__ void k_gather_u8(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, const u32* __restrict__ map, u32 shift, size_t n)

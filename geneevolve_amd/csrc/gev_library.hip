@@ -2858,7 +2858,7 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
                 GEVC(c->d_prange.ensure(std::max<size_t>(offp[2 * n], 1) * sizeof(uint2), st));
                 if (offp[2 * n]) hipLaunchKernelGGL(k_parts_locus_range, dim3((unsigned)ceil_div((size_t)offp[2 * n], 256)), dim3(256), 0, st, (const gev_part*)(in + pa), (size_t)offp[2 * n],
                                                     S.d_pos.as<u64>(), (u32)S.L, c->d_prange.as<uint2>());
-                hipLaunchKernelGGL(k_rebuild_rows, dim3((unsigned)(2 * n), (unsigned)ceil_div(chunks, 256)), dim3(256), 0, st, c->d_poff.as<u32>(), (const gev_part*)(in + pa),
+                hipLaunchKernelGGL(k_rebuild_rows, dim3((unsigned)(2 * n), (unsigned)ceil_div(chunks, 4 * REBUILD_CPW)), dim3(256), 0, st, c->d_poff.as<u32>(), (const gev_part*)(in + pa),
                                    c->d_prange.as<uint2>(), (u32)S.L, c->d_panels.as<PanelRef>(), c->n_pop, pool_rows(P, k, pw.phys_alt + r_old * S.nseg), chunks, c->d_flag.as<u32>());
                 KCHECK();
             }
