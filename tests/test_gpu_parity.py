@@ -444,6 +444,16 @@ def test_two_rank_migration_as_lists_beyond_fixture_size_with_full_plane_verific
         assert msg == "ok", f"rank {r}: {msg}"
 
 
+def test_config4_in_miniature_with_migrants_as_lists():
+    """fixture `c4mini` (22 autosomes of the reference's own map, assortative mating, mutation, two populations with migration,
+    each split 11 | 11 chromosomes over two processes): the exchange between the processes that hold the same chromosomes carries
+    lists only, every shard rebuilds the immigrants' rows of its chromosomes from the panels of both root populations"""
+    from tests import dist_worker
+    res = dist_worker.launch("gpu_lists", world=4, target=dist_worker.run_split_migration_c4mini)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
 def test_migrants_as_lists_payload_size_and_refusals(gpu_lib):
     """one context, two populations: the lists-only record is smaller by exactly the rows; an import without the root population's
     panel, or with the other end's setting, is refused; with the panel the imported rows equal the exported individuals' rows"""
