@@ -556,6 +556,7 @@ int gev_set_snps(gev_ctx* c, int pop, int chr, const u64* pos, size_t L)
     for (size_t i = 1; i < L; i++) if (pos[i] < pos[i - 1]) return fail(GEV_EUNSUPPORTED, "set_snps: positions must be non-decreasing (locus %zu)", i);
     ChrStatic& S = c->pop[pop].cs[chr];
     S.pos.assign(pos, pos + L); S.L = L;
+    S.panel_rows = 0;                                              // a founder panel kept for another grid is void
     S.stride = std::max<size_t>(round_up(ceil_div(L, 8), 128), 128);
     S.seg_shift = c->seg_shift;                                    // 2 KiB segments (GEV_SEG_CHUNKS) unless the row would need more than 64 of them
     while (ceil_div(S.stride / 16, (size_t)1 << S.seg_shift) > POOL_SEG_MAX) S.seg_shift++;
