@@ -1519,11 +1519,12 @@ __global__ void __launch_bounds__(256) k_copy_rows16(RowRef dst, RowRef src, con
 // The parts of the records are turned into locus ranges once (k_parts_locus_range), the rows are then assembled from the ranges alone.
 struct PanelRef { const u32* base; u64 w32; u64 rows; };        // flat rows of w32 words; rows == 0: no panel of this root population here
 // locus range of every part: locus ii lies in [st, en) exactly when lower_bound(pos, st) <= ii < lower_bound(pos, en) (pos ascends)
-__global__ void __launch_bounds__(256) k_parts_locus_range(const gev_part* __restrict__ parts, size_t n_parts, const u64* __restrict__ pos, u32 L, uint2* __restrict__ range)
+__global__ void __launch_bounds__(256) k_parts_locus_range(const gev_part* __restrict__ parts, size_t n_parts, const ChrDev* __restrict__ chrs, int chr, uint2* __restrict__ range)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_parts) return;
-    const u32 a = lower_bound_u64(pos, L, parts[i].st), b = lower_bound_u64(pos, L, parts[i].en);
+    const ChrDev& C = chrs[chr];
+    const u32 a = snp_lower_bound(C, parts[i].st), b = snp_lower_bound(C, parts[i].en);                // (one table read + a search inside the bucket)
     range[i] = make_uint2(a, max(a, b));
 }
 #define REBUILD_CPW 256u        // chunks per wave of k_rebuild_rows: four steps of 64 lanes behind one bisection
@@ -1544,6 +1545,23 @@ __global__ void __launch_bounds__(256) k_rebuild_rows(const u32* __restrict__ p_
     u32 lo = begin, hi = end;
     while (lo < hi) { const u32 m = (lo + hi) >> 1; if (range[m].y <= l0) lo = m + 1; else hi = m; }    // first part that ends behind it
     for (u32 q = qbase + (threadIdx.x & 63u); q < min(qbase + REBUILD_CPW, chunks); q += 64u) {
+        const u32 c0 = 128u * q, c1 = min(c0 + 128u, L);                                              // the chunk's loci [c0, c1)
+        if (c0 >= L) { *dst.chunk(r, q) = make_uint4(0u, 0u, 0u, 0u); continue; }                      // padding behind the last locus
+        while (lo < end && range[lo].y <= c0) lo++;
+        if (lo < end) {
+            // the usual case: one part covers the whole chunk -- one 16-byte load of the founder row (its pad bits are zero)
+            const uint2 g = range[lo];
+            if (g.x <= c0 && g.y >= c1) {
+                const u64 h = parts[lo].hap_index;
+                const int rp = parts[lo].root_population;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (rp < 0 || rp >= n_pop || !panels[rp].rows) atomicOr(status, 2u);
+                else if (h >= panels[rp].rows) atomicOr(status, 1u);
+                else v = *(const uint4*)(panels[rp].base + h * panels[rp].w32 + 4u * q);
+                *dst.chunk(r, q) = v;
+                continue;
+            }
+        }
         u32 o[4] = {0u, 0u, 0u, 0u};
         for (u32 t4 = 0; t4 < 4; t4++) {
             const u32 w = 4 * q + t4;

@@ -232,7 +232,7 @@ struct gev_ctx {
     std::vector<uint8_t> chr_active;        // 0: chromosome held by another context (gev_set_chr_active); sampling chain only
     bool any_inactive = false;
     bool migrant_rows = true;               // false (gev_set_migrant_rows): gev_export_rows packs no genotype rows, gev_import_rows rebuilds them from the founder panels
-    DevBuf d_panels, d_poff, d_prange;               // rebuild of immigrants' rows: PanelRef per root population, offsets of the rows' parts in the payload
+    DevBuf d_poff, d_prange;                      // rebuild of immigrants' rows: PanelRef per root population, offsets of the rows' parts in the payload
     bool dense = true;                      // false: no resident genotype planes (gev_set_dense_state); lists + CV planes only, output by gev_materialize
     hipStream_t stream_big = nullptr;
     bool planes_pending = false;            // a stitch may still be writing the current planes (stream_big)
@@ -2854,13 +2854,17 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
                     const ChrStatic& F = c->pop[q].cs[k];
                     pr[q] = PanelRef{F.panel.as<u32>(), (u64)(F.stride / 4), (F.panel_rows && F.L == S.L) ? (u64)F.panel_rows : 0ull};
                 }
-                GEVC(h2d(c, c->d_poff, offp.data(), offp.size() * sizeof(u32)));
-                GEVC(h2d(c, c->d_panels, pr.data(), pr.size() * sizeof(PanelRef)));
+                // one upload: the rows' part offsets, then the panel table (8-byte aligned behind them)
+                const size_t off_words = (offp.size() + 1) & ~(size_t)1;
+                std::vector<u32> up(off_words + pr.size() * sizeof(PanelRef) / sizeof(u32), 0);
+                memcpy(up.data(), offp.data(), offp.size() * sizeof(u32)); memcpy(up.data() + off_words, pr.data(), pr.size() * sizeof(PanelRef));
+                GEVC(h2d(c, c->d_poff, up.data(), up.size() * sizeof(u32)));
+                const PanelRef* d_panels = (const PanelRef*)(c->d_poff.as<u32>() + off_words);
                 GEVC(c->d_prange.ensure(std::max<size_t>(offp[2 * n], 1) * sizeof(uint2), st));
                 if (offp[2 * n]) hipLaunchKernelGGL(k_parts_locus_range, dim3((unsigned)ceil_div((size_t)offp[2 * n], 256)), dim3(256), 0, st, (const gev_part*)(in + pa), (size_t)offp[2 * n],
-                                                    S.d_pos.as<u64>(), (u32)S.L, c->d_prange.as<uint2>());
+                                                    P.d_chrdev.as<ChrDev>(), k, c->d_prange.as<uint2>());
                 hipLaunchKernelGGL(k_rebuild_rows, dim3((unsigned)(2 * n), (unsigned)ceil_div(chunks, 4 * REBUILD_CPW)), dim3(256), 0, st, c->d_poff.as<u32>(), (const gev_part*)(in + pa),
-                                   c->d_prange.as<uint2>(), (u32)S.L, c->d_panels.as<PanelRef>(), c->n_pop, pool_rows(P, k, pw.phys_alt + r_old * S.nseg), chunks, c->d_flag.as<u32>());
+                                   c->d_prange.as<uint2>(), (u32)S.L, d_panels, c->n_pop, pool_rows(P, k, pw.phys_alt + r_old * S.nseg), chunks, c->d_flag.as<u32>());
                 KCHECK();
             }
             mark("rows");
