@@ -678,7 +678,8 @@ __global__ void __launch_bounds__(256) k_pool_take(PoolWork pw, size_t slot0, si
     if (at >= n_free) { flag[0] = 1; *dst = n_free ? pw.freel[at % n_free] : 0u; return; }
     *dst = pw.freel[at];
 }
-__global__ void k_pool_taken(PoolWork pw, u32 n_units) { if (threadIdx.x == 0 && blockIdx.x == 0) pw.pctr[1] += n_units; }
+// (pctr[4] = where the cursor stood when the generation in progress began: units taken outside a generation move both)
+__global__ void k_pool_taken(PoolWork pw, u32 n_units) { if (threadIdx.x == 0 && blockIdx.x == 0) { pw.pctr[1] += n_units; pw.pctr[4] += n_units; } }
 __global__ void __launch_bounds__(256) k_iota_u32(u32* __restrict__ a, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

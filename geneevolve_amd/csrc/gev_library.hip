@@ -2831,12 +2831,17 @@ int gev_import_rows(gev_ctx* c, int pop, const void* device_buf, size_t bytes, s
         if (!c->chr_active[k]) continue;
         ChrStatic& S = P.cs[k]; ChrState& cs = P.st[k];
         if (c->dense) {
-            pool_new_stamp(cs);
+            // units for the immigrants' segments: from the free list the generations keep (its entries behind the cursor are named by
+            // no table, and nothing is in flight after gev_sync) while it lasts, else from a new one
+            const size_t need_units = 2 * n * S.nseg;
+            static const bool keep_list = !(getenv("GEV_IMPORT_KEEP_LIST") && atoi(getenv("GEV_IMPORT_KEEP_LIST")) == 0);
+            const bool reuse = keep_list && cs.pool_list_valid && !cs.pool_force_rebuild && (size_t)cs.pool_cursor + need_units <= cs.pool_n_free;
+            if (!reuse) pool_new_stamp(cs);
             const PoolWork pw = pool_work(c, P, k, P.pcur);           // new slots of the CURRENT generation
-            GEVC(pool_free_list(pw, r_old, st));
+            if (!reuse) GEVC(pool_free_list(pw, r_old, st));
             mark("free list");
             GEVC(pool_take(pw, r_old, 2 * n, st));
-            cs.pool_list_valid = false;
+            if (reuse) cs.pool_cursor += (u32)need_units; else cs.pool_list_valid = false;
             mark("units");
             const u32 chunks = (u32)(S.stride / 16);
             if (c->migrant_rows) {

@@ -107,6 +107,8 @@ const char* gev_version(void);
  *                               work and waited for separately (seeds: mating, sampling: unit table); default 0 (same rate at config 2)
  *   GEV_CHAIN_WG=0              serial-chain mode with one wave per link; GEV_CHAIN_MAX_TASKS=n: most tasks accepted without a mutation map
  *   GEV_TABLE_RING_BYTES=n      minimum size of the pinned ring the per-generation work tables are staged through
+ *   GEV_AD_SHARED=0             several root populations with bit-identical CV effects: per-haplotype a/d lookup anyway (default: the one-population term table)
+ *   GEV_IMPORT_KEEP_LIST=0      gev_import_rows builds a new free list of row units instead of taking from the one the generations keep
  *   GEV_OVF_CAP=n, GEV_LIST_HEADROOM=n  (tests) initial size of the breakpoint / new-mutation overflow regions, spare list entries per row:
  *                               tiny values make generations overflow their buffers, so that the grow-and-enqueue-again path runs */
 int  gev_create(gev_ctx** out, int device, int n_pop, int nchr, int nphen);

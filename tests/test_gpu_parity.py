@@ -457,8 +457,9 @@ def test_config4_in_miniature_with_migrants_as_lists():
 def test_migrants_as_lists_payload_size_and_refusals(gpu_lib):
     """one context, two populations: the lists-only record is smaller by exactly the rows; an import without the root population's
     panel, or with the other end's setting, is refused; with the panel the imported rows equal the exported individuals' rows"""
-    import torch
     from geneevolve_amd.capi import GevError
+    hip = C.CDLL("libamdhip64.so.7")                        # the HIP runtime the library itself is linked to (already loaded with it): a plain device buffer
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; hip.hipFree.argtypes = [C.c_void_p]
     n, L = 64, 5000
     cfg = SyntheticConfig(n, L, chrom_bp=2_000_000, map_step=1000, rec_per_row=1e-3, mut_per_row=1e-3, n_cv=16, seed=5)
     g = gpu_lib.create(2, 1, 1, 0)
@@ -479,10 +480,12 @@ def test_migrants_as_lists_payload_size_and_refusals(gpu_lib):
     small = g.export_size(0, who)
     stride = -(-L // 1024) * 128                                                  # bytes of a flat row: multiple of 128
     assert full - small == 2 * len(who) * stride, (full, small, stride)
-    buf = torch.zeros(small, dtype=torch.uint8, device="cuda:0"); torch.cuda.synchronize()
-    g.export_rows(0, who, buf.data_ptr(), small)
+    dbuf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dbuf), small) == 0 and dbuf.value
+    buf = dbuf.value
+    g.export_rows(0, who, buf, small)
     with pytest.raises(GevError, match="founder panel is not held here"):
-        g.import_rows(1, buf.data_ptr(), small, len(who))
+        g.import_rows(1, buf, small, len(who))
     g.close()
     # again with the panels: rows come out as they went in; with the other end's setting the record's size gives it away
     g = gpu_lib.create(2, 1, 1, 0)
@@ -498,17 +501,18 @@ def test_migrants_as_lists_payload_size_and_refusals(gpu_lib):
             sex[p] = g.reproduce(p, synthetic_random_mate(sex[p], n, rng), int(sd[0]), sd[1:])
     assert np.array_equal(g.download_haps(0, 0)[np.stack([2 * who, 2 * who + 1], 1).ravel().astype(np.int64)], want)
     g.set_migrant_rows(False)
-    g.export_rows(0, who, buf.data_ptr(), small)
+    g.export_rows(0, who, buf, small)
     g.set_migrant_rows(True)
     with pytest.raises(GevError, match="expected from its header"):
-        g.import_rows(1, buf.data_ptr(), small, len(who))
+        g.import_rows(1, buf, small, len(who))
     g.set_migrant_rows(False)
-    g.import_rows(1, buf.data_ptr(), small, len(who))
+    g.import_rows(1, buf, small, len(who))
     assert g.pop_size(1) == n + len(who)
     got = g.download_haps(1, 0)
     assert np.array_equal(got[2 * n:], want), "rebuilt rows (mutations applied) != the emigrants' rows"
     assert g.dbg_verify_planes(1, 0, [40, 41]) == (0, 0)
     g.close()
+    hip.hipFree(dbuf)
 
 
 def test_rccl_backend_single_rank_collectives_drive_the_device_buffer_branch():
