@@ -27,6 +27,7 @@ cfg = SyntheticConfig(args.n_ind, args.n_loci, nchr=1, n_cv=1000, seed=12345, ma
 ctx = lib.create(2, 1, 1, 0)
 for p in range(2):
     cfg.apply_static(ctx, p)
+ctx.reserve(0, args.n_ind + args.k)                  # room for the immigrants (they are appended before the emigrants' slots are reused)
 ctx.synth_founders(0, 0, 2 * args.n_ind, 1000); ctx.synth_cv_founders(0, 0, 0, 2 * args.n_ind, 2000)
 if not args.rows:
     ctx.synth_founder_panel(0, 0, 2 * args.n_ind, 1000)
