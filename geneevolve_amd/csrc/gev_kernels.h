@@ -1364,6 +1364,84 @@ __global__ void __launch_bounds__(256) k_ad_accumulate_wide(const AdWork* __rest
     if (aw.add_tot) { aw.add_tot[ih * tot_stride] = 0.0 + A_chr; aw.dom_tot[ih * tot_stride] = 0.0 + D_chr; }   // one chromosome: the sum over chromosomes (:2729-2746) is 0 + x
     if (A_chr != A_chr || D_chr != D_chr) atomicMin(nan_flag, (u32)(ih < 0xffffffffull ? ih : 0xfffffffeull));
 }
+// Several root populations with DIFFERENT CV effects (after migration a haplotype's a, d are its root population's, :2695-2696), CV
+// files in position order: the arithmetic of k_ad_accumulate, statement by statement, with its loads arranged as in
+// k_ad_accumulate_wide -- a thread reads the words of its two rows (alleles and the RPB root-population bit sub-rows) once per 128
+// CVs, and the piece's a / d values of every root population, its 2p, q - p and the three dominance coefficients sit in LDS
+// ([cv][population]: the lanes of a wave read neighbouring words).  k_ad_accumulate did eight dependent global loads per CV and lane.
+#define ADRP_PIECE 128u
+template <u32 RPB>
+__global__ void __launch_bounds__(256) k_ad_accumulate_rp(const AdWork* __restrict__ At, u32 n_pop, size_t n_human, size_t out_stride, size_t tot_stride, u32* __restrict__ nan_flag)
+{
+    extern __shared__ double s_ad[];                                  // [PIECE][n_pop] a | [PIECE][n_pop] d | [PIECE][5]: 2p, q - p, -2pp, 2pq, -2qq
+    const AdWork& aw = At[blockIdx.y];
+    double* s_a = s_ad; double* s_d = s_a + ADRP_PIECE * n_pop; double* s_c = s_d + ADRP_PIECE * n_pop;
+    const u32 Cn = aw.C, stride = aw.stride_w32, sub = aw.sub_w32;
+    const double vd = aw.vd; const u64 bp0 = aw.bp0, bp_end = aw.bp_end;
+    const size_t ih = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = ih < n_human;
+    const u32* r0 = aw.cvp + (live ? 2 * ih * stride : 0);
+    const u32* r1 = r0 + stride;
+    const bool vec = (sub & 3u) == 0 && (stride & 3u) == 0;           // whole 16-byte chunks of every sub-row
+    double A_chr = 0, D_chr = 0;
+    for (u32 base = 0; base < Cn; base += ADRP_PIECE) {
+        const u32 nj = min(ADRP_PIECE, Cn - base);
+        u32 w0[1 + RPB][4], w1[1 + RPB][4];                           // [alleles, root-population bit 0 ..][word of the piece]
+#pragma unroll
+        for (u32 sr = 0; sr <= RPB; sr++) {
+            const u32 wq = sr * sub + (base >> 5);
+            if (vec) {
+                const uint4 a = *(const uint4*)(r0 + wq), b = *(const uint4*)(r1 + wq);
+                w0[sr][0] = a.x; w0[sr][1] = a.y; w0[sr][2] = a.z; w0[sr][3] = a.w; w1[sr][0] = b.x; w1[sr][1] = b.y; w1[sr][2] = b.z; w1[sr][3] = b.w;
+            } else {
+#pragma unroll
+                for (u32 q = 0; q < 4; q++) { const bool in = (base >> 5) + q < sub; w0[sr][q] = in ? r0[wq + q] : 0u; w1[sr][q] = in ? r1[wq + q] : 0u; }
+            }
+        }
+        __syncthreads();                                              // the previous piece is consumed
+        for (u32 e = threadIdx.x; e < nj * n_pop; e += 256) {
+            const u32 cv = e / n_pop, r = e - cv * n_pop; const u32 icv = base + cv;
+            // a CV outside [bp0,bp_end) is covered by no part: its a, d stay 0 (Human_CV ctor, Population.h:99-108)
+            const u64 x = aw.pos_file[icv];
+            const bool covered = (x >= bp0 && x < bp_end);
+            s_a[e] = covered ? aw.aptr[r][icv] : 0.0; s_d[e] = covered ? aw.dptr[r][icv] : 0.0;
+        }
+        for (u32 e = threadIdx.x; e < nj; e += 256) {
+            const double p = aw.frq[base + e];
+            const double q = 1 - p;
+            s_c[5 * e] = 2 * p; s_c[5 * e + 1] = q - p; s_c[5 * e + 2] = -2 * p * p; s_c[5 * e + 3] = 2 * p * q; s_c[5 * e + 4] = -2 * q * q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) {
+            if (q * 32 >= nj) break;
+            const u32 m = min(32u, nj - q * 32);
+            for (u32 j = 0; j < m; j++) {
+                const u32 t = ((w0[0][q] >> j) & 1u) + ((w1[0][q] >> j) & 1u);
+                u32 rp0 = 0, rp1 = 0;
+#pragma unroll
+                for (u32 b = 0; b < RPB; b++) { rp0 |= ((w0[1 + b][q] >> j) & 1u) << b; rp1 |= ((w1[1 + b][q] >> j) & 1u) << b; }
+                rp0 = min(rp0, n_pop - 1u); rp1 = min(rp1, n_pop - 1u);
+                const u32 cv = q * 32 + j;
+                const double a0 = s_a[cv * n_pop + rp0], a1 = s_a[cv * n_pop + rp1];
+                const double d0 = s_d[cv * n_pop + rp0], d1 = s_d[cv * n_pop + rp1];
+                const double a = (a0 + a1) / 2;
+                double d = (d0 + d1) / 2;
+                if (vd == 0) d = 0;
+                const double* cc = s_c + 5 * cv;
+                const double alpha = a + d * cc[1];
+                A_chr += ((double)t - cc[0]) * alpha;
+                const double ct = (t == 0) ? cc[2] : (t == 1 ? cc[3] : cc[4]);
+                D_chr += ct * d;
+            }
+        }
+    }
+    if (!live) return;
+    aw.add_out[ih * out_stride] = A_chr;
+    aw.dom_out[ih * out_stride] = D_chr;
+    if (aw.add_tot) { aw.add_tot[ih * tot_stride] = 0.0 + A_chr; aw.dom_tot[ih * tot_stride] = 0.0 + D_chr; }   // one chromosome: the sum over chromosomes (:2729-2746) is 0 + x
+    if (A_chr != A_chr || D_chr != D_chr) atomicMin(nan_flag, (u32)(ih < 0xffffffffull ? ih : 0xfffffffeull));
+}
 // sum over chromosomes in order (:2729-2746), additive and dominance values in one launch
 __global__ void k_ad_sum_chr(const double* __restrict__ add_chr /*[n][nchr][nphen]*/, const double* __restrict__ dom_chr, double* __restrict__ add /*[n][nphen]*/, double* __restrict__ dom, size_t n, int nchr, int nphen)
 {

@@ -2243,7 +2243,18 @@ static int enqueue_ad(gev_ctx* c, int pop, int buf, size_t n, bool counts_ready,
                 else if (ipb == 128) hipLaunchKernelGGL((k_ad_accumulate_tab<128>), dim3(nb, nw), dim3(128), lds, st, At, S1, n, out_stride, tot_stride, flag, 0);
                 else hipLaunchKernelGGL((k_ad_accumulate_tab<64>), dim3(nb, nw), dim3(64), lds, st, At, S1, n, out_stride, tot_stride, flag, 0);
             }
-        } else hipLaunchKernelGGL(k_ad_accumulate, dim3((unsigned)ceil_div(n, 256), nw), dim3(256), 0, st, At, c->rp_bits, n, out_stride, tot_stride, flag);
+        } else {
+            // several root populations with their own CV effects: the piecewise kernel when every CV file is in position order
+            bool sorted_all = c->rp_bits >= 1 && c->rp_bits <= 3;
+            for (const AdWork& a : aw) sorted_all &= a.cols_sorted != 0;
+            static const bool no_rp = getenv("GEV_AD_RP_FAST") && atoi(getenv("GEV_AD_RP_FAST")) == 0;
+            const dim3 grid((unsigned)ceil_div(n, 256), nw);
+            const size_t lds = (size_t)ADRP_PIECE * ((size_t)c->n_pop * 2 + 5) * sizeof(double);
+            if (sorted_all && !no_rp && c->rp_bits == 1) hipLaunchKernelGGL((k_ad_accumulate_rp<1>), grid, dim3(256), lds, st, At, (u32)c->n_pop, n, out_stride, tot_stride, flag);
+            else if (sorted_all && !no_rp && c->rp_bits == 2) hipLaunchKernelGGL((k_ad_accumulate_rp<2>), grid, dim3(256), lds, st, At, (u32)c->n_pop, n, out_stride, tot_stride, flag);
+            else if (sorted_all && !no_rp && c->rp_bits == 3) hipLaunchKernelGGL((k_ad_accumulate_rp<3>), grid, dim3(256), lds, st, At, (u32)c->n_pop, n, out_stride, tot_stride, flag);
+            else hipLaunchKernelGGL(k_ad_accumulate, grid, dim3(256), 0, st, At, c->rp_bits, n, out_stride, tot_stride, flag);
+        }
         KCHECK();
     } else HIPC(hipMemsetAsync(c->d_flag.p, 0xff, 4, st));
     if (nchr > 1 || !nw) {                                   // one chromosome: the A/D kernels wrote the totals themselves

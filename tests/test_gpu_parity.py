@@ -404,6 +404,16 @@ def test_two_rank_migration_on_gpu_matches_reference_fixture():
         assert msg == "ok", f"rank {r}: {msg}"
 
 
+def test_two_rank_migration_fixture_with_the_per_haplotype_effect_lookup(monkeypatch):
+    """the same run with GEV_AD_RP_FAST=0: k_ad_accumulate (one a / d lookup per haplotype and CV in global memory) instead of the
+    piecewise kernel that position-ordered CV files get"""
+    monkeypatch.setenv("GEV_AD_RP_FAST", "0")
+    from tests import dist_worker
+    res = dist_worker.launch("gpu")
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
 def test_locus_split_population_on_gpu_matches_the_unsplit_reference_run():
     """gev_set_chr_active: one population split along chromosomes over two processes (BASELINE config 4's layout; both share
     the test box's GPU, gloo carries the per-chromosome A/D all-reduce).  Each context is given genotype / CV inputs of its
@@ -1666,6 +1676,53 @@ def test_mutations_on_cv_positions_flip_the_resolved_allele_once_and_are_inherit
     mg, _ = g.download_mutations(0, 0)
     cv_all = set(int(x) for x in cvbp)
     assert sum(int(x) in cv_all for x in mg) > 50, "the scenario was meant to put many mutations on CV positions"
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("n_cv", [300, 1000])
+def test_ad_with_root_population_specific_effects_in_position_ordered_cv_files(gpu_lib, oracle_lib, n_cv):
+    """Three populations whose CV files (in position order) carry DIFFERENT a and d: after migration a haplotype's effects are its
+    root population's (src/Simulation.cpp:2695-2696).  k_ad_accumulate_rp reads the two root-population bit sub-rows of the CV
+    plane and the per-population a / d of 128 CVs at a time; 300 CVs = rows of 10 words (4-byte loads, a ragged last piece), 1000
+    CVs = rows of 32 words (16-byte loads, eight pieces).  Two phenotypes (vd = 0 and vd = 0.5), migrations in both directions:
+    A/D of every population bit for bit against the oracle, whose statements are the reference's."""
+    rs = np.random.RandomState(11)
+    R = 41
+    bp = (100 + 5000 * np.arange(R)).astype(np.uint64)
+    prob = np.r_[0.0, np.full(R - 1, 0.04)]; rate = np.r_[0.0, np.full(R - 1, 0.05)]
+    L = 2000
+    pos = np.sort(rs.randint(0, 5000 * R + 500, L)).astype(np.uint64)
+    n, npop = 120, 3
+    g = gpu_lib.create(npop, 1, 2); o = oracle_lib.create(npop, 1, 2)
+    for ctx in (g, o):
+        for pop in range(npop):
+            ctx.set_rmap(pop, 0, bp, prob, 5000); ctx.set_mutmap(pop, 0, bp, rate); ctx.set_snps(pop, 0, pos)
+    for p in range(2):
+        cvbp = np.sort(rs.randint(0, 5000 * R + 400, n_cv)).astype(np.uint64)   # position order, duplicates, a few outside [bp0, bp_end)
+        a, d = rs.randn(n_cv), rs.randn(n_cv)
+        for pop in range(npop):
+            V = synth_packed(60 + 3 * p + pop, 2 * n, n_cv)
+            for ctx in (g, o):
+                ctx.set_cvs(pop, p, 0, cvbp, a * (1 + 0.5 * pop) + 0.25 * pop, d - 0.125 * pop, 0.5 if p else 0.0)
+                ctx.upload_cv_founders(pop, p, 0, V, n_cv)
+    for pop in range(npop):
+        F = synth_packed(70 + pop, 2 * n, L)
+        g.upload_founders(pop, 0, F, L); o.upload_founders(pop, 0, F, L)
+    sg, so = Simulation(g, 31, 1, True), Simulation(o, 31, 1, True)
+    for pop in range(npop):
+        sg.ras_initial_human_gen0(pop, n); so.ras_initial_human_gen0(pop, n)
+    for gen in range(1, 8):
+        for pop in range(npop):
+            npp = g.pop_size(pop)
+            ra = sg.next_generation_rm(pop, npp, want_couples=True); rb = so.next_generation_rm(pop, npp, want_couples=True)
+            assert np.array_equal(ra["couples"], rb["couples"]) and np.array_equal(ra["sex"], rb["sex"]), (gen, pop)
+            for x, y in zip(g.compute_ad(pop), o.compute_ad(pop)):
+                assert helpers.bits_equal(x, y), f"A/D gen {gen} pop {pop}"
+        if gen in (2, 4, 5):
+            moves = [(0, 5, 1), (0, 17, 2), (0, 60, 1), (1, 3, 0), (1, 40, 2), (1, 41, 0), (2, 7, 0), (2, 8, 1)]
+            g.migrate(moves); o.migrate(moves)
+    parts, _ = g.download_intervals(0, 0)
+    assert len(set(int(x) for x in parts["root_population"])) == 3, "population 0 was meant to hold parts of all three root populations"
     g.close(); o.close()
 
 
