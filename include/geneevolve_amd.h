@@ -108,6 +108,8 @@ const char* gev_version(void);
  *   GEV_CHAIN_WG=0              serial-chain mode with one wave per link; GEV_CHAIN_MAX_TASKS=n: most tasks accepted without a mutation map
  *   GEV_TABLE_RING_BYTES=n      minimum size of the pinned ring the per-generation work tables are staged through
  *   GEV_AD_SHARED=0             several root populations with bit-identical CV effects: per-haplotype a/d lookup anyway (default: the one-population term table)
+ *   GEV_AD_RP_FAST=0            several root populations with their own CV effects: per-haplotype a/d lookup in global memory (k_ad_accumulate) even
+ *                               when the CV files are in position order (default then: k_ad_accumulate_rp, the piece's values in LDS)
  *   GEV_IMPORT_KEEP_LIST=0      gev_import_rows builds a new free list of row units instead of taking from the one the generations keep
  *   GEV_OVF_CAP=n, GEV_LIST_HEADROOM=n  (tests) initial size of the breakpoint / new-mutation overflow regions, spare list entries per row:
  *                               tiny values make generations overflow their buffers, so that the grow-and-enqueue-again path runs */

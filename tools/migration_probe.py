@@ -21,12 +21,16 @@ ap.add_argument("--k", type=int, default=500)
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--rows", action="store_true")
 ap.add_argument("--no-migration", action="store_true")
+ap.add_argument("--distinct-effects", action="store_true", help="population 1 gets other CV effects than population 0: A/D looks a, d up by root population")
 args = ap.parse_args()
 lib = GevLibrary()
 cfg = SyntheticConfig(args.n_ind, args.n_loci, nchr=1, n_cv=1000, seed=12345, map_step=50_000, rec_per_row=5e-4, mut_per_row=5e-4)
 ctx = lib.create(2, 1, 1, 0)
 for p in range(2):
     cfg.apply_static(ctx, p)
+if args.distinct_effects:
+    bp, a, d = cfg.cv[0][0]
+    ctx.set_cvs(1, 0, 0, bp, a * 1.5 + 0.1, d, cfg.vd)
 ctx.reserve(0, args.n_ind + args.k)                  # room for the immigrants (they are appended before the emigrants' slots are reused)
 ctx.synth_founders(0, 0, 2 * args.n_ind, 1000); ctx.synth_cv_founders(0, 0, 0, 2 * args.n_ind, 2000)
 if not args.rows:
