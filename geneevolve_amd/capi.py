@@ -7,6 +7,7 @@ C call on caller-owned numpy buffers.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -101,6 +102,15 @@ class GevLibrary:
         if not os.path.exists(path):
             raise GevError(-3, f"native library not found: {path} (build it: python -c 'import __graft_entry__ as g; g.build()')")
         self.path, self.prefix = path, prefix
+        if prefix == "gev_" and "torch" not in sys.modules:
+            # This image holds two HIP runtimes: /opt/rocm's, which the library links, and the one PyTorch-ROCm bundles.  A process
+            # that uses both (the bench and the multi-rank tests hand torch's device buffers to the library) must load torch's first:
+            # with the library loaded before `import torch`, the runtime initialised second finds no device (measured on the
+            # MI355X box: build() followed by smoke() in one process).  Hosts without torch (C++, the bound program) are not affected.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         self.lib = C.CDLL(path)
         self.has_device_arg = prefix == "gev_"
         f = self._f("last_error"); f.restype = C.c_char_p; f.argtypes = []
