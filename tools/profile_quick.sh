@@ -1,5 +1,8 @@
+#!/bin/bash
+# The kernel-trace, HBM-traffic and two-rank steps of tools/profile_round.sh (about 4 GPU-minutes).  usage: tools/profile_quick.sh <tag>
 set -eo pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r03g; mkdir -p $O
+tag=${1:-quick}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/prof_$tag; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o runc -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --sustained-steps 0 > "$O/under_rocprof.jsonl" 2> "$O/trace.err"
 echo trace done
